@@ -1,0 +1,111 @@
+"""Pins the CPU oracle (oracle/dilithium.c) against the reference's ML-DSA vectors
+(SURVEY.md section 8c): NIST ACVP keyGen / sigGen / sigVer and Wycheproof verify.  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import hx, load_golden
+from oracle import orc
+
+PARAMS = {"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87}
+Q = 8380417
+
+
+def test_fixed_uniform_vector():
+    # sign/mldsa/mldsa65/internal/sample_test.go:12-63
+    want = load_golden("fixed_vectors.json.gz")["dilithium_uniform_seed_i_nonce30000"]
+    assert orc.dilithium_uniform(bytes(range(32)), 30000).tolist() == want
+
+
+def test_zetas_table():
+    # sign/internal/dilithium/ntt.go:19-57 (first / last entries)
+    z = orc.dilithium_zetas()
+    assert z[0] == 4193792 and z[1] == 25847 and z[2] == 5771523 and z[255] == 1976782
+
+
+def test_ntt_roundtrip():
+    # sign/internal/dilithium/ntt_test.go:25-51: InvNTT(NTT(p)) == p * R mod q
+    rng = np.random.default_rng(3)
+    R = (1 << 32) % Q
+    for _ in range(50):
+        p = rng.integers(0, Q, 256).astype(np.uint32)
+        t = orc.dilithium_ntt(p)
+        assert (t < 18 * Q).all()
+        t = orc.dilithium_normalize(orc.dilithium_invntt(orc.dilithium_normalize(t)))
+        assert (t.astype(np.uint64) == p.astype(np.uint64) * R % Q).all()
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_keygen(name):
+    p = PARAMS[name]
+    cases = load_golden("mldsa_acvp.json.gz")[name]["keygen"]
+    assert len(cases) == 25
+    seeds = np.frombuffer(b"".join(hx(c["seed"]) for c in cases), np.uint8)
+    pk, sk = orc.mldsa_keygen(p, seeds)
+    for i, c in enumerate(cases):
+        assert hashlib.sha256(pk[i].tobytes()).hexdigest() == c["pk_sha256"]
+        assert hashlib.sha256(sk[i].tobytes()).hexdigest() == c["sk_sha256"]
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_siggen(name):
+    # acvp_test.go:81-121: Sign_internal(sk, message, rnd)
+    p = PARAMS[name]
+    cases = load_golden("mldsa_acvp.json.gz")[name]["siggen"]
+    assert len(cases) == 8
+    for c in cases:
+        sig = orc.mldsa_sign_one(p, hx(c["sk"]), hx(c["message"]), rnd=hx(c["rnd"]), internal=True)
+        assert hashlib.sha256(sig).hexdigest() == c["sig_sha256"]
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_sigver(name):
+    # acvp_test.go:122-158: Verify_internal; only some cases are positive
+    p = PARAMS[name]
+    groups = load_golden("mldsa_acvp.json.gz")[name]["sigver"]
+    n = pos = 0
+    for g in groups:
+        for c in g["cases"]:
+            got = orc.mldsa_verify_one(p, hx(g["pk"]), hx(c["message"]), hx(c["signature"]), internal=True)
+            assert got == c["passed"]
+            n += 1
+            pos += got
+    assert n == 15 and 0 < pos < 15
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_wycheproof_verify(name):
+    # sign/schemes/wycheproof_test.go:116-151 (public Verify with contexts)
+    p = PARAMS[name]
+    PK = orc.DSA_SIZES[p][0]
+    groups = load_golden("mldsa_wycheproof_verify.json.gz")[name]
+    n = valid = 0
+    for g in groups:
+        pk = hx(g["pk"])
+        for t in g["tests"]:
+            n += 1
+            if len(pk) != PK:  # UnmarshalBinaryPublicKey fails -> only invalid cases allowed
+                assert t["result"] == "invalid"
+                continue
+            ok = orc.mldsa_verify_one(p, pk, hx(t["msg"]), hx(t["sig"]), ctx=hx(t["ctx"]))
+            assert ok == (t["result"] == "valid"), (t["id"], t["comment"])
+            valid += ok
+    assert n >= 60 and valid >= 40
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_sign_verify_roundtrip_batch(name):
+    # mldsa65/internal/dilithium_test.go:94-129
+    p = PARAMS[name]
+    rng = np.random.default_rng(p)
+    n = 16
+    pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 100)), dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = [b"ctx%d" % i for i in range(n)]
+    sig = orc.mldsa_sign(p, sk, msgs, ctxs)
+    assert orc.mldsa_verify(p, pk, sig, msgs, ctxs).all()
+    bad = sig.copy()
+    bad[:, 40] ^= 1
+    assert not orc.mldsa_verify(p, pk, bad, msgs, ctxs).any()
+    assert not orc.mldsa_verify(p, pk, sig, msgs, [b"other"] * n).any()
