@@ -1,0 +1,79 @@
+"""ctypes binding of libcirclhip.so -- the C ABI of include/circl_hip.h.
+
+Loading fails loudly when the library is missing: there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcirclhip.so")
+
+# every symbol include/circl_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "circl_hip_init", "circl_hip_device_count", "circl_hip_last_error", "circl_hip_version",
+    "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
+    "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size",
+    "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
+    "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
+    "circl_hip_mlkem_keygen_dev",
+    "circl_hip_mldsa_verify", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
+    "circl_hip_keccak_f1600", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_dilithium_ntt",
+    "circl_hip_shake", "circl_hip_alloc_host", "circl_hip_free_host",
+]
+
+OK, EPARAM, ENODEV, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
+ALL_DEVICES = -1
+
+
+class CirclHipError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        names = {EPARAM: "EPARAM", ENODEV: "ENODEV", EHIP: "EHIP", ENOMEM: "ENOMEM", EWORKSPACE: "EWORKSPACE"}
+        super().__init__(f"{where}: {names.get(code, code)} {detail}".strip())
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Returns the loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m circl_amd.build` "
+                "(circl_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for s in ("circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
+                  "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size"):
+            getattr(L, s).restype = C.c_size_t
+            getattr(L, s).argtypes = [C.c_int]
+        for s in ("circl_hip_mlkem_workspace_size", "circl_hip_mldsa_workspace_size"):
+            getattr(L, s).restype = C.c_size_t
+            getattr(L, s).argtypes = [C.c_int, C.c_size_t]
+        L.circl_hip_last_error.restype = C.c_char_p
+        L.circl_hip_version.restype = C.c_char_p
+        L.circl_hip_alloc_host.restype = C.c_void_p
+        L.circl_hip_alloc_host.argtypes = [C.c_size_t]
+        L.circl_hip_free_host.argtypes = [C.c_void_p]
+        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        L.circl_hip_mlkem_encaps.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_decaps.argtypes = [i, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_keygen.argtypes = [i, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_encaps_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mlkem_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mlkem_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mldsa_verify.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_verify_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_keccak_f1600.argtypes = [vp, sz, i, i]
+        L.circl_hip_kyber_ntt.argtypes = [vp, sz, i, i]
+        L.circl_hip_kyber_mulhat.argtypes = [vp, vp, vp, sz, i]
+        L.circl_hip_dilithium_ntt.argtypes = [vp, sz, i, i]
+        L.circl_hip_shake.argtypes = [i, i, vp, sz, vp, sz, sz, i]
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != 0:
+        raise CirclHipError(rc, where, (lib().circl_hip_last_error() or b"").decode())

@@ -1,0 +1,309 @@
+// circl_hip.hip -- host side of libcirclhip.so: the C ABI declared in include/circl_hip.h.
+//
+// There is deliberately no CPU path in this file: every compute entry point launches the HIP
+// kernels of mlkem_kernels.h / prim_kernels.h or fails with CIRCL_HIP_ENODEV.
+#include "../../include/circl_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mlkem_kernels.h"
+#include "prim_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int g_ndev = -1;
+std::once_flag g_once;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char b_[256];                                                                          \
+            snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            g_err = b_;                                                                            \
+            return CIRCL_HIP_EHIP;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+void do_init() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    g_ndev = n;
+}
+
+int ndev() {
+    std::call_once(g_once, do_init);
+    return g_ndev;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
+
+// ---- device-resident ML-KEM ---------------------------------------------------------------
+
+template <int K>
+int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                    void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < 32 * n || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+        return CIRCL_HIP_EWORKSPACE;
+    uint8_t *r_ws = static_cast<uint8_t *>(ws);
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
+    const unsigned eb = (unsigned)((n + Gm::G - 1) / Gm::G);
+    hipLaunchKernelGGL(circl::mlkem::mlkem_encrypt_kernel<K>, dim3(eb), dim3(64), Gm::LDS_TOTAL, st, ek, m, r_ws, ct, ss,
+                       status, n);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// ---- host-buffer plumbing -----------------------------------------------------------------
+
+struct Arena {
+    std::mutex mu;
+    void *base = nullptr;
+    size_t cap = 0;
+    hipStream_t st[2] = {nullptr, nullptr};
+};
+Arena g_arena[64];
+
+int arena_reserve(Arena &a, size_t bytes) {
+    if (!a.st[0]) {
+        HIP_TRY(hipStreamCreateWithFlags(&a.st[0], hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&a.st[1], hipStreamNonBlocking));
+    }
+    if (a.cap < bytes) {
+        if (a.base) HIP_TRY(hipFree(a.base));
+        a.base = nullptr;
+        a.cap = 0;
+        HIP_TRY(hipMalloc(&a.base, bytes));
+        a.cap = bytes;
+    }
+    return CIRCL_HIP_OK;
+}
+
+size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// Runs `n` items on one device in double-buffered chunks:  H2D(inputs) -> launch -> D2H(outputs).
+// in_sz / out_sz list the per-item byte sizes of the input and output arrays.
+template <class Launch>
+int run_chunked(int dev, size_t n, const std::vector<const uint8_t *> &in, const std::vector<size_t> &in_sz,
+                const std::vector<uint8_t *> &out, const std::vector<size_t> &out_sz, size_t ws_per_item, Launch launch) {
+    if (n == 0) return CIRCL_HIP_OK;
+    if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    Arena &a = g_arena[dev];
+    std::lock_guard<std::mutex> lk(a.mu);
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 16);
+    size_t slot_bytes = up256(ws_per_item * chunk);
+    for (size_t s : in_sz) slot_bytes += up256(s * chunk);
+    for (size_t s : out_sz) slot_bytes += up256(s * chunk);
+    int rc = arena_reserve(a, 2 * slot_bytes);
+    if (rc) return rc;
+    size_t done = 0;
+    for (int c = 0; done < n; c++) {
+        const int slot = c & 1;
+        const size_t cnt = std::min(chunk, n - done);
+        hipStream_t st = a.st[slot];
+        HIP_TRY(hipStreamSynchronize(st));  // the slot's previous chunk has fully drained
+        uint8_t *p = static_cast<uint8_t *>(a.base) + slot * slot_bytes;
+        std::vector<uint8_t *> din, dout;
+        for (size_t k = 0; k < in.size(); k++) {
+            din.push_back(p);
+            HIP_TRY(hipMemcpyAsync(p, in[k] + done * in_sz[k], cnt * in_sz[k], hipMemcpyHostToDevice, st));
+            p += up256(in_sz[k] * chunk);
+        }
+        for (size_t k = 0; k < out.size(); k++) {
+            dout.push_back(p);
+            p += up256(out_sz[k] * chunk);
+        }
+        rc = launch(din, dout, cnt, p, up256(ws_per_item * chunk), st);
+        if (rc) return rc;
+        for (size_t k = 0; k < out.size(); k++)
+            if (out[k]) HIP_TRY(hipMemcpyAsync(out[k] + done * out_sz[k], dout[k], cnt * out_sz[k], hipMemcpyDeviceToHost, st));
+        done += cnt;
+    }
+    HIP_TRY(hipStreamSynchronize(a.st[0]));
+    HIP_TRY(hipStreamSynchronize(a.st[1]));
+    return CIRCL_HIP_OK;
+}
+
+// Contiguous split of [0,n) over the visible devices, one host thread each, no collective.
+template <class PerDevice> int shard(size_t n, int device, PerDevice fn) {
+    const int nd = ndev();
+    if (nd <= 0) return CIRCL_HIP_ENODEV;
+    if (device >= 0) return device < nd ? fn(device, size_t(0), n) : CIRCL_HIP_ENODEV;
+    if (device != CIRCL_HIP_ALL_DEVICES) return CIRCL_HIP_EPARAM;
+    std::vector<int> rcs(nd, 0);
+    std::vector<std::string> errs(nd);
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; d++) {
+        const size_t lo = n * d / nd, hi = n * (d + 1) / nd;
+        th.emplace_back([&, d, lo, hi] {
+            rcs[d] = fn(d, lo, hi - lo);
+            errs[d] = g_err;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < nd; d++)
+        if (rcs[d]) {
+            g_err = errs[d];
+            return rcs[d];
+        }
+    return CIRCL_HIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int circl_hip_init(void) {
+    const int n = ndev();
+    return n > 0 ? n : CIRCL_HIP_ENODEV;
+}
+int circl_hip_device_count(void) { return std::max(ndev(), 0); }
+const char *circl_hip_last_error(void) { return g_err.c_str(); }
+const char *circl_hip_version(void) { return "circl-hip 0.1 (gfx950)"; }
+
+size_t circl_hip_mlkem_ek_size(int param) { const int k = kem_k(param); return k ? 384 * k + 32 : 0; }
+size_t circl_hip_mlkem_dk_size(int param) { const int k = kem_k(param); return k ? 768 * k + 96 : 0; }
+size_t circl_hip_mlkem_ct_size(int param) {
+    switch (param) {
+    case 512: return 768;
+    case 768: return 1088;
+    case 1024: return 1568;
+    }
+    return 0;
+}
+size_t circl_hip_mldsa_pk_size(int param) { return param == 44 ? 1312 : param == 65 ? 1952 : param == 87 ? 2592 : 0; }
+size_t circl_hip_mldsa_sig_size(int param) { return param == 44 ? 2420 : param == 65 ? 3309 : param == 87 ? 4627 : 0; }
+
+size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? up256(64 * n) : 0; }
+
+int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
+                               uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return encaps_dev_impl<2>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 3: return encaps_dev_impl<3>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 4: return encaps_dev_impl<4>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                           size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {ek + lo * EK, m + lo * 32}, {EK, 32},
+                           {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, 64,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
+                               hipStream_t st) {
+                               return circl_hip_mlkem_encaps_dev(param, in[0], in[1], out[0], out[1], out[2], c, ws, wsb, st);
+                           });
+    });
+}
+
+// ---- primitives -------------------------------------------------------------------------------
+
+int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device) {
+    if (rounds != 24 && rounds != 12) return CIRCL_HIP_EPARAM;
+    uint8_t *p = reinterpret_cast<uint8_t *>(states);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {p + lo * 200}, {200}, {p + lo * 200}, {200}, 0,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *, size_t,
+                               hipStream_t st) {
+                               HIP_TRY(hipMemcpyAsync(out[0], in[0], c * 200, hipMemcpyDeviceToDevice, st));
+                               hipLaunchKernelGGL(circl::prim::keccak_f1600_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256),
+                                                  0, st, reinterpret_cast<uint64_t *>(out[0]), c, 24 - rounds);
+                               HIP_TRY(hipGetLastError());
+                               return CIRCL_HIP_OK;
+                           });
+    });
+}
+
+int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device) {
+    uint8_t *p = reinterpret_cast<uint8_t *>(polys);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {p + lo * 512}, {512}, {p + lo * 512}, {512}, 0,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *, size_t,
+                               hipStream_t st) {
+                               HIP_TRY(hipMemcpyAsync(out[0], in[0], c * 512, hipMemcpyDeviceToDevice, st));
+                               hipLaunchKernelGGL(circl::prim::kyber_ntt_kernel, dim3((unsigned)c), dim3(64), 0, st,
+                                                  reinterpret_cast<int16_t *>(out[0]), inverse);
+                               HIP_TRY(hipGetLastError());
+                               return CIRCL_HIP_OK;
+                           });
+    });
+}
+
+int circl_hip_kyber_mulhat(int16_t *out, const int16_t *a, const int16_t *b, size_t n, int device) {
+    uint8_t *po = reinterpret_cast<uint8_t *>(out);
+    const uint8_t *pa = reinterpret_cast<const uint8_t *>(a), *pb = reinterpret_cast<const uint8_t *>(b);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {pa + lo * 512, pb + lo * 512}, {512, 512}, {po + lo * 512}, {512}, 0,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &o, size_t c, uint8_t *, size_t,
+                               hipStream_t st) {
+                               hipLaunchKernelGGL(circl::prim::kyber_mulhat_kernel, dim3((unsigned)c), dim3(64), 0, st,
+                                                  reinterpret_cast<int16_t *>(o[0]), reinterpret_cast<const int16_t *>(in[0]),
+                                                  reinterpret_cast<const int16_t *>(in[1]));
+                               HIP_TRY(hipGetLastError());
+                               return CIRCL_HIP_OK;
+                           });
+    });
+}
+
+int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen, size_t n, int device) {
+    if ((rate != 168 && rate != 136 && rate != 72) || (ds != 0x1f && ds != 0x06) || outlen == 0) return CIRCL_HIP_EPARAM;
+    const size_t il = inlen ? inlen : 1;  // keep the per-item stride non-zero for empty messages
+    std::vector<uint8_t> pad;
+    const uint8_t *src = in;
+    if (!inlen) { pad.assign(n, 0); src = pad.data(); }
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {src + lo * il}, {il}, {out + lo * outlen}, {outlen}, 0,
+                           [&](std::vector<uint8_t *> &i, std::vector<uint8_t *> &o, size_t c, uint8_t *, size_t,
+                               hipStream_t st) {
+                               // the kernel strides inputs by `inlen`; empty inputs never dereference
+                               hipLaunchKernelGGL(circl::prim::sponge_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st,
+                                                  rate / 8, (uint32_t)ds, i[0], inlen, o[0], outlen, c);
+                               HIP_TRY(hipGetLastError());
+                               return CIRCL_HIP_OK;
+                           });
+    });
+}
+
+// ---- not yet implemented in this build (filled in by later milestones) -----------------------
+#define CIRCL_HIP_EUNSUPPORTED (-6)
+int circl_hip_mlkem_decaps(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
+int circl_hip_mlkem_keygen(int, const uint8_t *, uint8_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
+int circl_hip_mlkem_decaps_dev(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
+int circl_hip_mlkem_keygen_dev(int, const uint8_t *, uint8_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
+int circl_hip_mldsa_verify(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
+size_t circl_hip_mldsa_workspace_size(int, size_t) { return 0; }
+int circl_hip_mldsa_verify_dev(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
+int circl_hip_dilithium_ntt(uint32_t *, size_t, int, int) { return CIRCL_HIP_EUNSUPPORTED; }
+
+void *circl_hip_alloc_host(size_t bytes) {
+    void *p = nullptr;
+    if (ndev() <= 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void circl_hip_free_host(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// keccak_dev.h -- Keccak-f[1600] for gfx950, one sponge state per lane (64 independent
+// permutations per wavefront).
+//
+// Replaces the reference's scalar internal/sha3/keccakf.go:12-391 and the 4-way AVX2
+// simd/keccakf1600 (f1600x.go:77-91).  CDNA4 has no 64-bit rotate or 3-input xor, but gfx950
+// has V_BITOP3_B32 (arbitrary 3-input boolean) and V_ALIGNBIT_B32 (funnel shift), so a state
+// is held as 25 (lo,hi) 32-bit register pairs and one round is
+//     theta : 20 bitop3 (5-way column xor) + 10 alignbit (rol 1) + 50 bitop3 (s ^ C ^ rol(C))
+//     rho/pi: 48 alignbit (register renaming is free)
+//     chi   : 50 bitop3 (a ^ (~b & c))
+//     iota  : 2 xor
+// = 180 VALU instructions per round, 4320 per permutation, no memory traffic.
+//
+// Lane-local code in this header is __host__ __device__ so tests/hostsim can run the very same
+// source on the CPU; the host branch of the three wrappers below exists only for that harness
+// (the product never calls it: every exported entry point launches kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CIRCL_HD __host__ __device__ __forceinline__
+
+namespace circl {
+
+CIRCL_HD uint32_t bitop3_xor(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+CIRCL_HD uint32_t bitop3_chi(uint32_t a, uint32_t b, uint32_t c) {  // a ^ (~b & c)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2);
+#else
+    return a ^ (~b & c);
+#endif
+}
+// ({hi,lo} >> s)[31:0], 0 < s < 32
+CIRCL_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+
+struct KeccakState {
+    uint32_t lo[25], hi[25];
+};
+
+// Round constants of FIPS 202 (the reference tabulates the same 24 values in
+// internal/sha3/rc.go:4-29), split into (hi,lo) halves.
+#define CIRCL_RC_LIST                                                                              \
+    RC(0x00000000, 0x00000001) RC(0x00000000, 0x00008082) RC(0x80000000, 0x0000808a)               \
+    RC(0x80000000, 0x80008000) RC(0x00000000, 0x0000808b) RC(0x00000000, 0x80000001)               \
+    RC(0x80000000, 0x80008081) RC(0x80000000, 0x00008009) RC(0x00000000, 0x0000008a)               \
+    RC(0x00000000, 0x00000088) RC(0x00000000, 0x80008009) RC(0x00000000, 0x8000000a)               \
+    RC(0x00000000, 0x8000808b) RC(0x80000000, 0x0000008b) RC(0x80000000, 0x00008089)               \
+    RC(0x80000000, 0x00008003) RC(0x80000000, 0x00008002) RC(0x80000000, 0x00000080)               \
+    RC(0x00000000, 0x0000800a) RC(0x80000000, 0x8000000a) RC(0x80000000, 0x80008081)               \
+    RC(0x80000000, 0x00008080) RC(0x00000000, 0x80000001) RC(0x80000000, 0x80008008)
+
+#define RC(h, l) l,
+static __device__ __constant__ const uint32_t kRcLoDev[24] = {CIRCL_RC_LIST};
+static const uint32_t kRcLoHost[24] = {CIRCL_RC_LIST};
+#undef RC
+#define RC(h, l) h,
+static __device__ __constant__ const uint32_t kRcHiDev[24] = {CIRCL_RC_LIST};
+static const uint32_t kRcHiHost[24] = {CIRCL_RC_LIST};
+#undef RC
+
+CIRCL_HD uint32_t rc_lo(int r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kRcLoDev[r];
+#else
+    return kRcLoHost[r];
+#endif
+}
+CIRCL_HD uint32_t rc_hi(int r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kRcHiDev[r];
+#else
+    return kRcHiHost[r];
+#endif
+}
+
+namespace detail {
+template <int I> struct IC { static constexpr int v = I; };
+template <int I, int N, class F> CIRCL_HD void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// rho offsets for lane x+5y (FIPS 202 table 2; keccakf.go's rotation literals)
+CIRCL_HD constexpr int rho_of(int i) {
+    constexpr int t[25] = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3,  10, 43,
+                           25, 39, 41, 45, 15, 21, 8,  18, 2,  61, 56, 14};
+    return t[i];
+}
+template <int N> CIRCL_HD void rol64(uint32_t lo, uint32_t hi, uint32_t &olo, uint32_t &ohi) {
+    if constexpr (N == 0) {
+        olo = lo; ohi = hi;
+    } else if constexpr (N < 32) {
+        olo = alignbit(lo, hi, 32 - N); ohi = alignbit(hi, lo, 32 - N);
+    } else if constexpr (N == 32) {
+        olo = hi; ohi = lo;
+    } else {
+        olo = alignbit(hi, lo, 64 - N); ohi = alignbit(lo, hi, 64 - N);
+    }
+}
+}  // namespace detail
+
+// Keccak-f[1600]; first_round = 0 for 24 rounds, 12 for the 12-round "turbo" variant
+// (keccakf.go:20-24).  The round loop is NOT unrolled: one round is ~1.5 KB of code and every
+// inlined call site stays I-cache resident.
+CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
+#pragma unroll 1
+    for (int r = first_round; r < 24; r++) {
+        uint32_t cl[5], ch[5], rl[5], rh[5], bl[25], bh[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            cl[x] = bitop3_xor(bitop3_xor(s.lo[x], s.lo[x + 5], s.lo[x + 10]), s.lo[x + 15], s.lo[x + 20]);
+            ch[x] = bitop3_xor(bitop3_xor(s.hi[x], s.hi[x + 5], s.hi[x + 10]), s.hi[x + 15], s.hi[x + 20]);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++) {  // rol(C[x], 1)
+            rl[x] = alignbit(cl[x], ch[x], 31);
+            rh[x] = alignbit(ch[x], cl[x], 31);
+        }
+        detail::static_for<0, 25>([&](auto ic) {
+            constexpr int i = decltype(ic)::v, x = i % 5, y = i / 5;
+            const uint32_t tl = bitop3_xor(s.lo[i], cl[(x + 4) % 5], rl[(x + 1) % 5]);
+            const uint32_t th = bitop3_xor(s.hi[i], ch[(x + 4) % 5], rh[(x + 1) % 5]);
+            constexpr int d = y + 5 * ((2 * x + 3 * y) % 5);  // pi
+            detail::rol64<detail::rho_of(i)>(tl, th, bl[d], bh[d]);
+        });
+#pragma unroll
+        for (int y = 0; y < 25; y += 5)
+#pragma unroll
+            for (int x = 0; x < 5; x++) {
+                s.lo[x + y] = bitop3_chi(bl[x + y], bl[(x + 1) % 5 + y], bl[(x + 2) % 5 + y]);
+                s.hi[x + y] = bitop3_chi(bh[x + y], bh[(x + 1) % 5 + y], bh[(x + 2) % 5 + y]);
+            }
+        s.lo[0] ^= rc_lo(r);
+        s.hi[0] ^= rc_hi(r);
+    }
+}
+
+CIRCL_HD void keccak_zero(KeccakState &s) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) s.lo[i] = s.hi[i] = 0;
+}
+
+// Sponge parameters (internal/sha3/shake.go:42-46, hashes.go:21-37): rate in 64-bit words.
+constexpr int kShake128Words = 21;  // 168 B
+constexpr int kShake256Words = 17;  // 136 B, also SHA3-256
+constexpr int kSha3_512Words = 9;   //  72 B
+constexpr uint32_t kDsShake = 0x1f, kDsSha3 = 0x06;
+
+}  // namespace circl

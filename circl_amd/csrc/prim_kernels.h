@@ -1,0 +1,116 @@
+// prim_kernels.h -- batch kernels for the unit-level building blocks the reference tests one by
+// one (KeccakF1600, Poly.NTT / InvNTT / MulHat, SHAKE/SHA3 sponges).  They exist so the parity
+// tests can compare every device function with the oracle in isolation; the fused ML-KEM kernels
+// use the same device functions.
+#pragma once
+#include "kyber_dev.h"
+
+namespace circl {
+namespace prim {
+
+// n states of 25 little-endian uint64 words (row-major), one state per lane.
+__global__ void __launch_bounds__(256) keccak_f1600_kernel(uint64_t *states, size_t n, int first_round) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t *p = states + i * 25;
+    KeccakState s;
+#pragma unroll
+    for (int w = 0; w < 25; w++) { s.lo[w] = (uint32_t)p[w]; s.hi[w] = (uint32_t)(p[w] >> 32); }
+    keccak_f1600(s, first_round);
+#pragma unroll
+    for (int w = 0; w < 25; w++) p[w] = ((uint64_t)s.hi[w] << 32) | s.lo[w];
+}
+
+// One polynomial per single-wave workgroup, int16[256] in standard order, in place.
+// Outputs are normalised to [0,q).
+__global__ void __launch_bounds__(64) kyber_ntt_kernel(int16_t *polys, int inverse) {
+    __shared__ __attribute__((aligned(16))) int16_t xch[256];
+    const int lane = threadIdx.x;
+    int16_t *p = polys + (size_t)blockIdx.x * 256;
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    int c[4];
+    if (!inverse) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[r] = kyber::barrett(p[kyber::idx_l1(lane, r)]);
+        kyber::ntt(c, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[kyber::idx_l4(lane, r)] = (int16_t)kyber::normalize(c[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[r] = kyber::barrett(p[kyber::idx_l4(lane, r)]);
+        kyber::invntt(c, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = (int16_t)kyber::normalize(c[r]);
+    }
+}
+
+__global__ void __launch_bounds__(64) kyber_mulhat_kernel(int16_t *out, const int16_t *a, const int16_t *b) {
+    const int lane = threadIdx.x;
+    const size_t off = (size_t)blockIdx.x * 256 + 4 * lane;
+    int x[4], y[4], acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) { x[r] = kyber::barrett(a[off + r]); y[r] = kyber::barrett(b[off + r]); }
+    kyber::mulhat_acc(acc, x, y, kyber::zeta(64 + lane));
+    kyber::mulhat_finish(acc);
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[off + r] = (int16_t)kyber::normalize(acc[r]);
+}
+
+// n independent sponges over equal-length byte strings; one stream per lane
+// (internal/sha3 State.Write / Read).  rate_words in {9, 17, 21}.
+__global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds, const uint8_t *in, size_t inlen,
+                                                     uint8_t *out, size_t outlen, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = in + i * inlen;
+    uint8_t *o = out + i * outlen;
+    const size_t rate = (size_t)rate_words * 8;
+    KeccakState s;
+    keccak_zero(s);
+    size_t pos = 0;
+    bool padded = false;
+    while (!padded) {
+        // xor one block: message bytes, then the ds byte, then 0x80 at the end of the final block
+#pragma unroll
+        for (int w = 0; w < 21; w++) {
+            if (w < rate_words) {
+                uint64_t v = 0;
+                for (int b = 0; b < 8; b++) {
+                    const size_t k = pos + 8 * (size_t)w + b;
+                    uint64_t byte = 0;
+                    if (k < inlen) byte = p[k];
+                    else if (k == inlen) byte = ds;
+                    v |= byte << (8 * b);
+                }
+                s.lo[w] ^= (uint32_t)v;
+                s.hi[w] ^= (uint32_t)(v >> 32);
+            }
+        }
+        if (pos + rate > inlen) {  // this block holds the ds byte: it is the last one
+            padded = true;
+#pragma unroll
+            for (int w = 0; w < 21; w++)
+                if (w == rate_words - 1) s.hi[w] ^= 0x80000000u;
+        }
+        keccak_f1600(s);
+        pos += rate;
+    }
+    size_t done = 0;
+    while (done < outlen) {
+#pragma unroll
+        for (int w = 0; w < 21; w++) {
+            if (w < rate_words) {
+                const uint64_t v = ((uint64_t)s.hi[w] << 32) | s.lo[w];
+                for (int b = 0; b < 8; b++) {
+                    const size_t k = done + 8 * (size_t)w + b;
+                    if (k < outlen) o[k] = (uint8_t)(v >> (8 * b));
+                }
+            }
+        }
+        done += rate;
+        if (done < outlen) keccak_f1600(s);
+    }
+}
+
+}  // namespace prim
+}  // namespace circl

@@ -1,0 +1,114 @@
+"""Host-buffer (numpy) wrappers over the C ABI -- what the cgo bridge would call."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
+DSA_SIZES = {44: (1312, 2420), 65: (1952, 3309), 87: (2592, 4627)}  # pk, sig
+
+
+def _u8(x, cols):
+    a = np.ascontiguousarray(np.frombuffer(x, np.uint8) if isinstance(x, (bytes, bytearray)) else x, dtype=np.uint8)
+    return a.reshape(-1, cols)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return nat.lib().circl_hip_device_count()
+
+
+def mlkem_encaps(param, ek, m, device=0):
+    EK, _, CT = KEM_SIZES[param]
+    ek, m = _u8(ek, EK), _u8(m, 32)
+    n = len(ek)
+    assert len(m) == n
+    ct = np.empty((n, CT), np.uint8)
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_encaps(param, _p(ek), _p(m), _p(ct), _p(ss), _p(st), n, device), "mlkem_encaps")
+    return ct, ss, st
+
+
+def mlkem_decaps(param, dk, ct, device=0):
+    _, DK, CT = KEM_SIZES[param]
+    dk, ct = _u8(dk, DK), _u8(ct, CT)
+    n = len(dk)
+    assert len(ct) == n
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_decaps(param, _p(dk), _p(ct), _p(ss), _p(st), n, device), "mlkem_decaps")
+    return ss, st
+
+
+def mlkem_keygen(param, seeds, device=0):
+    EK, DK, _ = KEM_SIZES[param]
+    seeds = _u8(seeds, 64)
+    n = len(seeds)
+    ek = np.empty((n, EK), np.uint8)
+    dk = np.empty((n, DK), np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_keygen(param, _p(seeds), _p(ek), _p(dk), n, device), "mlkem_keygen")
+    return ek, dk
+
+
+def _blob(items):
+    off = np.zeros(len(items) + 1, np.uint64)
+    if len(items):
+        off[1:] = np.cumsum([len(x) for x in items])
+    blob = np.frombuffer(b"".join(bytes(x) for x in items) + b"\0" * 16, dtype=np.uint8).copy()
+    return blob, off
+
+
+def mldsa_verify(param, pk, sig, msgs, ctxs=None, device=0):
+    PK, SIG = DSA_SIZES[param]
+    pk, sig = _u8(pk, PK), _u8(sig, SIG)
+    n = len(pk)
+    assert len(sig) == n and len(msgs) == n
+    mb, mo = _blob(msgs)
+    ok = np.empty(n, np.uint8)
+    if ctxs is None:
+        rc = nat.lib().circl_hip_mldsa_verify(param, _p(pk), _p(sig), _p(mb), _p(mo), None, None, _p(ok), n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_mldsa_verify(param, _p(pk), _p(sig), _p(mb), _p(mo), _p(cb), _p(co), _p(ok), n, device)
+    nat.check(rc, "mldsa_verify")
+    return ok
+
+
+def keccak_f1600(states, rounds=24, device=0):
+    a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25).copy()
+    nat.check(nat.lib().circl_hip_keccak_f1600(_p(a), len(a), rounds, device), "keccak_f1600")
+    return a
+
+
+def kyber_ntt(polys, inverse=False, device=0):
+    a = np.ascontiguousarray(polys, dtype=np.int16).reshape(-1, 256).copy()
+    nat.check(nat.lib().circl_hip_kyber_ntt(_p(a), len(a), int(inverse), device), "kyber_ntt")
+    return a
+
+
+def kyber_mulhat(a, b, device=0):
+    a = np.ascontiguousarray(a, dtype=np.int16).reshape(-1, 256)
+    b = np.ascontiguousarray(b, dtype=np.int16).reshape(-1, 256)
+    out = np.empty_like(a)
+    nat.check(nat.lib().circl_hip_kyber_mulhat(_p(out), _p(a), _p(b), len(a), device), "kyber_mulhat")
+    return out
+
+
+def dilithium_ntt(polys, inverse=False, device=0):
+    a = np.ascontiguousarray(polys, dtype=np.uint32).reshape(-1, 256).copy()
+    nat.check(nat.lib().circl_hip_dilithium_ntt(_p(a), len(a), int(inverse), device), "dilithium_ntt")
+    return a
+
+
+def shake(rate, ds, msgs, outlen, device=0):
+    """msgs: (n, inlen) uint8 (equal lengths) -> (n, outlen)"""
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+    n, inlen = msgs.shape
+    out = np.empty((n, outlen), np.uint8)
+    nat.check(nat.lib().circl_hip_shake(rate, ds, _p(msgs), inlen, _p(out), outlen, n, device), "shake")
+    return out

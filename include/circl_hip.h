@@ -1,0 +1,138 @@
+/* circl_hip.h -- C ABI of libcirclhip.so, the MI355X (gfx950) batch ML-KEM / ML-DSA engine.
+ *
+ * This is the drop-in boundary for cloudflare/circl's lattice hot path.  The reference has no
+ * FFI of its own (it is pure Go + Go assembler), so each entry point below cites the reference
+ * Go interface it replaces; INTEGRATION.md shows the cgo binding a CIRCL maintainer would add
+ * under kem/mlkem and sign/mldsa.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer; nothing is retained after
+ *     return (cgo pointer rule); no exceptions or aborts cross the ABI.
+ *   - batches are contiguous row-major arrays: ek[n][EK], m[n][32], ct[n][CT], ss[n][32] ...
+ *   - the ABI is deterministic: randomness (kem.Scheme.Encapsulate's 32 random bytes,
+ *     kem/mlkem/mlkem768/kyber.go:104-108) stays on the Go side and arrives as `m` / seeds.
+ *   - functions return 0 or a negative CIRCL_HIP_E* code; data-dependent, per-item failures
+ *     (the reference's kem.ErrPubKey / kem.ErrPrivKey) are written to status[n] and the
+ *     item's outputs are zero-filled.
+ *   - `device` >= 0 selects one GPU; CIRCL_HIP_ALL_DEVICES (-1) splits the batch into
+ *     contiguous shards, one per visible GPU, with no collective (items are independent).
+ *   - the *_dev variants take DEVICE pointers and a hipStream_t (as void*), enqueue the
+ *     kernels and return without synchronising: this is what bench.py times with inputs
+ *     already resident in HBM.  All device pointers must be 16-byte aligned.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     returns CIRCL_HIP_ENODEV.
+ */
+#ifndef CIRCL_HIP_H
+#define CIRCL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIRCL_HIP_OK 0
+#define CIRCL_HIP_EPARAM (-1)   /* unknown parameter set / bad argument */
+#define CIRCL_HIP_ENODEV (-2)   /* no HIP device, or device index out of range */
+#define CIRCL_HIP_EHIP (-3)     /* a HIP runtime call failed (see circl_hip_last_error) */
+#define CIRCL_HIP_ENOMEM (-4)
+#define CIRCL_HIP_EWORKSPACE (-5) /* workspace too small / misaligned pointer */
+
+#define CIRCL_HIP_ALL_DEVICES (-1)
+
+/* per-item status codes */
+#define CIRCL_HIP_ITEM_OK 0
+#define CIRCL_HIP_ITEM_ERR_PUBKEY 1  /* kem.ErrPubKey : pke/kyber/kyber768/internal/cpapke.go:45-55 */
+#define CIRCL_HIP_ITEM_ERR_PRIVKEY 2 /* kem.ErrPrivKey: kem/mlkem/mlkem768/kyber.go:219-228 */
+
+/* ---- library / device management ------------------------------------------------------ */
+int circl_hip_init(void);               /* idempotent; returns the number of devices or <0 */
+int circl_hip_device_count(void);
+const char *circl_hip_last_error(void); /* thread-local message for the last CIRCL_HIP_EHIP */
+const char *circl_hip_version(void);
+
+/* ---- sizes (kem.Scheme.PublicKeySize etc., kem/kem.go:33-82; sign/sign.go:48-94) -------- */
+size_t circl_hip_mlkem_ek_size(int param); /* 512|768|1024 -> 800|1184|1568, 0 if unknown */
+size_t circl_hip_mlkem_dk_size(int param); /*                1632|2400|3168 */
+size_t circl_hip_mlkem_ct_size(int param); /*                 768|1088|1568 */
+size_t circl_hip_mldsa_pk_size(int param); /* 44|65|87 -> 1312|1952|2592 */
+size_t circl_hip_mldsa_sig_size(int param);/*             2420|3309|4627 */
+
+/* ---- ML-KEM, host buffers (what cgo binds) ---------------------------------------------
+ * circl_hip_mlkem_encaps: scheme.UnmarshalBinaryPublicKey(ek_i) followed by
+ *   scheme.EncapsulateDeterministically(pk_i, m_i) for every i
+ *   (kem/mlkem/mlkem768/kyber.go:390-396, :359-370 -> :103-137 EncapsulateTo).
+ *   status[i] = CIRCL_HIP_ITEM_ERR_PUBKEY when ek_i holds a coefficient >= q.
+ * circl_hip_mlkem_decaps: scheme.UnmarshalBinaryPrivateKey(dk_i) followed by
+ *   scheme.Decapsulate(sk_i, ct_i) (kyber.go:398-407 -> :209-230 ; :376-386 -> :144-184).
+ *   status[i] = CIRCL_HIP_ITEM_ERR_PRIVKEY when H(ek) != the hash stored in dk_i.  An invalid
+ *   ciphertext is NOT an error (implicit rejection).
+ * circl_hip_mlkem_keygen: scheme.DeriveKeyPair(seed_i), seed = d || z, 64 bytes
+ *   (kyber.go:340-345 -> :57-78 NewKeyFromSeed), keys in MarshalBinary form.
+ * status may be NULL.
+ */
+int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss,
+                           uint8_t *status, size_t n, int device);
+int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss,
+                           uint8_t *status, size_t n, int device);
+int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n,
+                           int device);
+
+/* ---- ML-KEM, device-resident ------------------------------------------------------------
+ * Same semantics; every pointer is a device pointer on the device `stream` belongs to.
+ * `workspace` must hold circl_hip_mlkem_workspace_size(param, n) bytes.  status may NOT be NULL.
+ */
+size_t circl_hip_mlkem_workspace_size(int param, size_t n);
+int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct,
+                               uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
+int circl_hip_mlkem_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss,
+                               uint8_t *d_status, size_t n, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
+int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk,
+                               size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- ML-DSA verify ----------------------------------------------------------------------
+ * scheme.UnmarshalBinaryPublicKey(pk_i) + scheme.Verify(pk_i, msg_i, sig_i, &SignatureOpts{Context: ctx_i})
+ * (sign/mldsa/mldsa65/dilithium.go:305-327 -> :115-132 -> internal/dilithium.go:273-332).
+ * Messages / contexts are blobs with n+1 offsets; ctx_blob may be NULL (all contexts empty).
+ * ok[i] = 1 valid, 0 invalid (bad encoding, norm bound, hint, hash mismatch or ctx > 255 bytes).
+ */
+int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
+                           const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
+                           uint8_t *ok, size_t n, int device);
+size_t circl_hip_mldsa_workspace_size(int param, size_t n);
+int circl_hip_mldsa_verify_dev(int param, const uint8_t *d_pk, const uint8_t *d_sig,
+                               const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                               const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
+                               size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- primitives (host buffers), mirroring the reference's unit-tested building blocks ----
+ * circl_hip_keccak_f1600 : internal/sha3/keccakf.go:12 KeccakF1600 / simd/keccakf1600 StateX4.Permute
+ *                          on n states of 25 little-endian uint64 words each; rounds = 24 or 12.
+ * circl_hip_kyber_ntt    : pke/kyber/internal/common Poly.NTT (inverse=0) / Poly.InvNTT (1) on n
+ *                          polynomials int16[256] in standard order.  Outputs are normalised to
+ *                          [0,q) (the reference compares inverse transforms after Normalize,
+ *                          ntt_test.go:64-81).
+ * circl_hip_kyber_mulhat : Poly.MulHat, out[i] = a[i] (*) b[i], normalised.
+ * circl_hip_dilithium_ntt: sign/internal/dilithium Poly.NTT / InvNTT on n polynomials uint32[256],
+ *                          outputs normalised to [0,q).
+ * circl_hip_shake        : n independent SHAKE128 (rate=168) / SHAKE256 (136) / SHA3-256 (136, ds 6)
+ *                          / SHA3-512 (72, ds 6) computations over equal-length inputs
+ *                          (internal/sha3 State.Write/Read).
+ */
+int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device);
+int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device);
+int circl_hip_kyber_mulhat(int16_t *out, const int16_t *a, const int16_t *b, size_t n, int device);
+int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device);
+int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
+                    size_t n, int device);
+
+/* pinned host memory helpers for callers that want zero-copy-speed transfers */
+void *circl_hip_alloc_host(size_t bytes);
+void circl_hip_free_host(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: libcirclhip.so builds, loads and exports every symbol
+include/circl_hip.h declares; sizes match the reference's scheme constants; without a GPU every
+compute entry point fails loudly (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from circl_amd import _native as nat
+from circl_amd import build as cbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    cbuild.build()
+    return nat.lib()
+
+
+def test_header_symbols_all_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "circl_hip.h")).read()
+    declared = set(re.findall(r"\b(circl_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nat.SYMBOLS), declared ^ set(nat.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_sizes_match_reference_constants(L):
+    # kem/mlkem/mlkem{512,768,1024}/kyber.go:18-36 ; sign/mldsa/mldsa{44,65,87}/internal/dilithium.go:31-38
+    for p, (ek, dk, ct) in {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}.items():
+        assert (L.circl_hip_mlkem_ek_size(p), L.circl_hip_mlkem_dk_size(p), L.circl_hip_mlkem_ct_size(p)) == (ek, dk, ct)
+    for p, (pk, sig) in {44: (1312, 2420), 65: (1952, 3309), 87: (2592, 4627)}.items():
+        assert (L.circl_hip_mldsa_pk_size(p), L.circl_hip_mldsa_sig_size(p)) == (pk, sig)
+    assert L.circl_hip_mlkem_ek_size(999) == 0
+
+
+def test_product_does_not_reference_oracle():
+    # the oracle is test infrastructure: nothing in the shipped package may import, link or call it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "circl_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liborc" not in src and "orc_" not in src and not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_no_gpu_means_loud_failure(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert L.circl_hip_init() == nat.ENODEV
+    from circl_amd import hostapi
+    with pytest.raises(nat.CirclHipError):
+        hostapi.mlkem_encaps(768, np.zeros((1, 1184), np.uint8), np.zeros((1, 32), np.uint8))
+    with pytest.raises(nat.CirclHipError):
+        hostapi.keccak_f1600(np.zeros((1, 25), np.uint64))
