@@ -45,6 +45,32 @@ int ndev() {
     return g_ndev;
 }
 
+// ---- kernel-level profiling ---------------------------------------------------------------
+struct ProfRec { int kernel; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_pending;
+double g_prof_ms[CIRCL_HIP_KERNEL_COUNT];
+uint64_t g_prof_n[CIRCL_HIP_KERNEL_COUNT];
+
+// RAII bracket around one kernel launch on `st`
+struct ProfScope {
+    ProfRec r{-1, nullptr, nullptr};
+    hipStream_t st;
+    ProfScope(int kernel, hipStream_t s) : st(s) {
+        if (!g_prof_on) return;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        r.kernel = kernel;
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (r.kernel < 0) return;
+        (void)hipEventRecord(r.b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_pending.push_back(r);
+    }
+};
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
@@ -60,10 +86,16 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         return CIRCL_HIP_EWORKSPACE;
     uint8_t *r_ws = static_cast<uint8_t *>(ws);
     const unsigned hb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
+    }
     const unsigned eb = (unsigned)((n + Gm::G - 1) / Gm::G);
-    hipLaunchKernelGGL(circl::mlkem::mlkem_encrypt_kernel<K>, dim3(eb), dim3(64), Gm::LDS_TOTAL, st, ek, m, r_ws, ct, ss,
-                       status, n);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_encrypt_kernel<K>, dim3(eb), dim3(64), Gm::LDS_TOTAL, st, ek, m, r_ws, ct, ss,
+                           status, n);
+    }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -296,6 +328,31 @@ int circl_hip_mldsa_verify(int, const uint8_t *, const uint8_t *, const uint8_t 
 size_t circl_hip_mldsa_workspace_size(int, size_t) { return 0; }
 int circl_hip_mldsa_verify_dev(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
 int circl_hip_dilithium_ntt(uint32_t *, size_t, int, int) { return CIRCL_HIP_EUNSUPPORTED; }
+
+int circl_hip_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
+    if (kernel < 0 || kernel >= CIRCL_HIP_KERNEL_COUNT) return CIRCL_HIP_EPARAM;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_prof_ms[r.kernel] += ms;
+            g_prof_n[r.kernel] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof_pending.clear();
+    if (total_ms) *total_ms = g_prof_ms[kernel];
+    if (launches) *launches = g_prof_n[kernel];
+    g_prof_ms[kernel] = 0;
+    g_prof_n[kernel] = 0;
+    return CIRCL_HIP_OK;
+}
 
 void *circl_hip_alloc_host(size_t bytes) {
     void *p = nullptr;

@@ -128,6 +128,21 @@ int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device);
 int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
                     size_t n, int device);
 
+/* ---- kernel-level profiling (used by bench.py for the roofline figures) --------------------
+ * While enabled, every *_dev call brackets each kernel it enqueues with HIP events recorded on
+ * the caller's stream.  circl_hip_profile_read synchronises the pending events, returns the
+ * accumulated device time and launch count of one kernel and resets that kernel's counters. */
+#define CIRCL_HIP_KERNEL_MLKEM_HASH 0     /* H(ek), G(m||H(ek))                      */
+#define CIRCL_HIP_KERNEL_MLKEM_ENCRYPT 1  /* matrix expansion + PRF + K-PKE.Encrypt  */
+#define CIRCL_HIP_KERNEL_MLKEM_DECRYPT 2  /* K-PKE.Decrypt + G + J                   */
+#define CIRCL_HIP_KERNEL_MLKEM_KEYGEN 3
+#define CIRCL_HIP_KERNEL_MLKEM_FINISH 4   /* decapsulation compare / select          */
+#define CIRCL_HIP_KERNEL_MLDSA_HASH 5
+#define CIRCL_HIP_KERNEL_MLDSA_VERIFY 6
+#define CIRCL_HIP_KERNEL_COUNT 8
+int circl_hip_profile_enable(int on);
+int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
+
 /* pinned host memory helpers for callers that want zero-copy-speed transfers */
 void *circl_hip_alloc_host(size_t bytes);
 void circl_hip_free_host(void *p);
