@@ -36,6 +36,23 @@ class CirclHipError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """libcirclhip.so needs libamdhip64.so.7.  When PyTorch-ROCm is installed it bundles its own copy
+    of that runtime (same soname, requested by torch under the un-versioned file name), and two HIP
+    runtimes in one process do not work.  Loading torch's copy first -- by path, without importing
+    torch -- makes both libcirclhip.so and a later `import torch` share ONE runtime, whatever the
+    import order.  Without torch the system ROCm runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Returns the loaded library; raises if it has not been built (no fallback)."""
     global _lib
@@ -44,6 +61,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m circl_amd.build` "
                 "(circl_amd has no CPU fallback)")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for s in ("circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
                   "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size"):

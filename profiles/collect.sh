@@ -13,8 +13,8 @@ STEPS=${2:-5}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $CMD > "$OUT/kt.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $CMD > "$OUT/kt.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
 cd "$ROOT" && python profiles/summarize.py "$OUT" "$TAG" > "$OUT/summary_$TAG.log" 2>&1
 tail -40 "$OUT/summary_$TAG.log"
