@@ -93,8 +93,58 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     const unsigned eb = (unsigned)((n + Gm::G - 1) / Gm::G);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_encrypt_kernel<K>, dim3(eb), dim3(64), Gm::LDS_TOTAL, st, ek, m, r_ws, ct, ss,
-                           status, n);
+        hipLaunchKernelGGL((circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::ENCAPS>), dim3(eb), dim3(64), Gm::LDS_TOTAL, st,
+                           ek, (size_t)Gm::EK, m, r_ws, ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+template <int K>
+int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t ws_bytes,
+                    hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < 128 * n || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *mprime = static_cast<uint8_t *>(ws), *r_ws = mprime + 32 * n, *kbar = mprime + 64 * n, *ssrej = mprime + 96 * n;
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, ct, mprime, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dk, ct,
+                           (const uint8_t *)mprime, kbar, r_ws, ssrej, status, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL((circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::REENCRYPT>), dim3((unsigned)((n + Gm::G - 1) / Gm::G)),
+                           dim3(64), Gm::LDS_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+template <int K>
+int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < 64 * n || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *rs = static_cast<uint8_t *>(ws);
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_keygen_seed_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, rs, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_keygen_kernel<K>, dim3((unsigned)((n + Gm::G - 1) / Gm::G)), dim3(64), Gm::LDS_TOTAL, st,
+                           (const uint8_t *)rs, ek, dk, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_FINISH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_keygen_finish_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, (const uint8_t *)ek, dk, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -222,7 +272,7 @@ size_t circl_hip_mlkem_ct_size(int param) {
 size_t circl_hip_mldsa_pk_size(int param) { return param == 44 ? 1312 : param == 65 ? 1952 : param == 87 ? 2592 : 0; }
 size_t circl_hip_mldsa_sig_size(int param) { return param == 44 ? 2420 : param == 65 ? 3309 : param == 87 ? 4627 : 0; }
 
-size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? up256(64 * n) : 0; }
+size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? up256(128 * n) : 0; }
 
 int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
                                uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
@@ -242,10 +292,59 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_chunked(dev, cnt, {ek + lo * EK, m + lo * 32}, {EK, 32},
-                           {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, 64,
+                           {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, 128,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_encaps_dev(param, in[0], in[1], out[0], out[1], out[2], c, ws, wsb, st);
+                           });
+    });
+}
+
+int circl_hip_mlkem_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                               void *d_ws, size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return decaps_dev_impl<2>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 3: return decaps_dev_impl<3>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 4: return decaps_dev_impl<4>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk, size_t n, void *d_ws,
+                               size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return keygen_dev_impl<2>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    case 3: return keygen_dev_impl<3>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    case 4: return keygen_dev_impl<4>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {dk + lo * DK, ct + lo * CT}, {DK, CT}, {ss + lo * 32, status ? status + lo : nullptr}, {32, 1},
+                           128,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
+                               hipStream_t st) {
+                               return circl_hip_mlkem_decaps_dev(param, in[0], in[1], out[0], out[1], c, ws, wsb, st);
+                           });
+    });
+}
+
+int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, 64,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
+                               hipStream_t st) {
+                               return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
                            });
     });
 }
@@ -320,10 +419,6 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
 
 // ---- not yet implemented in this build (filled in by later milestones) -----------------------
 #define CIRCL_HIP_EUNSUPPORTED (-6)
-int circl_hip_mlkem_decaps(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
-int circl_hip_mlkem_keygen(int, const uint8_t *, uint8_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
-int circl_hip_mlkem_decaps_dev(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
-int circl_hip_mlkem_keygen_dev(int, const uint8_t *, uint8_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
 int circl_hip_mldsa_verify(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
 size_t circl_hip_mldsa_workspace_size(int, size_t) { return 0; }
 int circl_hip_mldsa_verify_dev(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }

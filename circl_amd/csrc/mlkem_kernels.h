@@ -1,6 +1,7 @@
 // mlkem_kernels.h -- batch ML-KEM kernels for gfx950 (included by circl_hip.hip).
 //
-// Two launches per batch of encapsulations, both over the same HBM-resident arrays:
+// Encapsulation = two launches over the same HBM-resident arrays (hash, encrypt); decapsulation =
+// decrypt, decaps-hash, encrypt<REENCRYPT>; key generation = seed-hash, keygen, keygen-finish.
 //
 //  mlkem_hash_kernel<K>      lane = item.  H(ek) = SHA3-256 over the packed key (9 absorb
 //                            blocks for ML-KEM-768), then (K,r) = SHA3-512(m || H(ek))
@@ -42,7 +43,7 @@ template <int K> struct Geom {
     static constexpr int PAIRS = K * K;
     static constexpr int G = 64 / PAIRS;                 // items per workgroup
     static constexpr int A_STREAMS = G * PAIRS;          // <= 64
-    static constexpr int NOISE = 2 * K + 1;              // PRF streams per item
+    static constexpr int NOISE = 2 * K + 1;              // PRF streams per item (encrypt); keygen uses 2K
     static constexpr int A_STRIDE = 520;                 // bytes per sampled polynomial (+1 spill slot, 8-B aligned)
     static constexpr int NOISE_BYTES = 64 * P::ETA1;     // eta1 stream length (eta2 streams use 128)
     static constexpr int NOISE_STRIDE = NOISE_BYTES + 8; // breaks the power-of-two bank stride
@@ -135,8 +136,11 @@ __device__ __forceinline__ void parse_shake128_block(const KeccakState &s, int16
     });
 }
 
-template <int K>
-__device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__restrict__ ek, size_t item0, size_t n, int lane) {
+// rho of item t is at rho + t * rho_stride (8-byte aligned).  TRANSPOSED samples stream (i,j) from
+// (x=i, y=j) -- the matrix A^T used by Encrypt -- otherwise from (x=j, y=i) (mat.go:13-74).
+template <int K, bool TRANSPOSED>
+__device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__restrict__ rho, size_t rho_stride, size_t item0,
+                                              size_t n, int lane) {
     using Gm = Geom<K>;
     const bool on = lane < Gm::A_STREAMS;
     const int g = on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
@@ -147,8 +151,8 @@ __device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__r
     keccak_zero(s);
     // SHAKE128(rho || x=i || y=j): 34 bytes -> words 0..3 = rho, word 4 = i | j<<8 | 0x1f<<16,
     // 0x80 into byte 167 (sample.go:105-119 builds the same first block).
-    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(ek + item * Gm::EK + 384 * K));
-    s.lo[4] = (uint32_t)i | ((uint32_t)j << 8) | (kDsShake << 16);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
+    s.lo[4] = (TRANSPOSED ? (uint32_t)i | ((uint32_t)j << 8) : (uint32_t)j | ((uint32_t)i << 8)) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
     int16_t *poly = reinterpret_cast<int16_t *>(lds_a + (on ? lane : 0) * Gm::A_STRIDE);
     int cnt = on ? 0 : 256;
@@ -162,21 +166,24 @@ __device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__r
 
 // ---- phase B: PRF ---------------------------------------------------------------------------
 
-// SHAKE256(r || nonce) -> NB bytes (128 for eta=2, 192 for eta=3) written to LDS as 64-bit words.
-template <int K>
-__device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *__restrict__ r_ws, size_t item0, size_t n, int lane) {
+// SHAKE256(seed || nonce) -> 128 bytes (eta=2) or 192 bytes (eta=3) written to LDS.  NOISE streams
+// per item; the first ETA1_COUNT of them use eta1, the rest eta2 = 2.  The seed of item t is at
+// seed + t * seed_stride.
+template <int K, int NOISE, int ETA1_COUNT>
+__device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *__restrict__ seed, size_t seed_stride,
+                                            size_t item0, size_t n, int lane) {
     using Gm = Geom<K>;
-    constexpr int STREAMS = Gm::G * Gm::NOISE;
+    constexpr int STREAMS = Gm::G * NOISE;
 #pragma unroll 1
     for (int base = 0; base < STREAMS; base += 64) {
         const int sidx = base + lane;
         const bool on = sidx < STREAMS;
-        const int g = on ? sidx / Gm::NOISE : 0, nonce = on ? sidx % Gm::NOISE : 0;
+        const int g = on ? sidx / NOISE : 0, nonce = on ? sidx % NOISE : 0;
         size_t item = item0 + g;
         if (item >= n) item = n - 1;
         KeccakState s;
         keccak_zero(s);
-        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(r_ws + item * 32));
+        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(seed + item * seed_stride));
         s.lo[4] = (uint32_t)nonce | (kDsShake << 8);
         s.hi[16] = 0x80000000u;
         keccak_f1600(s);
@@ -189,11 +196,11 @@ __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *_
             });
         }
         if constexpr (Params<K>::ETA1 == 3) {
-            // 192 bytes needed for eta1 = 3 streams (nonce < K): word 16 of this block, then 7 more
-            if (on && nonce < K) { out[32] = s.lo[16]; out[33] = s.hi[16]; }
-            if (__any(on && nonce < K)) {
+            // 192 bytes needed for eta1 = 3 streams: word 16 of this block, then 7 more
+            if (on && nonce < ETA1_COUNT) { out[32] = s.lo[16]; out[33] = s.hi[16]; }
+            if (__any(on && nonce < ETA1_COUNT)) {
                 keccak_f1600(s);
-                if (on && nonce < K) {
+                if (on && nonce < ETA1_COUNT) {
                     detail::static_for<0, 7>([&](auto ic) {
                         constexpr int w = decltype(ic)::v;
                         out[34 + 2 * w] = s.lo[w];
@@ -242,12 +249,74 @@ template <int D> __device__ __forceinline__ void pack_bits_store(uint32_t *dst, 
     }
 }
 
+// Same bit stream, but compared with an existing ciphertext instead of stored (decapsulation's
+// ct == ct' test, kyber.go:177-181); returns a per-lane "differs" flag.
+template <int D> __device__ __forceinline__ bool pack_bits_differs(const uint32_t *ref, const uint16_t *vals, int lane) {
+    constexpr int WORDS = 8 * D;
+    bool diff = false;
+#pragma unroll
+    for (int w0 = 0; w0 < WORDS; w0 += 64) {
+        const int w = w0 + lane;
+        if (w < WORDS) {
+            const int lo = 32 * w;
+            int c = lo / D;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 32 / D + 2; k++, c++) {
+                const int sh = c * D - lo;
+                if (c < 256 && sh < 32) {
+                    const uint32_t v = vals[c];
+                    acc |= sh >= 0 ? (v << sh) : (v >> (-sh));
+                }
+            }
+            diff |= ref[w] != acc;
+        }
+    }
+    return diff;
+}
+
+// 12-bit decode of 4 consecutive coefficients (layout L4) from a packed polynomial (poly.go:123-129)
+__device__ __forceinline__ void unpack12_l4(int (&c)[4], const uint8_t *poly, int lane) {
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(poly + 6 * lane);
+    const uint32_t h0 = src[0], h1 = src[1], h2 = src[2];
+    c[0] = (int)(h0 & 0xfff);
+    c[1] = (int)((h0 >> 12) | ((h1 & 0xff) << 4));
+    c[2] = (int)((h1 >> 8) | ((h2 & 0xf) << 8));
+    c[3] = (int)(h2 >> 4);
+}
+// 12-bit encode (poly.go:106-117), coefficients in [0,q), layout L4
+__device__ __forceinline__ void pack12_l4(uint8_t *poly, const int (&c)[4], int lane) {
+    uint16_t *dst = reinterpret_cast<uint16_t *>(poly + 6 * lane);
+    dst[0] = (uint16_t)(c[0] | (c[1] << 12));
+    dst[1] = (uint16_t)((c[1] >> 4) | (c[2] << 8));
+    dst[2] = (uint16_t)((c[2] >> 8) | (c[3] << 4));
+}
+
+// D-bit field number n of a little-endian bit stream in global memory (poly.go:170-243 Decompress)
+template <int D> __device__ __forceinline__ unsigned get_bits(const uint8_t *p, int n) {
+    const int bit = n * D, b = bit >> 3, sh = bit & 7;
+    unsigned w = p[b];
+    if (sh + D > 8) w |= (unsigned)p[b + 1] << 8;   // never reads past the last byte of the stream
+    if (sh + D > 16) w |= (unsigned)p[b + 2] << 16;
+    return (w >> sh) & ((1u << D) - 1);
+}
+
 // ---- kernel 2: K-PKE.Encrypt ------------------------------------------------------------------
 
-template <int K>
-__global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ m,
-                                                          const uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ct,
-                                                          uint8_t *__restrict__ ss, uint8_t *__restrict__ status, size_t n) {
+enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
+
+// ENCAPS   : ek rows of stride EK, canonical check, ciphertext stored, status written.
+// REENCRYPT: decapsulation's second half (kyber.go:158-181).  `ek` points at the ek embedded in dk
+//            (row stride DK), coefficients >= q are reduced, not rejected (cpapke.go:58-63 Unpack);
+//            m = m', r = r' come from the workspace; ct' is compared with ct instead of stored and
+//            ss = (ct == ct') ? K' : J(z || ct), both candidates parked in the workspace by
+//            mlkem_decaps_hash_kernel.  Items whose status is already non-zero get ss = 0.
+template <int K, int MODE>
+__global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
+                                                          const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
+                                                          uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
+                                                          uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
+                                                          const uint8_t *__restrict__ ssrej_ws, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -257,8 +326,8 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
     const int lane = threadIdx.x;
     const size_t item0 = (size_t)blockIdx.x * Gm::G;
 
-    sample_matrix<K>(lds_a, ek, item0, n, lane);
-    prf_streams<K>(lds_noise, r_ws, item0, n, lane);
+    sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
+    prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     __syncthreads();
 
@@ -266,24 +335,22 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
     for (int g = 0; g < Gm::G; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
-        const uint8_t *ekp = ek + item * Gm::EK;
+        const uint8_t *ekp = ek + item * ek_stride;
         const uint8_t *noise = lds_noise + g * Gm::NOISE * Gm::NOISE_STRIDE;
 
-        // t-hat (12-bit codec, poly.go:123-129) in layout L4 and UnpackMLKEM's range check
+        // t-hat (12-bit codec) in layout L4; ENCAPS applies UnpackMLKEM's range check
         int th[K][4];
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const uint16_t *src = reinterpret_cast<const uint16_t *>(ekp + 384 * j + 6 * lane);
-            const uint32_t h0 = src[0], h1 = src[1], h2 = src[2];
-            th[j][0] = (int)(h0 & 0xfff);
-            th[j][1] = (int)((h0 >> 12) | ((h1 & 0xff) << 4));
-            th[j][2] = (int)((h1 >> 8) | ((h2 & 0xf) << 8));
-            th[j][3] = (int)(h2 >> 4);
+            unpack12_l4(th[j], ekp + 384 * j, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) bad |= th[j][r] >= Q;
+            for (int r = 0; r < 4; r++) {
+                if (MODE == ENCAPS) bad |= th[j][r] >= Q;
+                else th[j][r] = kyber::csubq(th[j][r]);  // 12-bit value < 2q: Normalize == csubq
+            }
         }
-        const bool reject = __any(bad);
+        const bool reject = MODE == ENCAPS ? __any(bad) : false;
 
         // r-hat = NTT(CBD_eta1(PRF(r, j))), Barrett-reduced (cpapke.go:142-144), layout L4
         int rh[K][4];
@@ -297,6 +364,7 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
         }
 
         uint8_t *ctp = ct + item * Gm::CT;
+        bool differs = false;
         // u[i] = InvNTT(sum_j A^T[i][j] * r-hat[j]) + e1[i]  (cpapke.go:150-164), compressed to du bits
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
@@ -319,9 +387,11 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
                 cq[nidx] = (uint16_t)kyber::compress_coeff<P::DU>(x);
             }
             __syncthreads();
-            if (!reject) pack_bits_store<P::DU>(reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i), cq, lane);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i);
+            if (MODE == REENCRYPT) differs |= pack_bits_differs<P::DU>(dst, cq, lane);
+            else if (!reject) pack_bits_store<P::DU>(dst, cq, lane);
             else {
-                for (int w = lane; w < 8 * P::DU; w += 64) reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i)[w] = 0;
+                for (int w = lane; w < 8 * P::DU; w += 64) dst[w] = 0;
             }
         }
         // v = InvNTT(<t-hat, r-hat>) + e2 + Decompress_q(m, 1)  (cpapke.go:167-173), dv bits
@@ -344,13 +414,217 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
             }
             __syncthreads();
             uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * K);
-            if (!reject) pack_bits_store<P::DV>(dst, cq, lane);
+            if (MODE == REENCRYPT) differs |= pack_bits_differs<P::DV>(dst, cq, lane);
+            else if (!reject) pack_bits_store<P::DV>(dst, cq, lane);
             else {
                 for (int w = lane; w < 8 * P::DV; w += 64) dst[w] = 0;
             }
         }
-        if (lane == 0) status[item] = reject ? 1 : 0;
-        if (reject && lane < 8) reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = 0;
+        if (MODE == ENCAPS) {
+            if (lane == 0) status[item] = reject ? 1 : 0;
+            if (reject && lane < 8) reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = 0;
+        } else {
+            // subtle.ConstantTimeCopy(ConstantTimeCompare(ct, ct'), ss2, K')  -- a lane-wise select here
+            const bool mismatch = __any(differs);
+            const bool dead = status[item] != 0;
+            if (lane < 8) {
+                const uint32_t kb = reinterpret_cast<const uint32_t *>(kbar_ws + item * 32)[lane];
+                const uint32_t rj = reinterpret_cast<const uint32_t *>(ssrej_ws + item * 32)[lane];
+                reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = dead ? 0u : (mismatch ? rj : kb);
+            }
+        }
+    }
+}
+
+// ---- decapsulation ---------------------------------------------------------------------------
+
+// K-PKE.Decrypt (cpapke.go:113-130), one item per single-wave workgroup: m' -> workspace.
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, const uint8_t *__restrict__ ct,
+                                                          uint8_t *__restrict__ mprime_ws, size_t n) {
+    using Gm = Geom<K>;
+    using P = Params<K>;
+    __shared__ __attribute__((aligned(16))) int16_t xch[256];
+    const int lane = threadIdx.x;
+    const size_t item = blockIdx.x;
+    const uint8_t *dkp = dk + item * Gm::DK;
+    const uint8_t *ctp = ct + item * Gm::CT;
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        int sh[4], u[4];
+        unpack12_l4(sh, dkp + 384 * j, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            sh[r] = kyber::csubq(sh[r]);  // PrivateKey.Unpack normalises (cpapke.go:33-36)
+            u[r] = kyber::decompress_coeff<P::DU>(get_bits<P::DU>(ctp + 32 * P::DU * j, kyber::idx_l1(lane, r)));
+        }
+        kyber::ntt(u, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) u[r] = kyber::barrett(u[r]);
+        kyber::mulhat_acc(acc, sh, u, z.f6);
+    }
+    kyber::mulhat_finish(acc);
+    kyber::invntt(acc, z, xch, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int nidx = kyber::idx_l1(lane, r);
+        const int v = kyber::decompress_coeff<P::DV>(get_bits<P::DV>(ctp + 32 * P::DU * K, nidx));
+        const unsigned bit = kyber::msg_bit(kyber::normalize(v - acc[r]));
+        const unsigned long long mask = __ballot(bit != 0);  // bits of coefficients 64r .. 64r+63
+        if (lane == 0) reinterpret_cast<unsigned long long *>(mprime_ws + item * 32)[r] = mask;
+    }
+}
+
+// lane = item: the three sponges of decapsulation.
+//   H(ek) over the ek embedded in dk, compared with the stored hash -> status 2 (kyber.go:219-228)
+//   (K', r') = G(m' || hpk)   with hpk = the STORED hash (kyber.go:158-162 uses sk.hpk)
+//   ss_rej   = J(z || ct) = SHAKE256(z || ct)[:32]  (kyber.go:171-174)
+template <int K>
+__global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *__restrict__ dk, const uint8_t *__restrict__ ct,
+                                                                const uint8_t *__restrict__ mprime_ws, uint8_t *__restrict__ kbar_ws,
+                                                                uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ssrej_ws,
+                                                                uint8_t *__restrict__ status, size_t n) {
+    using Gm = Geom<K>;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    const uint8_t *dkp = dk + idx * Gm::DK;
+    const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
+    KeccakState h, g;
+    sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(dkp + 384 * K));
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
+    // G(m' || stored hpk)
+    keccak_zero(g);
+    xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(mprime_ws + idx * 32));
+    xor_words<4, 4>(g, stored);
+    g.lo[8] = kDsSha3;
+    g.hi[8] = 0x80000000u;
+    keccak_f1600(g);
+    if (live) {
+        store_words<0, 4>(reinterpret_cast<uint64_t *>(kbar_ws + idx * 32), g);
+        store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
+        status[idx] = ok ? 0 : 2;
+    }
+    // J(z || ct): 4 + CT/8 words through SHAKE256 (rate 17 words)
+    constexpr int CTW = Gm::CT / 8, TOTAL = 4 + CTW, FULL = TOTAL / 17, REM = TOTAL % 17;
+    const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
+    const uint64_t *cw = reinterpret_cast<const uint64_t *>(ct + idx * Gm::CT);
+    keccak_zero(h);
+    xor_words<0, 4>(h, zw);
+    xor_words<4, 13>(h, cw);
+    keccak_f1600(h);
+#pragma unroll 1
+    for (int b = 1; b < FULL; b++) {
+        xor_words<0, 17>(h, cw + 17 * b - 4);
+        keccak_f1600(h);
+    }
+    xor_words<0, REM>(h, cw + 17 * FULL - 4);
+    h.lo[REM] ^= kDsShake;
+    h.hi[16] ^= 0x80000000u;
+    keccak_f1600(h);
+    if (live) store_words<0, 4>(reinterpret_cast<uint64_t *>(ssrej_ws + idx * 32), h);
+}
+
+// ---- key generation ---------------------------------------------------------------------------
+
+// lane = item: (rho, sigma) = G(d || K) (cpapke.go:72-79 with the FIPS 203 domain byte,
+// pke/kyber/kyber768/kyber.go:77-86) -> workspace (rho 32 B, sigma 32 B per item).
+template <int K>
+__global__ void __launch_bounds__(256) mlkem_keygen_seed_kernel(const uint8_t *__restrict__ seed64, uint8_t *__restrict__ rs_ws, size_t n) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState g;
+    keccak_zero(g);
+    xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(seed64 + idx * 64));
+    g.lo[4] = (uint32_t)K | (kDsSha3 << 8);
+    g.hi[8] = 0x80000000u;
+    keccak_f1600(g);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(rs_ws + idx * 64), g);
+}
+
+// One wavefront per workgroup, G items: K-PKE.KeyGen (cpapke.go:66-110).
+//   t-hat[i] = ToMont(sum_j A[i][j] s-hat[j]) + e-hat[i], normalised; ek = Pack(t-hat) || rho;
+//   dk = Pack(s-hat) || ek || (H(ek), z filled in by mlkem_keygen_finish_kernel).
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_keygen_kernel(const uint8_t *__restrict__ rs_ws, uint8_t *__restrict__ ek,
+                                                         uint8_t *__restrict__ dk, size_t n) {
+    using Gm = Geom<K>;
+    using P = Params<K>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *lds_a = smem;
+    uint8_t *lds_noise = smem + Gm::LDS_A;
+    int16_t *xch = reinterpret_cast<int16_t *>(smem + Gm::LDS_A + Gm::LDS_NOISE);
+    const int lane = threadIdx.x;
+    const size_t item0 = (size_t)blockIdx.x * Gm::G;
+
+    sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
+    prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int g = 0; g < Gm::G; g++) {
+        const size_t item = item0 + g;
+        if (item >= n) break;
+        const uint8_t *noise = lds_noise + g * (2 * K) * Gm::NOISE_STRIDE;
+        uint8_t *ekp = ek + item * Gm::EK, *dkp = dk + item * Gm::DK;
+        int sh[K][4];
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) sh[j][r] = cbd_coeff<P::ETA1>(noise + j * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+            kyber::ntt(sh[j], z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) sh[j][r] = kyber::normalize(sh[j][r]);
+            pack12_l4(dkp + 384 * j, sh[j], lane);
+        }
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            int eh[4], acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; r++) eh[r] = cbd_coeff<P::ETA1>(noise + (K + i) * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+            kyber::ntt(eh, z, xch, lane);
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int16_t *ap = reinterpret_cast<const int16_t *>(lds_a + ((g * K + i) * K + j) * Gm::A_STRIDE) + 4 * lane;
+                const int a[4] = {ap[0], ap[1], ap[2], ap[3]};
+                kyber::mulhat_acc(acc, a, sh[j], z.f6);
+            }
+            kyber::mulhat_finish(acc);
+            int t[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = kyber::normalize(kyber::mont_mul(acc[r], 1353) + eh[r]);  // ToMont, field.go:35-39
+            pack12_l4(ekp + 384 * i, t, lane);
+            pack12_l4(dkp + 384 * K + 384 * i, t, lane);
+        }
+        if (lane < 8) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(rs_ws + item * 64)[lane];
+            reinterpret_cast<uint32_t *>(ekp + 384 * K)[lane] = w;
+            reinterpret_cast<uint32_t *>(dkp + 768 * K)[lane] = w;
+        }
+    }
+}
+
+// lane = item: dk tail = H(ek) || z  (kem/mlkem/mlkem768/kyber.go:69-75, :189-201)
+template <int K>
+__global__ void __launch_bounds__(256) mlkem_keygen_finish_kernel(const uint8_t *__restrict__ seed64, const uint8_t *__restrict__ ek,
+                                                                  uint8_t *__restrict__ dk, size_t n) {
+    using Gm = Geom<K>;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    KeccakState h;
+    sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek + idx * Gm::EK));
+    if (live) {
+        uint64_t *tail = reinterpret_cast<uint64_t *>(dk + idx * Gm::DK + 768 * K + 32);
+        store_words<0, 4>(tail, h);
+        const uint64_t *zsrc = reinterpret_cast<const uint64_t *>(seed64 + idx * 64 + 32);
+#pragma unroll
+        for (int i = 0; i < 4; i++) tail[4 + i] = zsrc[i];
     }
 }
 
