@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mlkem_kernels.h"
+#include "mldsa_kernels.h"
 #include "prim_kernels.h"
 
 namespace {
@@ -246,6 +247,104 @@ template <class PerDevice> int shard(size_t n, int device, PerDevice fn) {
     return CIRCL_HIP_OK;
 }
 
+// ---- device-resident ML-DSA verify ------------------------------------------------------------
+
+template <int MODE> size_t mldsa_ws_bytes(size_t n) {
+    using G = circl::mldsa::DG<MODE>;
+    return up256(n * G::MUW1) + up256(n * circl::mldsa::kBallStateBytes) + up256(n);
+}
+
+template <int MODE>
+int mldsa_verify_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                          const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
+                          size_t ws_bytes, hipStream_t st) {
+    using G = circl::mldsa::DG<MODE>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < mldsa_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(pk)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *muw1 = static_cast<uint8_t *>(ws);
+    uint8_t *ball = muw1 + up256(n * G::MUW1);
+    uint8_t *fail = ball + up256(n * circl::mldsa::kBallStateBytes);
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob,
+                           ctx_off, internal, muw1, ball, fail, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_verify_kernel<MODE>, dim3((unsigned)((n + G::IT - 1) / G::IT)), dim3(64), G::LDS_TOTAL, st,
+                           pk, sig, muw1, (const uint8_t *)ball, fail, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_final_kernel<MODE>, dim3(hb), dim3(256), 0, st, sig, (const uint8_t *)muw1,
+                           (const uint8_t *)fail, ok, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+int mldsa_verify_dev_any(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                         const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
+                         size_t wsb, hipStream_t st) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    switch (param) {
+    case 44: return mldsa_verify_dev_impl<44>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 65: return mldsa_verify_dev_impl<65>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 87: return mldsa_verify_dev_impl<87>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+// Host-buffer ML-DSA verify on one device: fixed-size rows are chunked like ML-KEM; the message /
+// context blobs of a chunk are copied as the byte range their offsets span and addressed through
+// rebased device pointers, so the kernels keep using the caller's absolute offsets.
+int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
+                          const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok,
+                          size_t n) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    Arena &a = g_arena[dev];
+    std::lock_guard<std::mutex> lk(a.mu);
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 14);
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t cnt = std::min(chunk, n - done);
+        const size_t mlo = msg_off[done], mhi = msg_off[done + cnt];
+        const size_t clo = ctx_blob ? ctx_off[done] : 0, chi = ctx_blob ? ctx_off[done + cnt] : 0;
+        const size_t wsb = circl_hip_mldsa_workspace_size(param, cnt);
+        const size_t need = up256(cnt * PK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
+                            up256(chi - clo + 16) + up256(cnt) + wsb;
+        int rc = arena_reserve(a, need);
+        if (rc) return rc;
+        hipStream_t st = a.st[0];
+        uint8_t *p = static_cast<uint8_t *>(a.base);
+        uint8_t *d_pk = p; p += up256(cnt * PK);
+        uint8_t *d_sig = p; p += up256(cnt * SIG + 16);
+        uint8_t *d_msg = p; p += up256(mhi - mlo + 16);
+        uint64_t *d_moff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
+        uint8_t *d_ctx = p; p += up256(chi - clo + 16);
+        uint64_t *d_coff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
+        uint8_t *d_ok = p; p += up256(cnt);
+        uint8_t *d_ws = p;
+        HIP_TRY(hipMemcpyAsync(d_pk, pk + done * PK, cnt * PK, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_sig, sig + done * SIG, cnt * SIG, hipMemcpyHostToDevice, st));
+        if (mhi > mlo) HIP_TRY(hipMemcpyAsync(d_msg, msg_blob + mlo, mhi - mlo, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_moff, msg_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        if (ctx_blob) {
+            if (chi > clo) HIP_TRY(hipMemcpyAsync(d_ctx, ctx_blob + clo, chi - clo, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_coff, ctx_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        }
+        rc = mldsa_verify_dev_any(param, d_pk, d_sig, d_msg - mlo, d_moff, ctx_blob ? d_ctx - clo : nullptr,
+                                  ctx_blob ? d_coff : nullptr, internal, d_ok, cnt, d_ws, wsb, st);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ok + done, d_ok, cnt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return CIRCL_HIP_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -349,6 +448,42 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     });
 }
 
+size_t circl_hip_mldsa_workspace_size(int param, size_t n) {
+    switch (param) {
+    case 44: return mldsa_ws_bytes<44>(n);
+    case 65: return mldsa_ws_bytes<65>(n);
+    case 87: return mldsa_ws_bytes<87>(n);
+    }
+    return 0;
+}
+
+int circl_hip_mldsa_verify_dev(int param, const uint8_t *d_pk, const uint8_t *d_sig, const uint8_t *d_msg_blob,
+                               const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
+                               size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    return mldsa_verify_dev_any(param, d_pk, d_sig, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, 0, d_ok, n, d_ws, ws_bytes,
+                                static_cast<hipStream_t>(stream));
+}
+
+static int mldsa_verify_host(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                             const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, int device) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    if (!PK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return mldsa_verify_host_one(param, dev, pk + lo * PK, sig + lo * SIG, msg_blob, msg_off + lo, ctx_blob,
+                                     ctx_blob ? ctx_off + lo : nullptr, internal, ok + lo, cnt);
+    });
+}
+
+int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                           const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n, int device) {
+    return mldsa_verify_host(param, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, 0, ok, n, device);
+}
+
+int circl_hip_mldsa_verify_internal(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
+                                    const uint64_t *msg_off, uint8_t *ok, size_t n, int device) {
+    return mldsa_verify_host(param, pk, sig, msg_blob, msg_off, nullptr, nullptr, 1, ok, n, device);
+}
+
 // ---- primitives -------------------------------------------------------------------------------
 
 int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device) {
@@ -376,6 +511,21 @@ int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device) {
                                HIP_TRY(hipMemcpyAsync(out[0], in[0], c * 512, hipMemcpyDeviceToDevice, st));
                                hipLaunchKernelGGL(circl::prim::kyber_ntt_kernel, dim3((unsigned)c), dim3(64), 0, st,
                                                   reinterpret_cast<int16_t *>(out[0]), inverse);
+                               HIP_TRY(hipGetLastError());
+                               return CIRCL_HIP_OK;
+                           });
+    });
+}
+
+int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device) {
+    uint8_t *p = reinterpret_cast<uint8_t *>(polys);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {p + lo * 1024}, {1024}, {p + lo * 1024}, {1024}, 0,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *, size_t,
+                               hipStream_t st) {
+                               HIP_TRY(hipMemcpyAsync(out[0], in[0], c * 1024, hipMemcpyDeviceToDevice, st));
+                               hipLaunchKernelGGL(circl::prim::dilithium_ntt_kernel, dim3((unsigned)c), dim3(64), 0, st,
+                                                  reinterpret_cast<uint32_t *>(out[0]), inverse);
                                HIP_TRY(hipGetLastError());
                                return CIRCL_HIP_OK;
                            });
@@ -419,10 +569,6 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
 
 // ---- not yet implemented in this build (filled in by later milestones) -----------------------
 #define CIRCL_HIP_EUNSUPPORTED (-6)
-int circl_hip_mldsa_verify(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, int) { return CIRCL_HIP_EUNSUPPORTED; }
-size_t circl_hip_mldsa_workspace_size(int, size_t) { return 0; }
-int circl_hip_mldsa_verify_dev(int, const uint8_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint64_t *, uint8_t *, size_t, void *, size_t, void *) { return CIRCL_HIP_EUNSUPPORTED; }
-int circl_hip_dilithium_ntt(uint32_t *, size_t, int, int) { return CIRCL_HIP_EUNSUPPORTED; }
 
 int circl_hip_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -1,0 +1,414 @@
+// mldsa_kernels.h -- batch ML-DSA verification for gfx950 (included by circl_hip.hip).
+//
+// sign/mldsa/mldsa65/internal/dilithium.go:273-332 Verify (+ :114-126 PublicKey.Unpack, which the
+// reference caches per key but a batch of distinct keys must pay per item) as three launches:
+//
+//  mldsa_prep_kernel<MODE>    lane = item.  tr = SHAKE256(pk)[:64]; mu = SHAKE256(tr || M')[:64]
+//                             with M' = 0 || len(ctx) || ctx || msg (mldsa65/dilithium.go:115-132);
+//                             first SHAKE256(c~) block for SampleInBall.  -> workspace.
+//  mldsa_verify_kernel<MODE>  one wavefront per workgroup, IT = 64 / (K L) items:
+//    phase 1  per item, one polynomial per wavefront: decode z (norm check), z-hat = NTT(z),
+//             strict hint decoding, c-hat = NTT(SampleInBall(c~)).
+//    phase 2  lane = (item, i, j): ExpandA stream SHAKE128(rho || j || i), 23-bit rejection
+//             (sample.go:92-123).  A is never materialised: each accepted coefficient a_k is
+//             multiplied with z-hat[j][k] at once (the Dilithium NTT splits completely, so MulHat
+//             is coefficient-wise, poly.go:88-92) and added to w[i][k] with an LDS atomic.
+//    phase 3  per (item, i): w - c-hat * NTT(t1 2^13), inverse NTT, UseHint, w1 bit-packing
+//             -> workspace.
+//  mldsa_final_kernel<MODE>   lane = item.  c' = SHAKE256(mu || w1)[:len(c~)], ok = (c' == c~)
+//                             and no decoding failure.
+#pragma once
+#include "dilithium_dev.h"
+#include "mlkem_kernels.h"
+
+namespace circl {
+namespace mldsa {
+
+using dilithium::Q;
+using mlkem::store_words;
+using mlkem::xor_words;
+
+template <int MODE> struct DP;
+template <> struct DP<44> { static constexpr int K = 4, L = 4, ETA = 2, TAU = 39, OMEGA = 80, G1BITS = 17, CT = 32; static constexpr uint32_t GAMMA2 = 95232; };
+template <> struct DP<65> { static constexpr int K = 6, L = 5, ETA = 4, TAU = 49, OMEGA = 55, G1BITS = 19, CT = 48; static constexpr uint32_t GAMMA2 = 261888; };
+template <> struct DP<87> { static constexpr int K = 8, L = 7, ETA = 2, TAU = 60, OMEGA = 75, G1BITS = 19, CT = 64; static constexpr uint32_t GAMMA2 = 261888; };
+
+template <int MODE> struct DG {
+    using P = DP<MODE>;
+    static constexpr int K = P::K, L = P::L;
+    static constexpr int PK = 32 + 320 * K;
+    static constexpr int ZBITS = P::G1BITS + 1;
+    static constexpr int ZSZ = 32 * ZBITS;
+    static constexpr int SIG = P::CT + L * ZSZ + P::OMEGA + K;
+    static constexpr int W1BITS = 23 - P::G1BITS;
+    static constexpr int W1SZ = 32 * W1BITS;
+    static constexpr uint32_t GAMMA1 = 1u << P::G1BITS;
+    static constexpr uint32_t BETA = P::TAU * P::ETA;
+    static constexpr int STREAMS = K * L;
+    static constexpr int IT = 64 / STREAMS;            // items per workgroup
+    static constexpr int PSTRIDE = 257;                // dwords per polynomial in LDS (bank spread)
+    static constexpr int MUW1 = 64 + K * W1SZ;         // bytes of mu || w1 per item in the workspace
+    static constexpr int LDS_ZHAT = IT * L * PSTRIDE * 4;
+    static constexpr int LDS_ACC = IT * K * PSTRIDE * 4;
+    static constexpr int LDS_XCH = 1024;
+    static constexpr int LDS_HINT = IT * K * 32;       // 256-bit bitmap per polynomial
+    static constexpr int LDS_MISC = 256;               // ball block bytes, positions
+    static constexpr int LDS_TOTAL = LDS_ZHAT + LDS_ACC + LDS_XCH + LDS_HINT + LDS_MISC;
+};
+
+constexpr size_t kBallStateBytes = 200;
+
+// SHAKE256 / SHA3-256 style absorb of NWORDS 64-bit words (rate 17 words) and final padding.
+template <int NWORDS> __device__ __forceinline__ void sponge17_words(KeccakState &s, const uint64_t *p, uint32_t ds) {
+    constexpr int FULL = NWORDS / 17, REM = NWORDS % 17;
+    keccak_zero(s);
+#pragma unroll 1
+    for (int b = 0; b < FULL; b++) {
+        xor_words<0, 17>(s, p + 17 * b);
+        keccak_f1600(s);
+    }
+    xor_words<0, REM>(s, p + 17 * FULL);
+    s.lo[REM] ^= ds;
+    s.hi[16] ^= 0x80000000u;
+    keccak_f1600(s);
+}
+
+// ---- kernel P ---------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
+                                                         const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
+                                                         const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
+                                                         int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
+                                                         uint8_t *__restrict__ fail_ws, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState s;
+    // tr = SHAKE256(pk)[:64]  (dilithium.go:123-125)
+    sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
+    KeccakState h;
+    keccak_zero(h);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+    // M' byte stream
+    const uint8_t *mp = msg_blob + msg_off[idx];
+    const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+    const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
+    const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+    const size_t pre = internal ? 0 : 2;
+    const size_t total = pre + (internal ? 0 : clen) + mlen;  // length of M'
+    auto mbyte = [&](size_t k) -> uint64_t {
+        if (k > total) return 0;
+        if (k == total) return kDsShake;
+        if (!internal) {
+            if (k == 0) return 0;
+            if (k == 1) return (uint64_t)(clen & 0xff);
+            if (k < 2 + clen) return cp[k - 2];
+            return mp[k - 2 - clen];
+        }
+        return mp[k];
+    };
+    // first block: words 0..7 hold tr, words 8..16 the first 72 bytes of M'
+    size_t pos = 0;  // M' bytes consumed
+    bool done = false;
+    {
+        detail::static_for<8, 17>([&](auto ic) {
+            constexpr int w = decltype(ic)::v;
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v |= mbyte(8 * (size_t)(w - 8) + b) << (8 * b);
+            h.lo[w] ^= (uint32_t)v;
+            h.hi[w] ^= (uint32_t)(v >> 32);
+        });
+        if (total < 72) { done = true; h.hi[16] ^= 0x80000000u; }
+        keccak_f1600(h);
+        pos = 72;
+    }
+    while (!done) {
+        detail::static_for<0, 17>([&](auto ic) {
+            constexpr int w = decltype(ic)::v;
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v |= mbyte(pos + 8 * (size_t)w + b) << (8 * b);
+            h.lo[w] ^= (uint32_t)v;
+            h.hi[w] ^= (uint32_t)(v >> 32);
+        });
+        if (total < pos + 136) { done = true; h.hi[16] ^= 0x80000000u; }
+        keccak_f1600(h);
+        pos += 136;
+    }
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), h);  // mu
+    // SampleInBall's sponge: SHAKE256(c~), first block (sample.go:299-306); the whole state is
+    // parked so that the verify kernel can squeeze further blocks in the (rare) case it must.
+    const uint8_t *sg = sig + idx * G::SIG;
+    keccak_zero(s);
+    detail::static_for<0, P::CT / 8>([&](auto ic) {
+        constexpr int w = decltype(ic)::v;
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)sg[8 * w + b] << (8 * b);
+        s.lo[w] = (uint32_t)v;
+        s.hi[w] = (uint32_t)(v >> 32);
+    });
+    s.lo[P::CT / 8] ^= kDsShake;
+    s.hi[16] ^= 0x80000000u;
+    keccak_f1600(s);
+    store_words<0, 25>(reinterpret_cast<uint64_t *>(ball_ws + idx * kBallStateBytes), s);
+    fail_ws[idx] = (!internal && clen > 255) ? 1 : 0;  // mldsa65/dilithium.go:116-118
+}
+
+// ---- verify kernel helpers ----------------------------------------------------------------------
+
+// D-bit field n of a little-endian bit stream (byte loads; never reads past the stream's end)
+template <int D> __device__ __forceinline__ uint32_t get_bits32(const uint8_t *p, int n) {
+    const int bit = n * D, b = bit >> 3, sh = bit & 7;
+    uint32_t w = p[b];
+    if (sh + D > 8) w |= (uint32_t)p[b + 1] << 8;
+    if (sh + D > 16) w |= (uint32_t)p[b + 2] << 16;
+    uint32_t hi = 0;
+    if (sh + D > 24) hi = p[b + 3];
+    return (uint32_t)(((((uint64_t)hi << 24) | w) >> sh) & ((1u << D) - 1));
+}
+
+// One squeezed SHAKE128 block of ExpandA: 56 candidates of 3 bytes, 23 bits each.
+template <class F> __device__ __forceinline__ void for_each_candidate23(const KeccakState &s, F &&f) {
+    detail::static_for<0, 56>([&](auto ic) {
+        constexpr int c = decltype(ic)::v;
+        constexpr int bit = 24 * c, w = bit / 32, sh = bit % 32;
+        auto word = [&](int i) -> uint32_t { return (i & 1) ? s.hi[i >> 1] : s.lo[i >> 1]; };
+        uint32_t v;
+        if constexpr (sh <= 8) v = (word(w) >> sh) & 0x7fffffu;
+        else v = alignbit(word(w + 1), word(w), sh) & 0x7fffffu;
+        f(v);
+    });
+}
+
+// ---- kernel V -----------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
+                                                         uint8_t *__restrict__ muw1_ws, const uint8_t *__restrict__ ball_ws,
+                                                         uint8_t *__restrict__ fail_ws, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    constexpr int K = P::K, L = P::L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *zhat = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *acc = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT);
+    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC);
+    uint32_t *hintbits = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH);
+    uint8_t *misc = smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH + G::LDS_HINT;
+    const int lane = threadIdx.x;
+    const size_t item0 = (size_t)blockIdx.x * G::IT;
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+
+    uint32_t chat[G::IT][4];
+    bool fail[G::IT];
+
+    // zero the accumulators and hint bitmaps
+    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
+    for (int i = lane; i < G::IT * K * 8; i += 64) hintbits[i] = 0;
+
+    // ------------------------------ phase 1 ------------------------------
+#pragma unroll
+    for (int g = 0; g < G::IT; g++) {
+        fail[g] = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) chat[g][r] = 0;
+        const size_t item = item0 + g;
+        if (item >= n) continue;  // wave-uniform
+        const uint8_t *sg = sig + item * G::SIG;
+        bool bad = false;
+        // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
+        for (int j = 0; j < L; j++) {
+            uint32_t c[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t f = get_bits32<G::ZBITS>(sg + P::CT + j * G::ZSZ, kyber::idx_l1(lane, r));
+                uint32_t x = G::GAMMA1 - f;
+                x += (uint32_t)((int32_t)x >> 31) & Q;
+                bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
+                c[r] = x;
+            }
+            dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                zhat[(g * L + j) * G::PSTRIDE + 4 * lane + r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // z-hat * 2^24
+        }
+        // hints: strict decoding (pack.go:113-141)
+        {
+            const uint8_t *hb = sg + P::CT + L * G::ZSZ;
+            uint32_t sop[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) sop[i] = hb[P::OMEGA + i];
+#pragma unroll
+            for (int i = 0; i < K; i++) bad |= sop[i] > (uint32_t)P::OMEGA || (i > 0 && sop[i] < sop[i - 1]);
+            for (int j0 = 0; j0 < P::OMEGA; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < P::OMEGA) {
+                    int poly = 0;
+                    uint32_t start = 0;
+#pragma unroll
+                    for (int i = 0; i < K; i++)
+                        if (sop[i] <= (uint32_t)j) { poly = i + 1; start = sop[i]; }
+                    const uint32_t v = hb[j];
+                    if (poly < K) {
+                        if ((uint32_t)j > start && v <= hb[j - 1]) bad = true;
+                        atomicOr(&hintbits[(g * K + poly) * 8 + (v >> 5)], 1u << (v & 31));
+                    } else if (v != 0) {
+                        bad = true;
+                    }
+                }
+            }
+        }
+        fail[g] = __any(bad);
+
+        // SampleInBall (sample.go:299-339): 8 sign bytes, then bytes b <= i pick the positions
+        {
+            __syncthreads();
+            const uint8_t *st = ball_ws + item * kBallStateBytes;
+            uint8_t *blk = misc;          // current 136-byte block
+            uint8_t *jpos = misc + 144;   // chosen positions j_t, t < tau
+            for (int i = lane; i < 34; i += 64) reinterpret_cast<uint32_t *>(blk)[i] = reinterpret_cast<const uint32_t *>(st)[i];
+            __syncthreads();
+            const unsigned long long signs = reinterpret_cast<const unsigned long long *>(blk)[0];
+            int off = 8;  // next unread byte of blk
+            KeccakState bs;
+            bool have_state = false;
+            for (int t = 0; t < P::TAU; t++) {
+                const uint32_t i = 256 - P::TAU + t;
+                int found = -1;
+                while (found < 0) {
+                    // lanes look at bytes off+lane, off+64+lane, off+128+lane of the block
+                    unsigned long long m0 = __ballot(off + lane < 136 && blk[min(off + lane, 135)] <= i);
+                    unsigned long long m1 = __ballot(off + 64 + lane < 136 && blk[min(off + 64 + lane, 135)] <= i);
+                    unsigned long long m2 = __ballot(off + 128 + lane < 136 && blk[min(off + 128 + lane, 135)] <= i);
+                    if (m0) found = off + __ffsll((long long)m0) - 1;
+                    else if (m1) found = off + 64 + __ffsll((long long)m1) - 1;
+                    else if (m2) found = off + 128 + __ffsll((long long)m2) - 1;
+                    else {
+                        // block exhausted: squeeze the next one (every lane runs the same permutation)
+                        if (!have_state) {
+                            const uint64_t *sw = reinterpret_cast<const uint64_t *>(st);
+                            keccak_zero(bs);
+                            xor_words<0, 25>(bs, sw);
+                            have_state = true;
+                        }
+                        keccak_f1600(bs);
+                        __syncthreads();
+                        if (lane == 0) store_words<0, 17>(reinterpret_cast<uint64_t *>(blk), bs);
+                        __syncthreads();
+                        off = 0;
+                    }
+                }
+                if (lane == 0) jpos[t] = blk[found];
+                off = found + 1;
+            }
+            __syncthreads();
+            // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a
+            // later step t' with j_t' == (its current position) moves it to i_t'
+            uint32_t *cpoly = xch;
+            for (int i = lane; i < 256; i += 64) cpoly[i] = 0;
+            __syncthreads();
+            if (lane < P::TAU) {
+                uint32_t pos = jpos[lane];
+                for (int t2 = lane + 1; t2 < P::TAU; t2++)
+                    if (jpos[t2] == pos) pos = 256 - P::TAU + t2;
+                cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
+            }
+            __syncthreads();
+            uint32_t c[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
+            dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) chat[g][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // c-hat * 2^24
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------ phase 2 ------------------------------
+    {
+        const bool on = lane < G::IT * G::STREAMS;
+        const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
+        const int i = p / L, j = p % L;
+        size_t item = item0 + g;
+        if (item >= n) item = n - 1;
+        KeccakState s;
+        keccak_zero(s);
+        // SHAKE128(rho || LE16((i << 8) + j))  (mat.go:15-49, sample.go:92-123)
+        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(pk + item * G::PK));
+        s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+        s.hi[20] = 0x80000000u;
+        const uint32_t *zrow = zhat + (g * L + j) * G::PSTRIDE;
+        uint32_t *arow = acc + (g * K + i) * G::PSTRIDE;
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
+            keccak_f1600(s);
+            for_each_candidate23(s, [&](uint32_t a) {
+                if (a < Q && cnt < 256) {
+                    atomicAdd(&arow[cnt], dilithium::mont24(a, zrow[cnt]));  // a * z-hat[j][cnt], < 2q
+                    cnt++;
+                }
+            });
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------ phase 3 ------------------------------
+#pragma unroll 1
+    for (int g = 0; g < G::IT; g++) {
+        const size_t item = item0 + g;
+        if (item >= n) break;
+        uint8_t *w1out = muw1_ws + item * G::MUW1 + 64;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint32_t t[4], w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = get_bits32<10>(pk + item * G::PK + 32 + 320 * i, kyber::idx_l1(lane, r)) << dilithium::D;
+            dilithium::ntt(t, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ct1 = dilithium::mont24(dilithium::fold(t[r]), chat[g][r]);  // c-hat * t1-hat, < 3q
+                w[r] = dilithium::fold(acc[(g * K + i) * G::PSTRIDE + 4 * lane + r] + 4 * Q - ct1);
+            }
+            dilithium::invntt(w, z, xch, lane);
+            uint16_t *w1v = reinterpret_cast<uint16_t *>(xch);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                const uint32_t hbit = (hintbits[(g * K + i) * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
+                w1v[nidx] = (uint16_t)dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
+            }
+            __syncthreads();
+            mlkem::pack_bits_store<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), w1v, lane);
+        }
+        if (lane == 0 && fail[g]) fail_ws[item] = 1;
+    }
+}
+
+// ---- kernel F -----------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_final_kernel(const uint8_t *__restrict__ sig, const uint8_t *__restrict__ muw1_ws,
+                                                          const uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ ok, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState s;
+    sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(muw1_ws + idx * G::MUW1), kDsShake);
+    const uint8_t *sg = sig + idx * G::SIG;
+    bool same = true;
+    detail::static_for<0, P::CT / 8>([&](auto ic) {
+        constexpr int w = decltype(ic)::v;
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)sg[8 * w + b] << (8 * b);
+        same &= v == (((uint64_t)s.hi[w] << 32) | s.lo[w]);
+    });
+    ok[idx] = (same && fail_ws[idx] == 0) ? 1 : 0;
+}
+
+}  // namespace mldsa
+}  // namespace circl

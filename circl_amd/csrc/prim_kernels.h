@@ -4,6 +4,7 @@
 // use the same device functions.
 #pragma once
 #include "kyber_dev.h"
+#include "dilithium_dev.h"
 
 namespace circl {
 namespace prim {
@@ -54,6 +55,32 @@ __global__ void __launch_bounds__(64) kyber_mulhat_kernel(int16_t *out, const in
     kyber::mulhat_finish(acc);
 #pragma unroll
     for (int r = 0; r < 4; r++) out[off + r] = (int16_t)kyber::normalize(acc[r]);
+}
+
+// sign/internal/dilithium Poly.NTT / Poly.InvNTT, one polynomial per single-wave workgroup,
+// uint32[256] in standard order, in place, outputs normalised to [0,q).  The reference's InvNTT
+// returns 2^32/256 times the exact inverse (ntt.go:212-216); the device transform is exact, so the
+// factor 2^32 mod q is applied here to expose the reference's semantics.
+__global__ void __launch_bounds__(64) dilithium_ntt_kernel(uint32_t *polys, int inverse) {
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    const int lane = threadIdx.x;
+    uint32_t *p = polys + (size_t)blockIdx.x * 256;
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    uint32_t c[4];
+    if (!inverse) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[r] = dilithium::normalize(p[kyber::idx_l1(lane, r)]);
+        dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[kyber::idx_l4(lane, r)] = dilithium::normalize(c[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[r] = dilithium::normalize(p[kyber::idx_l4(lane, r)]);
+        dilithium::invntt(c, z, xch, lane);
+        constexpr uint32_t R32R24 = (uint32_t)((uint64_t)((1ull << 32) % dilithium::Q) * dilithium::R24 % dilithium::Q);
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = dilithium::normalize(dilithium::mont24(dilithium::fold(c[r]), R32R24));
+    }
 }
 
 // n independent sponges over equal-length byte strings; one stream per lane

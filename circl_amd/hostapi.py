@@ -63,6 +63,16 @@ def _blob(items):
     return blob, off
 
 
+def mldsa_verify_internal(param, pk, sig, msgs, device=0):
+    PK, SIG = DSA_SIZES[param]
+    pk, sig = _u8(pk, PK), _u8(sig, SIG)
+    n = len(pk)
+    mb, mo = _blob(msgs)
+    ok = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mldsa_verify_internal(param, _p(pk), _p(sig), _p(mb), _p(mo), _p(ok), n, device), "mldsa_verify_internal")
+    return ok
+
+
 def mldsa_verify(param, pk, sig, msgs, ctxs=None, device=0):
     PK, SIG = DSA_SIZES[param]
     pk, sig = _u8(pk, PK), _u8(sig, SIG)

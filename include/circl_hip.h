@@ -101,6 +101,11 @@ int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek
 int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
                            const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
                            uint8_t *ok, size_t n, int device);
+/* ML-DSA.Verify_internal (message hashed without the context prefix): the reference's
+ * unsafeVerifyInternal, sign/mldsa/mldsa65/dilithium.go:101-109, which its ACVP tests drive. */
+int circl_hip_mldsa_verify_internal(int param, const uint8_t *pk, const uint8_t *sig,
+                                    const uint8_t *msg_blob, const uint64_t *msg_off, uint8_t *ok,
+                                    size_t n, int device);
 size_t circl_hip_mldsa_workspace_size(int param, size_t n);
 int circl_hip_mldsa_verify_dev(int param, const uint8_t *d_pk, const uint8_t *d_sig,
                                const uint8_t *d_msg_blob, const uint64_t *d_msg_off,

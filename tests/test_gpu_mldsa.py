@@ -1,0 +1,114 @@
+"""GPU parity of batch ML-DSA verification against the oracle, NIST ACVP sigVer and Wycheproof,
+through the C ABI (test bodies follow sign/mldsa/mldsa65/acvp_test.go:122-158 and
+sign/schemes/wycheproof_test.go:116-151)."""
+import numpy as np
+import pytest
+
+from conftest import hx, load_golden
+from circl_amd import hostapi
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+PARAMS = {"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87}
+Q = 8380417
+
+
+def test_dilithium_ntt_against_oracle():
+    # sign/internal/dilithium/ntt_test.go:53-88 (asm vs generic), here device vs oracle
+    rng = np.random.default_rng(41)
+    p = rng.integers(0, Q, (200, 256)).astype(np.uint32)
+    got = hostapi.dilithium_ntt(p)
+    inv = hostapi.dilithium_ntt(p, inverse=True)
+    for i in range(200):
+        assert (got[i] == orc.dilithium_normalize(orc.dilithium_ntt(p[i]))).all(), i
+        assert (inv[i] == orc.dilithium_normalize(orc.dilithium_invntt(p[i]))).all(), i
+    back = hostapi.dilithium_ntt(got, inverse=True)
+    assert (back.astype(np.uint64) == p.astype(np.uint64) * ((1 << 32) % Q) % Q).all()
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_sigver(name):
+    p = PARAMS[name]
+    pks, sigs, msgs, want = [], [], [], []
+    for g in load_golden("mldsa_acvp.json.gz")[name]["sigver"]:
+        for c in g["cases"]:
+            pks.append(hx(g["pk"])); sigs.append(hx(c["signature"])); msgs.append(hx(c["message"])); want.append(c["passed"])
+    ok = hostapi.mldsa_verify_internal(p, b"".join(pks), b"".join(sigs), msgs)
+    assert ok.tolist() == [int(w) for w in want]
+    assert 0 < sum(want) < len(want)
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_wycheproof_verify(name):
+    p = PARAMS[name]
+    PK, SIG = hostapi.DSA_SIZES[p]
+    pks, sigs, msgs, ctxs, want, ids = [], [], [], [], [], []
+    for g in load_golden("mldsa_wycheproof_verify.json.gz")[name]:
+        pk = hx(g["pk"])
+        for t in g["tests"]:
+            sig, ctx = hx(t["sig"]), hx(t["ctx"])
+            if len(pk) != PK or len(sig) != SIG:
+                # the Go wrapper rejects these before any arithmetic (UnmarshalBinaryPublicKey /
+                # sig.Unpack length check, dilithium.go:90-93); the fixed-row C ABI never sees them
+                assert t["result"] == "invalid"
+                continue
+            pks.append(pk); sigs.append(sig); msgs.append(hx(t["msg"])); ctxs.append(ctx)
+            want.append(t["result"] == "valid"); ids.append(t["id"])
+    ok = hostapi.mldsa_verify(p, b"".join(pks), b"".join(sigs), msgs, ctxs)
+    bad = [(i, w) for i, o, w in zip(ids, ok.tolist(), want) if bool(o) != w]
+    assert not bad, bad
+    assert sum(want) >= 40 and len(want) - sum(want) >= 5
+    # cross-check the whole set against the oracle as well
+    assert ok.tolist() == orc.mldsa_verify(p, b"".join(pks), b"".join(sigs), msgs, ctxs).tolist()
+
+
+def _signed_batch(p, n, seed):
+    rng = np.random.default_rng(seed)
+    pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = [rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sig = orc.mldsa_sign(p, sk, msgs, ctxs)
+    return pk, sig, msgs, ctxs
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+@pytest.mark.parametrize("n", [1, 3, 130])
+def test_verify_matches_oracle_with_corruptions(name, n):
+    p = PARAMS[name]
+    PK, SIG = hostapi.DSA_SIZES[p]
+    pk, sig, msgs, ctxs = _signed_batch(p, n, seed=n * 7 + p)
+    sig = sig.copy()
+    rng = np.random.default_rng(5)
+    ct = {44: 32, 65: 48, 87: 64}[p]
+    for i in range(0, n, 4):
+        kind = (i // 4) % 5
+        if kind == 0:
+            sig[i, int(rng.integers(0, ct))] ^= 1                      # c~
+        elif kind == 1:
+            sig[i, ct + int(rng.integers(0, 600))] ^= 0x40             # z
+        elif kind == 2:
+            sig[i, SIG - 1] = 0xFF                                     # hint switch-over point > omega
+        elif kind == 3:
+            msgs[i] = msgs[i] + b"x"                                   # different message
+        else:
+            sig[i, ct:ct + 3] = 0                                      # z coefficient out of range / garbage
+    ok = hostapi.mldsa_verify(p, pk, sig, msgs, ctxs)
+    want = orc.mldsa_verify(p, pk, sig, msgs, ctxs)
+    assert ok.tolist() == want.tolist()
+    untouched = [i for i in range(n) if i % 4]
+    assert ok[untouched].all()
+    assert not ok[::4].all() or n == 1
+
+
+def test_verify_without_contexts_and_long_messages():
+    p = 65
+    rng = np.random.default_rng(9)
+    n = 20
+    pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, m, dtype=np.uint8).tobytes() for m in (0, 1, 69, 70, 71, 72, 73, 135, 205, 206, 207, 208, 341, 342, 343, 1000, 5000, 32, 32, 32)]
+    sig = orc.mldsa_sign(p, sk, msgs)
+    assert hostapi.mldsa_verify(p, pk, sig, msgs).all()
+    assert hostapi.mldsa_verify(p, pk, sig, msgs, [b""] * n).all()
+    assert not hostapi.mldsa_verify(p, pk, sig, msgs, [b"c"] * n).any()
+    # ctx longer than 255 bytes -> false (mldsa65/dilithium.go:116-118)
+    assert not hostapi.mldsa_verify(p, pk[:1], sig[:1], msgs[:1], [b"a" * 256]).any()
