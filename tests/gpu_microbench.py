@@ -1,4 +1,7 @@
-"""Not a test: device-resident timing of the ML-KEM kernels (run on the GPU box via gpurun)."""
+"""Not a test: device-resident timings of every batch operation (run on the GPU box via gpurun).
+
+    python tests/gpu_microbench.py [logn]
+"""
 import ctypes as C
 import sys
 import time
@@ -8,44 +11,80 @@ import torch
 
 sys.path.insert(0, ".")
 from circl_amd import _native as nat  # noqa: E402
+from circl_amd import device as cdev  # noqa: E402
 from oracle import orc  # noqa: E402
 
 
-def main(n=1 << 18, param=768, pool=1 << 12, iters=5):
-    L = nat.lib()
-    EK, _, CT = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}[param]
-    rng = np.random.default_rng(1)
-    ekp, _ = orc.mlkem_keygen(param, rng.integers(0, 256, (pool, 64), dtype=np.uint8))
-    ek = torch.from_numpy(np.tile(ekp, (n // pool, 1))).cuda()
-    m = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).cuda()
-    ct = torch.empty((n, CT), dtype=torch.uint8, device="cuda")
-    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
-    st = torch.empty(n, dtype=torch.uint8, device="cuda")
-    wsb = L.circl_hip_mlkem_workspace_size(param, n)
-    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def run():
-        rc = L.circl_hip_mlkem_encaps_dev(param, ek.data_ptr(), m.data_ptr(), ct.data_ptr(), ss.data_ptr(), st.data_ptr(), n,
-                                          ws.data_ptr(), wsb, C.c_void_p(stream))
-        assert rc == 0, rc
-
-    run()
+def timeit(fn, iters=5):
+    fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        run()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"ML-KEM-{param} n={n}: {ms:.3f} ms/batch -> {n / ms * 1e3:.3e} encaps/s")
-    # spot parity
-    idx = rng.integers(0, n, 256)
-    ct0, ss0, _ = orc.mlkem_encaps(param, ek[idx].cpu().numpy(), m[idx].cpu().numpy())
-    print("parity:", bool((ct[idx].cpu().numpy() == ct0).all() and (ss[idx].cpu().numpy() == ss0).all()), "status", int(st.sum()))
+    return e0.elapsed_time(e1) / iters
+
+
+def kem(param, n, pool=1 << 12):
+    rng = np.random.default_rng(param)
+    eng = cdev.MLKEMDevice(param, n)
+    seeds = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
+    ek, dk = eng.keygen(seeds)
+    ms = timeit(lambda: eng.keygen(seeds, ek, dk))
+    print(f"ML-KEM-{param} keygen  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
+    m = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).cuda()
+    ct = torch.empty((n, eng.CT), dtype=torch.uint8, device="cuda")
+    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: eng.encaps(ek, m, ct, ss))
+    print(f"ML-KEM-{param} encaps  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
+    ss2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: eng.decaps(dk, ct, ss2))
+    torch.cuda.synchronize()
+    print(f"ML-KEM-{param} decaps  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   roundtrip ok: {bool((ss == ss2).all())}, status {int(eng.status.sum())}")
+    idx = rng.integers(0, n, 128)
+    ek0, dk0 = orc.mlkem_keygen(param, seeds[idx].cpu().numpy())
+    print("   keygen parity:", bool((ek0 == ek[idx].cpu().numpy()).all() and (dk0 == dk[idx].cpu().numpy()).all()))
+
+
+def dsa(param, n, pool=1 << 11):
+    L = nat.lib()
+    PK, SK, SIG = orc.DSA_SIZES[param]
+    rng = np.random.default_rng(param)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (pool, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(pool)]
+    sig = orc.mldsa_sign(param, sk, msgs)
+    bad = rng.choice(pool, pool // 64, replace=False)
+    sig[bad, 100] ^= 4
+    reps = n // pool
+    d_pk = torch.from_numpy(np.tile(pk, (reps, 1))).cuda()
+    d_sig = torch.from_numpy(np.tile(sig, (reps, 1))).cuda()
+    d_msg = torch.from_numpy(np.frombuffer(b"".join(msgs) * reps, np.uint8).copy()).cuda()
+    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+    ok = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wsb = L.circl_hip_mldsa_workspace_size(param, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        rc = L.circl_hip_mldsa_verify_dev(param, d_pk.data_ptr(), d_sig.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), None, None,
+                                          ok.data_ptr(), n, ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+    ms = timeit(run, 3)
+    want = np.ones(pool, np.uint8)
+    want[bad] = 0
+    good = bool((ok.cpu().numpy() == np.tile(want, reps)).all())
+    print(f"ML-DSA-{param} verify  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   results as expected: {good}")
+    cdev.profile_enable(True)
+    run(); torch.cuda.synchronize()
+    cdev.profile_enable(False)
+    print("   kernel ms: prep+final %.3f  verify %.3f" % (cdev.profile_read("mldsa_hash")[0], cdev.profile_read("mldsa_verify")[0]))
 
 
 if __name__ == "__main__":
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 18
     for p in (768, 512, 1024):
-        main(param=p)
+        kem(p, 1 << logn)
+    for p in (65, 44, 87):
+        dsa(p, 1 << (logn - 2))
