@@ -1,0 +1,72 @@
+//go:build cgo && hip
+
+// Package hipbatch is the cgo bridge for batched ML-DSA verification on libcirclhip.so.
+// NOT COMPILED HERE (no Go toolchain in the build image); see INTEGRATION.md.
+package hipbatch
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../../include
+#cgo LDFLAGS: -lcirclhip
+#include <circl_hip.h>
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+
+	"github.com/cloudflare/circl/sign"
+)
+
+var params = map[string]C.int{"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87}
+
+// VerifyBatch is n times scheme.UnmarshalBinaryPublicKey + scheme.Verify(pk, msg, sig, &opts)
+// (sign/mldsa/mldsa65/dilithium.go:305-343).  Signatures of the wrong length and contexts longer
+// than 255 bytes verify as false, exactly like the single-shot call.
+func VerifyBatch(s sign.Scheme, pks [][]byte, msgs [][]byte, sigs [][]byte, ctxs []string, device int) ([]bool, error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		panic(sign.ErrTypeMismatch)
+	}
+	n := len(pks)
+	res := make([]bool, n)
+	pkRows := make([]byte, 0, n*s.PublicKeySize())
+	sigRows := make([]byte, 0, n*s.SignatureSize())
+	var msgBlob, ctxBlob []byte
+	msgOff := make([]uint64, 1, n+1)
+	ctxOff := make([]uint64, 1, n+1)
+	idx := make([]int, 0, n)
+	for i := 0; i < n; i++ {
+		if len(pks[i]) != s.PublicKeySize() {
+			return nil, sign.ErrPubKeySize
+		}
+		if len(sigs[i]) != s.SignatureSize() || len(ctxs[i]) > 255 {
+			continue // false, without touching the device
+		}
+		idx = append(idx, i)
+		pkRows = append(pkRows, pks[i]...)
+		sigRows = append(sigRows, sigs[i]...)
+		msgBlob = append(msgBlob, msgs[i]...)
+		ctxBlob = append(ctxBlob, ctxs[i]...)
+		msgOff = append(msgOff, uint64(len(msgBlob)))
+		ctxOff = append(ctxOff, uint64(len(ctxBlob)))
+	}
+	if len(idx) == 0 {
+		return res, nil
+	}
+	msgBlob = append(msgBlob, 0) // keep the blobs non-empty so that &blob[0] is valid
+	ctxBlob = append(ctxBlob, 0)
+	okb := make([]byte, len(idx))
+	rc := C.circl_hip_mldsa_verify(p,
+		(*C.uint8_t)(unsafe.Pointer(&pkRows[0])), (*C.uint8_t)(unsafe.Pointer(&sigRows[0])),
+		(*C.uint8_t)(unsafe.Pointer(&msgBlob[0])), (*C.uint64_t)(unsafe.Pointer(&msgOff[0])),
+		(*C.uint8_t)(unsafe.Pointer(&ctxBlob[0])), (*C.uint64_t)(unsafe.Pointer(&ctxOff[0])),
+		(*C.uint8_t)(unsafe.Pointer(&okb[0])), C.size_t(len(idx)), C.int(device))
+	if rc != 0 {
+		return nil, fmt.Errorf("circl-hip verify: error %d: %s", int(rc), C.GoString(C.circl_hip_last_error()))
+	}
+	for k, i := range idx {
+		res[i] = okb[k] == 1
+	}
+	return res, nil
+}

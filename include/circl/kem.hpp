@@ -1,0 +1,171 @@
+// circl/kem.hpp -- host-side mirror of cloudflare/circl's kem.Scheme for the HIP batch engine.
+//
+// The reference's host language is Go; this image has no Go toolchain, so the host layer above the
+// C ABI (include/circl_hip.h) is C++ and keeps the reference's names, argument meaning and error
+// behaviour so that tests read like kem/schemes/schemes_test.go:
+//
+//   kem.Scheme (kem/kem.go:33-82)            circl::kem::Scheme
+//     Name, PublicKeySize, PrivateKeySize,     same names
+//     SeedSize, SharedKeySize, CiphertextSize,
+//     EncapsulationSeedSize
+//     DeriveKeyPair(seed)                      DeriveKeyPair(seed)   throws std::invalid_argument on a bad
+//                                              seed length (the reference panics, kyber.go:341-343)
+//     UnmarshalBinaryPublicKey(buf)            -> PublicKey; throws ErrPubKeySize / ErrPubKey
+//     UnmarshalBinaryPrivateKey(buf)           -> PrivateKey; throws ErrPrivKeySize / ErrPrivKey
+//     EncapsulateDeterministically(pk, seed)   -> {ct, ss}; throws ErrSeedSize
+//     Encapsulate(pk)                          seed from std::random_device (crypto/rand in Go)
+//     Decapsulate(sk, ct)                      -> ss; throws ErrCiphertextSize; an invalid
+//                                              ciphertext is NOT an error (implicit rejection)
+//   kem/schemes.ByName (schemes.go:70-75)    circl::kem::ByName
+// plus the batch calls the reference lacks (EncapsulateBatch, DecapsulateBatch, DeriveKeyPairBatch).
+//
+// Keys are kept in MarshalBinary form; the GPU re-derives A^T and H(ek) per item (the reference
+// caches them per key object, kem/mlkem/mlkem768/kyber.go:39-43), which is the right trade for
+// batches of distinct keys.  Every operation runs on the GPU: there is no CPU path.
+#pragma once
+#include <cstdint>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../circl_hip.h"
+
+namespace circl {
+namespace kem {
+
+using Bytes = std::vector<uint8_t>;
+
+// kem/kem.go:85-121 error values
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ErrTypeMismatch : Error { ErrTypeMismatch() : Error("kem: type mismatch") {} };
+struct ErrSeedSize : Error { ErrSeedSize() : Error("kem: wrong seed size") {} };
+struct ErrPubKeySize : Error { ErrPubKeySize() : Error("kem: wrong size for public key") {} };
+struct ErrCiphertextSize : Error { ErrCiphertextSize() : Error("kem: wrong size for ciphertext") {} };
+struct ErrPrivKeySize : Error { ErrPrivKeySize() : Error("kem: wrong size for private key") {} };
+struct ErrPubKey : Error { ErrPubKey() : Error("kem: invalid public key") {} };
+struct ErrPrivKey : Error { ErrPrivKey() : Error("kem: invalid private key") {} };
+struct ErrDevice : Error { explicit ErrDevice(const std::string &m) : Error("circl-hip: " + m) {} };
+
+class Scheme;
+
+class PublicKey {
+  public:
+    const Scheme *scheme = nullptr;
+    Bytes packed;  // MarshalBinary form
+    Bytes MarshalBinary() const { return packed; }
+    bool Equal(const PublicKey &o) const { return scheme == o.scheme && packed == o.packed; }
+};
+class PrivateKey {
+  public:
+    const Scheme *scheme = nullptr;
+    Bytes packed;
+    Bytes MarshalBinary() const { return packed; }
+    bool Equal(const PrivateKey &o) const { return scheme == o.scheme && packed == o.packed; }
+    PublicKey Public() const;
+};
+
+class Scheme {
+  public:
+    Scheme(int param, const char *name) : param_(param), name_(name) {}
+    std::string Name() const { return name_; }
+    int PublicKeySize() const { return (int)circl_hip_mlkem_ek_size(param_); }
+    int PrivateKeySize() const { return (int)circl_hip_mlkem_dk_size(param_); }
+    int CiphertextSize() const { return (int)circl_hip_mlkem_ct_size(param_); }
+    int SeedSize() const { return 64; }
+    int SharedKeySize() const { return 32; }
+    int EncapsulationSeedSize() const { return 32; }
+    int device = 0;  // CIRCL_HIP_ALL_DEVICES splits batches over every GPU
+
+    std::pair<PublicKey, PrivateKey> DeriveKeyPair(const Bytes &seed) const {
+        if ((int)seed.size() != SeedSize()) throw std::invalid_argument("seed must be of length KeySeedSize");
+        PublicKey pk{this, Bytes(PublicKeySize())};
+        PrivateKey sk{this, Bytes(PrivateKeySize())};
+        check(circl_hip_mlkem_keygen(param_, seed.data(), pk.packed.data(), sk.packed.data(), 1, dev1()));
+        return {pk, sk};
+    }
+    std::pair<PublicKey, PrivateKey> GenerateKeyPair() const { return DeriveKeyPair(random_bytes(SeedSize())); }
+
+    PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
+        if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
+        // canonical check == cpapke.go:45-55; done on the device by an encapsulation's status byte
+        Bytes ct(CiphertextSize()), ss(32), m(32, 0);
+        uint8_t st = 0;
+        check(circl_hip_mlkem_encaps(param_, buf.data(), m.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (st == CIRCL_HIP_ITEM_ERR_PUBKEY) throw ErrPubKey();
+        return PublicKey{this, buf};
+    }
+    PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
+        if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
+        Bytes ct(CiphertextSize(), 0), ss(32);
+        uint8_t st = 0;
+        check(circl_hip_mlkem_decaps(param_, buf.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (st == CIRCL_HIP_ITEM_ERR_PRIVKEY) throw ErrPrivKey();
+        return PrivateKey{this, buf};
+    }
+
+    std::pair<Bytes, Bytes> EncapsulateDeterministically(const PublicKey &pk, const Bytes &seed) const {
+        if (pk.scheme != this) throw ErrTypeMismatch();
+        if ((int)seed.size() != EncapsulationSeedSize()) throw ErrSeedSize();
+        Bytes ct(CiphertextSize()), ss(32);
+        uint8_t st = 0;
+        check(circl_hip_mlkem_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (st) throw ErrPubKey();
+        return {ct, ss};
+    }
+    std::pair<Bytes, Bytes> Encapsulate(const PublicKey &pk) const {
+        return EncapsulateDeterministically(pk, random_bytes(EncapsulationSeedSize()));
+    }
+    Bytes Decapsulate(const PrivateKey &sk, const Bytes &ct) const {
+        if (sk.scheme != this) throw ErrTypeMismatch();
+        if ((int)ct.size() != CiphertextSize()) throw ErrCiphertextSize();
+        Bytes ss(32);
+        uint8_t st = 0;
+        check(circl_hip_mlkem_decaps(param_, sk.packed.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (st) throw ErrPrivKey();
+        return ss;
+    }
+
+    // ---- batch API (new; rows are MarshalBinary-form keys) -------------------------------------
+    // status[i]: 0 ok, 1 = ErrPubKey, 2 = ErrPrivKey; failed items have zeroed outputs.
+    void EncapsulateBatch(const uint8_t *eks, const uint8_t *seeds, uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
+        check(circl_hip_mlkem_encaps(param_, eks, seeds, cts, sss, status, n, device));
+    }
+    void DecapsulateBatch(const uint8_t *dks, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
+        check(circl_hip_mlkem_decaps(param_, dks, cts, sss, status, n, device));
+    }
+    void DeriveKeyPairBatch(const uint8_t *seeds64, uint8_t *eks, uint8_t *dks, size_t n) const {
+        check(circl_hip_mlkem_keygen(param_, seeds64, eks, dks, n, device));
+    }
+
+  private:
+    int param_;
+    const char *name_;
+    int dev1() const { return device < 0 ? 0 : device; }
+    static void check(int rc) {
+        if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("error ") + std::to_string(rc) + " " + circl_hip_last_error());
+    }
+    static Bytes random_bytes(int n) {
+        std::random_device rd;
+        Bytes b((size_t)n);
+        for (auto &x : b) x = (uint8_t)rd();
+        return b;
+    }
+};
+
+inline PublicKey PrivateKey::Public() const {
+    const int k = (scheme->PublicKeySize() - 32) / 384;
+    return PublicKey{scheme, Bytes(packed.begin() + 384 * k, packed.begin() + 384 * k + scheme->PublicKeySize())};
+}
+
+// kem/schemes/schemes.go:35-75
+inline const Scheme *ByName(const std::string &name) {
+    static const Scheme s512(512, "ML-KEM-512"), s768(768, "ML-KEM-768"), s1024(1024, "ML-KEM-1024");
+    for (const Scheme *s : {&s512, &s768, &s1024})
+        if (s->Name() == name) return s;
+    return nullptr;
+}
+
+}  // namespace kem
+}  // namespace circl

@@ -1,0 +1,87 @@
+// circl/sign.hpp -- host-side mirror of cloudflare/circl's sign.Scheme (verification half) for the
+// HIP batch engine.  sign/sign.go:48-94; ML-DSA wrappers sign/mldsa/mldsa65/dilithium.go:256-345.
+//
+//   Scheme.Name / PublicKeySize / SignatureSize          same names
+//   UnmarshalBinaryPublicKey(buf)                        length check only (dilithium.go:330-343)
+//   Verify(pk, msg, sig, opts) bool                      false for a bad signature, malformed encoding,
+//                                                        wrong signature length or ctx > 255 bytes;
+//                                                        throws ErrTypeMismatch on a foreign key
+//                                                        (the reference panics, dilithium.go:311-314)
+//   VerifyBatch(...)                                     new: the batch call
+// Signing (sign.Scheme.Sign) is SURVEY.md 8(f) row f1 and not part of this layer yet.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../circl_hip.h"
+
+namespace circl {
+namespace sign {
+
+using Bytes = std::vector<uint8_t>;
+struct ErrTypeMismatch : std::runtime_error { ErrTypeMismatch() : std::runtime_error("sign: type mismatch") {} };
+struct ErrPubKeySize : std::runtime_error { ErrPubKeySize() : std::runtime_error("sign: wrong size for public key") {} };
+struct ErrDevice : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct SignatureOpts {
+    std::string Context;  // sign/sign.go:24-31
+};
+
+class Scheme;
+struct PublicKey {
+    const Scheme *scheme = nullptr;
+    Bytes packed;
+    Bytes MarshalBinary() const { return packed; }
+};
+
+class Scheme {
+  public:
+    Scheme(int param, const char *name) : param_(param), name_(name) {}
+    std::string Name() const { return name_; }
+    int PublicKeySize() const { return (int)circl_hip_mldsa_pk_size(param_); }
+    int SignatureSize() const { return (int)circl_hip_mldsa_sig_size(param_); }
+    bool SupportsContext() const { return true; }
+    int device = 0;
+
+    PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
+        if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
+        return PublicKey{this, buf};
+    }
+    bool Verify(const PublicKey &pk, const Bytes &msg, const Bytes &sig, const SignatureOpts *opts = nullptr) const {
+        if (pk.scheme != this) throw ErrTypeMismatch();
+        if ((int)sig.size() != SignatureSize()) return false;  // internal/dilithium.go:90-93
+        const std::string ctx = opts ? opts->Context : std::string();
+        if (ctx.size() > 255) return false;                    // dilithium.go:116-118
+        const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
+        const uint8_t pad = 0;
+        uint8_t ok = 0;
+        const int rc = circl_hip_mldsa_verify(param_, pk.packed.data(), sig.data(), msg.empty() ? &pad : msg.data(), moff,
+                                              ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data()), coff, &ok, 1,
+                                              device < 0 ? 0 : device);
+        if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
+        return ok != 0;
+    }
+    // rows: pk[n][PublicKeySize], sig[n][SignatureSize]; messages / contexts as blobs + n+1 offsets
+    void VerifyBatch(const uint8_t *pks, const uint8_t *sigs, const uint8_t *msg_blob, const uint64_t *msg_off,
+                     const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n) const {
+        const int rc = circl_hip_mldsa_verify(param_, pks, sigs, msg_blob, msg_off, ctx_blob, ctx_off, ok, n, device);
+        if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
+    }
+
+  private:
+    int param_;
+    const char *name_;
+};
+
+// sign/schemes/schemes.go:31-74
+inline const Scheme *ByName(const std::string &name) {
+    static const Scheme s44(44, "ML-DSA-44"), s65(65, "ML-DSA-65"), s87(87, "ML-DSA-87");
+    for (const Scheme *s : {&s44, &s65, &s87})
+        if (s->Name() == name) return s;
+    return nullptr;
+}
+
+}  // namespace sign
+}  // namespace circl

@@ -1,0 +1,86 @@
+// Exercises the C++ host mirror of kem.Scheme / sign.Scheme the way kem/schemes/schemes_test.go:53-167
+// and sign/schemes/schemes_test.go:17-108 exercise the Go interfaces.  Needs a GPU (run from
+// tests/test_gpu_host_mirror.py).  Prints "OK" on success.
+#include <cstdio>
+#include <cstring>
+
+#include "circl/kem.hpp"
+#include "circl/sign.hpp"
+
+#define REQUIRE(c)                                                        \
+    do {                                                                  \
+        if (!(c)) { std::printf("FAILED %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } \
+    } while (0)
+
+template <class E, class F> bool throws(F &&f) {
+    try { f(); } catch (const E &) { return true; } catch (...) { return false; }
+    return false;
+}
+
+int main() {
+    using namespace circl;
+    for (const char *name : {"ML-KEM-512", "ML-KEM-768", "ML-KEM-1024"}) {
+        const kem::Scheme *s = kem::ByName(name);
+        REQUIRE(s && s->Name() == name);
+        kem::Bytes seed(s->SeedSize());
+        for (size_t i = 0; i < seed.size(); i++) seed[i] = (uint8_t)(3 * i + 1);
+        auto [pk, sk] = s->DeriveKeyPair(seed);
+        auto [pk2, sk2] = s->DeriveKeyPair(seed);
+        REQUIRE(pk.Equal(pk2) && sk.Equal(sk2));
+        REQUIRE((int)pk.MarshalBinary().size() == s->PublicKeySize() && (int)sk.MarshalBinary().size() == s->PrivateKeySize());
+        REQUIRE(sk.Public().Equal(pk));
+        kem::PublicKey pk3 = s->UnmarshalBinaryPublicKey(pk.MarshalBinary());
+        kem::PrivateKey sk3 = s->UnmarshalBinaryPrivateKey(sk.MarshalBinary());
+        REQUIRE(pk3.Equal(pk) && sk3.Equal(sk));
+        kem::Bytes eseed(32, 7);
+        auto [ct, ss] = s->EncapsulateDeterministically(pk, eseed);
+        auto [ct2, ss2] = s->EncapsulateDeterministically(pk3, eseed);
+        REQUIRE(ct == ct2 && ss == ss2 && (int)ct.size() == s->CiphertextSize() && (int)ss.size() == s->SharedKeySize());
+        REQUIRE(s->Decapsulate(sk, ct) == ss);
+        auto [ct3, ss3] = s->Encapsulate(pk);
+        REQUIRE(s->Decapsulate(sk3, ct3) == ss3);
+        // error behaviour (kem/kem.go:85-121)
+        kem::Bytes shortbuf(10);
+        REQUIRE(throws<kem::ErrPubKeySize>([&] { s->UnmarshalBinaryPublicKey(shortbuf); }));
+        REQUIRE(throws<kem::ErrPrivKeySize>([&] { s->UnmarshalBinaryPrivateKey(shortbuf); }));
+        REQUIRE(throws<kem::ErrCiphertextSize>([&] { s->Decapsulate(sk, shortbuf); }));
+        REQUIRE(throws<kem::ErrSeedSize>([&] { s->EncapsulateDeterministically(pk, shortbuf); }));
+        REQUIRE(throws<std::invalid_argument>([&] { s->DeriveKeyPair(shortbuf); }));
+        kem::Bytes badpk = pk.MarshalBinary();
+        badpk[0] = 0xff; badpk[1] |= 0x0f;
+        REQUIRE(throws<kem::ErrPubKey>([&] { s->UnmarshalBinaryPublicKey(badpk); }));
+        kem::Bytes badsk = sk.MarshalBinary();
+        badsk[badsk.size() - 40] ^= 1;
+        REQUIRE(throws<kem::ErrPrivKey>([&] { s->UnmarshalBinaryPrivateKey(badsk); }));
+        ct[3] ^= 1;  // invalid ciphertext: no error, different key
+        REQUIRE(s->Decapsulate(sk, ct) != ss);
+        const kem::Scheme *other = kem::ByName(std::strcmp(name, "ML-KEM-768") ? "ML-KEM-768" : "ML-KEM-512");
+        REQUIRE(throws<kem::ErrTypeMismatch>([&] { other->EncapsulateDeterministically(pk, eseed); }));
+        // batch
+        const size_t n = 100;
+        std::vector<uint8_t> seeds(64 * n), eks(n * s->PublicKeySize()), dks(n * s->PrivateKeySize()), ms(32 * n), cts(n * s->CiphertextSize()),
+            sss(32 * n), sss2(32 * n), st(n);
+        for (size_t i = 0; i < seeds.size(); i++) seeds[i] = (uint8_t)(i * 7 + i / 64);
+        for (size_t i = 0; i < ms.size(); i++) ms[i] = (uint8_t)(i * 13);
+        s->DeriveKeyPairBatch(seeds.data(), eks.data(), dks.data(), n);
+        s->EncapsulateBatch(eks.data(), ms.data(), cts.data(), sss.data(), st.data(), n);
+        for (auto x : st) REQUIRE(x == 0);
+        s->DecapsulateBatch(dks.data(), cts.data(), sss2.data(), st.data(), n);
+        REQUIRE(sss == sss2);
+    }
+    REQUIRE(kem::ByName("Kyber768") == nullptr);
+    for (const char *name : {"ML-DSA-44", "ML-DSA-65", "ML-DSA-87"}) {
+        const sign::Scheme *s = sign::ByName(name);
+        REQUIRE(s && s->Name() == name && s->SupportsContext());
+        sign::Bytes junk(s->PublicKeySize(), 1), sig(s->SignatureSize(), 2), msg{1, 2, 3};
+        sign::PublicKey pk = s->UnmarshalBinaryPublicKey(junk);
+        REQUIRE(!s->Verify(pk, msg, sig));
+        sign::Bytes shortsig(5);
+        REQUIRE(!s->Verify(pk, msg, shortsig));
+        sign::SignatureOpts longctx{std::string(256, 'a')};
+        REQUIRE(!s->Verify(pk, msg, sig, &longctx));
+        REQUIRE(throws<sign::ErrPubKeySize>([&] { s->UnmarshalBinaryPublicKey(shortsig); }));
+    }
+    std::printf("OK\n");
+    return 0;
+}
