@@ -104,29 +104,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (circl_amd has no CPU path)", file=sys.stderr)
         sys.exit(2)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    from circl_amd import parallel
+    ranks = parallel.Ranks("nccl", dev)  # nccl == RCCL on ROCm; used for the barrier / reductions only
+    world, rank = ranks.world, ranks.rank
 
     from circl_amd import device as cdev
     B = args.batch
     ek, m = make_inputs(B, rank, dev)
     eng = cdev.MLKEMDevice(PARAM, B, dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = ranks.barrier
 
     for _ in range(args.warmup):
         eng.encaps(ek, m)
@@ -140,10 +132,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cdev.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    value, elapsed = parallel.whole_job_rate(ranks, B * args.steps, elapsed)
     enc_ms, enc_n = cdev.profile_read("mlkem_encrypt")
     hash_ms, hash_n = cdev.profile_read("mlkem_hash")
 
@@ -157,8 +146,6 @@ def main():
         parity = bool((eng.ct[idx].cpu().numpy() == ct0).all() and (eng.ss[idx].cpu().numpy() == ss0).all())
 
     if rank == 0:
-        total_ops = world * B * args.steps
-        value = total_ops / elapsed
         enc_avg_ms = enc_ms / max(enc_n, 1)
         achieved = B * BYTES_PER_OP / (enc_avg_ms * 1e-3) / 1e9 if enc_n else None
         out = {
@@ -184,8 +171,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ek, m)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
