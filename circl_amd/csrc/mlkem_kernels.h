@@ -311,7 +311,8 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
 //            m = m', r = r' come from the workspace; ct' is compared with ct instead of stored and
 //            ss = (ct == ct') ? K' : J(z || ct), both candidates parked in the workspace by
 //            mlkem_decaps_hash_kernel.  Items whose status is already non-zero get ss = 0.
-template <int K, int MODE>
+// ABLATE is a profiling aid (tools/ablate.hip): bit 0 skips phase A, bit 1 phase B, bit 2 phase C.
+template <int K, int MODE, int ABLATE = 0>
 __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
@@ -326,13 +327,13 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
     const int lane = threadIdx.x;
     const size_t item0 = (size_t)blockIdx.x * Gm::G;
 
-    sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
-    prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
+    if (!(ABLATE & 1)) sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
+    if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     __syncthreads();
 
 #pragma unroll 1
-    for (int g = 0; g < Gm::G; g++) {
+    for (int g = 0; g < ((ABLATE & 4) ? 0 : Gm::G); g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
         const uint8_t *ekp = ek + item * ek_stride;
