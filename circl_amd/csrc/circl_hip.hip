@@ -72,6 +72,34 @@ struct ProfScope {
     }
 };
 
+// ---- persistent-launch geometry for the scratch-based kernels ---------------------------------
+constexpr int kMaxBlocksPerCU = 16;  // 4 single-wave workgroups per SIMD
+int g_cu_count = 0;
+
+int cu_count() {
+    if (g_cu_count == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_cu_count = cus;
+        else
+            g_cu_count = 256;
+    }
+    return g_cu_count;
+}
+// upper bound on resident single-wave workgroups, used to size the scratch part of the workspace
+size_t max_resident_blocks() { return (size_t)cu_count() * kMaxBlocksPerCU; }
+
+template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
+    if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
+    return (unsigned)(cu_count() * occ);
+}
+
+size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
+// ML-KEM workspace: 128 B per item + one 32 KB scratch slice per resident workgroup
+size_t kem_ws_bytes(size_t n) { return up256(128 * n) + max_resident_blocks() * 64 * 512; }
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
@@ -83,19 +111,21 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
                     void *ws, size_t ws_bytes, hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < 32 * n || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
         return CIRCL_HIP_EWORKSPACE;
     uint8_t *r_ws = static_cast<uint8_t *>(ws);
+    uint8_t *scratch = r_ws + up256(128 * n);
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
     }
-    const unsigned eb = (unsigned)((n + Gm::G - 1) / Gm::G);
     {
+        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::ENCAPS, 0, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL((circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::ENCAPS>), dim3(eb), dim3(64), Gm::LDS_TOTAL, st,
-                           ek, (size_t)Gm::EK, m, r_ws, ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, n);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -106,8 +136,9 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
                     hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < 128 * n || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *mprime = static_cast<uint8_t *>(ws), *r_ws = mprime + 32 * n, *kbar = mprime + 64 * n, *ssrej = mprime + 96 * n;
+    uint8_t *scratch = mprime + up256(128 * n);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
         hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, ct, mprime, n);
@@ -119,9 +150,11 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL((circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::REENCRYPT>), dim3((unsigned)((n + Gm::G - 1) / Gm::G)),
-                           dim3(64), Gm::LDS_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,
-                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, n);
+        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::REENCRYPT, 0, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
+                           (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej,
+                           scratch, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -131,8 +164,9 @@ template <int K>
 int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < 64 * n || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *rs = static_cast<uint8_t *>(ws);
+    uint8_t *scratch = rs + up256(128 * n);
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -140,8 +174,9 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_keygen_kernel<K>, dim3((unsigned)((n + Gm::G - 1) / Gm::G)), dim3(64), Gm::LDS_TOTAL, st,
-                           (const uint8_t *)rs, ek, dk, n);
+        auto kern = circl::mlkem::mlkem_keygen_kernel<K, true>;
+        const unsigned kb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, (const uint8_t *)rs, ek, dk, scratch, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_FINISH, st);
@@ -176,20 +211,20 @@ int arena_reserve(Arena &a, size_t bytes) {
     return CIRCL_HIP_OK;
 }
 
-size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
-
 // Runs `n` items on one device in double-buffered chunks:  H2D(inputs) -> launch -> D2H(outputs).
 // in_sz / out_sz list the per-item byte sizes of the input and output arrays.
 template <class Launch>
 int run_chunked(int dev, size_t n, const std::vector<const uint8_t *> &in, const std::vector<size_t> &in_sz,
-                const std::vector<uint8_t *> &out, const std::vector<size_t> &out_sz, size_t ws_per_item, Launch launch) {
+                const std::vector<uint8_t *> &out, const std::vector<size_t> &out_sz, size_t ws_per_item, Launch launch,
+                size_t ws_fixed = 0) {
     if (n == 0) return CIRCL_HIP_OK;
     if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
     HIP_TRY(hipSetDevice(dev));
     Arena &a = g_arena[dev];
     std::lock_guard<std::mutex> lk(a.mu);
     const size_t chunk = std::min<size_t>(n, size_t(1) << 16);
-    size_t slot_bytes = up256(ws_per_item * chunk);
+    const size_t ws_slot = up256(ws_per_item * chunk) + up256(ws_fixed);
+    size_t slot_bytes = ws_slot;
     for (size_t s : in_sz) slot_bytes += up256(s * chunk);
     for (size_t s : out_sz) slot_bytes += up256(s * chunk);
     int rc = arena_reserve(a, 2 * slot_bytes);
@@ -211,7 +246,7 @@ int run_chunked(int dev, size_t n, const std::vector<const uint8_t *> &in, const
             dout.push_back(p);
             p += up256(out_sz[k] * chunk);
         }
-        rc = launch(din, dout, cnt, p, up256(ws_per_item * chunk), st);
+        rc = launch(din, dout, cnt, p, ws_slot, st);
         if (rc) return rc;
         for (size_t k = 0; k < out.size(); k++)
             if (out[k]) HIP_TRY(hipMemcpyAsync(out[k] + done * out_sz[k], dout[k], cnt * out_sz[k], hipMemcpyDeviceToHost, st));
@@ -371,7 +406,7 @@ size_t circl_hip_mlkem_ct_size(int param) {
 size_t circl_hip_mldsa_pk_size(int param) { return param == 44 ? 1312 : param == 65 ? 1952 : param == 87 ? 2592 : 0; }
 size_t circl_hip_mldsa_sig_size(int param) { return param == 44 ? 2420 : param == 65 ? 3309 : param == 87 ? 4627 : 0; }
 
-size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? up256(128 * n) : 0; }
+size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? kem_ws_bytes(n) : 0; }
 
 int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
                                uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
@@ -395,7 +430,7 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_encaps_dev(param, in[0], in[1], out[0], out[1], out[2], c, ws, wsb, st);
-                           });
+                           }, max_resident_blocks() * 64 * 512);
     });
 }
 
@@ -432,7 +467,7 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_decaps_dev(param, in[0], in[1], out[0], out[1], c, ws, wsb, st);
-                           });
+                           }, max_resident_blocks() * 64 * 512);
     });
 }
 
@@ -444,7 +479,7 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
-                           });
+                           }, max_resident_blocks() * 64 * 512);
     });
 }
 

@@ -44,13 +44,23 @@ template <int K> struct Geom {
     static constexpr int G = 64 / PAIRS;                 // items per workgroup
     static constexpr int A_STREAMS = G * PAIRS;          // <= 64
     static constexpr int NOISE = 2 * K + 1;              // PRF streams per item (encrypt); keygen uses 2K
+#ifndef CIRCL_EXPERIMENT_A_STRIDE
     static constexpr int A_STRIDE = 520;                 // bytes per sampled polynomial (+1 spill slot, 8-B aligned)
+#else
+    static constexpr int A_STRIDE = CIRCL_EXPERIMENT_A_STRIDE;  // tools/ablate.hip occupancy experiment (wrong results)
+#endif
     static constexpr int NOISE_BYTES = 64 * P::ETA1;     // eta1 stream length (eta2 streams use 128)
     static constexpr int NOISE_STRIDE = NOISE_BYTES + 8; // breaks the power-of-two bank stride
     static constexpr int LDS_A = A_STREAMS * A_STRIDE;
     static constexpr int LDS_NOISE = G * NOISE * NOISE_STRIDE;
     static constexpr int LDS_XCH = 512;
     static constexpr int LDS_TOTAL = LDS_A + LDS_NOISE + LDS_XCH;
+    // "scratch" variant: the sampled matrix goes through a per-workgroup global scratch (L2 / Infinity
+    // Cache resident) instead of LDS, which cuts LDS per wave from ~40 KB to ~7 KB (4 waves per SIMD).
+    static constexpr int FIFO_STRIDE = 80;               // 32 int16 slots + 16 B pad per lane
+    static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;
+    static constexpr int LDS_SCRATCH_TOTAL = (LDS_FIFO > LDS_NOISE + LDS_XCH) ? LDS_FIFO : LDS_NOISE + LDS_XCH;
+    static constexpr int SCRATCH_BYTES = 64 * 512;       // per resident workgroup
 };
 
 // ---- little helpers -------------------------------------------------------------------------
@@ -131,7 +141,11 @@ __device__ __forceinline__ void parse_shake128_block(const KeccakState &s, int16
         uint32_t v;
         if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
         else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
+#ifndef CIRCL_EXPERIMENT_A_STRIDE
         poly[cnt] = (int16_t)v;
+#else
+        poly[cnt & (CIRCL_EXPERIMENT_A_STRIDE / 2 - 1)] = (int16_t)v;
+#endif
         cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
     });
 }
@@ -163,6 +177,74 @@ __device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__r
         if (on) parse_shake128_block(s, poly, cnt);
     }
 }
+
+// Scratch variant of phase A.  Each lane appends accepted coefficients to a 32-slot LDS FIFO and
+// flushes 8 of them (16 bytes) at a time to its 512-byte row of the workgroup's global scratch, so
+// every global store is a full 16-byte segment.  Same branch-free acceptance as above.
+__device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, int16_t *fifo, int16_t *row, int &cnt, int &flushed) {
+    detail::static_for<0, 112>([&](auto ic) {
+        constexpr int c = decltype(ic)::v;
+        constexpr int bit = 12 * c, w = bit / 32, sh = bit % 32;
+        auto word = [&](int i) -> uint32_t { return (i & 1) ? s.hi[i >> 1] : s.lo[i >> 1]; };
+        uint32_t v;
+        if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
+        else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
+        fifo[cnt & 31] = (int16_t)v;
+        cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
+        if constexpr (c % 8 == 7) {
+            if (cnt - flushed >= 8) {  // at most 15 pending here, so one flush per check suffices
+                const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 31));
+                *reinterpret_cast<uint4 *>(row + flushed) = d;
+                flushed += 8;
+            }
+        }
+    });
+}
+
+template <int K, bool TRANSPOSED>
+__device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t *rows, const uint8_t *__restrict__ rho,
+                                                      size_t rho_stride, size_t item0, size_t n, int lane) {
+    using Gm = Geom<K>;
+    const bool on = lane < Gm::A_STREAMS;
+    const int g = on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
+    const int i = p / K, j = p % K;
+    size_t item = item0 + g;
+    if (item >= n) item = n - 1;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
+    s.lo[4] = (TRANSPOSED ? (uint32_t)i | ((uint32_t)j << 8) : (uint32_t)j | ((uint32_t)i << 8)) | (kDsShake << 16);
+    s.hi[20] = 0x80000000u;
+    int16_t *fifo = reinterpret_cast<int16_t *>(lds_fifo + lane * Gm::FIFO_STRIDE);
+    int16_t *row = rows + lane * 256;
+    int cnt = on ? 0 : 256, flushed = cnt;
+#pragma unroll 1
+    for (int blk = 0; blk < 3 || __any(cnt < 256); blk++) {
+        keccak_f1600(s);
+        if (on) parse_shake128_block_fifo(s, fifo, row, cnt, flushed);
+    }
+}
+
+// Matrix polynomial accessors for phase C (4 consecutive coefficients of stream `stream`, layout L4).
+struct AFromLds {
+    const uint8_t *base;
+    int stride;
+    __device__ __forceinline__ void load(int (&a)[4], int stream, int lane) const {
+        const int16_t *ap = reinterpret_cast<const int16_t *>(base + stream * stride) + 4 * lane;
+        a[0] = ap[0]; a[1] = ap[1]; a[2] = ap[2]; a[3] = ap[3];
+    }
+};
+struct AFromScratch {
+    const int16_t *rows;
+    __device__ __forceinline__ void load(int (&a)[4], int stream, int lane) const {
+        // agent-scope relaxed load = global_load_dwordx2 sc1: served by L2, never by a stale L1 line
+        // left over from the previous group that used this scratch row
+        const uint64_t w = __hip_atomic_load(reinterpret_cast<const uint64_t *>(rows + stream * 256 + 4 * lane), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        a[0] = (int16_t)(w & 0xffff); a[1] = (int16_t)((w >> 16) & 0xffff);
+        a[2] = (int16_t)((w >> 32) & 0xffff); a[3] = (int16_t)(w >> 48);
+    }
+};
 
 // ---- phase B: PRF ---------------------------------------------------------------------------
 
@@ -312,24 +394,40 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
 //            ss = (ct == ct') ? K' : J(z || ct), both candidates parked in the workspace by
 //            mlkem_decaps_hash_kernel.  Items whose status is already non-zero get ss = 0.
 // ABLATE is a profiling aid (tools/ablate.hip): bit 0 skips phase A, bit 1 phase B, bit 2 phase C.
-template <int K, int MODE, int ABLATE = 0>
+// SCRATCH selects where the sampled matrix lives between phase A and phase C: the workgroup's slice of
+// a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
+// or LDS (one group per workgroup; kept for A/B measurements).
+template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true>
 __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                           uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
-                                                          const uint8_t *__restrict__ ssrej_ws, size_t n) {
+                                                          const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *lds_a = smem;
-    uint8_t *lds_noise = smem + Gm::LDS_A;
-    int16_t *xch = reinterpret_cast<int16_t *>(smem + Gm::LDS_A + Gm::LDS_NOISE);
+    uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
+    uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
+    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + Gm::LDS_NOISE);
+    int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
-    const size_t item0 = (size_t)blockIdx.x * Gm::G;
-
-    if (!(ABLATE & 1)) sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
-    if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    const size_t ngroups = (n + Gm::G - 1) / Gm::G;
+
+#pragma unroll 1
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const size_t item0 = grp * Gm::G;
+    if (!(ABLATE & 1)) {
+        if constexpr (SCRATCH) {
+            __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
+            sample_matrix_scratch<K, true>(lds_a, rows, ek + 384 * K, ek_stride, item0, n, lane);
+            __threadfence_block();  // the rows are in L2 before anybody loads them
+        } else {
+            sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
+        }
+    }
+    __syncthreads();
+    if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
     __syncthreads();
 
 #pragma unroll 1
@@ -372,8 +470,9 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
             int acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                const int16_t *ap = reinterpret_cast<const int16_t *>(lds_a + ((g * K + i) * K + j) * Gm::A_STRIDE) + 4 * lane;
-                const int a[4] = {ap[0], ap[1], ap[2], ap[3]};
+                int a[4];
+                if constexpr (SCRATCH) AFromScratch{rows}.load(a, (g * K + i) * K + j, lane);
+                else AFromLds{lds_a, Gm::A_STRIDE}.load(a, (g * K + i) * K + j, lane);
                 kyber::mulhat_acc(acc, a, rh[j], z.f6);
             }
             kyber::mulhat_finish(acc);
@@ -435,6 +534,7 @@ __global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__rest
             }
         }
     }
+  }
 }
 
 // ---- decapsulation ---------------------------------------------------------------------------
@@ -550,21 +650,32 @@ __global__ void __launch_bounds__(256) mlkem_keygen_seed_kernel(const uint8_t *_
 // One wavefront per workgroup, G items: K-PKE.KeyGen (cpapke.go:66-110).
 //   t-hat[i] = ToMont(sum_j A[i][j] s-hat[j]) + e-hat[i], normalised; ek = Pack(t-hat) || rho;
 //   dk = Pack(s-hat) || ek || (H(ek), z filled in by mlkem_keygen_finish_kernel).
-template <int K>
+template <int K, bool SCRATCH = true>
 __global__ void __launch_bounds__(64) mlkem_keygen_kernel(const uint8_t *__restrict__ rs_ws, uint8_t *__restrict__ ek,
-                                                         uint8_t *__restrict__ dk, size_t n) {
+                                                         uint8_t *__restrict__ dk, uint8_t *__restrict__ scratch, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;
-    uint8_t *lds_noise = smem + Gm::LDS_A;
-    int16_t *xch = reinterpret_cast<int16_t *>(smem + Gm::LDS_A + Gm::LDS_NOISE);
+    uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;
+    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + Gm::LDS_NOISE);
+    int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
-    const size_t item0 = (size_t)blockIdx.x * Gm::G;
-
-    sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
-    prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    const size_t ngroups = (n + Gm::G - 1) / Gm::G;
+
+#pragma unroll 1
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const size_t item0 = grp * Gm::G;
+    if constexpr (SCRATCH) {
+        __syncthreads();
+        sample_matrix_scratch<K, false>(lds_a, rows, rs_ws, 64, item0, n, lane);
+        __threadfence_block();
+    } else {
+        sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
+    }
+    __syncthreads();
+    prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
     __syncthreads();
 
 #pragma unroll 1
@@ -591,8 +702,9 @@ __global__ void __launch_bounds__(64) mlkem_keygen_kernel(const uint8_t *__restr
             kyber::ntt(eh, z, xch, lane);
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                const int16_t *ap = reinterpret_cast<const int16_t *>(lds_a + ((g * K + i) * K + j) * Gm::A_STRIDE) + 4 * lane;
-                const int a[4] = {ap[0], ap[1], ap[2], ap[3]};
+                int a[4];
+                if constexpr (SCRATCH) AFromScratch{rows}.load(a, (g * K + i) * K + j, lane);
+                else AFromLds{lds_a, Gm::A_STRIDE}.load(a, (g * K + i) * K + j, lane);
                 kyber::mulhat_acc(acc, a, sh[j], z.f6);
             }
             kyber::mulhat_finish(acc);
@@ -608,6 +720,7 @@ __global__ void __launch_bounds__(64) mlkem_keygen_kernel(const uint8_t *__restr
             reinterpret_cast<uint32_t *>(dkp + 768 * K)[lane] = w;
         }
     }
+  }
 }
 
 // lane = item: dk tail = H(ek) || z  (kem/mlkem/mlkem768/kyber.go:69-75, :189-201)

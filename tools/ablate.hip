@@ -91,17 +91,28 @@ int main() {
     CK(hipMemcpy(m, h.data(), 32 * n, hipMemcpyHostToDevice));
     const unsigned hb = (unsigned)((n + 255) / 256), eb = (unsigned)((n + Gm::G - 1) / Gm::G);
     hipLaunchKernelGGL(mlkem::mlkem_keygen_seed_kernel<K>, dim3(hb), dim3(256), 0, 0, seed, ws, n);
-    hipLaunchKernelGGL(mlkem::mlkem_keygen_kernel<K>, dim3(eb), dim3(64), Gm::LDS_TOTAL, 0, (const uint8_t *)ws, ek, dk, n);
+    uint8_t *scratch; CK(hipMalloc(&scratch, (size_t)256 * 32 * Gm::SCRATCH_BYTES));
+    hipLaunchKernelGGL((mlkem::mlkem_keygen_kernel<K, false>), dim3(eb), dim3(64), Gm::LDS_TOTAL, 0, (const uint8_t *)ws, ek, dk, scratch, n);
     hipLaunchKernelGGL(mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, 0, ek, m, ss, ws, n);
     CK(hipDeviceSynchronize());
-    struct E { const uint8_t *ek, *m, *r; uint8_t *ct, *ss, *st; size_t n; unsigned eb; } e{ek, m, ws, ct, ss, st, n, eb};
+    struct E { const uint8_t *ek, *m, *r; uint8_t *ct, *ss, *st, *scratch; size_t n; unsigned eb; } e{ek, m, ws, ct, ss, st, scratch, n, eb};
 #define RUN(MASK, NAME)                                                                                                         \
     {                                                                                                                           \
         float ms = time_ms([](void *v) { E *e = (E *)v;                                                                         \
-            hipLaunchKernelGGL((mlkem::mlkem_encrypt_kernel<K, mlkem::ENCAPS, MASK>), dim3(e->eb), dim3(64), Gm::LDS_TOTAL, 0, e->ek, \
-                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->n); }, &e); \
+            hipLaunchKernelGGL((mlkem::mlkem_encrypt_kernel<K, mlkem::ENCAPS, MASK, false>), dim3(e->eb), dim3(64), Gm::LDS_TOTAL, 0, e->ek, \
+                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, e->n); }, &e); \
         printf("  %-28s %.3f ms\n", NAME, ms);                                                                                  \
     }
+#define RUNS(MASK, BPC, NAME)                                                                                                   \
+    {                                                                                                                           \
+        e.eb = 256 * BPC;                                                                                                       \
+        float ms = time_ms([](void *v) { E *e = (E *)v;                                                                         \
+            hipLaunchKernelGGL((mlkem::mlkem_encrypt_kernel<K, mlkem::ENCAPS, MASK, true>), dim3(e->eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, 0, e->ek, \
+                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, e->n); }, &e); \
+        printf("  %-28s %.3f ms  (%d blocks/CU)\n", NAME, ms, BPC);                                                              \
+        e.eb = eb;                                                                                                              \
+    }
+    printf("  LDS per workgroup: %d bytes\n", Gm::LDS_TOTAL);
     RUN(0, "full");
     RUN(1, "without A (matrix)");
     RUN(2, "without B (prf)");
@@ -110,6 +121,15 @@ int main() {
     RUN(5, "B only");
     RUN(3, "C only");
     RUN(7, "nothing (launch + zetas)");
+    printf("  -- scratch variant (persistent), LDS %d bytes --\n", Gm::LDS_SCRATCH_TOTAL);
+    RUNS(0, 4, "scratch full");
+    RUNS(0, 8, "scratch full");
+    RUNS(0, 12, "scratch full");
+    RUNS(0, 16, "scratch full");
+    RUNS(0, 20, "scratch full");
+    RUNS(6, 16, "scratch A only");
+    RUNS(3, 16, "scratch C only");
+    RUNS(5, 16, "scratch B only");
     {
         float ms = time_ms([](void *v) { E *e = (E *)v;
             hipLaunchKernelGGL(mlkem::mlkem_hash_kernel<K>, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, 0, e->ek, e->m, e->ss, (uint8_t *)e->r, e->n); }, &e);
