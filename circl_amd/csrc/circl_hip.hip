@@ -475,7 +475,7 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, 64,
+        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, 128,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);

@@ -25,6 +25,11 @@
 #pragma once
 #include "kyber_dev.h"
 
+// minimum waves per SIMD the scratch-variant kernels are register-allocated for (<= 512 / VGPRs)
+#ifndef CIRCL_KEM_WAVES_PER_EU
+#define CIRCL_KEM_WAVES_PER_EU 4
+#endif
+
 namespace circl {
 namespace mlkem {
 
@@ -398,7 +403,7 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
 // a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
 // or LDS (one group per workgroup; kept for A/B measurements).
 template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true>
-__global__ void __launch_bounds__(64) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
+__global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                           uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
@@ -651,7 +656,7 @@ __global__ void __launch_bounds__(256) mlkem_keygen_seed_kernel(const uint8_t *_
 //   t-hat[i] = ToMont(sum_j A[i][j] s-hat[j]) + e-hat[i], normalised; ek = Pack(t-hat) || rho;
 //   dk = Pack(s-hat) || ek || (H(ek), z filled in by mlkem_keygen_finish_kernel).
 template <int K, bool SCRATCH = true>
-__global__ void __launch_bounds__(64) mlkem_keygen_kernel(const uint8_t *__restrict__ rs_ws, uint8_t *__restrict__ ek,
+__global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_keygen_kernel(const uint8_t *__restrict__ rs_ws, uint8_t *__restrict__ ek,
                                                          uint8_t *__restrict__ dk, uint8_t *__restrict__ scratch, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
