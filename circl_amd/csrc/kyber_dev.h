@@ -215,10 +215,19 @@ CIRCL_HD int cbd3_from_6bits(unsigned t) {
 // poly.go:248-332 CompressTo arithmetic for x in [0,q): round(x 2^d / q) mod 2^d with the
 // reference's multiply-shift constants (proven exact on that domain, poly.go:254-260).
 template <int D> CIRCL_HD unsigned compress_coeff(int x) {
+    const unsigned y = ((unsigned)x << D) + Q / 2;
     if constexpr (D == 4 || D == 5) {
-        return ((((unsigned)x << D) + Q / 2) * 315u >> 20) & ((1u << D) - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (__umul24(y, 315u) >> 20) & ((1u << D) - 1);  // y < 2^17: one full-rate 24-bit multiply
+#else
+        return (y * 315u >> 20) & ((1u << D) - 1);
+#endif
     } else {
-        return (unsigned)(((uint64_t)(((unsigned)x << D) + Q / 2) * 20642679ull) >> 36) & ((1u << D) - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (__umulhi(y, 20642679u) >> 4) & ((1u << D) - 1);  // (y * M) >> 36 via the high half
+#else
+        return (unsigned)(((uint64_t)y * 20642679ull) >> 36) & ((1u << D) - 1);
+#endif
     }
 }
 // poly.go:170-243 Decompress arithmetic

@@ -362,6 +362,42 @@ template <int D> __device__ __forceinline__ bool pack_bits_differs(const uint32_
     return diff;
 }
 
+// Lane-local bit packing.  `v[r]` is the D-bit value of coefficient l + 64 r (layout L1).  Field n
+// starts at bit D*n = D*l + 64*D*r, so all four fields of a lane share the shift (D*l) mod 32 and
+// sit 2*D dwords apart: each is OR-ed into a zeroed LDS staging area with at most two 32-bit
+// atomics, then the 8*D dwords of the polynomial are streamed out (or compared) coalesced.
+template <int D> __device__ __forceinline__ void stage_bits_l1(uint32_t *stage, const unsigned (&v)[4], int lane) {
+    constexpr int WORDS = 8 * D;
+    __syncthreads();  // previous users of the staging area are done
+    for (int w = lane; w < WORDS; w += 64) stage[w] = 0;
+    __syncthreads();
+    const int bit = D * lane, w0 = bit >> 5, sh = bit & 31;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        atomicOr(&stage[w0 + 2 * D * r], v[r] << sh);
+        if (sh + D > 32) atomicOr(&stage[w0 + 2 * D * r + 1], v[r] >> (32 - sh));
+    }
+    __syncthreads();
+}
+template <int D> __device__ __forceinline__ void store_staged(uint32_t *dst, const uint32_t *stage, int lane, bool zero) {
+    constexpr int WORDS = 8 * D;
+#pragma unroll
+    for (int w0 = 0; w0 < WORDS; w0 += 64) {
+        const int w = w0 + lane;
+        if (w < WORDS) dst[w] = zero ? 0u : stage[w];
+    }
+}
+template <int D> __device__ __forceinline__ bool staged_differs(const uint32_t *ref, const uint32_t *stage, int lane) {
+    constexpr int WORDS = 8 * D;
+    bool diff = false;
+#pragma unroll
+    for (int w0 = 0; w0 < WORDS; w0 += 64) {
+        const int w = w0 + lane;
+        if (w < WORDS) diff |= ref[w] != stage[w];
+    }
+    return diff;
+}
+
 // 12-bit decode of 4 consecutive coefficients (layout L4) from a packed polynomial (poly.go:123-129)
 __device__ __forceinline__ void unpack12_l4(int (&c)[4], const uint8_t *poly, int lane) {
     const uint16_t *src = reinterpret_cast<const uint16_t *>(poly + 6 * lane);
@@ -483,21 +519,15 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             kyber::mulhat_finish(acc);
             kyber::invntt(acc, z, xch, lane);
             const uint8_t *e1 = noise + (K + i) * Gm::NOISE_STRIDE;
-            uint16_t *cq = reinterpret_cast<uint16_t *>(xch);
-            __syncthreads();
+            unsigned cv[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int nidx = kyber::idx_l1(lane, r);
-                const int x = kyber::normalize(acc[r] + cbd_coeff<2>(e1, nidx));
-                cq[nidx] = (uint16_t)kyber::compress_coeff<P::DU>(x);
-            }
-            __syncthreads();
+            for (int r = 0; r < 4; r++)
+                cv[r] = kyber::compress_coeff<P::DU>(kyber::normalize(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r))));
+            uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
+            stage_bits_l1<P::DU>(stage, cv, lane);
             uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i);
-            if (MODE == REENCRYPT) differs |= pack_bits_differs<P::DU>(dst, cq, lane);
-            else if (!reject) pack_bits_store<P::DU>(dst, cq, lane);
-            else {
-                for (int w = lane; w < 8 * P::DU; w += 64) dst[w] = 0;
-            }
+            if (MODE == REENCRYPT) differs |= staged_differs<P::DU>(dst, stage, lane);
+            else store_staged<P::DU>(dst, stage, lane, reject);
         }
         // v = InvNTT(<t-hat, r-hat>) + e2 + Decompress_q(m, 1)  (cpapke.go:167-173), dv bits
         {
@@ -508,22 +538,18 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             kyber::invntt(acc, z, xch, lane);
             const uint8_t *e2 = noise + 2 * K * Gm::NOISE_STRIDE;
             const uint8_t *mp = m + item * 32;
-            uint16_t *cq = reinterpret_cast<uint16_t *>(xch);
-            __syncthreads();
+            unsigned cv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
                 const int mbit = (mp[nidx >> 3] >> (nidx & 7)) & 1;
-                const int x = kyber::normalize(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2)));
-                cq[nidx] = (uint16_t)kyber::compress_coeff<P::DV>(x);
+                cv[r] = kyber::compress_coeff<P::DV>(kyber::normalize(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2))));
             }
-            __syncthreads();
+            uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
+            stage_bits_l1<P::DV>(stage, cv, lane);
             uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * K);
-            if (MODE == REENCRYPT) differs |= pack_bits_differs<P::DV>(dst, cq, lane);
-            else if (!reject) pack_bits_store<P::DV>(dst, cq, lane);
-            else {
-                for (int w = lane; w < 8 * P::DV; w += 64) dst[w] = 0;
-            }
+            if (MODE == REENCRYPT) differs |= staged_differs<P::DV>(dst, stage, lane);
+            else store_staged<P::DV>(dst, stage, lane, reject);
         }
         if (MODE == ENCAPS) {
             if (lane == 0) status[item] = reject ? 1 : 0;
