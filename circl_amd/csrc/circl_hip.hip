@@ -98,7 +98,7 @@ template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
 
 size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
 // ML-KEM workspace: 128 B per item + one 32 KB scratch slice per resident workgroup
-size_t kem_ws_bytes(size_t n) { return up256(128 * n) + max_resident_blocks() * 64 * 512; }
+size_t kem_ws_bytes(size_t n) { return up256(128 * n) + 256 + max_resident_blocks() * 64 * 512; }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -114,7 +114,9 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
         return CIRCL_HIP_EWORKSPACE;
     uint8_t *r_ws = static_cast<uint8_t *>(ws);
-    uint8_t *scratch = r_ws + up256(128 * n);
+    unsigned *work = reinterpret_cast<unsigned *>(r_ws + up256(128 * n));
+    uint8_t *scratch = r_ws + up256(128 * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -125,7 +127,7 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, n);
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, work, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -138,7 +140,9 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *mprime = static_cast<uint8_t *>(ws), *r_ws = mprime + 32 * n, *kbar = mprime + 64 * n, *ssrej = mprime + 96 * n;
-    uint8_t *scratch = mprime + up256(128 * n);
+    unsigned *work = reinterpret_cast<unsigned *>(mprime + up256(128 * n));
+    uint8_t *scratch = mprime + up256(128 * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
         hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, ct, mprime, n);
@@ -154,7 +158,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
                            (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej,
-                           scratch, n);
+                           scratch, work, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -166,7 +170,9 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *rs = static_cast<uint8_t *>(ws);
-    uint8_t *scratch = rs + up256(128 * n);
+    unsigned *work = reinterpret_cast<unsigned *>(rs + up256(128 * n));
+    uint8_t *scratch = rs + up256(128 * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -176,7 +182,7 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
         auto kern = circl::mlkem::mlkem_keygen_kernel<K, true>;
         const unsigned kb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
-        hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, (const uint8_t *)rs, ek, dk, scratch, n);
+        hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, (const uint8_t *)rs, ek, dk, scratch, work, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_FINISH, st);
@@ -430,7 +436,7 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_encaps_dev(param, in[0], in[1], out[0], out[1], out[2], c, ws, wsb, st);
-                           }, max_resident_blocks() * 64 * 512);
+                           }, 256 + max_resident_blocks() * 64 * 512);
     });
 }
 
@@ -467,7 +473,7 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_decaps_dev(param, in[0], in[1], out[0], out[1], c, ws, wsb, st);
-                           }, max_resident_blocks() * 64 * 512);
+                           }, 256 + max_resident_blocks() * 64 * 512);
     });
 }
 
@@ -479,7 +485,7 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
-                           }, max_resident_blocks() * 64 * 512);
+                           }, 256 + max_resident_blocks() * 64 * 512);
     });
 }
 

@@ -424,6 +424,16 @@ template <int D> __device__ __forceinline__ unsigned get_bits(const uint8_t *p, 
     return (w >> sh) & ((1u << D) - 1);
 }
 
+// Resident workgroups pull groups of G items from a global ticket counter (zeroed by the host before
+// the launch): equal finish times without a static schedule.  work == nullptr means one group per
+// workgroup (grid = number of groups).
+__device__ __forceinline__ size_t next_group(unsigned *work, int lane, bool first, size_t ngroups) {
+    if (work == nullptr) return first ? (size_t)blockIdx.x : ngroups;  // wave-uniform
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(work, 1u);
+    return (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+}
+
 // ---- kernel 2: K-PKE.Encrypt ------------------------------------------------------------------
 
 enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                           uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
-                                                          const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, size_t n) {
+                                                          const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -456,7 +466,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     const size_t ngroups = (n + Gm::G - 1) / Gm::G;
 
 #pragma unroll 1
-  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
     if (!(ABLATE & 1)) {
         if constexpr (SCRATCH) {
@@ -683,7 +693,7 @@ __global__ void __launch_bounds__(256) mlkem_keygen_seed_kernel(const uint8_t *_
 //   dk = Pack(s-hat) || ek || (H(ek), z filled in by mlkem_keygen_finish_kernel).
 template <int K, bool SCRATCH = true>
 __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_keygen_kernel(const uint8_t *__restrict__ rs_ws, uint8_t *__restrict__ ek,
-                                                         uint8_t *__restrict__ dk, uint8_t *__restrict__ scratch, size_t n) {
+                                                         uint8_t *__restrict__ dk, uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -696,7 +706,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     const size_t ngroups = (n + Gm::G - 1) / Gm::G;
 
 #pragma unroll 1
-  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
     if constexpr (SCRATCH) {
         __syncthreads();
