@@ -184,7 +184,8 @@ template <class F> __device__ __forceinline__ void for_each_candidate23(const Ke
 
 // ---- kernel V -----------------------------------------------------------------------------------
 
-template <int MODE>
+// ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase 1, bit 1 phase 2, bit 2 phase 3.
+template <int MODE, int ABLATE = 0>
 __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
                                                          uint8_t *__restrict__ muw1_ws, const uint8_t *__restrict__ ball_ws,
                                                          uint8_t *__restrict__ fail_ws, size_t n) {
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
 #pragma unroll
         for (int r = 0; r < 4; r++) chat[g][r] = 0;
         const size_t item = item0 + g;
-        if (item >= n) continue;  // wave-uniform
+        if (item >= n || (ABLATE & 1)) continue;  // wave-uniform
         const uint8_t *sg = sig + item * G::SIG;
         bool bad = false;
         // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
     __syncthreads();
 
     // ------------------------------ phase 2 ------------------------------
-    {
+    if (!(ABLATE & 2)) {
         const bool on = lane < G::IT * G::STREAMS;
         const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
         const int i = p / L, j = p % L;
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
 
     // ------------------------------ phase 3 ------------------------------
 #pragma unroll 1
-    for (int g = 0; g < G::IT; g++) {
+    for (int g = 0; g < ((ABLATE & 4) ? 0 : G::IT); g++) {
         const size_t item = item0 + g;
         if (item >= n) break;
         uint8_t *w1out = muw1_ws + item * G::MUW1 + 64;

@@ -49,11 +49,7 @@ template <int K> struct Geom {
     static constexpr int G = 64 / PAIRS;                 // items per workgroup
     static constexpr int A_STREAMS = G * PAIRS;          // <= 64
     static constexpr int NOISE = 2 * K + 1;              // PRF streams per item (encrypt); keygen uses 2K
-#ifndef CIRCL_EXPERIMENT_A_STRIDE
     static constexpr int A_STRIDE = 520;                 // bytes per sampled polynomial (+1 spill slot, 8-B aligned)
-#else
-    static constexpr int A_STRIDE = CIRCL_EXPERIMENT_A_STRIDE;  // tools/ablate.hip occupancy experiment (wrong results)
-#endif
     static constexpr int NOISE_BYTES = 64 * P::ETA1;     // eta1 stream length (eta2 streams use 128)
     static constexpr int NOISE_STRIDE = NOISE_BYTES + 8; // breaks the power-of-two bank stride
     static constexpr int LDS_A = A_STREAMS * A_STRIDE;
@@ -146,11 +142,7 @@ __device__ __forceinline__ void parse_shake128_block(const KeccakState &s, int16
         uint32_t v;
         if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
         else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
-#ifndef CIRCL_EXPERIMENT_A_STRIDE
         poly[cnt] = (int16_t)v;
-#else
-        poly[cnt & (CIRCL_EXPERIMENT_A_STRIDE / 2 - 1)] = (int16_t)v;
-#endif
         cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
     });
 }
