@@ -182,6 +182,28 @@ template <class F> __device__ __forceinline__ void for_each_candidate23(const Ke
     });
 }
 
+// Copies `nbytes` starting at the (arbitrarily aligned) global address `src` into LDS as aligned
+// dwords: aligned 32-bit loads plus a funnel shift by the (wave-uniform) misalignment.  Never reads
+// at or beyond src + nbytes rounded up to the enclosing aligned dword.
+__device__ __forceinline__ void stage_unaligned(uint32_t *dst, const uint8_t *src, int nbytes, int lane) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src) & 3;
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(src - a);
+    const int ndw = (nbytes + 3) >> 2;                   // dwords to produce
+    const int last = (int)((a + nbytes - 1) >> 2);       // last aligned dword that holds payload
+    for (int d = lane; d < ndw; d += 64) {
+        const uint32_t w0 = base[d];
+        const uint32_t w1 = (d + 1 <= last) ? base[d + 1] : 0u;
+        dst[d] = a ? alignbit(w1, w0, 8 * (uint32_t)a) : w0;
+    }
+}
+// D-bit field n of a little-endian bit stream held as dwords in LDS (one dword of slack after the
+// stream is required: the staging buffer is over-allocated)
+template <int D> __device__ __forceinline__ uint32_t lds_bits(const uint32_t *p, int byte_off_dw, int n) {
+    const int bit = n * D, w = byte_off_dw + (bit >> 5), sh = bit & 31;
+    const uint32_t lo = p[w], hi = p[w + 1];
+    return (sh ? alignbit(hi, lo, (uint32_t)sh) : lo) & ((1u << D) - 1);
+}
+
 // ---- kernel V -----------------------------------------------------------------------------------
 
 // ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase 1, bit 1 phase 2, bit 2 phase 3.
@@ -205,11 +227,14 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
     uint32_t chat[G::IT][4];
     bool fail[G::IT];
 
-    // zero the accumulators and hint bitmaps
-    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
     for (int i = lane; i < G::IT * K * 8; i += 64) hintbits[i] = 0;
 
     // ------------------------------ phase 1 ------------------------------
+    // The accumulator area is free until phase 2: it stages the (unaligned) z || hint part of the
+    // signature as aligned dwords.
+    uint32_t *stg = acc;
+    constexpr int ZH_BYTES = L * G::ZSZ + P::OMEGA + K;
+    static_assert(ZH_BYTES + 8 <= G::LDS_ACC, "staging fits in the accumulator area");
 #pragma unroll
     for (int g = 0; g < G::IT; g++) {
         fail[g] = false;
@@ -219,12 +244,16 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
         if (item >= n || (ABLATE & 1)) continue;  // wave-uniform
         const uint8_t *sg = sig + item * G::SIG;
         bool bad = false;
+        __syncthreads();
+        stage_unaligned(stg, sg + P::CT, ZH_BYTES, lane);
+        if (lane == 0) stg[(ZH_BYTES + 3) >> 2] = 0;  // slack dword for lds_bits
+        __syncthreads();
         // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
         for (int j = 0; j < L; j++) {
             uint32_t c[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t f = get_bits32<G::ZBITS>(sg + P::CT + j * G::ZSZ, kyber::idx_l1(lane, r));
+                const uint32_t f = lds_bits<G::ZBITS>(stg, j * (G::ZSZ / 4), kyber::idx_l1(lane, r));
                 uint32_t x = G::GAMMA1 - f;
                 x += (uint32_t)((int32_t)x >> 31) & Q;
                 bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
@@ -237,7 +266,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
         }
         // hints: strict decoding (pack.go:113-141)
         {
-            const uint8_t *hb = sg + P::CT + L * G::ZSZ;
+            const uint8_t *hb = reinterpret_cast<const uint8_t *>(stg) + L * G::ZSZ;
             uint32_t sop[K];
 #pragma unroll
             for (int i = 0; i < K; i++) sop[i] = hb[P::OMEGA + i];
@@ -263,59 +292,60 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
         }
         fail[g] = __any(bad);
 
-        // SampleInBall (sample.go:299-339): 8 sign bytes, then bytes b <= i pick the positions
+        // SampleInBall (sample.go:299-339): 8 sign bytes, then bytes b <= i pick the positions.
+        // Lane p keeps bytes p, p+64 and p+128 of the current 136-byte block in registers; one step is
+        // three compares + ballots, scalar bit tricks and one v_readlane -- no memory traffic.
         {
-            __syncthreads();
             const uint8_t *st = ball_ws + item * kBallStateBytes;
-            uint8_t *blk = misc;          // current 136-byte block
-            uint8_t *jpos = misc + 144;   // chosen positions j_t, t < tau
-            for (int i = lane; i < 34; i += 64) reinterpret_cast<uint32_t *>(blk)[i] = reinterpret_cast<const uint32_t *>(st)[i];
-            __syncthreads();
-            const unsigned long long signs = reinterpret_cast<const unsigned long long *>(blk)[0];
-            int off = 8;  // next unread byte of blk
+            const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
+            uint32_t b0 = st[lane], b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
+            int off = 8;  // next unread byte of the block
+            uint32_t jt = 0;  // lane t keeps j_t
             KeccakState bs;
             bool have_state = false;
             for (int t = 0; t < P::TAU; t++) {
                 const uint32_t i = 256 - P::TAU + t;
                 int found = -1;
+                uint32_t jv = 0;
                 while (found < 0) {
-                    // lanes look at bytes off+lane, off+64+lane, off+128+lane of the block
-                    unsigned long long m0 = __ballot(off + lane < 136 && blk[min(off + lane, 135)] <= i);
-                    unsigned long long m1 = __ballot(off + 64 + lane < 136 && blk[min(off + 64 + lane, 135)] <= i);
-                    unsigned long long m2 = __ballot(off + 128 + lane < 136 && blk[min(off + 128 + lane, 135)] <= i);
-                    if (m0) found = off + __ffsll((long long)m0) - 1;
-                    else if (m1) found = off + 64 + __ffsll((long long)m1) - 1;
-                    else if (m2) found = off + 128 + __ffsll((long long)m2) - 1;
+                    unsigned long long m0 = __ballot(b0 <= i), m1 = __ballot(b1 <= i), m2 = __ballot(b2 <= i);
+                    if (off >= 128) { m0 = 0; m1 = 0; m2 &= ~0ull << (off - 128); }
+                    else if (off >= 64) { m0 = 0; m1 &= ~0ull << (off - 64); }
+                    else m0 &= ~0ull << off;
+                    if (m0) { const int p = __ffsll((long long)m0) - 1; found = p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b0, p); }
+                    else if (m1) { const int p = __ffsll((long long)m1) - 1; found = 64 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b1, p); }
+                    else if (m2) { const int p = __ffsll((long long)m2) - 1; found = 128 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b2, p); }
                     else {
-                        // block exhausted: squeeze the next one (every lane runs the same permutation)
+                        // block exhausted (rare): squeeze the next one; every lane runs the same permutation
                         if (!have_state) {
-                            const uint64_t *sw = reinterpret_cast<const uint64_t *>(st);
                             keccak_zero(bs);
-                            xor_words<0, 25>(bs, sw);
+                            xor_words<0, 25>(bs, reinterpret_cast<const uint64_t *>(st));
                             have_state = true;
                         }
                         keccak_f1600(bs);
+                        uint8_t *blk = misc;
                         __syncthreads();
                         if (lane == 0) store_words<0, 17>(reinterpret_cast<uint64_t *>(blk), bs);
                         __syncthreads();
+                        b0 = blk[lane]; b1 = blk[64 + lane]; b2 = lane < 8 ? (uint32_t)blk[128 + lane] : 0xfffu;
                         off = 0;
                     }
                 }
-                if (lane == 0) jpos[t] = blk[found];
+                if (lane == t) jt = jv;
                 off = found + 1;
             }
-            __syncthreads();
             // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a
-            // later step t' with j_t' == (its current position) moves it to i_t'
+            // later step t2 with j_t2 == (its current position) moves it to i_t2
+            uint32_t pos = jt;
+            for (int t2 = 1; t2 < P::TAU; t2++) {
+                const uint32_t j2 = (uint32_t)__builtin_amdgcn_readlane((int)jt, t2);
+                if (t2 > lane && j2 == pos) pos = 256 - P::TAU + t2;
+            }
             uint32_t *cpoly = xch;
+            __syncthreads();
             for (int i = lane; i < 256; i += 64) cpoly[i] = 0;
             __syncthreads();
-            if (lane < P::TAU) {
-                uint32_t pos = jpos[lane];
-                for (int t2 = lane + 1; t2 < P::TAU; t2++)
-                    if (jpos[t2] == pos) pos = 256 - P::TAU + t2;
-                cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
-            }
+            if (lane < P::TAU) cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
             __syncthreads();
             uint32_t c[4];
 #pragma unroll
@@ -325,6 +355,9 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
             for (int r = 0; r < 4; r++) chat[g][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // c-hat * 2^24
         }
     }
+    __syncthreads();
+    // zero the accumulators (they held the staged signature bytes)
+    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
     __syncthreads();
 
     // ------------------------------ phase 2 ------------------------------
@@ -374,16 +407,15 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
                 w[r] = dilithium::fold(acc[(g * K + i) * G::PSTRIDE + 4 * lane + r] + 4 * Q - ct1);
             }
             dilithium::invntt(w, z, xch, lane);
-            uint16_t *w1v = reinterpret_cast<uint16_t *>(xch);
-            __syncthreads();
+            unsigned w1v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
                 const uint32_t hbit = (hintbits[(g * K + i) * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
-                w1v[nidx] = (uint16_t)dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
+                w1v[r] = dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
             }
-            __syncthreads();
-            mlkem::pack_bits_store<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), w1v, lane);
+            mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
+            mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), xch, lane, false);
         }
         if (lane == 0 && fail[g]) fail_ws[item] = 1;
     }
