@@ -1,0 +1,130 @@
+"""BASELINE.json's full batch sizes on the GPU, checked through size-independent properties
+(keygen -> encaps -> decaps round trip on all items, verification results of a tiled signed pool)
+plus bit-exact oracle parity on a uniform sample.  Device-resident (torch owns the HBM buffers)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mlkem768_roundtrip_2p20_device_resident():
+    # configs[1] / configs[2] shape: ML-KEM-768 Encaps + Decaps, batch 2^20 per GPU
+    import torch
+    from circl_amd import device as cdev
+    from oracle import orc
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(20)
+    seeds = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    m = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    eng = cdev.MLKEMDevice(768, n)
+    ek, dk = eng.keygen(seeds)
+    ct = torch.empty((n, 1088), dtype=torch.uint8, device="cuda")
+    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.uint8, device="cuda")
+    eng.encaps(ek, m, ct, ss, st)
+    ss2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    st2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    eng.decaps(dk, ct, ss2, st2)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0 and int(st2.sum()) == 0
+    assert bool((ss == ss2).all())                      # all 2^20 items round-trip
+    assert int((ss == 0).all(dim=1).sum()) == 0          # no untouched rows
+    # corrupted ciphertexts decapsulate to something else (implicit rejection), for every item
+    ct[:, 17] ^= 0x20
+    ss3 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    eng.decaps(dk, ct, ss3, st2)
+    torch.cuda.synchronize()
+    assert int((ss3 == ss).all(dim=1).sum()) == 0
+    ct[:, 17] ^= 0x20
+    # bit-exact oracle parity on a uniform sample of 2^12 items, all three operations
+    idx = torch.from_numpy(np.random.default_rng(1).choice(n, 1 << 12, replace=False)).cuda()
+    ek0, dk0 = orc.mlkem_keygen(768, seeds[idx].cpu().numpy())
+    assert (ek0 == ek[idx].cpu().numpy()).all() and (dk0 == dk[idx].cpu().numpy()).all()
+    ct0, ss0, _ = orc.mlkem_encaps(768, ek0, m[idx].cpu().numpy())
+    assert (ct0 == ct[idx].cpu().numpy()).all() and (ss0 == ss[idx].cpu().numpy()).all()
+    ss30, _ = orc.mlkem_decaps(768, dk0, np.ascontiguousarray(ct0 ^ np.eye(1, 1088, 17, dtype=np.uint8) * 0x20))
+    assert (ss30 == ss3[idx].cpu().numpy()).all()
+
+
+def test_mlkem1024_roundtrip_2p18():
+    import torch
+    from circl_amd import device as cdev
+    n = 1 << 18
+    g = torch.Generator(device="cuda").manual_seed(21)
+    seeds = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    m = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    eng = cdev.MLKEMDevice(1024, n)
+    ek, dk = eng.keygen(seeds)
+    ct = torch.empty((n, 1568), dtype=torch.uint8, device="cuda")
+    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    eng.encaps(ek, m, ct, ss)
+    ss2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    eng.decaps(dk, ct, ss2)
+    torch.cuda.synchronize()
+    assert bool((ss == ss2).all()) and int(eng.status.sum()) == 0
+
+
+@pytest.mark.parametrize("param", [65, 87])
+def test_mldsa_verify_2p18_tiled_pool(param):
+    # configs[3] shape: ML-DSA-65 verify, batch 2^18, >= 1 % corrupted signatures
+    import torch
+    from circl_amd import _native as nat
+    from oracle import orc
+    L = nat.lib()
+    n, pool = 1 << 18, 1 << 9
+    rng = np.random.default_rng(param)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (pool, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(pool)]
+    sig = orc.mldsa_sign(param, sk, msgs)
+    want = np.ones(pool, np.uint8)
+    bad = rng.choice(pool, pool // 32, replace=False)
+    ct = {65: 48, 87: 64}[param]
+    for k, i in enumerate(bad):
+        if k % 3 == 0:
+            sig[i, int(rng.integers(0, ct))] ^= 1            # c~
+        elif k % 3 == 1:
+            sig[i, ct + int(rng.integers(0, 2000))] ^= 8     # z
+        else:
+            sig[i, -1] = 0xFF                                # non-canonical hint
+    want[bad] = 0
+    assert (orc.mldsa_verify(param, pk, sig, msgs) == want).all()
+    reps = n // pool
+    d_pk = torch.from_numpy(np.tile(pk, (reps, 1))).cuda()
+    d_sig = torch.from_numpy(np.tile(sig, (reps, 1))).cuda()
+    d_msg = torch.from_numpy(np.frombuffer(b"".join(msgs) * reps + b"\0" * 16, np.uint8).copy()).cuda()
+    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+    ok = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wsb = L.circl_hip_mldsa_workspace_size(param, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    rc = L.circl_hip_mldsa_verify_dev(param, d_pk.data_ptr(), d_sig.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), None, None,
+                                      ok.data_ptr(), n, ws.data_ptr(), wsb, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (ok.cpu().numpy() == np.tile(want, reps)).all()
+
+
+def test_two_streams_concurrently():
+    # entry points are re-entrant: two device-resident batches on two streams with separate workspaces
+    import torch
+    from circl_amd import device as cdev
+    from oracle import orc
+    n = 5000
+    rng = np.random.default_rng(8)
+    res = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    inputs = []
+    for k in range(2):
+        ek, _ = orc.mlkem_keygen(768, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+        m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        inputs.append((ek, m, torch.from_numpy(ek).cuda(), torch.from_numpy(m).cuda(), cdev.MLKEMDevice(768, n)))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                inputs[k][4].encaps(inputs[k][2], inputs[k][3])
+    torch.cuda.synchronize()
+    for k in range(2):
+        ct0, ss0, _ = orc.mlkem_encaps(768, inputs[k][0], inputs[k][1])
+        assert (inputs[k][4].ct.cpu().numpy() == ct0).all() and (inputs[k][4].ss.cpu().numpy() == ss0).all()
