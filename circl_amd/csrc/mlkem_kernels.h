@@ -178,21 +178,28 @@ __device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__r
 // Scratch variant of phase A.  Each lane appends accepted coefficients to a 32-slot LDS FIFO and
 // flushes 8 of them (16 bytes) at a time to its 512-byte row of the workgroup's global scratch, so
 // every global store is a full 16-byte segment.  Same branch-free acceptance as above.
+// TAIL = true is used from the 4th block on, where only the few unfinished streams still matter: the
+// wave leaves the block as soon as every stream is complete (checked at the 8-candidate flush points).
+template <bool TAIL>
 __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, int16_t *fifo, int16_t *row, int &cnt, int &flushed) {
+    bool live = true;
     detail::static_for<0, 112>([&](auto ic) {
         constexpr int c = decltype(ic)::v;
         constexpr int bit = 12 * c, w = bit / 32, sh = bit % 32;
         auto word = [&](int i) -> uint32_t { return (i & 1) ? s.hi[i >> 1] : s.lo[i >> 1]; };
-        uint32_t v;
-        if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
-        else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
-        fifo[cnt & 31] = (int16_t)v;
-        cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
-        if constexpr (c % 8 == 7) {
-            if (cnt - flushed >= 8) {  // at most 15 pending here, so one flush per check suffices
-                const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 31));
-                *reinterpret_cast<uint4 *>(row + flushed) = d;
-                flushed += 8;
+        if (!TAIL || live) {
+            uint32_t v;
+            if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
+            else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
+            fifo[cnt & 31] = (int16_t)v;
+            cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
+            if constexpr (c % 8 == 7) {
+                if (cnt - flushed >= 8) {  // at most 15 pending here, so one flush per check suffices
+                    const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 31));
+                    *reinterpret_cast<uint4 *>(row + flushed) = d;
+                    flushed += 8;
+                }
+                if constexpr (TAIL) live = __any(flushed < 256);  // wave-uniform
             }
         }
     });
@@ -216,9 +223,15 @@ __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t
     int16_t *row = rows + lane * 256;
     int cnt = on ? 0 : 256, flushed = cnt;
 #pragma unroll 1
-    for (int blk = 0; blk < 3 || __any(cnt < 256); blk++) {
+    for (int blk = 0; blk < 3; blk++) {
         keccak_f1600(s);
-        if (on) parse_shake128_block_fifo(s, fifo, row, cnt, flushed);
+        if (on) parse_shake128_block_fifo<false>(s, fifo, row, cnt, flushed);
+    }
+    // a fourth block is needed by 0.83 % of the streams, more essentially never
+#pragma unroll 1
+    while (__any(flushed < 256)) {
+        keccak_f1600(s);
+        parse_shake128_block_fifo<true>(s, fifo, row, cnt, flushed);
     }
 }
 
