@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libcirclhip.so")
 SYMBOLS = [
     "circl_hip_init", "circl_hip_device_count", "circl_hip_last_error", "circl_hip_version",
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
-    "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size",
+    "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
+    "circl_hip_mldsa_keygen", "circl_hip_mldsa_keygen_dev",
     "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
     "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
     "circl_hip_mlkem_keygen_dev",
@@ -64,7 +65,7 @@ def lib():
         _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for s in ("circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
-                  "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size"):
+                  "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size"):
             getattr(L, s).restype = C.c_size_t
             getattr(L, s).argtypes = [C.c_int]
         for s in ("circl_hip_mlkem_workspace_size", "circl_hip_mldsa_workspace_size"):
@@ -83,6 +84,8 @@ def lib():
         L.circl_hip_mlkem_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_keygen.argtypes = [i, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify_internal.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_verify_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_keccak_f1600.argtypes = [vp, sz, i, i]

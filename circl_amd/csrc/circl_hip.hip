@@ -325,6 +325,31 @@ int mldsa_verify_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *
     return CIRCL_HIP_OK;
 }
 
+template <int MODE>
+int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using G = circl::mldsa::DG<MODE>;
+    using Kg = circl::mldsa::KG<MODE>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < 128 * n || !aligned16(ws) || !aligned16(seed32) || !aligned16(pk) || !aligned16(sk)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *es = static_cast<uint8_t *>(ws);
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_keygen_seed_kernel<MODE>, dim3(hb), dim3(256), 0, st, seed32, es, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYGEN, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_keygen_kernel<MODE>, dim3((unsigned)((n + G::IT - 1) / G::IT)), dim3(64), Kg::LDS_TOTAL, st,
+                           (const uint8_t *)es, pk, sk, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_keygen_finish_kernel<MODE>, dim3(hb), dim3(256), 0, st, (const uint8_t *)pk, sk, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
 int mldsa_verify_dev_any(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
                          const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
                          size_t wsb, hipStream_t st) {
@@ -411,6 +436,7 @@ size_t circl_hip_mlkem_ct_size(int param) {
 }
 size_t circl_hip_mldsa_pk_size(int param) { return param == 44 ? 1312 : param == 65 ? 1952 : param == 87 ? 2592 : 0; }
 size_t circl_hip_mldsa_sig_size(int param) { return param == 44 ? 2420 : param == 65 ? 3309 : param == 87 ? 4627 : 0; }
+size_t circl_hip_mldsa_sk_size(int param) { return param == 44 ? 2560 : param == 65 ? 4032 : param == 87 ? 4896 : 0; }
 
 size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? kem_ws_bytes(n) : 0; }
 
@@ -512,6 +538,30 @@ static int mldsa_verify_host(int param, const uint8_t *pk, const uint8_t *sig, c
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return mldsa_verify_host_one(param, dev, pk + lo * PK, sig + lo * SIG, msg_blob, msg_off + lo, ctx_blob,
                                      ctx_blob ? ctx_off + lo : nullptr, internal, ok + lo, cnt);
+    });
+}
+
+int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes,
+                               void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (param) {
+    case 44: return mldsa_keygen_dev_impl<44>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    case 65: return mldsa_keygen_dev_impl<65>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    case 87: return mldsa_keygen_dev_impl<87>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_t n, int device) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SK = circl_hip_mldsa_sk_size(param);
+    if (!PK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {seed32 + lo * 32}, {32}, {pk + lo * PK, sk + lo * SK}, {PK, SK}, 128,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
+                               hipStream_t st) {
+                               return circl_hip_mldsa_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
+                           });
     });
 }
 

@@ -204,6 +204,40 @@ template <int D> __device__ __forceinline__ uint32_t lds_bits(const uint32_t *p,
     return (sh ? alignbit(hi, lo, (uint32_t)sh) : lo) & ((1u << D) - 1);
 }
 
+// Phase 2 of verification and of key generation: lane = (item, i, j) runs the ExpandA stream
+// SHAKE128(rho || LE16((i << 8) + j)) (mat.go:15-49, sample.go:92-123) and folds every accepted
+// coefficient a_k straight into acc[item][i][k] += a_k * vhat[item][j][k] (vhat is stored times 2^24,
+// so mont24 yields the plain product).  rho of item t is at rho + t * rho_stride (8-byte aligned).
+template <int MODE>
+__device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32_t *acc, const uint8_t *__restrict__ rho,
+                                                    size_t rho_stride, size_t item0, size_t n, int lane) {
+    using G = DG<MODE>;
+    constexpr int K = G::K, L = G::L;
+    const bool on = lane < G::IT * G::STREAMS;
+    const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
+    const int i = p / L, j = p % L;
+    size_t item = item0 + g;
+    if (item >= n) item = n - 1;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
+    s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+    s.hi[20] = 0x80000000u;
+    const uint32_t *zrow = vhat + (g * L + j) * G::PSTRIDE;
+    uint32_t *arow = acc + (g * K + i) * G::PSTRIDE;
+    int cnt = on ? 0 : 256;
+#pragma unroll 1
+    for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
+        keccak_f1600(s);
+        for_each_candidate23(s, [&](uint32_t a) {
+            if (a < Q && cnt < 256) {
+                atomicAdd(&arow[cnt], dilithium::mont24(a, zrow[cnt]));  // a * v-hat[j][cnt], < 2q
+                cnt++;
+            }
+        });
+    }
+}
+
 // ---- kernel V -----------------------------------------------------------------------------------
 
 // ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase 1, bit 1 phase 2, bit 2 phase 3.
@@ -361,32 +395,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
     __syncthreads();
 
     // ------------------------------ phase 2 ------------------------------
-    if (!(ABLATE & 2)) {
-        const bool on = lane < G::IT * G::STREAMS;
-        const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
-        const int i = p / L, j = p % L;
-        size_t item = item0 + g;
-        if (item >= n) item = n - 1;
-        KeccakState s;
-        keccak_zero(s);
-        // SHAKE128(rho || LE16((i << 8) + j))  (mat.go:15-49, sample.go:92-123)
-        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(pk + item * G::PK));
-        s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
-        s.hi[20] = 0x80000000u;
-        const uint32_t *zrow = zhat + (g * L + j) * G::PSTRIDE;
-        uint32_t *arow = acc + (g * K + i) * G::PSTRIDE;
-        int cnt = on ? 0 : 256;
-#pragma unroll 1
-        for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
-            keccak_f1600(s);
-            for_each_candidate23(s, [&](uint32_t a) {
-                if (a < Q && cnt < 256) {
-                    atomicAdd(&arow[cnt], dilithium::mont24(a, zrow[cnt]));  // a * z-hat[j][cnt], < 2q
-                    cnt++;
-                }
-            });
-        }
-    }
+    if (!(ABLATE & 2)) expand_a_accumulate<MODE>(zhat, acc, pk, (size_t)G::PK, item0, n, lane);
     __syncthreads();
 
     // ------------------------------ phase 3 ------------------------------
@@ -441,6 +450,180 @@ __global__ void __launch_bounds__(256) mldsa_final_kernel(const uint8_t *__restr
         same &= v == (((uint64_t)s.hi[w] << 32) | s.lo[w]);
     });
     ok[idx] = (same && fail_ws[idx] == 0) ? 1 : 0;
+}
+
+// ---- key generation (sign/mldsa/mldsa65/internal/dilithium.go:181-267 NewKeyFromSeed) ------------
+
+template <int MODE> struct KG {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    static constexpr int ETABITS = P::ETA == 2 ? 3 : 4;              // params.go DoubleEtaBits
+    static constexpr int ETASZ = 32 * ETABITS;
+    static constexpr int SK = 32 + 32 + 64 + ETASZ * (G::L + G::K) + 416 * G::K;
+    static constexpr int NS = G::L + G::K;                            // secret polynomials per item
+    static constexpr int S_STRIDE = 264;                              // int8 row + spill slot
+    static constexpr int LDS_S = G::IT * NS * S_STRIDE;
+    static constexpr int LDS_TOTAL = G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH + LDS_S;
+};
+
+// lane = item: (rho, rho', key) = SHAKE256(seed || K || L)[:128]  (dilithium.go:195-206)
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_keygen_seed_kernel(const uint8_t *__restrict__ seed32, uint8_t *__restrict__ es_ws, size_t n) {
+    using P = DP<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(seed32 + idx * 32));
+    s.lo[4] = (uint32_t)P::K | ((uint32_t)P::L << 8) | (kDsShake << 16);
+    s.hi[16] = 0x80000000u;
+    keccak_f1600(s);
+    store_words<0, 16>(reinterpret_cast<uint64_t *>(es_ws + idx * 128), s);
+}
+
+// One wavefront per workgroup, IT items.  phase 1: lane = (item, secret polynomial) samples s1, s2
+// (sample.go:125-175, SHAKE256(rho' || LE16(nonce)), nibble rejection) into LDS as small integers;
+// then s1-hat = NTT(s1) per polynomial, eta-packing of s1, s2 into sk.  phase 2: ExpandA with
+// multiply-accumulate against s1-hat (same code as verification).  phase 3: t = InvNTT(A s1-hat) + s2,
+// Power2Round (field.go:35-52), t1 -> pk, t0 -> sk.
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_keygen_kernel(const uint8_t *__restrict__ es_ws, uint8_t *__restrict__ pk,
+                                                         uint8_t *__restrict__ sk, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    constexpr int K = P::K, L = P::L, NS = Kg::NS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *shat = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *acc = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT);
+    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC);
+    int8_t *sec = reinterpret_cast<int8_t *>(smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH);
+    const int lane = threadIdx.x;
+    const size_t item0 = (size_t)blockIdx.x * G::IT;
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
+
+    // ---- phase 1a: sample the secrets, one stream per lane ----
+    {
+        const bool on = lane < G::IT * NS;
+        const int g = on ? lane / NS : 0, nonce = on ? lane % NS : 0;
+        size_t item = item0 + g;
+        if (item >= n) item = n - 1;
+        KeccakState s;
+        keccak_zero(s);
+        xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(es_ws + item * 128 + 32));
+        s.lo[8] = (uint32_t)nonce | (kDsShake << 16);
+        s.hi[16] = 0x80000000u;
+        int8_t *row = sec + (on ? lane : 0) * Kg::S_STRIDE;
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        while (__any(cnt < 256)) {
+            keccak_f1600(s);
+            if (on) {
+                detail::static_for<0, 34>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;  // 32-bit word w of the 136-byte block
+                    const uint32_t word = (w & 1) ? s.hi[w >> 1] : s.lo[w >> 1];
+#pragma unroll
+                    for (int nb = 0; nb < 8; nb++) {  // low nibble of each byte first (t1 then t2)
+                        uint32_t t = (word >> (4 * nb)) & 15u;
+                        bool ok;
+                        if constexpr (P::ETA == 2) {
+                            ok = t <= 14;
+                            t -= ((205 * t) >> 10) * 5;
+                        } else {
+                            ok = t <= 8;
+                        }
+                        row[cnt] = (int8_t)(P::ETA - (int)t);
+                        cnt = min(cnt + (ok ? 1 : 0), 256);
+                    }
+                });
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1b: NTT(s1), pack s1 and s2 ----
+#pragma unroll 1
+    for (int g = 0; g < G::IT; g++) {
+        const size_t item = item0 + g;
+        if (item >= n) break;
+        uint8_t *skp = sk + item * Kg::SK;
+#pragma unroll 1
+        for (int k = 0; k < NS; k++) {
+            const int8_t *row = sec + (g * NS + k) * Kg::S_STRIDE;
+            unsigned fld[4];
+            uint32_t c[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int v = row[kyber::idx_l1(lane, r)];   // in [-eta, eta]
+                fld[r] = (unsigned)(P::ETA - v);              // pack.go:9-37: field = q + eta - coefficient
+                c[r] = v < 0 ? Q + v : (uint32_t)v;
+            }
+            mlkem::stage_bits_l1<Kg::ETABITS>(xch, fld, lane);
+            mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + 128 + Kg::ETASZ * k), xch, lane, false);
+            if (k < L) {
+                dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    shat[(g * L + k) * G::PSTRIDE + 4 * lane + r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: t-hat = A s1-hat ----
+    expand_a_accumulate<MODE>(shat, acc, es_ws, 128, item0, n, lane);
+    __syncthreads();
+
+    // ---- phase 3: t = InvNTT(t-hat) + s2, Power2Round, pack ----
+#pragma unroll 1
+    for (int g = 0; g < G::IT; g++) {
+        const size_t item = item0 + g;
+        if (item >= n) break;
+        uint8_t *pkp = pk + item * G::PK, *skp = sk + item * Kg::SK;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] = dilithium::fold(acc[(g * K + i) * G::PSTRIDE + 4 * lane + r]);
+            dilithium::invntt(w, z, xch, lane);
+            const int8_t *s2 = sec + (g * NS + L + i) * Kg::S_STRIDE;
+            unsigned t1[4], t0[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int v = s2[kyber::idx_l1(lane, r)];
+                const uint32_t a = dilithium::csubq(dilithium::fold(w[r] + (v < 0 ? Q + v : (uint32_t)v)));
+                // field.go:35-52 power2round
+                uint32_t a0 = a & ((1u << dilithium::D) - 1);
+                a0 -= (1u << (dilithium::D - 1)) + 1;
+                a0 += (uint32_t)((int32_t)a0 >> 31) & (1u << dilithium::D);
+                a0 -= (1u << (dilithium::D - 1)) - 1;
+                t1[r] = (a - a0) >> dilithium::D;
+                t0[r] = ((1u << (dilithium::D - 1)) - a0) & ((1u << dilithium::D) - 1);  // pack.go:23-50 PackT0 field
+            }
+            mlkem::stage_bits_l1<10>(xch, t1, lane);
+            mlkem::store_staged<10>(reinterpret_cast<uint32_t *>(pkp + 32 + 320 * i), xch, lane, false);
+            mlkem::stage_bits_l1<13>(xch, t0, lane);
+            mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + 128 + Kg::ETASZ * NS + 416 * i), xch, lane, false);
+        }
+        if (lane < 8) {
+            const uint32_t r = reinterpret_cast<const uint32_t *>(es_ws + item * 128)[lane];
+            reinterpret_cast<uint32_t *>(pkp)[lane] = r;                                                     // rho
+            reinterpret_cast<uint32_t *>(skp)[lane] = r;
+            reinterpret_cast<uint32_t *>(skp + 32)[lane] = reinterpret_cast<const uint32_t *>(es_ws + item * 128 + 96)[lane];  // key
+        }
+    }
+}
+
+// lane = item: tr = SHAKE256(pk)[:64] -> sk[64:128]  (dilithium.go:257-262)
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_keygen_finish_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ sk, size_t n) {
+    using G = DG<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState s;
+    sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64), s);
 }
 
 }  // namespace mldsa

@@ -7,6 +7,7 @@ from . import _native as nat
 
 KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
 DSA_SIZES = {44: (1312, 2420), 65: (1952, 3309), 87: (2592, 4627)}  # pk, sig
+DSA_SK_SIZES = {44: 2560, 65: 4032, 87: 4896}
 
 
 def _u8(x, cols):
@@ -61,6 +62,17 @@ def _blob(items):
         off[1:] = np.cumsum([len(x) for x in items])
     blob = np.frombuffer(b"".join(bytes(x) for x in items) + b"\0" * 16, dtype=np.uint8).copy()
     return blob, off
+
+
+def mldsa_keygen(param, seeds, device=0):
+    PK, _ = DSA_SIZES[param]
+    SK = DSA_SK_SIZES[param]
+    seeds = _u8(seeds, 32)
+    n = len(seeds)
+    pk = np.empty((n, PK), np.uint8)
+    sk = np.empty((n, SK), np.uint8)
+    nat.check(nat.lib().circl_hip_mldsa_keygen(param, _p(seeds), _p(pk), _p(sk), n, device), "mldsa_keygen")
+    return pk, sk
 
 
 def mldsa_verify_internal(param, pk, sig, msgs, device=0):

@@ -57,6 +57,7 @@ size_t circl_hip_mlkem_dk_size(int param); /*                1632|2400|3168 */
 size_t circl_hip_mlkem_ct_size(int param); /*                 768|1088|1568 */
 size_t circl_hip_mldsa_pk_size(int param); /* 44|65|87 -> 1312|1952|2592 */
 size_t circl_hip_mldsa_sig_size(int param);/*             2420|3309|4627 */
+size_t circl_hip_mldsa_sk_size(int param); /*             2560|4032|4896 */
 
 /* ---- ML-KEM, host buffers (what cgo binds) ---------------------------------------------
  * circl_hip_mlkem_encaps: scheme.UnmarshalBinaryPublicKey(ek_i) followed by
@@ -112,6 +113,15 @@ int circl_hip_mldsa_verify_dev(int param, const uint8_t *d_pk, const uint8_t *d_
                                const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- ML-DSA key generation ----------------------------------------------------------------
+ * scheme.DeriveKey(seed_i), seed 32 bytes (sign/mldsa/mldsa65/dilithium.go:272-281 ->
+ * internal/dilithium.go:181-267 NewKeyFromSeed); keys in MarshalBinary form.  The _dev variant
+ * needs circl_hip_mldsa_workspace_size(param, n) bytes of workspace. */
+int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_t n,
+                           int device);
+int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk, uint8_t *d_sk,
+                               size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- primitives (host buffers), mirroring the reference's unit-tested building blocks ----
  * circl_hip_keccak_f1600 : internal/sha3/keccakf.go:12 KeccakF1600 / simd/keccakf1600 StateX4.Permute
  *                          on n states of 25 little-endian uint64 words each; rounds = 24 or 12.
@@ -144,6 +154,7 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
 #define CIRCL_HIP_KERNEL_MLKEM_FINISH 4   /* decapsulation compare / select          */
 #define CIRCL_HIP_KERNEL_MLDSA_HASH 5
 #define CIRCL_HIP_KERNEL_MLDSA_VERIFY 6
+#define CIRCL_HIP_KERNEL_MLDSA_KEYGEN 7
 #define CIRCL_HIP_KERNEL_COUNT 8
 int circl_hip_profile_enable(int on);
 int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);

@@ -76,6 +76,15 @@ def dsa(param, n, pool=1 << 11):
     want[bad] = 0
     good = bool((ok.cpu().numpy() == np.tile(want, reps)).all())
     print(f"ML-DSA-{param} verify  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   results as expected: {good}")
+    seeds = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).cuda()
+    kpk = torch.empty((n, PK), dtype=torch.uint8, device="cuda")
+    ksk = torch.empty((n, SK), dtype=torch.uint8, device="cuda")
+
+    def kg():
+        rc = L.circl_hip_mldsa_keygen_dev(param, seeds.data_ptr(), kpk.data_ptr(), ksk.data_ptr(), n, ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+    ms = timeit(kg, 3)
+    print(f"ML-DSA-{param} keygen  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
     cdev.profile_enable(True)
     run(); torch.cuda.synchronize()
     cdev.profile_enable(False)

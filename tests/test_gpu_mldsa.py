@@ -112,3 +112,34 @@ def test_verify_without_contexts_and_long_messages():
     assert not hostapi.mldsa_verify(p, pk, sig, msgs, [b"c"] * n).any()
     # ctx longer than 255 bytes -> false (mldsa65/dilithium.go:116-118)
     assert not hostapi.mldsa_verify(p, pk[:1], sig[:1], msgs[:1], [b"a" * 256]).any()
+
+
+# ---- key generation ----------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_keygen(name):
+    # sign/mldsa/mldsa65/acvp_test.go:39-79
+    import hashlib
+    p = PARAMS[name]
+    cases = load_golden("mldsa_acvp.json.gz")[name]["keygen"]
+    seeds = np.frombuffer(b"".join(hx(c["seed"]) for c in cases), np.uint8).reshape(-1, 32)
+    pk, sk = hostapi.mldsa_keygen(p, seeds)
+    for i, c in enumerate(cases):
+        assert hashlib.sha256(pk[i].tobytes()).hexdigest() == c["pk_sha256"], i
+        assert hashlib.sha256(sk[i].tobytes()).hexdigest() == c["sk_sha256"], i
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+@pytest.mark.parametrize("n", [1, 5, 300])
+def test_keygen_matches_oracle_and_keys_work(name, n):
+    p = PARAMS[name]
+    rng = np.random.default_rng(n + p)
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = hostapi.mldsa_keygen(p, seeds)
+    pk0, sk0 = orc.mldsa_keygen(p, seeds)
+    assert (pk == pk0).all()
+    assert (sk == sk0).all()
+    # sign with the oracle using the GPU-made secret keys, verify on the GPU with the GPU-made public keys
+    msgs = [b"m%d" % i for i in range(n)]
+    sig = orc.mldsa_sign(p, sk, msgs)
+    assert hostapi.mldsa_verify(p, pk, sig, msgs).all()
