@@ -14,6 +14,7 @@ SYMBOLS = [
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
     "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
     "circl_hip_mldsa_keygen", "circl_hip_mldsa_keygen_dev",
+    "circl_hip_mldsa_sign", "circl_hip_mldsa_sign_internal", "circl_hip_mldsa_sign_workspace_size", "circl_hip_mldsa_sign_dev",
     "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
     "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
     "circl_hip_mlkem_keygen_dev",
@@ -68,7 +69,7 @@ def lib():
                   "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size"):
             getattr(L, s).restype = C.c_size_t
             getattr(L, s).argtypes = [C.c_int]
-        for s in ("circl_hip_mlkem_workspace_size", "circl_hip_mldsa_workspace_size"):
+        for s in ("circl_hip_mlkem_workspace_size", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_sign_workspace_size"):
             getattr(L, s).restype = C.c_size_t
             getattr(L, s).argtypes = [C.c_int, C.c_size_t]
         L.circl_hip_last_error.restype = C.c_char_p
@@ -84,6 +85,9 @@ def lib():
         L.circl_hip_mlkem_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_sign.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_sign_internal.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_sign_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_keygen.argtypes = [i, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify_internal.argtypes = [i, vp, vp, vp, vp, vp, sz, i]

@@ -411,6 +411,112 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *
     return CIRCL_HIP_OK;
 }
 
+// ---- ML-DSA sign ------------------------------------------------------------------------------
+constexpr int kSignBlocksPerCU = 8;
+
+template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
+    using S = circl::mldsa::SG<MODE>;
+    return up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
+}
+
+template <int MODE>
+int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                        const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, size_t ws_bytes,
+                        hipStream_t st) {
+    using S = circl::mldsa::SG<MODE>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < mldsa_sign_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(rnd) || rnd == nullptr)
+        return CIRCL_HIP_EWORKSPACE;
+    uint8_t *mr = static_cast<uint8_t *>(ws);
+    unsigned *work = reinterpret_cast<unsigned *>(mr + up256(128 * n));
+    uint8_t *scratch = mr + up256(128 * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_sign_prep_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sk, msg_blob,
+                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n);
+    }
+    {
+        auto kern = circl::mldsa::mldsa_sign_kernel<MODE>;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)S::LDS_TOTAL) != hipSuccess || occ < 1) occ = 1;
+        if (occ > kSignBlocksPerCU) occ = kSignBlocksPerCU;
+        const unsigned blocks = (unsigned)std::min<size_t>(n, (size_t)cu_count() * occ);
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+int mldsa_sign_dev_any(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                       const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, size_t wsb,
+                       hipStream_t st) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    switch (param) {
+    case 44: return mldsa_sign_dev_impl<44>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 65: return mldsa_sign_dev_impl<65>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 87: return mldsa_sign_dev_impl<87>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+
+size_t mldsa_sign_ws_any(int param, size_t n) {
+    switch (param) {
+    case 44: return mldsa_sign_ws_bytes<44>(n);
+    case 65: return mldsa_sign_ws_bytes<65>(n);
+    case 87: return mldsa_sign_ws_bytes<87>(n);
+    }
+    return 0;
+}
+
+// Host-buffer sign on one device (same blob handling as mldsa_verify_host_one).
+int mldsa_sign_host_one(int param, int dev, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
+                        const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n) {
+    const size_t SK = circl_hip_mldsa_sk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    Arena &a = g_arena[dev];
+    std::lock_guard<std::mutex> lk(a.mu);
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 14);
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t cnt = std::min(chunk, n - done);
+        const size_t mlo = msg_off[done], mhi = msg_off[done + cnt];
+        const size_t clo = ctx_blob ? ctx_off[done] : 0, chi = ctx_blob ? ctx_off[done + cnt] : 0;
+        const size_t wsb = mldsa_sign_ws_any(param, cnt);
+        const size_t need = up256(cnt * SK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
+                            up256(chi - clo + 16) + up256(cnt * 32) + wsb;
+        int rc = arena_reserve(a, need);
+        if (rc) return rc;
+        hipStream_t st = a.st[0];
+        uint8_t *p = static_cast<uint8_t *>(a.base);
+        uint8_t *d_sk = p; p += up256(cnt * SK);
+        uint8_t *d_sig = p; p += up256(cnt * SIG + 16);
+        uint8_t *d_msg = p; p += up256(mhi - mlo + 16);
+        uint64_t *d_moff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
+        uint8_t *d_ctx = p; p += up256(chi - clo + 16);
+        uint64_t *d_coff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
+        uint8_t *d_rnd = p; p += up256(cnt * 32);
+        uint8_t *d_ws = p;
+        HIP_TRY(hipMemcpyAsync(d_sk, sk + done * SK, cnt * SK, hipMemcpyHostToDevice, st));
+        if (mhi > mlo) HIP_TRY(hipMemcpyAsync(d_msg, msg_blob + mlo, mhi - mlo, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_moff, msg_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        if (ctx_blob) {
+            if (chi > clo) HIP_TRY(hipMemcpyAsync(d_ctx, ctx_blob + clo, chi - clo, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_coff, ctx_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
+        }
+        if (rnd) HIP_TRY(hipMemcpyAsync(d_rnd, rnd + done * 32, cnt * 32, hipMemcpyHostToDevice, st));
+        else HIP_TRY(hipMemsetAsync(d_rnd, 0, cnt * 32, st));
+        rc = mldsa_sign_dev_any(param, d_sk, d_msg - mlo, d_moff, ctx_blob ? d_ctx - clo : nullptr, ctx_blob ? d_coff : nullptr, d_rnd,
+                                internal, d_sig, cnt, d_ws, wsb, st);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(sig + done * SIG, d_sig, cnt * SIG, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return CIRCL_HIP_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -573,6 +679,38 @@ int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, con
 int circl_hip_mldsa_verify_internal(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
                                     const uint64_t *msg_off, uint8_t *ok, size_t n, int device) {
     return mldsa_verify_host(param, pk, sig, msg_blob, msg_off, nullptr, nullptr, 1, ok, n, device);
+}
+
+size_t circl_hip_mldsa_sign_workspace_size(int param, size_t n) { return mldsa_sign_ws_any(param, n); }
+
+int circl_hip_mldsa_sign_dev(int param, const uint8_t *d_sk, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                             const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig,
+                             size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    return mldsa_sign_dev_any(param, d_sk, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, d_rnd, internal, d_sig, n, d_ws, ws_bytes,
+                              static_cast<hipStream_t>(stream));
+}
+
+static int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                           const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, int device) {
+    const size_t SK = circl_hip_mldsa_sk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    if (!SK) return CIRCL_HIP_EPARAM;
+    if (ctx_blob)
+        for (size_t i = 0; i < n; i++)
+            if (ctx_off[i + 1] - ctx_off[i] > 255) return CIRCL_HIP_EPARAM;  // sign.ErrContextTooLong
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return mldsa_sign_host_one(param, dev, sk + lo * SK, msg_blob, msg_off + lo, ctx_blob, ctx_blob ? ctx_off + lo : nullptr,
+                                   rnd ? rnd + lo * 32 : nullptr, internal, sig + lo * SIG, cnt);
+    });
+}
+
+int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                         const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n, int device) {
+    return mldsa_sign_host(param, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, 0, sig, n, device);
+}
+
+int circl_hip_mldsa_sign_internal(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *rnd,
+                                  uint8_t *sig, size_t n, int device) {
+    return mldsa_sign_host(param, sk, msg_blob, msg_off, nullptr, nullptr, rnd, 1, sig, n, device);
 }
 
 // ---- primitives -------------------------------------------------------------------------------

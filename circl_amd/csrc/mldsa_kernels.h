@@ -73,30 +73,11 @@ template <int NWORDS> __device__ __forceinline__ void sponge17_words(KeccakState
     keccak_f1600(s);
 }
 
-// ---- kernel P ---------------------------------------------------------------------------------
-
-template <int MODE>
-__global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
-                                                         const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
-                                                         const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
-                                                         int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
-                                                         uint8_t *__restrict__ fail_ws, size_t n) {
-    using G = DG<MODE>;
-    using P = DP<MODE>;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    KeccakState s;
-    // tr = SHAKE256(pk)[:64]  (dilithium.go:123-125)
-    sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
-    KeccakState h;
-    keccak_zero(h);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
-    // M' byte stream
-    const uint8_t *mp = msg_blob + msg_off[idx];
-    const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
-    const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
-    const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+// mu = SHAKE256(tr || M')[:64] with M' = 0 || len(ctx) || ctx || msg (mldsa65/dilithium.go:115-132;
+// internal = the ACVP interface without the prefix).  On entry words 0..7 of h hold tr and the rest is
+// zero; on exit words 0..7 hold mu.  One sponge per lane, message lengths may differ per lane.
+__device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const uint8_t *mp, size_t mlen, const uint8_t *cp,
+                                                           size_t clen, int internal) {
     const size_t pre = internal ? 0 : 2;
     const size_t total = pre + (internal ? 0 : clen) + mlen;  // length of M'
     auto mbyte = [&](size_t k) -> uint64_t {
@@ -137,6 +118,32 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
         keccak_f1600(h);
         pos += 136;
     }
+}
+
+// ---- kernel P ---------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
+                                                         const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
+                                                         const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
+                                                         int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
+                                                         uint8_t *__restrict__ fail_ws, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState s;
+    // tr = SHAKE256(pk)[:64]  (dilithium.go:123-125)
+    sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
+    KeccakState h;
+    keccak_zero(h);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+    const uint8_t *mp = msg_blob + msg_off[idx];
+    const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+    const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
+    const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+    absorb_message_and_squeeze(h, mp, mlen, cp, clen, internal);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), h);  // mu
     // SampleInBall's sponge: SHAKE256(c~), first block (sample.go:299-306); the whole state is
     // parked so that the verify kernel can squeeze further blocks in the (rare) case it must.
@@ -238,6 +245,73 @@ __device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32
     }
 }
 
+// SampleInBall (sample.go:299-339) followed by the NTT: c-hat * 2^24 in layout L4.
+// `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
+// 8 sign bytes, then bytes b <= i pick the positions.  Lane p keeps bytes p, p+64 and p+128 of the
+// current 136-byte block in registers; one step is three compares + ballots, scalar bit tricks and
+// one v_readlane -- no memory traffic.  `blk` (>= 136 B of LDS) is only used if a second block is
+// needed (rare).
+template <int MODE>
+__device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const uint8_t *st, uint8_t *blk, uint32_t *xch,
+                                                   const dilithium::LaneZetas &z, int lane) {
+    using P = DP<MODE>;
+    const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
+    uint32_t b0 = st[lane], b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
+    int off = 8;      // next unread byte of the block
+    uint32_t jt = 0;  // lane t keeps j_t
+    KeccakState bs;
+    bool have_state = false;
+    for (int t = 0; t < P::TAU; t++) {
+        const uint32_t i = 256 - P::TAU + t;
+        int found = -1;
+        uint32_t jv = 0;
+        while (found < 0) {
+            unsigned long long m0 = __ballot(b0 <= i), m1 = __ballot(b1 <= i), m2 = __ballot(b2 <= i);
+            if (off >= 128) { m0 = 0; m1 = 0; m2 &= ~0ull << (off - 128); }
+            else if (off >= 64) { m0 = 0; m1 &= ~0ull << (off - 64); }
+            else m0 &= ~0ull << off;
+            if (m0) { const int p = __ffsll((long long)m0) - 1; found = p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b0, p); }
+            else if (m1) { const int p = __ffsll((long long)m1) - 1; found = 64 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b1, p); }
+            else if (m2) { const int p = __ffsll((long long)m2) - 1; found = 128 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b2, p); }
+            else {
+                // block exhausted (rare): squeeze the next one; every lane runs the same permutation
+                if (!have_state) {
+                    keccak_zero(bs);
+                    xor_words<0, 25>(bs, reinterpret_cast<const uint64_t *>(st));
+                    have_state = true;
+                }
+                keccak_f1600(bs);
+                __syncthreads();
+                if (lane == 0) store_words<0, 17>(reinterpret_cast<uint64_t *>(blk), bs);
+                __syncthreads();
+                b0 = blk[lane]; b1 = blk[64 + lane]; b2 = lane < 8 ? (uint32_t)blk[128 + lane] : 0xfffu;
+                off = 0;
+            }
+        }
+        if (lane == t) jt = jv;
+        off = found + 1;
+    }
+    // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a later
+    // step t2 with j_t2 == (its current position) moves it to i_t2
+    uint32_t pos = jt;
+    for (int t2 = 1; t2 < P::TAU; t2++) {
+        const uint32_t j2 = (uint32_t)__builtin_amdgcn_readlane((int)jt, t2);
+        if (t2 > lane && j2 == pos) pos = 256 - P::TAU + t2;
+    }
+    uint32_t *cpoly = xch;
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) cpoly[i] = 0;
+    __syncthreads();
+    if (lane < P::TAU) cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
+    __syncthreads();
+    uint32_t c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
+    dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) chat[r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
+}
+
 // ---- kernel V -----------------------------------------------------------------------------------
 
 // ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase 1, bit 1 phase 2, bit 2 phase 3.
@@ -326,68 +400,7 @@ __global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restr
         }
         fail[g] = __any(bad);
 
-        // SampleInBall (sample.go:299-339): 8 sign bytes, then bytes b <= i pick the positions.
-        // Lane p keeps bytes p, p+64 and p+128 of the current 136-byte block in registers; one step is
-        // three compares + ballots, scalar bit tricks and one v_readlane -- no memory traffic.
-        {
-            const uint8_t *st = ball_ws + item * kBallStateBytes;
-            const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
-            uint32_t b0 = st[lane], b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
-            int off = 8;  // next unread byte of the block
-            uint32_t jt = 0;  // lane t keeps j_t
-            KeccakState bs;
-            bool have_state = false;
-            for (int t = 0; t < P::TAU; t++) {
-                const uint32_t i = 256 - P::TAU + t;
-                int found = -1;
-                uint32_t jv = 0;
-                while (found < 0) {
-                    unsigned long long m0 = __ballot(b0 <= i), m1 = __ballot(b1 <= i), m2 = __ballot(b2 <= i);
-                    if (off >= 128) { m0 = 0; m1 = 0; m2 &= ~0ull << (off - 128); }
-                    else if (off >= 64) { m0 = 0; m1 &= ~0ull << (off - 64); }
-                    else m0 &= ~0ull << off;
-                    if (m0) { const int p = __ffsll((long long)m0) - 1; found = p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b0, p); }
-                    else if (m1) { const int p = __ffsll((long long)m1) - 1; found = 64 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b1, p); }
-                    else if (m2) { const int p = __ffsll((long long)m2) - 1; found = 128 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b2, p); }
-                    else {
-                        // block exhausted (rare): squeeze the next one; every lane runs the same permutation
-                        if (!have_state) {
-                            keccak_zero(bs);
-                            xor_words<0, 25>(bs, reinterpret_cast<const uint64_t *>(st));
-                            have_state = true;
-                        }
-                        keccak_f1600(bs);
-                        uint8_t *blk = misc;
-                        __syncthreads();
-                        if (lane == 0) store_words<0, 17>(reinterpret_cast<uint64_t *>(blk), bs);
-                        __syncthreads();
-                        b0 = blk[lane]; b1 = blk[64 + lane]; b2 = lane < 8 ? (uint32_t)blk[128 + lane] : 0xfffu;
-                        off = 0;
-                    }
-                }
-                if (lane == t) jt = jv;
-                off = found + 1;
-            }
-            // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a
-            // later step t2 with j_t2 == (its current position) moves it to i_t2
-            uint32_t pos = jt;
-            for (int t2 = 1; t2 < P::TAU; t2++) {
-                const uint32_t j2 = (uint32_t)__builtin_amdgcn_readlane((int)jt, t2);
-                if (t2 > lane && j2 == pos) pos = 256 - P::TAU + t2;
-            }
-            uint32_t *cpoly = xch;
-            __syncthreads();
-            for (int i = lane; i < 256; i += 64) cpoly[i] = 0;
-            __syncthreads();
-            if (lane < P::TAU) cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
-            __syncthreads();
-            uint32_t c[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
-            dilithium::ntt(c, z, xch, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) chat[g][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // c-hat * 2^24
-        }
+        sample_in_ball_hat<MODE>(chat[g], ball_ws + item * kBallStateBytes, misc, xch, z, lane);
     }
     __syncthreads();
     // zero the accumulators (they held the staged signature bytes)
@@ -624,6 +637,318 @@ __global__ void __launch_bounds__(256) mldsa_keygen_finish_kernel(const uint8_t 
     KeccakState s;
     sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64), s);
+}
+
+// ---- signing (sign/mldsa/mldsa65/internal/dilithium.go:340-470 SignTo) ------
+//
+// First version, organised for correctness: one wavefront owns one signature through all of its
+// rejection iterations (expected 4-7), resident wavefronts pull items from a ticket counter.  The
+// expanded matrix and the NTT-domain secrets of the current item live in the wave's slice of a global
+// scratch (L2 resident) because they are re-read in every iteration.  The in-loop sponges (ExpandMask:
+// L streams, c~ = H(mu || w1): one stream) use few lanes; batching them across items is the obvious
+// next optimisation.
+
+template <int MODE> struct SG {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    static constexpr int K = P::K, L = P::L;
+    static constexpr int A_ROW = 260;                                   // dwords per matrix row (+ spill slot)
+    static constexpr int SCRATCH_DW = K * L * A_ROW + (L + 2 * K) * 256; // A rows, then s1-hat, s2-hat, t0-hat
+    static constexpr int SCRATCH_BYTES = ((SCRATCH_DW * 4 + 255) / 256) * 256;
+    static constexpr int YROW = 696;                                    // 5 blocks of 136 B + slack, per ExpandMask stream
+    static constexpr int LDS_Y = L * YROW;
+    static constexpr int LDS_W0 = K * 1024;                             // w0 (later w0 - c s2), u32, standard order
+    static constexpr int LDS_W1 = K * 256;                              // w1 values, one byte each
+    static constexpr int LDS_MUW1 = G::MUW1 + 8;                        // mu || packed w1 (hashed as is)
+    static constexpr int LDS_Z = L * G::ZSZ;                            // packed z
+    static constexpr int LDS_H = 96;                                    // hint bytes (omega + K <= 84)
+    static constexpr int LDS_XCH = 1024;
+    static constexpr int LDS_MISC = 256;                                // ball block (200 B)
+    static constexpr int LDS_TOTAL = LDS_Y + LDS_W0 + LDS_W1 + LDS_MUW1 + LDS_Z + LDS_H + LDS_XCH + LDS_MISC;
+};
+
+// lane = item: mu = H(tr || M'), rho'' = H(key || rnd || mu)[:64]  (dilithium.go:355-368) -> workspace
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ msg_blob,
+                                                              const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
+                                                              const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
+                                                              int internal, uint8_t *__restrict__ mr_ws, size_t n) {
+    using Kg = KG<MODE>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const uint8_t *skp = sk + idx * Kg::SK;
+    KeccakState h;
+    keccak_zero(h);
+    xor_words<0, 8>(h, reinterpret_cast<const uint64_t *>(skp + 64));  // tr
+    const uint8_t *mp = msg_blob + msg_off[idx];
+    const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+    const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
+    const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+    absorb_message_and_squeeze(h, mp, mlen, cp, clen, internal);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128), h);  // mu
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(skp + 32));          // key
+    xor_words<4, 4>(s, reinterpret_cast<const uint64_t *>(rnd + idx * 32));    // rnd (zero = deterministic)
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s.lo[8 + i] = h.lo[i]; s.hi[8 + i] = h.hi[i]; }
+    s.lo[16] ^= kDsShake;
+    s.hi[16] ^= 0x80000000u;
+    keccak_f1600(s);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), s);  // rho''
+}
+
+// D-bit field n of a little-endian bit stream of aligned dwords in global memory
+template <int D> __device__ __forceinline__ uint32_t gbits(const uint32_t *p, int n, int ndwords) {
+    const int bit = n * D, w = bit >> 5, sh = bit & 31;
+    const uint32_t lo = p[w], hi = (w + 1 < ndwords) ? p[w + 1] : 0u;
+    return (sh ? alignbit(hi, lo, (uint32_t)sh) : lo) & ((1u << D) - 1);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ mr_ws,
+                                                       uint8_t *__restrict__ sig, uint8_t *__restrict__ scratch,
+                                                       unsigned *__restrict__ work, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    using S = SG<MODE>;
+    constexpr int K = P::K, L = P::L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *ybuf = smem;
+    uint32_t *w0 = reinterpret_cast<uint32_t *>(smem + S::LDS_Y);
+    uint8_t *w1b = smem + S::LDS_Y + S::LDS_W0;
+    uint8_t *muw1 = w1b + S::LDS_W1;
+    uint8_t *zpk = muw1 + S::LDS_MUW1;
+    uint8_t *hbytes = zpk + S::LDS_Z;
+    uint32_t *xch = reinterpret_cast<uint32_t *>(hbytes + S::LDS_H);
+    uint8_t *misc = reinterpret_cast<uint8_t *>(xch) + S::LDS_XCH;
+    uint32_t *arows = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * S::SCRATCH_BYTES);
+    uint32_t *sec = arows + K * L * S::A_ROW;  // s1-hat (L), s2-hat (K), t0-hat (K), 256 dwords each, standard order
+    const int lane = threadIdx.x;
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+
+#pragma unroll 1
+    for (size_t item = mlkem::next_group(work, lane, true, n); item < n; item = mlkem::next_group(work, lane, false, n)) {
+        const uint8_t *skp = sk + item * Kg::SK;
+        const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
+        __syncthreads();
+        // ---- setup 1: ExpandA(rho) into the scratch, lane = (i, j) ----
+        {
+            const bool on = lane < K * L;
+            const int i = on ? lane / L : 0, j = on ? lane % L : 0;
+            KeccakState s;
+            keccak_zero(s);
+            xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(skp));
+            s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+            s.hi[20] = 0x80000000u;
+            uint32_t *row = arows + (on ? lane : 0) * S::A_ROW;
+            int cnt = on ? 0 : 256;
+#pragma unroll 1
+            for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
+                keccak_f1600(s);
+                if (on) {
+                    for_each_candidate23(s, [&](uint32_t a) {
+                        row[cnt] = a;  // rejected values are overwritten; slot 256 is a spill slot
+                        cnt = min(cnt + (a < Q ? 1 : 0), 256);
+                    });
+                }
+            }
+        }
+        // ---- setup 2: NTT of s1, s2, t0 (dilithium.go:149-179 PrivateKey.Unpack) into the scratch ----
+#pragma unroll 1
+        for (int k = 0; k < L + 2 * K; k++) {
+            uint32_t c[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                int v;
+                if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (128 + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
+                else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (128 + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
+                c[r] = v < 0 ? Q + v : (uint32_t)v;
+            }
+            dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) sec[k * 256 + 4 * lane + r] = dilithium::fold(c[r]);
+        }
+        // mu into the hashing buffer
+        if (lane < 16) reinterpret_cast<uint32_t *>(muw1)[lane] = reinterpret_cast<const uint32_t *>(mr_ws + item * 128)[lane];
+        // the scratch rows were written by this wave (stores reach L2) and the same addresses were read for
+        // the previous item: drop this CU's possibly stale L1 lines before re-reading them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+
+        unsigned nonce = 0;
+        bool accepted = false;
+        KeccakState cs;  // c~ sponge (uniform across lanes)
+#pragma unroll 1
+        while (!accepted) {
+            // ---- y = ExpandMask(rho'', nonce) (sample.go:178-196): lane l < L squeezes L streams ----
+            {
+                const bool on = lane < L;
+                KeccakState s;
+                keccak_zero(s);
+                xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(mr_ws + item * 128 + 64));
+                s.lo[8] = ((nonce + (on ? lane : 0)) & 0xffff) | (kDsShake << 16);
+                s.hi[16] = 0x80000000u;
+                uint32_t *yrow = reinterpret_cast<uint32_t *>(ybuf + (on ? lane : 0) * S::YROW);
+#pragma unroll 1
+                for (int blk = 0; blk < 5; blk++) {
+                    keccak_f1600(s);
+                    if (on) {
+                        detail::static_for<0, 17>([&](auto ic) {
+                            constexpr int w = decltype(ic)::v;
+                            yrow[34 * blk + 2 * w] = s.lo[w];
+                            yrow[34 * blk + 2 * w + 1] = s.hi[w];
+                        });
+                    }
+                }
+                nonce += L;
+            }
+            __syncthreads();
+            // ---- y-hat ----
+            uint32_t yh[L][4];
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    uint32_t x = G::GAMMA1 - lds_bits<G::ZBITS>(reinterpret_cast<const uint32_t *>(ybuf + l * S::YROW), 0, kyber::idx_l1(lane, r));
+                    x += (uint32_t)((int32_t)x >> 31) & Q;
+                    yh[l][r] = x;
+                }
+                dilithium::ntt(yh[l], z, xch, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont24(dilithium::fold(yh[l][r]), dilithium::R24SQ);  // y-hat * 2^24
+            }
+            // ---- w = InvNTT(A y-hat), Decompose, w1 packing (dilithium.go:385-398) ----
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * S::A_ROW + 4 * lane);
+                    w[0] += dilithium::mont24(a.x, yh[j][0]);
+                    w[1] += dilithium::mont24(a.y, yh[j][1]);
+                    w[2] += dilithium::mont24(a.z, yh[j][2]);
+                    w[3] += dilithium::mont24(a.w, yh[j][3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
+                dilithium::invntt(w, z, xch, lane);
+                unsigned w1v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int nidx = kyber::idx_l1(lane, r);
+                    uint32_t a0, a1;
+                    dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
+                    w0[i * 256 + nidx] = a0;
+                    w1b[i * 256 + nidx] = (uint8_t)a1;
+                    w1v[r] = a1;
+                }
+                mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
+                for (int d = lane; d < 8 * G::W1BITS; d += 64) reinterpret_cast<uint32_t *>(muw1 + 64 + G::W1SZ * i)[d] = xch[d];
+            }
+            __syncthreads();
+            // ---- c~ = H(mu || w1), c-hat (dilithium.go:400-407); every lane computes the same sponge ----
+            sponge17_words<G::MUW1 / 8>(cs, reinterpret_cast<const uint64_t *>(muw1), kDsShake);
+            uint32_t chat[4];
+            {
+                KeccakState bs;
+                keccak_zero(bs);
+#pragma unroll
+                for (int i = 0; i < P::CT / 8; i++) { bs.lo[i] = cs.lo[i]; bs.hi[i] = cs.hi[i]; }
+                bs.lo[P::CT / 8] ^= kDsShake;
+                bs.hi[16] ^= 0x80000000u;
+                keccak_f1600(bs);
+                __syncthreads();
+                if (lane == 0) store_words<0, 25>(reinterpret_cast<uint64_t *>(misc), bs);
+                __syncthreads();
+                // misc holds the whole sponge state; the packed-z area is free until z is formed below and
+                // serves as the (rarely needed) second-block buffer
+                sample_in_ball_hat<MODE>(chat, misc, zpk, xch, z, lane);
+            }
+            bool bad = false;
+            // ---- w0 - c s2 (dilithium.go:409-418) ----
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(sec + (L + i) * 256 + 4 * lane);
+                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                dilithium::invntt(t, z, xch, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int nidx = kyber::idx_l1(lane, r);
+                    const uint32_t v = dilithium::normalize(w0[i * 256 + nidx] + (2 * Q - t[r]));
+                    bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
+                    w0[i * 256 + nidx] = v;
+                }
+            }
+            if (__any(bad)) continue;
+            // ---- z = y + c s1 (dilithium.go:420-429), packed as it will appear in the signature ----
+#pragma unroll 1
+            for (int l = 0; l < L; l++) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(sec + l * 256 + 4 * lane);
+                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                dilithium::invntt(t, z, xch, lane);
+                unsigned fld[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    uint32_t y = G::GAMMA1 - lds_bits<G::ZBITS>(reinterpret_cast<const uint32_t *>(ybuf + l * S::YROW), 0, kyber::idx_l1(lane, r));
+                    y += (uint32_t)((int32_t)y >> 31) & Q;
+                    const uint32_t zz = dilithium::normalize(t[r] + y);
+                    bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
+                    uint32_t f = G::GAMMA1 - zz;                 // pack.go:202-254 PolyPackLeGamma1
+                    f += (uint32_t)((int32_t)f >> 31) & Q;
+                    fld[r] = f;
+                }
+                mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
+                for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+            }
+            if (__any(bad)) continue;
+            // ---- c t0, hints (dilithium.go:431-450) ----
+            unsigned pop = 0;
+            __syncthreads();
+            for (int i = lane; i < (int)(S::LDS_H / 4); i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(sec + (L + K + i) * 256 + 4 * lane);
+                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                dilithium::invntt(t, z, xch, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int nidx = kyber::idx_l1(lane, r);
+                    const uint32_t ct0 = dilithium::csubq(t[r]);
+                    bad |= dilithium::exceeds(ct0, P::GAMMA2);
+                    const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
+                    const uint32_t r1 = w1b[i * 256 + nidx];
+                    // rounding.go:55-62 makeHint
+                    const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+                    const unsigned long long mask = __ballot(hbit);  // coefficients 64 r .. 64 r + 63, ascending
+                    if (hbit) {
+                        const unsigned slot = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
+                        if (slot < (unsigned)P::OMEGA) hbytes[slot] = (uint8_t)nidx;
+                    }
+                    pop += (unsigned)__popcll(mask);
+                }
+                if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
+            }
+            if (__any(bad) || pop > (unsigned)P::OMEGA) continue;
+            accepted = true;
+        }
+        // ---- sig = c~ || z || hints (dilithium.go:84-88), byte-wise because rows are unaligned ----
+        __syncthreads();
+        uint8_t *sg = sig + item * G::SIG;
+        if (lane == 0) store_words<0, P::CT / 8>(reinterpret_cast<uint64_t *>(misc), cs);
+        __syncthreads();
+        for (int b = lane; b < P::CT; b += 64) sg[b] = misc[b];
+        for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
+        for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
+    }
 }
 
 }  // namespace mldsa

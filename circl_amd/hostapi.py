@@ -75,6 +75,27 @@ def mldsa_keygen(param, seeds, device=0):
     return pk, sk
 
 
+def mldsa_sign(param, sk, msgs, ctxs=None, rnd=None, internal=False, device=0):
+    """deterministic when rnd is None"""
+    _, SIG = DSA_SIZES[param]
+    SK = DSA_SK_SIZES[param]
+    sk = _u8(sk, SK)
+    n = len(sk)
+    assert len(msgs) == n
+    mb, mo = _blob(msgs)
+    sig = np.empty((n, SIG), np.uint8)
+    r = None if rnd is None else _p(_u8(rnd, 32))
+    if internal:
+        rc = nat.lib().circl_hip_mldsa_sign_internal(param, _p(sk), _p(mb), _p(mo), r, _p(sig), n, device)
+    elif ctxs is None:
+        rc = nat.lib().circl_hip_mldsa_sign(param, _p(sk), _p(mb), _p(mo), None, None, r, _p(sig), n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_mldsa_sign(param, _p(sk), _p(mb), _p(mo), _p(cb), _p(co), r, _p(sig), n, device)
+    nat.check(rc, "mldsa_sign")
+    return sig
+
+
 def mldsa_verify_internal(param, pk, sig, msgs, device=0):
     PK, SIG = DSA_SIZES[param]
     pk, sig = _u8(pk, PK), _u8(sig, SIG)

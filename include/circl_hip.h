@@ -122,6 +122,26 @@ int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_
 int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk, uint8_t *d_sk,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- ML-DSA signing ----------------------------------------------------
+ * scheme.UnmarshalBinaryPrivateKey(sk_i) + scheme.Sign(sk_i, msg_i, &SignatureOpts{Context: ctx_i})
+ * (sign/mldsa/mldsa65/dilithium.go:283-303 -> :56-88 SignTo -> internal/dilithium.go:340-470).
+ * rnd[n][32] is the per-signature randomness the Go wrapper draws from crypto/rand when
+ * `randomized` is set; rnd == NULL means deterministic signing (32 zero bytes).  A context longer
+ * than 255 bytes makes the host-buffer call return CIRCL_HIP_EPARAM (sign.ErrContextTooLong).
+ * circl_hip_mldsa_sign_internal is ML-DSA.Sign_internal (unsafeSignInternal, dilithium.go:90-99).
+ * The _dev variant needs circl_hip_mldsa_sign_workspace_size(param, n) bytes; d_rnd must not be NULL. */
+int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
+                         const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig,
+                         size_t n, int device);
+int circl_hip_mldsa_sign_internal(int param, const uint8_t *sk, const uint8_t *msg_blob,
+                                  const uint64_t *msg_off, const uint8_t *rnd, uint8_t *sig, size_t n,
+                                  int device);
+size_t circl_hip_mldsa_sign_workspace_size(int param, size_t n);
+int circl_hip_mldsa_sign_dev(int param, const uint8_t *d_sk, const uint8_t *d_msg_blob,
+                             const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off,
+                             const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n, void *d_workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* ---- primitives (host buffers), mirroring the reference's unit-tested building blocks ----
  * circl_hip_keccak_f1600 : internal/sha3/keccakf.go:12 KeccakF1600 / simd/keccakf1600 StateX4.Permute
  *                          on n states of 25 little-endian uint64 words each; rounds = 24 or 12.
@@ -155,7 +175,8 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
 #define CIRCL_HIP_KERNEL_MLDSA_HASH 5
 #define CIRCL_HIP_KERNEL_MLDSA_VERIFY 6
 #define CIRCL_HIP_KERNEL_MLDSA_KEYGEN 7
-#define CIRCL_HIP_KERNEL_COUNT 8
+#define CIRCL_HIP_KERNEL_MLDSA_SIGN 8
+#define CIRCL_HIP_KERNEL_COUNT 10
 int circl_hip_profile_enable(int on);
 int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
 

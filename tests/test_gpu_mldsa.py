@@ -143,3 +143,45 @@ def test_keygen_matches_oracle_and_keys_work(name, n):
     msgs = [b"m%d" % i for i in range(n)]
     sig = orc.mldsa_sign(p, sk, msgs)
     assert hostapi.mldsa_verify(p, pk, sig, msgs).all()
+
+
+# ---- signing -------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_acvp_siggen(name):
+    # sign/mldsa/mldsa65/acvp_test.go:81-121: Sign_internal(sk, message, rnd), deterministic and hedged
+    import hashlib
+    p = PARAMS[name]
+    cases = load_golden("mldsa_acvp.json.gz")[name]["siggen"]
+    sk = b"".join(hx(c["sk"]) for c in cases)
+    msgs = [hx(c["message"]) for c in cases]
+    rnd = np.frombuffer(b"".join(hx(c["rnd"]) for c in cases), np.uint8).reshape(-1, 32)
+    sig = hostapi.mldsa_sign(p, sk, msgs, rnd=rnd, internal=True)
+    for i, c in enumerate(cases):
+        assert hashlib.sha256(sig[i].tobytes()).hexdigest() == c["sig_sha256"], i
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+@pytest.mark.parametrize("n", [1, 3, 200])
+def test_sign_matches_oracle_and_verifies(name, n):
+    # mldsa65/internal/dilithium_test.go:94-129 sign -> verify, and bit-exact signatures vs the oracle
+    p = PARAMS[name]
+    rng = np.random.default_rng(n * 3 + p)
+    pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = [rng.integers(0, 256, int(rng.integers(0, 60)), dtype=np.uint8).tobytes() for _ in range(n)]
+    rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    rnd[::2] = 0  # half deterministic, half hedged
+    sig = hostapi.mldsa_sign(p, sk, msgs, ctxs, rnd=rnd)
+    want = orc.mldsa_sign(p, sk, msgs, ctxs, rnd=rnd)
+    assert (sig == want).all()
+    assert hostapi.mldsa_verify(p, pk, sig, msgs, ctxs).all()
+    det = hostapi.mldsa_sign(p, sk[:3], msgs[:3])            # no contexts, deterministic
+    assert (det == orc.mldsa_sign(p, sk[:3], msgs[:3])).all()
+
+
+def test_sign_rejects_long_context():
+    from circl_amd import _native as nat
+    pk, sk = orc.mldsa_keygen(65, np.zeros((1, 32), np.uint8))
+    with pytest.raises(nat.CirclHipError):
+        hostapi.mldsa_sign(65, sk, [b"m"], [b"c" * 256])
