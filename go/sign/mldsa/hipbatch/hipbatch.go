@@ -70,3 +70,70 @@ func VerifyBatch(s sign.Scheme, pks [][]byte, msgs [][]byte, sigs [][]byte, ctxs
 	}
 	return res, nil
 }
+
+// SignBatch is n times scheme.Sign(sk, msg, &SignatureOpts{Context: ctx}) (sign/mldsa/mldsa65/dilithium.go:283-303).
+// rnd is nil for deterministic signatures (what scheme.Sign produces) or n*32 bytes from crypto/rand
+// for hedged ones (SignTo(..., randomized=true, ...), dilithium.go:56-88).
+func SignBatch(s sign.Scheme, sks [][]byte, msgs [][]byte, ctxs []string, rnd []byte, device int) ([][]byte, error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		panic(sign.ErrTypeMismatch)
+	}
+	n := len(sks)
+	skRows := make([]byte, 0, n*s.PrivateKeySize())
+	var msgBlob, ctxBlob []byte
+	msgOff := make([]uint64, 1, n+1)
+	ctxOff := make([]uint64, 1, n+1)
+	for i := 0; i < n; i++ {
+		if len(sks[i]) != s.PrivateKeySize() {
+			return nil, sign.ErrPrivKeySize
+		}
+		if len(ctxs[i]) > 255 {
+			return nil, sign.ErrContextTooLong
+		}
+		skRows = append(skRows, sks[i]...)
+		msgBlob = append(msgBlob, msgs[i]...)
+		ctxBlob = append(ctxBlob, ctxs[i]...)
+		msgOff = append(msgOff, uint64(len(msgBlob)))
+		ctxOff = append(ctxOff, uint64(len(ctxBlob)))
+	}
+	msgBlob = append(msgBlob, 0)
+	ctxBlob = append(ctxBlob, 0)
+	sigRows := make([]byte, n*s.SignatureSize())
+	var rndPtr *C.uint8_t
+	if rnd != nil {
+		rndPtr = (*C.uint8_t)(unsafe.Pointer(&rnd[0]))
+	}
+	rc := C.circl_hip_mldsa_sign(p, (*C.uint8_t)(unsafe.Pointer(&skRows[0])),
+		(*C.uint8_t)(unsafe.Pointer(&msgBlob[0])), (*C.uint64_t)(unsafe.Pointer(&msgOff[0])),
+		(*C.uint8_t)(unsafe.Pointer(&ctxBlob[0])), (*C.uint64_t)(unsafe.Pointer(&ctxOff[0])),
+		rndPtr, (*C.uint8_t)(unsafe.Pointer(&sigRows[0])), C.size_t(n), C.int(device))
+	if rc != 0 {
+		return nil, fmt.Errorf("circl-hip sign: error %d: %s", int(rc), C.GoString(C.circl_hip_last_error()))
+	}
+	out := make([][]byte, n)
+	for i := range out {
+		out[i] = sigRows[i*s.SignatureSize() : (i+1)*s.SignatureSize()]
+	}
+	return out, nil
+}
+
+// DeriveKeyBatch is n times scheme.DeriveKey(seed) (dilithium.go:272-281); seeds are [n][SeedSize].
+func DeriveKeyBatch(s sign.Scheme, seeds []byte, device int) (pks, sks []byte, err error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		panic(sign.ErrTypeMismatch)
+	}
+	if len(seeds)%s.SeedSize() != 0 {
+		panic(sign.ErrSeedSize)
+	}
+	n := len(seeds) / s.SeedSize()
+	pks = make([]byte, n*s.PublicKeySize())
+	sks = make([]byte, n*s.PrivateKeySize())
+	rc := C.circl_hip_mldsa_keygen(p, (*C.uint8_t)(unsafe.Pointer(&seeds[0])), (*C.uint8_t)(unsafe.Pointer(&pks[0])),
+		(*C.uint8_t)(unsafe.Pointer(&sks[0])), C.size_t(n), C.int(device))
+	if rc != 0 {
+		err = fmt.Errorf("circl-hip keygen: error %d: %s", int(rc), C.GoString(C.circl_hip_last_error()))
+	}
+	return
+}

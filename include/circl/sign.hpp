@@ -1,5 +1,5 @@
-// circl/sign.hpp -- host-side mirror of cloudflare/circl's sign.Scheme (verification half) for the
-// HIP batch engine.  sign/sign.go:48-94; ML-DSA wrappers sign/mldsa/mldsa65/dilithium.go:256-345.
+// circl/sign.hpp -- host-side mirror of cloudflare/circl's sign.Scheme for the HIP batch engine.
+// sign/sign.go:48-94; ML-DSA wrappers sign/mldsa/mldsa65/dilithium.go:256-345.
 //
 //   Scheme.Name / PublicKeySize / SignatureSize          same names
 //   UnmarshalBinaryPublicKey(buf)                        length check only (dilithium.go:330-343)
@@ -7,12 +7,17 @@
 //                                                        wrong signature length or ctx > 255 bytes;
 //                                                        throws ErrTypeMismatch on a foreign key
 //                                                        (the reference panics, dilithium.go:311-314)
-//   VerifyBatch(...)                                     new: the batch call
-// Signing (sign.Scheme.Sign) is SURVEY.md 8(f) row f1 and not part of this layer yet.
+//   DeriveKey(seed) -> (PublicKey, PrivateKey)           throws std::invalid_argument on a bad seed length
+//                                                        (the reference panics, dilithium.go:272-281)
+//   Sign(sk, msg, opts) []byte                           deterministic (like the reference's scheme.Sign,
+//                                                        dilithium.go:283-303, which passes randomized=false);
+//                                                        throws ErrContextTooLong for ctx > 255 bytes
+//   VerifyBatch / SignBatch / DeriveKeyBatch             new: the batch calls
 #pragma once
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../circl_hip.h"
@@ -23,6 +28,8 @@ namespace sign {
 using Bytes = std::vector<uint8_t>;
 struct ErrTypeMismatch : std::runtime_error { ErrTypeMismatch() : std::runtime_error("sign: type mismatch") {} };
 struct ErrPubKeySize : std::runtime_error { ErrPubKeySize() : std::runtime_error("sign: wrong size for public key") {} };
+struct ErrPrivKeySize : std::runtime_error { ErrPrivKeySize() : std::runtime_error("sign: wrong size for private key") {} };
+struct ErrContextTooLong : std::runtime_error { ErrContextTooLong() : std::runtime_error("sign: context string too long") {} };
 struct ErrDevice : std::runtime_error { using std::runtime_error::runtime_error; };
 
 struct SignatureOpts {
@@ -35,6 +42,11 @@ struct PublicKey {
     Bytes packed;
     Bytes MarshalBinary() const { return packed; }
 };
+struct PrivateKey {
+    const Scheme *scheme = nullptr;
+    Bytes packed;
+    Bytes MarshalBinary() const { return packed; }
+};
 
 class Scheme {
   public:
@@ -42,12 +54,36 @@ class Scheme {
     std::string Name() const { return name_; }
     int PublicKeySize() const { return (int)circl_hip_mldsa_pk_size(param_); }
     int SignatureSize() const { return (int)circl_hip_mldsa_sig_size(param_); }
+    int PrivateKeySize() const { return (int)circl_hip_mldsa_sk_size(param_); }
+    int SeedSize() const { return 32; }
     bool SupportsContext() const { return true; }
     int device = 0;
 
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
         if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
         return PublicKey{this, buf};
+    }
+    PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
+        if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
+        return PrivateKey{this, buf};
+    }
+    std::pair<PublicKey, PrivateKey> DeriveKey(const Bytes &seed) const {
+        if ((int)seed.size() != SeedSize()) throw std::invalid_argument("seed must be of length SeedSize");
+        PublicKey pk{this, Bytes(PublicKeySize())};
+        PrivateKey sk{this, Bytes(PrivateKeySize())};
+        check(circl_hip_mldsa_keygen(param_, seed.data(), pk.packed.data(), sk.packed.data(), 1, dev1()));
+        return {pk, sk};
+    }
+    Bytes Sign(const PrivateKey &sk, const Bytes &msg, const SignatureOpts *opts = nullptr) const {
+        if (sk.scheme != this) throw ErrTypeMismatch();
+        const std::string ctx = opts ? opts->Context : std::string();
+        if (ctx.size() > 255) throw ErrContextTooLong();
+        const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
+        const uint8_t pad = 0;
+        Bytes sig(SignatureSize());
+        check(circl_hip_mldsa_sign(param_, sk.packed.data(), msg.empty() ? &pad : msg.data(), moff,
+                                   ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data()), coff, nullptr, sig.data(), 1, dev1()));
+        return sig;
     }
     bool Verify(const PublicKey &pk, const Bytes &msg, const Bytes &sig, const SignatureOpts *opts = nullptr) const {
         if (pk.scheme != this) throw ErrTypeMismatch();
@@ -70,9 +106,23 @@ class Scheme {
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
     }
 
+    // rnd = n x 32 random bytes (hedged signing) or nullptr (deterministic)
+    void SignBatch(const uint8_t *sks, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
+                   const uint8_t *rnd, uint8_t *sigs, size_t n) const {
+        check(circl_hip_mldsa_sign(param_, sks, msg_blob, msg_off, ctx_blob, ctx_off, rnd, sigs, n, device));
+    }
+    void DeriveKeyBatch(const uint8_t *seeds32, uint8_t *pks, uint8_t *sks, size_t n) const {
+        check(circl_hip_mldsa_keygen(param_, seeds32, pks, sks, n, device));
+    }
+
   private:
     int param_;
     const char *name_;
+    int dev1() const { return device < 0 ? 0 : device; }
+    static void check(int rc) {
+        if (rc == CIRCL_HIP_EPARAM) throw ErrContextTooLong();
+        if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
+    }
 };
 
 // sign/schemes/schemes.go:31-74

@@ -80,6 +80,25 @@ int main() {
         sign::SignatureOpts longctx{std::string(256, 'a')};
         REQUIRE(!s->Verify(pk, msg, sig, &longctx));
         REQUIRE(throws<sign::ErrPubKeySize>([&] { s->UnmarshalBinaryPublicKey(shortsig); }));
+        // sign/schemes/schemes_test.go:17-108: derive, sign, verify, tamper
+        sign::Bytes seed(s->SeedSize());
+        for (size_t i = 0; i < seed.size(); i++) seed[i] = (uint8_t)(i * 5 + 2);
+        auto [gpk, gsk] = s->DeriveKey(seed);
+        auto [gpk2, gsk2] = s->DeriveKey(seed);
+        REQUIRE(gpk.packed == gpk2.packed && gsk.packed == gsk2.packed);
+        REQUIRE((int)gsk.MarshalBinary().size() == s->PrivateKeySize());
+        sign::SignatureOpts ctx{"a context"};
+        sign::Bytes sg = s->Sign(gsk, msg, &ctx);
+        REQUIRE((int)sg.size() == s->SignatureSize());
+        REQUIRE(sg == s->Sign(s->UnmarshalBinaryPrivateKey(gsk.MarshalBinary()), msg, &ctx));  // deterministic
+        REQUIRE(s->Verify(gpk, msg, sg, &ctx));
+        REQUIRE(!s->Verify(gpk, msg, sg));                    // wrong context
+        sign::Bytes msg2 = msg; msg2[0] ^= 1;
+        REQUIRE(!s->Verify(gpk, msg2, sg, &ctx));
+        sg[sg.size() / 2] ^= 4;
+        REQUIRE(!s->Verify(gpk, msg, sg, &ctx));
+        REQUIRE(throws<sign::ErrContextTooLong>([&] { s->Sign(gsk, msg, &longctx); }));
+        REQUIRE(throws<std::invalid_argument>([&] { s->DeriveKey(shortsig); }));
     }
     std::printf("OK\n");
     return 0;
