@@ -14,6 +14,9 @@ reference's own tests read):
                        signatures as SHA-256 digests; sigVer complete.
   mldsa_wycheproof_verify.json.gz  sign/schemes/testdata/wycheproof/mldsa_{44,65,87}_verify_test
                        (test logic: sign/schemes/wycheproof_test.go:116-151).
+  mldsa_wycheproof_sign.json.gz  sign/schemes/testdata/wycheproof/mldsa_*_sign_{seed,noseed}_test (test logic:
+                       sign/schemes/wycheproof_test.go:57-115; deterministic signatures through the public Sign
+                       with contexts).  Signatures are stored as SHA-256 digests.
   sha3_kats.json.gz    internal/sha3/testdata/keccakKats.json.deflate: every 8th ShortMsgKAT of
                        SHA3-256, SHA3-512, SHAKE128, SHAKE256 (byte-aligned lengths only).
   fixed_vectors.json.gz  the literal expected arrays of the reference's fixed-vector unit tests:
@@ -122,6 +125,23 @@ def wycheproof():
     dump("mldsa_wycheproof_verify.json.gz", out)
 
 
+def wycheproof_sign():
+    out = {}
+    names = {44: ("mldsa_44_sign_seed_test", "mldsa_44_sign_noseed_test"),
+             65: ("mldsa_65_seed_sign_test", "mldsa_65_noseed_sign_test"),
+             87: ("mldsa_87_sign_seed_test", "mldsa_87_sign_noseed_test")}
+    for mode, files in names.items():
+        gs = []
+        for fn in files:
+            w = load_gz(f"sign/schemes/testdata/wycheproof/{fn}.json.gz")
+            for g in w["testGroups"]:
+                gs.append({"seed": g.get("privateSeed"), "sk": g.get("privateKey"), "tests": [
+                    {"id": t["tcId"], "comment": t["comment"], "msg": t["msg"], "ctx": t.get("ctx", ""),
+                     "sig_sha256": sha(t["sig"]) if t["sig"] else "", "result": t["result"]} for t in g["tests"]]})
+        out[f"ML-DSA-{mode}"] = gs
+    dump("mldsa_wycheproof_sign.json.gz", out)
+
+
 def sha3():
     with open(os.path.join(REF, "internal/sha3/testdata/keccakKats.json.deflate"), "rb") as f:
         kats = json.loads(zlib.decompress(f.read(), -15))["kats"]
@@ -159,4 +179,5 @@ if __name__ == "__main__":
     mlkem()
     mldsa()
     wycheproof()
+    wycheproof_sign()
     sha3()

@@ -185,3 +185,19 @@ def test_sign_rejects_long_context():
     pk, sk = orc.mldsa_keygen(65, np.zeros((1, 32), np.uint8))
     with pytest.raises(nat.CirclHipError):
         hostapi.mldsa_sign(65, sk, [b"m"], [b"c" * 256])
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_wycheproof_sign_on_device(name):
+    # sign/schemes/wycheproof_test.go:57-115 through the batch ABI: one batch per parameter set
+    import hashlib
+    from test_oracle_mldsa import _wycheproof_sign_cases
+    sks, msgs, ctxs, want = [], [], [], []
+    for p, SK, sk, t in _wycheproof_sign_cases(name):
+        ctx = hx(t["ctx"])
+        if len(sk) != SK or len(ctx) > 255:
+            continue
+        sks.append(sk); msgs.append(hx(t["msg"])); ctxs.append(ctx); want.append(t["sig_sha256"])
+    sig = hostapi.mldsa_sign(PARAMS[name], b"".join(sks), msgs, ctxs)
+    got = [hashlib.sha256(sig[i].tobytes()).hexdigest() for i in range(len(want))]
+    assert got == want and len(want) >= 100

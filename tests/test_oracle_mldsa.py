@@ -109,3 +109,35 @@ def test_sign_verify_roundtrip_batch(name):
     bad[:, 40] ^= 1
     assert not orc.mldsa_verify(p, pk, bad, msgs, ctxs).any()
     assert not orc.mldsa_verify(p, pk, sig, msgs, [b"other"] * n).any()
+
+
+def _wycheproof_sign_cases(name):
+    p = PARAMS[name]
+    SK = orc.DSA_SIZES[p][1]
+    for g in load_golden("mldsa_wycheproof_sign.json.gz")[name]:
+        if g["seed"] is not None:
+            _, sk = orc.mldsa_keygen(p, np.frombuffer(hx(g["seed"]), np.uint8))
+            sk = sk[0].tobytes()
+        else:
+            sk = hx(g["sk"])
+        for t in g["tests"]:
+            # sign/schemes/wycheproof_test.go:79-84 skips these two (keys the reference does not reject)
+            if t["comment"] in ("private key with s1 vector out of range", "private key with s2 vector out of range"):
+                continue
+            yield p, SK, sk, t
+
+
+@pytest.mark.parametrize("name", list(PARAMS))
+def test_wycheproof_sign(name):
+    # sign/schemes/wycheproof_test.go:57-115: deterministic Sign with contexts, from seeds and from packed keys
+    n = 0
+    for p, SK, sk, t in _wycheproof_sign_cases(name):
+        ctx = hx(t["ctx"])
+        if len(sk) != SK or len(ctx) > 255:
+            assert t["result"] == "invalid"   # UnmarshalBinaryPrivateKey / ErrContextTooLong
+            continue
+        assert t["result"] == "valid", t["comment"]
+        sig = orc.mldsa_sign_one(p, sk, hx(t["msg"]), ctx=ctx)
+        assert hashlib.sha256(sig).hexdigest() == t["sig_sha256"], (t["id"], t["comment"])
+        n += 1
+    assert n >= 100
