@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -89,11 +90,18 @@ int cu_count() {
 // upper bound on resident single-wave workgroups, used to size the scratch part of the workspace
 size_t max_resident_blocks() { return (size_t)cu_count() * kMaxBlocksPerCU; }
 
+// one instantiation (and one cached answer) per kernel: the occupancy query is not free
 template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
-    if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
-    return (unsigned)(cu_count() * occ);
+    static std::atomic<unsigned> cached{0};
+    unsigned v = cached.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
+        if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
+        v = (unsigned)(cu_count() * occ);
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 size_t up256(size_t x) { return (x + 255) & ~size_t(255); }

@@ -1,0 +1,103 @@
+// tests/hostsim/hostsim.hip -- TEST INFRASTRUCTURE: runs the lane-local __host__ __device__ functions
+// of circl_amd/csrc/*_dev.h on the CPU (their host instantiation), so that the CPU-only test tier
+// can check the very source the kernels are built from against the oracle.  Nothing here is linked
+// into libcirclhip.so, and the product never calls a host instantiation.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "dilithium_dev.h"
+#include "kyber_dev.h"
+
+using namespace circl;
+
+extern "C" {
+
+void hs_keccak_f1600(uint64_t *a, int rounds) {
+    KeccakState s;
+    for (int i = 0; i < 25; i++) { s.lo[i] = (uint32_t)a[i]; s.hi[i] = (uint32_t)(a[i] >> 32); }
+    keccak_f1600(s, 24 - rounds);
+    for (int i = 0; i < 25; i++) a[i] = ((uint64_t)s.hi[i] << 32) | s.lo[i];
+}
+
+int hs_kyber_mont_reduce(int x) { return kyber::mont_reduce(x); }
+int hs_kyber_barrett(int x) { return kyber::barrett(x); }
+int hs_kyber_normalize(int x) { return kyber::normalize(x); }
+int hs_kyber_zeta(int i) { return kyber::zeta(i); }
+unsigned hs_kyber_compress(int x, int d) {
+    switch (d) {
+    case 4: return kyber::compress_coeff<4>(x);
+    case 5: return kyber::compress_coeff<5>(x);
+    case 10: return kyber::compress_coeff<10>(x);
+    default: return kyber::compress_coeff<11>(x);
+    }
+}
+int hs_kyber_decompress(unsigned t, int d) {
+    switch (d) {
+    case 4: return kyber::decompress_coeff<4>(t);
+    case 5: return kyber::decompress_coeff<5>(t);
+    case 10: return kyber::decompress_coeff<10>(t);
+    default: return kyber::decompress_coeff<11>(t);
+    }
+}
+unsigned hs_kyber_msg_bit(int x) { return kyber::msg_bit(x); }
+int hs_kyber_cbd2(unsigned t) { return kyber::cbd2_from_nibble(t); }
+int hs_kyber_cbd3(unsigned t) { return kyber::cbd3_from_6bits(t); }
+// one lane's share of MulHat: a[4], b[4] are coefficients 4l..4l+3; returns the four products (Montgomery form)
+void hs_kyber_mulhat4(int *out, const int *a, const int *b, int lane) {
+    int acc[4] = {0, 0, 0, 0}, x[4], y[4];
+    for (int i = 0; i < 4; i++) { x[i] = a[i]; y[i] = b[i]; }
+    kyber::mulhat_acc(acc, x, y, kyber::zeta(64 + lane));
+    kyber::mulhat_finish(acc);
+    for (int i = 0; i < 4; i++) out[i] = acc[i];
+}
+// the 4-register butterfly network of the wave-level NTT, executed lane by lane on the host:
+// exactly the layer/zeta schedule of kyber::ntt / invntt with the LDS exchanges replaced by array indexing
+void hs_kyber_ntt(int16_t *p, int inverse) {
+    int c[64][4];
+    auto idx = [](int which, int l, int r) { return which == 1 ? kyber::idx_l1(l, r) : which == 2 ? kyber::idx_l2(l, r) : which == 3 ? kyber::idx_l3(l, r) : kyber::idx_l4(l, r); };
+    auto relayout = [&](int from, int to) {
+        int16_t x[256];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) x[idx(from, l, r)] = (int16_t)c[l][r];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = x[idx(to, l, r)];
+    };
+    const int z1 = kyber::zeta(1), z2 = kyber::zeta(2), z3 = kyber::zeta(3);
+    if (!inverse) {
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = p[idx(1, l, r)];
+        for (int l = 0; l < 64; l++) { int *v = c[l]; kyber::ct(v[0], v[2], z1); kyber::ct(v[1], v[3], z1); kyber::ct(v[0], v[1], z2); kyber::ct(v[2], v[3], z3); }
+        relayout(1, 2);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f2); kyber::ct(v[1], v[3], z.f2); kyber::ct(v[0], v[1], z.f3a); kyber::ct(v[2], v[3], z.f3b); }
+        relayout(2, 3);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f4); kyber::ct(v[1], v[3], z.f4); kyber::ct(v[0], v[1], z.f5a); kyber::ct(v[2], v[3], z.f5b); }
+        relayout(3, 4);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f6); kyber::ct(v[1], v[3], z.f6); }
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(4, l, r)] = (int16_t)c[l][r];
+    } else {
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = p[idx(4, l, r)];
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[2], z.i6); kyber::gs(v[1], v[3], z.i6); }
+        relayout(4, 3);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[1], z.i5a); kyber::gs(v[2], v[3], z.i5b); kyber::gs(v[0], v[2], z.i4); kyber::gs(v[1], v[3], z.i4); for (int r = 0; r < 4; r++) v[r] = kyber::barrett(v[r]); }
+        relayout(3, 2);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[1], z.i3a); kyber::gs(v[2], v[3], z.i3b); kyber::gs(v[0], v[2], z.i2); kyber::gs(v[1], v[3], z.i2); for (int r = 0; r < 4; r++) v[r] = kyber::barrett(v[r]); }
+        relayout(2, 1);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; kyber::gs(v[0], v[1], z3); kyber::gs(v[2], v[3], z2); kyber::gs(v[0], v[2], z1); kyber::gs(v[1], v[3], z1); for (int r = 0; r < 4; r++) v[r] = kyber::mont_mul(1441, v[r]); }
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(1, l, r)] = (int16_t)c[l][r];
+    }
+}
+
+uint32_t hs_dil_mont24(uint32_t a, uint32_t b) { return dilithium::mont24(a, b); }
+uint32_t hs_dil_fold(uint32_t x) { return dilithium::fold(x); }
+uint32_t hs_dil_normalize(uint32_t x) { return dilithium::normalize(x); }
+uint32_t hs_dil_zeta(int i) { return dilithium::zeta(i); }
+uint32_t hs_dil_r24(void) { return dilithium::R24; }
+uint32_t hs_dil_use_hint(uint32_t a, uint32_t h, int gamma2_is_88) {
+    return gamma2_is_88 ? dilithium::use_hint<95232>(a, h) : dilithium::use_hint<261888>(a, h);
+}
+void hs_dil_decompose(uint32_t a, int gamma2_is_88, uint32_t *a0, uint32_t *a1) {
+    if (gamma2_is_88) dilithium::decompose<95232>(a, *a0, *a1);
+    else dilithium::decompose<261888>(a, *a0, *a1);
+}
+int hs_dil_exceeds(uint32_t x, uint32_t bound) { return dilithium::exceeds(x, bound) ? 1 : 0; }
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""CPU-side checks of the device source itself: the lane-local __host__ __device__ functions of
+circl_amd/csrc/*_dev.h are compiled for the host (tests/hostsim/hostsim.hip) and compared with the
+oracle / exact arithmetic.  Mirrors the reference's field_test.go / ntt_test.go / poly_test.go."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q, DQ = 3329, 8380417
+
+
+@pytest.fixture(scope="module")
+def hs():
+    out = os.path.join(ROOT, "build", "libhostsim.so")
+    src = os.path.join(ROOT, "tests", "hostsim", "hostsim.hip")
+    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h")]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
+                               os.path.join(ROOT, "circl_amd", "csrc"), src, "-o", out])
+    L = C.CDLL(out)
+    for f in ("hs_kyber_compress", "hs_kyber_msg_bit", "hs_dil_mont24", "hs_dil_fold", "hs_dil_normalize", "hs_dil_zeta", "hs_dil_r24", "hs_dil_use_hint"):
+        getattr(L, f).restype = C.c_uint32
+    L.hs_dil_mont24.argtypes = [C.c_uint32, C.c_uint32]
+    L.hs_dil_fold.argtypes = [C.c_uint32]
+    L.hs_dil_normalize.argtypes = [C.c_uint32]
+    L.hs_dil_use_hint.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    L.hs_dil_exceeds.argtypes = [C.c_uint32, C.c_uint32]
+    return L
+
+
+def test_keccak_host_instantiation(hs):
+    want = np.array(load_golden("fixed_vectors.json.gz")["keccak_f1600_of_zero"], dtype=np.uint64)
+    a = np.zeros(25, np.uint64)
+    hs.hs_keccak_f1600(a.ctypes.data_as(C.c_void_p), 24)
+    assert (a == want).all()
+    rng = np.random.default_rng(0)
+    for rounds in (24, 12):
+        st = rng.integers(0, 1 << 63, 25, dtype=np.uint64)
+        b = st.copy()
+        hs.hs_keccak_f1600(b.ctypes.data_as(C.c_void_p), rounds)
+        assert (b == orc.keccak_f1600(st, rounds)).all()
+
+
+def test_kyber_field_and_zetas(hs):
+    # field_test.go: montReduce / barrettReduce over their whole documented ranges (sampled), zetas table
+    z = orc.kyber_zetas()
+    assert [hs.hs_kyber_zeta(i) for i in range(128)] == z.tolist()
+    rng = np.random.default_rng(1)
+    for x in np.concatenate([rng.integers(-(1 << 30), 1 << 30, 20000), np.arange(-70000, 70000, 7)]):
+        r = hs.hs_kyber_mont_reduce(int(x))
+        assert (r * (1 << 16) - int(x)) % Q == 0 and abs(r) <= abs(int(x)) // 65536 + Q // 2 + 1
+    for x in range(-32768, 32768):
+        r = hs.hs_kyber_barrett(x)
+        assert 0 <= r <= Q and (r - x) % Q == 0
+        n = hs.hs_kyber_normalize(x)
+        assert n == x % Q
+
+
+@pytest.mark.parametrize("d", [4, 5, 10, 11])
+def test_compress_exact_for_all_x(hs, d):
+    # poly_test.go:351-378
+    for x in range(Q):
+        want = ((x << d) + Q // 2) // Q % (1 << d)
+        assert hs.hs_kyber_compress(x, d) == want
+    for t in range(1 << d):
+        assert hs.hs_kyber_decompress(t, d) == (t * Q + (1 << (d - 1))) >> d
+    assert [hs.hs_kyber_msg_bit(x) for x in range(Q)] == [1 if 833 <= x <= 2496 else 0 for x in range(Q)]
+
+
+def test_cbd_tables(hs):
+    assert [hs.hs_kyber_cbd2(t) for t in range(16)] == [bin(t & 3).count("1") - bin(t >> 2).count("1") for t in range(16)]
+    assert [hs.hs_kyber_cbd3(t) for t in range(64)] == [bin(t & 7).count("1") - bin(t >> 3).count("1") for t in range(64)]
+
+
+def test_ntt_network_matches_oracle(hs):
+    # ntt_test.go:49-81 with the device's layer / layout / zeta schedule executed on the host
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        p = rng.integers(-Q + 1, Q, 256).astype(np.int16)
+        a = p.copy()
+        hs.hs_kyber_ntt(a.ctypes.data_as(C.c_void_p), 0)
+        assert (a == orc.kyber_ntt(p)).all()          # forward: identical without normalisation
+        p = rng.integers(0, Q, 256).astype(np.int16)
+        b = p.copy()
+        hs.hs_kyber_ntt(b.ctypes.data_as(C.c_void_p), 1)
+        assert (orc.kyber_normalize(b) == orc.kyber_normalize(orc.kyber_invntt(p))).all()
+
+
+def test_mulhat_lane_share(hs):
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, Q + 1, 256).astype(np.int16)
+    b = rng.integers(0, Q + 1, 256).astype(np.int16)
+    want = orc.kyber_normalize(orc.kyber_mulhat(a, b))
+    out = (C.c_int * 4)()
+    for lane in range(64):
+        ai = (C.c_int * 4)(*[int(v) for v in a[4 * lane:4 * lane + 4]])
+        bi = (C.c_int * 4)(*[int(v) for v in b[4 * lane:4 * lane + 4]])
+        hs.hs_kyber_mulhat4(out, ai, bi, lane)
+        assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
+
+
+def test_dilithium_mont24_and_zetas(hs):
+    R24 = (1 << 24) % DQ
+    assert hs.hs_dil_r24() == R24
+    z = orc.dilithium_zetas().astype(np.uint64)   # zeta^brv * 2^32
+    inv32 = pow(1 << 32, -1, DQ)
+    for i in range(256):
+        assert hs.hs_dil_zeta(i) == int(z[i]) * inv32 % DQ * R24 % DQ
+    rng = np.random.default_rng(4)
+    inv24 = pow(1 << 24, -1, DQ)
+    for a, b in zip(rng.integers(0, 1 << 24, 20000), rng.integers(0, DQ, 20000)):
+        r = hs.hs_dil_mont24(int(a), int(b))
+        assert r < 2 * DQ and r % DQ == int(a) * int(b) * inv24 % DQ
+    for x in rng.integers(0, 1 << 32, 20000, dtype=np.uint64):
+        f = hs.hs_dil_fold(int(x))
+        assert f < (1 << 24) and f % DQ == int(x) % DQ
+        assert hs.hs_dil_normalize(int(x)) == int(x) % DQ
+
+
+@pytest.mark.parametrize("g88", [0, 1])
+def test_decompose_use_hint_laws(hs, g88):
+    # sign/mldsa/mldsa65/internal/rounding_test.go:14-67
+    gamma2 = 95232 if g88 else 261888
+    alpha = 2 * gamma2
+    m = (DQ - 1) // alpha
+    a0, a1 = C.c_uint32(), C.c_uint32()
+    rng = np.random.default_rng(5)
+    for a in np.concatenate([rng.integers(0, DQ, 20000), np.arange(0, 3000), np.arange(DQ - 3000, DQ)]):
+        a = int(a)
+        hs.hs_dil_decompose(a, g88, C.byref(a0), C.byref(a1))
+        r0 = a0.value - DQ if a0.value > (DQ - 1) // 2 else a0.value   # a0 + q representation -> centred
+        if a0.value >= DQ:
+            r0 = a0.value - DQ
+        assert 0 <= a1.value < m or a1.value == 0
+        assert (a1.value * alpha + r0 - a) % DQ == 0 and -gamma2 <= r0 <= gamma2
+        assert hs.hs_dil_use_hint(a, 0, g88) == a1.value
+        up = hs.hs_dil_use_hint(a, 1, g88)
+        assert up == ((a1.value + 1) % m if r0 > 0 else (a1.value - 1) % m)
+    assert hs.hs_dil_exceeds(5, 6) == 0 and hs.hs_dil_exceeds(DQ - 6, 6) == 1 and hs.hs_dil_exceeds(6, 6) == 1
