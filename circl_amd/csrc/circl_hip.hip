@@ -90,17 +90,19 @@ int cu_count() {
 // upper bound on resident single-wave workgroups, used to size the scratch part of the workspace
 size_t max_resident_blocks() { return (size_t)cu_count() * kMaxBlocksPerCU; }
 
-// one instantiation (and one cached answer) per kernel: the occupancy query is not free
+// cached per kernel address: the occupancy query is not free
 template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
-    static std::atomic<unsigned> cached{0};
-    unsigned v = cached.load(std::memory_order_relaxed);
-    if (v == 0) {
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
-        if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
-        v = (unsigned)(cu_count() * occ);
-        cached.store(v, std::memory_order_relaxed);
-    }
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, unsigned>> cache;
+    const void *key = reinterpret_cast<const void *>(kern);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : cache)
+        if (e.first == key) return e.second;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
+    if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
+    const unsigned v = (unsigned)(cu_count() * occ);
+    cache.emplace_back(key, v);
     return v;
 }
 
