@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcirclhip.so")
 SOURCES = ["circl_hip.hip"]
-HEADERS = ["keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "mlkem_kernels.h", "mldsa_kernels.h", "prim_kernels.h"]
+HEADERS = ["keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "mlkem_kernels.h", "mldsa_kernels.h", "mldsa_sign_batched.h", "prim_kernels.h"]
 ARCH = "gfx950"
 
 

@@ -17,6 +17,7 @@
 
 #include "mlkem_kernels.h"
 #include "mldsa_kernels.h"
+#include "mldsa_sign_batched.h"
 #include "prim_kernels.h"
 
 namespace {
@@ -424,9 +425,70 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *
 // ---- ML-DSA sign ------------------------------------------------------------------------------
 constexpr int kSignBlocksPerCU = 8;
 
+constexpr size_t kSignBatchedMin = 16;  // below this the single persistent kernel has less launch overhead
+
 template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
     using S = circl::mldsa::SG<MODE>;
-    return up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
+    using B = circl::mldsa::SB<MODE>;
+    const size_t persistent = up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
+    const size_t batched = up256(n * B::PER_ITEM) + up256(4 * n) * 3 + up256(n) + 256;
+    return n < kSignBatchedMin ? persistent : std::max(persistent, batched);
+}
+
+// Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h).  Synchronises the
+// stream once per round to read the number of items that are still unsigned.
+template <int MODE>
+int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                       const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, hipStream_t st) {
+    using namespace circl::mldsa;
+    using B = SB<MODE>;
+    constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
+    uint8_t *p = static_cast<uint8_t *>(ws);
+    SignState S;
+    S.mr = p; p += up256(128 * n);
+    S.A = reinterpret_cast<uint32_t *>(p); p += n * B::A_BYTES;
+    S.sec = reinterpret_cast<uint32_t *>(p); p += n * B::SEC_BYTES;
+    S.y = reinterpret_cast<uint32_t *>(p); p += n * B::Y_BYTES;
+    S.w0 = reinterpret_cast<uint32_t *>(p); p += n * B::W0_BYTES;
+    S.w1 = p; p += n * B::W1_BYTES;
+    S.muw1 = p; p += n * B::MUW1_BYTES;
+    S.cb = p; p += n * B::CB_BYTES;
+    p = static_cast<uint8_t *>(ws) + up256(n * B::PER_ITEM);
+    S.attempts = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
+    S.list[0] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
+    S.list[1] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
+    S.done = p; p += up256(n);
+    S.count = reinterpret_cast<uint32_t *>(p);
+    const unsigned nb256 = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
+                           S.mr, n);
+    }
+    const uint32_t counts0[2] = {(uint32_t)n, 0};
+    HIP_TRY(hipMemcpyAsync(S.count, counts0, 8, hipMemcpyHostToDevice, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((n * K * L + 255) / 256)), dim3(256), 0, st, sk, S, n);
+        hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n);
+    }
+    int cur = 0;
+    uint32_t upper = (uint32_t)n;
+    for (int round = 0; upper > 0; round++) {
+        if (round > 4096) { g_err = "mldsa sign: rejection loop did not terminate"; return CIRCL_HIP_EHIP; }
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3((unsigned)(((size_t)upper * L + 255) / 256)), dim3(256), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig);
+        HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
+        hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
+        cur ^= 1;
+        HIP_TRY(hipMemcpyAsync(&upper, S.count + cur, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
 }
 
 template <int MODE>
@@ -437,6 +499,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < mldsa_sign_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(rnd) || rnd == nullptr)
         return CIRCL_HIP_EWORKSPACE;
+    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st);
     uint8_t *mr = static_cast<uint8_t *>(ws);
     unsigned *work = reinterpret_cast<unsigned *>(mr + up256(128 * n));
     uint8_t *scratch = mr + up256(128 * n) + 256;

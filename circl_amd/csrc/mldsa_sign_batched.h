@@ -1,0 +1,344 @@
+// mldsa_sign_batched.h -- phase-split batch ML-DSA signing (included by circl_hip.hip).
+//
+// Same arithmetic as mldsa_sign_kernel (mldsa_kernels.h), reorganised so that every sponge runs with
+// full lanes: the rejection loop of sign/mldsa/mldsa65/internal/dilithium.go:371-455 is executed as
+// rounds over the list of still-unsigned items.  Per-item state lives in the workspace:
+//   A rows (K L KB), s1-hat / s2-hat / t0-hat ((L+2K) KB), y bytes, w0, w1, mu || w1, c~ + ball sponge.
+// One round = five launches over the active list:
+//   mask   lane = (active item, l)      ExpandMask streams, 64 useful lanes per wave
+//   w      wave = active item           y-hat, w = InvNTT(A y-hat), Decompose, w1 packing
+//   chal   lane = active item           c~ = H(mu || w1), first SampleInBall block
+//   finish wave = active item           c s2 / z / c t0 / hints, accept or bump the attempt counter
+//   compact                             next active list
+// The host reads the active count back every few rounds and stops when it is zero.
+#pragma once
+#include "mldsa_kernels.h"
+
+namespace circl {
+namespace mldsa {
+
+template <int MODE> struct SB {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    static constexpr int K = P::K, L = P::L;
+    static constexpr size_t A_BYTES = (size_t)K * L * 1024;
+    static constexpr size_t SEC_BYTES = (size_t)(L + 2 * K) * 1024;
+    static constexpr size_t Y_BYTES = (size_t)L * (G::ZSZ + 64);   // ZSZ payload + slack, per polynomial
+    static constexpr int YROW_DW = (G::ZSZ + 64) / 4;
+    static constexpr size_t W0_BYTES = (size_t)K * 1024;
+    static constexpr size_t W1_BYTES = (size_t)K * 256;
+    static constexpr size_t MUW1_BYTES = ((G::MUW1 + 63) / 64) * 64;
+    static constexpr size_t CB_BYTES = 320;                          // c~ (<= 64 B), 56 B pad, ball state (200 B)
+    static constexpr size_t PER_ITEM = A_BYTES + SEC_BYTES + Y_BYTES + W0_BYTES + W1_BYTES + MUW1_BYTES + CB_BYTES + 128 /* mu, rho'' */;
+};
+
+struct SignState {          // device pointers into the workspace, passed by value to the kernels
+    uint8_t *mr;            // n x 128: mu, rho''
+    uint32_t *A;            // n x K L x 256
+    uint32_t *sec;          // n x (L + 2K) x 256
+    uint32_t *y;            // n x L x YROW_DW
+    uint32_t *w0;           // n x K x 256
+    uint8_t *w1;            // n x K x 256
+    uint8_t *muw1;          // n x MUW1_BYTES
+    uint8_t *cb;            // n x 320
+    uint32_t *attempts;     // n
+    uint8_t *done;          // n
+    uint32_t *list[2];      // active lists
+    uint32_t *count;        // [0], [1]: list lengths
+};
+
+// ---- setup ---------------------------------------------------------------------------------------
+
+// lane = (item, i, j): ExpandA into the per-item A rows (mat.go:15-49), full lanes across items
+template <int MODE>
+__global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__restrict__ sk, SignState st, size_t n) {
+    using Kg = KG<MODE>;
+    constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
+    const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = sidx < n * K * L;
+    const size_t item = on ? sidx / (K * L) : n - 1;
+    const int p = on ? (int)(sidx % (K * L)) : 0;
+    const int i = p / L, j = p % L;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(sk + item * Kg::SK));
+    s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+    s.hi[20] = 0x80000000u;
+    uint32_t *row = st.A + (item * K * L + p) * 256;
+    int cnt = on ? 0 : 256;
+#pragma unroll 1
+    for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
+        keccak_f1600(s);
+        for_each_candidate23(s, [&](uint32_t a) {
+            if (a < Q && cnt < 256) row[cnt++] = a;
+        });
+    }
+}
+
+// wave = item: NTT of s1, s2, t0 (dilithium.go:149-179) into the workspace; initial active list
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restrict__ sk, SignState st, size_t n) {
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    constexpr int K = P::K, L = P::L;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    const int lane = threadIdx.x;
+    const size_t item = blockIdx.x;
+    const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(sk + item * Kg::SK);
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    uint32_t *sec = st.sec + item * (L + 2 * K) * 256;
+#pragma unroll 1
+    for (int k = 0; k < L + 2 * K; k++) {
+        uint32_t c[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            int v;
+            if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (128 + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
+            else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (128 + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
+            c[r] = v < 0 ? Q + v : (uint32_t)v;
+        }
+        dilithium::ntt(c, z, xch, lane);
+        *reinterpret_cast<uint4 *>(sec + k * 256 + 4 * lane) =
+            make_uint4(dilithium::fold(c[0]), dilithium::fold(c[1]), dilithium::fold(c[2]), dilithium::fold(c[3]));
+    }
+    if (lane == 0) {
+        st.attempts[item] = 0;
+        st.done[item] = 0;
+        st.list[0][item] = (uint32_t)item;
+    }
+    if (lane < 16) reinterpret_cast<uint32_t *>(st.muw1 + item * SB<MODE>::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
+}
+
+// ---- one round -------------------------------------------------------------------------------------
+
+// lane = (active item, l): y = ExpandMask(rho'', L * attempts + l)  (sample.go:178-196)
+template <int MODE>
+__global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
+    using G = DG<MODE>;
+    using B = SB<MODE>;
+    constexpr int L = DP<MODE>::L;
+    const unsigned cnt = st.count[cur];
+    const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((size_t)(blockIdx.x * 256) >= (size_t)cnt * L) return;  // whole block idle
+    const bool on = sidx < (size_t)cnt * L;
+    const size_t item = st.list[cur][on ? sidx / L : 0];
+    const int l = on ? (int)(sidx % L) : 0;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
+    s.lo[8] = ((st.attempts[item] * L + l) & 0xffff) | (kDsShake << 16);
+    s.hi[16] = 0x80000000u;
+    uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+#pragma unroll 1
+    for (int blk = 0; blk < 5; blk++) {
+        keccak_f1600(s);
+        if (on) {
+            detail::static_for<0, 17>([&](auto ic) {
+                constexpr int w = decltype(ic)::v;
+                if (34 * blk + 2 * w < G::ZSZ / 4) {  // only the ZSZ payload bytes are kept
+                    yrow[34 * blk + 2 * w] = s.lo[w];
+                    yrow[34 * blk + 2 * w + 1] = s.hi[w];
+                }
+            });
+        }
+    }
+}
+
+// wave = active item: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398)
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    constexpr int K = P::K, L = P::L;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    if (blockIdx.x >= st.count[cur]) return;
+    const int lane = threadIdx.x;
+    const size_t item = st.list[cur][blockIdx.x];
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    uint32_t yh[L][4];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        const uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+            x += (uint32_t)((int32_t)x >> 31) & Q;
+            yh[l][r] = x;
+        }
+        dilithium::ntt(yh[l], z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont24(dilithium::fold(yh[l][r]), dilithium::R24SQ);
+    }
+    const uint32_t *arows = st.A + item * K * L * 256;
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * 256 + 4 * lane);
+            w[0] += dilithium::mont24(a.x, yh[j][0]);
+            w[1] += dilithium::mont24(a.y, yh[j][1]);
+            w[2] += dilithium::mont24(a.z, yh[j][2]);
+            w[3] += dilithium::mont24(a.w, yh[j][3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
+        dilithium::invntt(w, z, xch, lane);
+        unsigned w1v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            uint32_t a0, a1;
+            dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
+            st.w0[(item * K + i) * 256 + nidx] = a0;
+            st.w1[(item * K + i) * 256 + nidx] = (uint8_t)a1;
+            w1v[r] = a1;
+        }
+        mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
+        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + item * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
+    }
+}
+
+// lane = active item: c~ = SHAKE256(mu || w1)[:CT] and the first SampleInBall block (dilithium.go:400-405)
+template <int MODE>
+__global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int cur) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= st.count[cur]) return;
+    const size_t item = st.list[cur][a];
+    KeccakState s;
+    sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + item * B::MUW1_BYTES), kDsShake);
+    uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + item * B::CB_BYTES);
+    store_words<0, P::CT / 8>(cb, s);
+    KeccakState bs;
+    keccak_zero(bs);
+#pragma unroll
+    for (int i = 0; i < P::CT / 8; i++) { bs.lo[i] = s.lo[i]; bs.hi[i] = s.hi[i]; }
+    bs.lo[P::CT / 8] ^= kDsShake;
+    bs.hi[16] ^= 0x80000000u;
+    keccak_f1600(bs);
+    store_words<0, 25>(cb + 15, bs);  // ball state at byte 120
+}
+
+// wave = active item: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88)
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    constexpr int K = P::K, L = P::L;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t zpk[L * G::ZSZ];
+    __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    if (blockIdx.x >= st.count[cur]) return;
+    const int lane = threadIdx.x;
+    const size_t item = st.list[cur][blockIdx.x];
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    const uint8_t *cb = st.cb + item * B::CB_BYTES;
+    uint32_t chat[4];
+    sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
+    const uint32_t *sec = st.sec + item * (L + 2 * K) * 256;
+    uint32_t *w0 = st.w0 + item * K * 256;
+    auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
+        const uint4 sv = *reinterpret_cast<const uint4 *>(row + 4 * lane);
+        t[0] = dilithium::fold(dilithium::mont24(sv.x, chat[0]));
+        t[1] = dilithium::fold(dilithium::mont24(sv.y, chat[1]));
+        t[2] = dilithium::fold(dilithium::mont24(sv.z, chat[2]));
+        t[3] = dilithium::fold(dilithium::mont24(sv.w, chat[3]));
+        dilithium::invntt(t, z, xch, lane);
+    };
+    bool bad = false;
+    // w0 - c s2
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+        uint32_t t[4];
+        mul_c(t, sec + (L + i) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            const uint32_t v = dilithium::normalize(w0[i * 256 + nidx] + (2 * Q - t[r]));
+            bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
+            w0[i * 256 + nidx] = v;
+        }
+    }
+    bool reject = __any(bad);
+    // z = y + c s1
+    if (!reject) {
+#pragma unroll 1
+        for (int l = 0; l < L; l++) {
+            uint32_t t[4];
+            mul_c(t, sec + l * 256);
+            const uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+            unsigned fld[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t y = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+                y += (uint32_t)((int32_t)y >> 31) & Q;
+                const uint32_t zz = dilithium::normalize(t[r] + y);
+                bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
+                uint32_t f = G::GAMMA1 - zz;
+                f += (uint32_t)((int32_t)f >> 31) & Q;
+                fld[r] = f;
+            }
+            mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
+            for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+        }
+        reject = __any(bad);
+    }
+    // c t0, hints
+    unsigned pop = 0;
+    if (!reject) {
+        __syncthreads();
+        for (int i = lane; i < 24; i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint32_t t[4];
+            mul_c(t, sec + (L + K + i) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                const uint32_t ct0 = dilithium::csubq(t[r]);
+                bad |= dilithium::exceeds(ct0, P::GAMMA2);
+                const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
+                const uint32_t r1 = st.w1[(item * K + i) * 256 + nidx];
+                const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+                const unsigned long long mask = __ballot(hbit);
+                if (hbit) {
+                    const unsigned slot = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
+                    if (slot < (unsigned)P::OMEGA) hbytes[slot] = (uint8_t)nidx;
+                }
+                pop += (unsigned)__popcll(mask);
+            }
+            if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
+        }
+        reject = __any(bad) || pop > (unsigned)P::OMEGA;
+    }
+    if (reject) {
+        if (lane == 0) st.attempts[item] += 1;
+        return;
+    }
+    __syncthreads();
+    uint8_t *sg = sig + item * G::SIG;
+    for (int b = lane; b < P::CT; b += 64) sg[b] = cb[b];
+    for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
+    for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
+    if (lane == 0) st.done[item] = 1;
+}
+
+// next active list = the items of the current one that are still unsigned
+__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur) {
+    const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= st.count[cur]) return;
+    const uint32_t item = st.list[cur][a];
+    if (!st.done[item]) st.list[cur ^ 1][atomicAdd(&st.count[cur ^ 1], 1u)] = item;
+}
+
+}  // namespace mldsa
+}  // namespace circl

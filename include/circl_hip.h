@@ -129,7 +129,10 @@ int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk
  * `randomized` is set; rnd == NULL means deterministic signing (32 zero bytes).  A context longer
  * than 255 bytes makes the host-buffer call return CIRCL_HIP_EPARAM (sign.ErrContextTooLong).
  * circl_hip_mldsa_sign_internal is ML-DSA.Sign_internal (unsafeSignInternal, dilithium.go:90-99).
- * The _dev variant needs circl_hip_mldsa_sign_workspace_size(param, n) bytes; d_rnd must not be NULL. */
+ * The _dev variant needs circl_hip_mldsa_sign_workspace_size(param, n) bytes (about 60 KB per item for
+ * ML-DSA-65: expanded matrix and NTT-domain secrets per item); d_rnd must not be NULL.  Unlike the other
+ * _dev calls it SYNCHRONISES the stream: the rejection loop runs as rounds over the unsigned items and
+ * the host reads their count after each round. */
 int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
                          const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig,
                          size_t n, int device);
