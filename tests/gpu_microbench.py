@@ -86,7 +86,7 @@ def dsa(param, n, pool=1 << 11):
         assert rc == 0, rc
     ms = timeit(kg, 3)
     print(f"ML-DSA-{param} keygen  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
-    ns = max(n // 4, 1)
+    ns = n
     d_sk = torch.from_numpy(np.tile(sk, (max(ns // pool, 1), 1))[:ns].copy()).cuda()
     d_rnd = torch.zeros((ns, 32), dtype=torch.uint8, device="cuda")
     ssig = torch.empty((ns, SIG), dtype=torch.uint8, device="cuda")
