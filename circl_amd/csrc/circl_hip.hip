@@ -431,8 +431,8 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
     using S = circl::mldsa::SG<MODE>;
     using B = circl::mldsa::SB<MODE>;
     const size_t persistent = up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
-    const size_t batched = up256(n * B::PER_ITEM) + up256(4 * n) * 3 + up256(n) + 256;
-    return n < kSignBatchedMin ? persistent : std::max(persistent, batched);
+    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 3 + up256(n) + 256;
+    return n < kSignBatchedMin ? persistent : persistent + batched;  // the batched path finishes its tail persistently
 }
 
 // Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h).  Synchronises the
@@ -453,12 +453,15 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     S.w1 = p; p += n * B::W1_BYTES;
     S.muw1 = p; p += n * B::MUW1_BYTES;
     S.cb = p; p += n * B::CB_BYTES;
-    p = static_cast<uint8_t *>(ws) + up256(n * B::PER_ITEM);
+    p = static_cast<uint8_t *>(ws) + up256(n * B::PER_ITEM) + 256;  // (mr was rounded up separately)
     S.attempts = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.list[0] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.list[1] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.done = p; p += up256(n);
-    S.count = reinterpret_cast<uint32_t *>(p);
+    S.count = reinterpret_cast<uint32_t *>(p); p += 256;
+    unsigned *tail_work = reinterpret_cast<unsigned *>(p);          // persistent-kernel ticket counter
+    uint8_t *tail_scratch = p + 256;
+    const uint32_t tail_threshold = (uint32_t)cu_count() * kSignBlocksPerCU;  // one resident wave per leftover item
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -477,6 +480,14 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     for (int round = 0; upper > 0; round++) {
         if (round > 4096) { g_err = "mldsa sign: rejection loop did not terminate"; return CIRCL_HIP_EHIP; }
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        if (upper <= tail_threshold) {
+            // few items left: rounds would be launch-bound, so every leftover item gets its own wavefront, which
+            // runs that item's remaining rejection iterations to the end (continuing its nonce sequence)
+            HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
+            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3(upper), dim3(64), SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig,
+                               tail_scratch, tail_work, (const uint32_t *)S.list[cur], (const uint32_t *)S.attempts, (size_t)upper);
+            break;
+        }
         hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3((unsigned)(((size_t)upper * L + 255) / 256)), dim3(256), 0, st, S, cur);
         hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur);
         hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
@@ -516,7 +527,8 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         if (occ > kSignBlocksPerCU) occ = kSignBlocksPerCU;
         const unsigned blocks = (unsigned)std::min<size_t>(n, (size_t)cu_count() * occ);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work, n);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

@@ -709,7 +709,8 @@ template <int D> __device__ __forceinline__ uint32_t gbits(const uint32_t *p, in
 template <int MODE>
 __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ mr_ws,
                                                        uint8_t *__restrict__ sig, uint8_t *__restrict__ scratch,
-                                                       unsigned *__restrict__ work, size_t n) {
+                                                       unsigned *__restrict__ work, const uint32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ attempts, size_t n) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
@@ -730,7 +731,10 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
 
 #pragma unroll 1
-    for (size_t item = mlkem::next_group(work, lane, true, n); item < n; item = mlkem::next_group(work, lane, false, n)) {
+    // `list` (optional) names the n items to sign and `attempts` how many rejection rounds each of them
+    // has already been through (the tail of mldsa_sign_batched); otherwise items are 0..n-1 from scratch.
+    for (size_t t = mlkem::next_group(work, lane, true, n); t < n; t = mlkem::next_group(work, lane, false, n)) {
+        const size_t item = list ? list[t] : t;
         const uint8_t *skp = sk + item * Kg::SK;
         const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
         __syncthreads();
@@ -780,7 +784,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
 
-        unsigned nonce = 0;
+        unsigned nonce = attempts ? attempts[item] * L : 0;
         bool accepted = false;
         KeccakState cs;  // c~ sponge (uniform across lanes)
 #pragma unroll 1
