@@ -874,7 +874,7 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
                                hipStream_t st) {
                                // the kernel strides inputs by `inlen`; empty inputs never dereference
                                hipLaunchKernelGGL(circl::prim::sponge_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st,
-                                                  rate / 8, (uint32_t)ds, i[0], inlen, o[0], outlen, c);
+                                                  rate / 8, (uint32_t)ds, 0, (const uint8_t *)i[0], inlen, (const uint64_t *)nullptr, o[0], outlen, c);
                                HIP_TRY(hipGetLastError());
                                return CIRCL_HIP_OK;
                            });
@@ -906,6 +906,36 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
     if (launches) *launches = g_prof_n[kernel];
     g_prof_ms[kernel] = 0;
     g_prof_n[kernel] = 0;
+    return CIRCL_HIP_OK;
+}
+
+// Batched XOF service: n sponges over variable-length messages, 24 or 12 rounds.
+int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const uint64_t *in_off, uint8_t *out, size_t outlen, size_t n,
+                  int device) {
+    if ((rate != 168 && rate != 136 && rate != 72 && rate != 104 && rate != 144) || ds < 1 || ds > 0x7f || (rounds != 24 && rounds != 12) ||
+        outlen == 0)
+        return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    const int dev = device < 0 ? 0 : device;
+    if (dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    Arena &a = g_arena[dev];
+    std::lock_guard<std::mutex> lk(a.mu);
+    const size_t total = in_off[n];
+    int rc = arena_reserve(a, up256(total + 16) + up256((n + 1) * 8) + up256(n * outlen));
+    if (rc) return rc;
+    hipStream_t st = a.st[0];
+    uint8_t *d_in = static_cast<uint8_t *>(a.base);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(d_in + up256(total + 16));
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(d_off) + up256((n + 1) * 8);
+    if (total) HIP_TRY(hipMemcpyAsync(d_in, in_blob, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_off, in_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(circl::prim::sponge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rate / 8, (uint32_t)ds, 24 - rounds,
+                       (const uint8_t *)d_in, (size_t)0, (const uint64_t *)d_off, d_out, outlen, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * outlen, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return CIRCL_HIP_OK;
 }
 

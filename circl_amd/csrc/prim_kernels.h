@@ -85,11 +85,14 @@ __global__ void __launch_bounds__(64) dilithium_ntt_kernel(uint32_t *polys, int 
 
 // n independent sponges over equal-length byte strings; one stream per lane
 // (internal/sha3 State.Write / Read).  rate_words in {9, 17, 21}.
-__global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds, const uint8_t *in, size_t inlen,
-                                                     uint8_t *out, size_t outlen, size_t n) {
+// in_off == nullptr: equal-length messages of `inlen` bytes; otherwise message i is in[in_off[i] .. in_off[i+1]).
+// first_round = 0 for Keccak-f[1600], 12 for the 12-round TurboSHAKE permutation (shake.go:60-90).
+__global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds, int first_round, const uint8_t *in, size_t inlen_eq,
+                                                     const uint64_t *in_off, uint8_t *out, size_t outlen, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *p = in + i * inlen;
+    const uint8_t *p = in_off ? in + in_off[i] : in + i * inlen_eq;
+    const size_t inlen = in_off ? (size_t)(in_off[i + 1] - in_off[i]) : inlen_eq;
     uint8_t *o = out + i * outlen;
     const size_t rate = (size_t)rate_words * 8;
     KeccakState s;
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
             for (int w = 0; w < 21; w++)
                 if (w == rate_words - 1) s.hi[w] ^= 0x80000000u;
         }
-        keccak_f1600(s);
+        keccak_f1600(s, first_round);
         pos += rate;
     }
     size_t done = 0;
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
             }
         }
         done += rate;
-        if (done < outlen) keccak_f1600(s);
+        if (done < outlen) keccak_f1600(s, first_round);
     }
 }
 

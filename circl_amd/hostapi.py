@@ -155,3 +155,12 @@ def shake(rate, ds, msgs, outlen, device=0):
     out = np.empty((n, outlen), np.uint8)
     nat.check(nat.lib().circl_hip_shake(rate, ds, _p(msgs), inlen, _p(out), outlen, n, device), "shake")
     return out
+
+
+def xof(rate, ds, msgs, outlen, rounds=24, device=0):
+    """variable-length messages -> (n, outlen); rounds=12 gives TurboSHAKE"""
+    n = len(msgs)
+    mb, mo = _blob(msgs)
+    out = np.empty((n, outlen), np.uint8)
+    nat.check(nat.lib().circl_hip_xof(rate, ds, rounds, _p(mb), _p(mo), _p(out), outlen, n, device), "xof")
+    return out

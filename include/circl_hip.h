@@ -165,6 +165,11 @@ int circl_hip_kyber_mulhat(int16_t *out, const int16_t *a, const int16_t *b, siz
 int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device);
 int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
                     size_t n, int device);
+/* Batched XOF service (xof/xof.go, internal/sha3/shake.go:56-100): n independent
+ * sponges over variable-length messages (blob + n+1 offsets), `rounds` = 24 (SHA3 / SHAKE) or 12
+ * (TurboSHAKE128/256 with domain byte `ds` in 0x01..0x7f), every output `outlen` bytes. */
+int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const uint64_t *in_off,
+                  uint8_t *out, size_t outlen, size_t n, int device);
 
 /* ---- kernel-level profiling (used by bench.py for the roofline figures) --------------------
  * While enabled, every *_dev call brackets each kernel it enqueues with HIP events recorded on

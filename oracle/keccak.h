@@ -45,6 +45,8 @@ void orc_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t len);
 /* generic one-shot used by the KAT tests: rate in bytes, ds byte */
 void orc_sponge_oneshot(uint8_t *out, size_t outlen, const uint8_t *in, size_t len,
                         unsigned rate, uint8_t ds);
+void orc_sponge_oneshot_rounds(uint8_t *out, size_t outlen, const uint8_t *in, size_t len, unsigned rate,
+                               uint8_t ds, int rounds);
 
 #ifdef __cplusplus
 }

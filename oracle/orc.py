@@ -74,6 +74,13 @@ def sponge(data, outlen, rate, ds):
     return out.tobytes()
 
 
+def sponge_rounds(data, outlen, rate, ds, rounds):
+    d = _u8(bytes(data) + b"\0")
+    out = np.zeros(outlen, np.uint8)
+    lib().orc_sponge_oneshot_rounds(_p(out), C.c_size_t(outlen), _p(d), C.c_size_t(len(data)), C.c_uint(rate), C.c_uint8(ds), C.c_int(rounds))
+    return out.tobytes()
+
+
 def sha3_256(d):
     return sponge(d, 32, 136, 0x06)
 

@@ -80,3 +80,22 @@ def test_mulhat_against_oracle():
     got = hostapi.kyber_mulhat(a, b)
     for i in range(200):
         assert (got[i] == orc.kyber_normalize(orc.kyber_mulhat(a[i], b[i]))).all(), i
+
+
+def test_xof_service_variable_length_and_turboshake():
+    # batched XOF over ragged messages; TurboSHAKE128 vectors of internal/sha3/sha3_test.go:264-284
+    rng = np.random.default_rng(77)
+    msgs = [rng.integers(0, 256, int(k), dtype=np.uint8).tobytes() for k in [0, 1, 135, 136, 137, 167, 168, 169, 1000] + list(rng.integers(0, 600, 300))]
+    got = hostapi.xof(136, 0x1F, msgs, 200)
+    for i, m in enumerate(msgs):
+        assert got[i].tobytes() == hashlib.shake_256(m).digest(200), i
+    got = hostapi.xof(168, 0x1F, msgs, 33)
+    for i in (0, 5, 8, 100):
+        assert got[i].tobytes() == hashlib.shake_128(msgs[i]).digest(33)
+    t = hostapi.xof(168, 0x07, [b""], 10032, rounds=12)[0].tobytes()
+    assert t[:64].hex() == "5a223ad30b3b8c66a243048cfced430f54e7529287d15150b973133adfac6a2ffe2708e73061e09a4000168ba9c8ca1813198f7bbed4984b4185f2c2580ee623"
+    assert t[-32:].hex() == "7593a28020a3c4ae0d605fd61f5eb56eccd27cc3d12ff09f78369772a460c55d"
+    assert hostapi.xof(168, 0x06, [b"\xff"], 32, rounds=12)[0].tobytes().hex() == "8ec9c66465ed0d4a6c35d13506718d687a25cb05c74cca1e42501abd83874a67"
+    tm = hostapi.xof(136, 0x0B, msgs[:50], 64, rounds=12)
+    for i in range(50):
+        assert tm[i].tobytes() == orc.sponge_rounds(msgs[i], 64, 136, 0x0B, 12)

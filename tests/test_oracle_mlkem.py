@@ -212,3 +212,12 @@ def test_decaps_rejects_bad_hash_and_implicit_rejection():
     ss2, st = orc.mlkem_decaps(768, dk, bad_ct)
     assert st[0] == 0 and (ss2 != ss).any()
     assert ss2[0].tobytes() == hashlib.shake_256(dk[0, -32:].tobytes() + bad_ct[0].tobytes()).digest(32)
+
+
+def test_turboshake128_reference_vectors():
+    # internal/sha3/sha3_test.go:264-284 TestTurboShake128
+    assert orc.sponge_rounds(b"", 64, 168, 0x07, 12).hex() == (
+        "5a223ad30b3b8c66a243048cfced430f54e7529287d15150b973133adfac6a2ffe2708e73061e09a4000168ba9c8ca1813198f7bbed4984b4185f2c2580ee623")
+    assert orc.sponge_rounds(b"", 10032, 168, 0x07, 12)[-32:].hex() == "7593a28020a3c4ae0d605fd61f5eb56eccd27cc3d12ff09f78369772a460c55d"
+    assert orc.sponge_rounds(b"\xff", 32, 168, 0x06, 12).hex() == "8ec9c66465ed0d4a6c35d13506718d687a25cb05c74cca1e42501abd83874a67"
+    assert orc.sponge_rounds(b"abc", 77, 136, 0x1F, 24) == hashlib.shake_256(b"abc").digest(77)
