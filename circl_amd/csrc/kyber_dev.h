@@ -198,6 +198,37 @@ CIRCL_HD void mulhat_acc(int (&acc)[4], const int (&a)[4], const int (&b)[4], in
     acc[2] = mad24(a[2], b[2], mad24(t1, -zeta64, acc[2]));
     acc[3] = mad24(a[2], b[3], mad24(a[3], b[2], acc[3]));
 }
+// The same accumulation on packed int16 pairs with V_DOT2_I32_I16 (two multiplies and the add per
+// instruction).  The b side is prepared once per polynomial and reused for every row of the matrix:
+//   p0 = (b0, mont(zeta b1))   q0 = (b1, b0)     p1 = (b2, mont(-zeta b3))   q1 = (b3, b2)
+// so that  acc0 += a0 b0 + a1 zeta b1 R^-1,  acc1 += a0 b1 + a1 b0  (and likewise for the second pair).
+// The a side is the pair of dwords exactly as they lie in memory (int16 coefficients 4l..4l+3).
+struct HatOperand {
+    uint32_t p0, q0, p1, q1;
+};
+CIRCL_HD uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+CIRCL_HD HatOperand hat_prepare(const int (&b)[4], int zeta64) {
+    HatOperand h;
+    h.p0 = pack16(b[0], mont_mul(b[1], zeta64));
+    h.q0 = pack16(b[1], b[0]);
+    h.p1 = pack16(b[2], mont_mul(b[3], -zeta64));
+    h.q1 = pack16(b[3], b[2]);
+    return h;
+}
+CIRCL_HD int dot2(uint32_t a, uint32_t b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+#else
+    return (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16) + c;
+#endif
+}
+CIRCL_HD void mulhat_acc_packed(int (&acc)[4], uint32_t a01, uint32_t a23, const HatOperand &b) {
+    acc[0] = dot2(a01, b.p0, acc[0]);
+    acc[1] = dot2(a01, b.q0, acc[1]);
+    acc[2] = dot2(a23, b.p1, acc[2]);
+    acc[3] = dot2(a23, b.q1, acc[3]);
+}
 CIRCL_HD void mulhat_finish(int (&acc)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[r] = mont_reduce(acc[r]);

@@ -239,20 +239,19 @@ __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t
 struct AFromLds {
     const uint8_t *base;
     int stride;
-    __device__ __forceinline__ void load(int (&a)[4], int stream, int lane) const {
-        const int16_t *ap = reinterpret_cast<const int16_t *>(base + stream * stride) + 4 * lane;
-        a[0] = ap[0]; a[1] = ap[1]; a[2] = ap[2]; a[3] = ap[3];
+    __device__ __forceinline__ void load(uint32_t &a01, uint32_t &a23, int stream, int lane) const {
+        const uint2 w = *reinterpret_cast<const uint2 *>(base + stream * stride + 8 * lane);
+        a01 = w.x; a23 = w.y;
     }
 };
 struct AFromScratch {
     const int16_t *rows;
-    __device__ __forceinline__ void load(int (&a)[4], int stream, int lane) const {
+    __device__ __forceinline__ void load(uint32_t &a01, uint32_t &a23, int stream, int lane) const {
         // agent-scope relaxed load = global_load_dwordx2 sc1: served by L2, never by a stale L1 line
         // left over from the previous group that used this scratch row
         const uint64_t w = __hip_atomic_load(reinterpret_cast<const uint64_t *>(rows + stream * 256 + 4 * lane), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
-        a[0] = (int16_t)(w & 0xffff); a[1] = (int16_t)((w >> 16) & 0xffff);
-        a[2] = (int16_t)((w >> 32) & 0xffff); a[3] = (int16_t)(w >> 48);
+        a01 = (uint32_t)w; a23 = (uint32_t)(w >> 32);
     }
 };
 
@@ -517,6 +516,9 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll
             for (int r = 0; r < 4; r++) rh[j][r] = kyber::barrett(rh[j][r]);
         }
+        kyber::HatOperand rop[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) rop[j] = kyber::hat_prepare(rh[j], z.f6);
 
         uint8_t *ctp = ct + item * Gm::CT;
         bool differs = false;
@@ -526,10 +528,10 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             int acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                int a[4];
-                if constexpr (SCRATCH) AFromScratch{rows}.load(a, (g * K + i) * K + j, lane);
-                else AFromLds{lds_a, Gm::A_STRIDE}.load(a, (g * K + i) * K + j, lane);
-                kyber::mulhat_acc(acc, a, rh[j], z.f6);
+                uint32_t a01, a23;
+                if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, (g * K + i) * K + j, lane);
+                else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, (g * K + i) * K + j, lane);
+                kyber::mulhat_acc_packed(acc, a01, a23, rop[j]);
             }
             kyber::mulhat_finish(acc);
             kyber::invntt(acc, z, xch, lane);
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         {
             int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < K; j++) kyber::mulhat_acc(acc, th[j], rh[j], z.f6);
+            for (int j = 0; j < K; j++) kyber::mulhat_acc_packed(acc, kyber::pack16(th[j][0], th[j][1]), kyber::pack16(th[j][2], th[j][3]), rop[j]);
             kyber::mulhat_finish(acc);
             kyber::invntt(acc, z, xch, lane);
             const uint8_t *e2 = noise + 2 * K * Gm::NOISE_STRIDE;
@@ -740,6 +742,9 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             for (int r = 0; r < 4; r++) sh[j][r] = kyber::normalize(sh[j][r]);
             pack12_l4(dkp + 384 * j, sh[j], lane);
         }
+        kyber::HatOperand sop[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) sop[j] = kyber::hat_prepare(sh[j], z.f6);
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             int eh[4], acc[4] = {0, 0, 0, 0};
@@ -748,10 +753,10 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             kyber::ntt(eh, z, xch, lane);
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                int a[4];
-                if constexpr (SCRATCH) AFromScratch{rows}.load(a, (g * K + i) * K + j, lane);
-                else AFromLds{lds_a, Gm::A_STRIDE}.load(a, (g * K + i) * K + j, lane);
-                kyber::mulhat_acc(acc, a, sh[j], z.f6);
+                uint32_t a01, a23;
+                if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, (g * K + i) * K + j, lane);
+                else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, (g * K + i) * K + j, lane);
+                kyber::mulhat_acc_packed(acc, a01, a23, sop[j]);
             }
             kyber::mulhat_finish(acc);
             int t[4];

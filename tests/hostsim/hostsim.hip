@@ -52,6 +52,14 @@ void hs_kyber_mulhat4(int *out, const int *a, const int *b, int lane) {
     kyber::mulhat_finish(acc);
     for (int i = 0; i < 4; i++) out[i] = acc[i];
 }
+void hs_kyber_mulhat4_packed(int *out, const int *a, const int *b, int lane) {
+    int acc[4] = {0, 0, 0, 0}, y[4];
+    for (int i = 0; i < 4; i++) y[i] = b[i];
+    const kyber::HatOperand op = kyber::hat_prepare(y, kyber::zeta(64 + lane));
+    kyber::mulhat_acc_packed(acc, kyber::pack16(a[0], a[1]), kyber::pack16(a[2], a[3]), op);
+    kyber::mulhat_finish(acc);
+    for (int i = 0; i < 4; i++) out[i] = acc[i];
+}
 // the 4-register butterfly network of the wave-level NTT, executed lane by lane on the host:
 // exactly the layer/zeta schedule of kyber::ntt / invntt with the LDS exchanges replaced by array indexing
 void hs_kyber_ntt(int16_t *p, int inverse) {

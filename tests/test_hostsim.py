@@ -104,6 +104,8 @@ def test_mulhat_lane_share(hs):
         bi = (C.c_int * 4)(*[int(v) for v in b[4 * lane:4 * lane + 4]])
         hs.hs_kyber_mulhat4(out, ai, bi, lane)
         assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
+        hs.hs_kyber_mulhat4_packed(out, ai, bi, lane)   # V_DOT2 formulation used by the kernels
+        assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
 
 
 def test_dilithium_mont24_and_zetas(hs):
