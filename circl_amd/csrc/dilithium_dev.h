@@ -57,7 +57,7 @@ CIRCL_HD uint32_t umulhi24(uint32_t a, uint32_t b) {  // bits 32..47 of the 48-b
 // a b 2^-24 mod q for a < 2^24, b < 2^24 with a*b < 2^24 * q; result < 2q.
 CIRCL_HD uint32_t mont24(uint32_t a, uint32_t b) {
     const uint32_t lo = umul24(a, b), hi = umulhi24(a, b);
-    const uint32_t m = umul24(lo, NEG_QINV24);  // only its low 24 bits are used below
+    const uint32_t m = kyber::umul24_lowbits<NEG_QINV24>(lo);  // only its low 24 bits are used below
     const uint32_t mlo = umul24(m, Q), mhi = umulhi24(m, Q);
     const uint32_t s = lo + mlo;               // low 24 bits are zero by construction
     const uint32_t top = hi + mhi + (s < lo ? 1u : 0u);

@@ -33,15 +33,23 @@ CIRCL_HD int mul24(int a, int b) {
 #endif
 }
 CIRCL_HD int mad24(int a, int b, int c) { return mul24(a, b) + c; }
+// (x mod 2^24) * C on the full-rate 24-bit multiplier, for callers that keep only low bits of the product.
+// Written as C (or with __umul24, which is C underneath) LLVM's demanded-bits analysis drops the 24-bit
+// masks -- they cannot change the low bits -- and then has to select the quarter-rate V_MUL_LO_U32.
+template <uint32_t C> CIRCL_HD uint32_t umul24_lowbits(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "i"(C), "v"(x));
+    return r;
+#else
+    return (x & 0xffffffu) * C;
+#endif
+}
 
 // field.go:4-32 montReduce: x R^-1 mod q, q^-1 = 62209 (mod 2^16).  |x| < 2^31; result is
 // x/2^16 + (-q/2, q/2).
 CIRCL_HD int mont_reduce(int x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int m = (int)(int16_t)__umul24((unsigned)x, 62209u);
-#else
-    const int m = (int)(int16_t)(uint16_t)((uint32_t)x * 62209u);
-#endif
+    const int m = (int)(int16_t)(uint16_t)umul24_lowbits<62209u>((uint32_t)x);
     return (x - mul24(m, Q)) >> 16;
 }
 CIRCL_HD int mont_mul(int a, int b) { return mont_reduce(mul24(a, b)); }
@@ -248,17 +256,15 @@ CIRCL_HD int cbd3_from_6bits(unsigned t) {
 template <int D> CIRCL_HD unsigned compress_coeff(int x) {
     const unsigned y = ((unsigned)x << D) + Q / 2;
     if constexpr (D == 4 || D == 5) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return (__umul24(y, 315u) >> 20) & ((1u << D) - 1);  // y < 2^17: one full-rate 24-bit multiply
-#else
-        return (y * 315u >> 20) & ((1u << D) - 1);
-#endif
+        return (umul24_lowbits<315u>(y) >> 20) & ((1u << D) - 1);  // y < 2^17: one full-rate 24-bit multiply
     } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return (__umulhi(y, 20642679u) >> 4) & ((1u << D) - 1);  // (y * M) >> 36 via the high half
-#else
-        return (unsigned)(((uint64_t)y * 20642679ull) >> 36) & ((1u << D) - 1);
-#endif
+        // floor(y / q) for y < 2^23 as (y * ceil(2^35 / q)) >> 35: both factors fit the full-rate 24-bit
+        // multiplier (V_MUL_HI_U32_U24 gives bits 32..47); the rounding error y * 2492 / (q 2^35) < 2^-15 is
+        // below the 1/q slack of a floor.  Same value as the reference's 64-bit multiply-shift; checked for
+        // every x in tests/test_hostsim.py.
+        static_assert(D == 10 || D == 11, "du");
+        const unsigned hi = (unsigned)(((uint64_t)(y & 0xffffffu) * (uint64_t)10321340u) >> 32);
+        return (hi >> 3) & ((1u << D) - 1);
     }
 }
 // poly.go:170-243 Decompress arithmetic

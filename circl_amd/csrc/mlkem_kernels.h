@@ -180,7 +180,7 @@ __device__ __forceinline__ void sample_matrix(uint8_t *lds_a, const uint8_t *__r
 // every global store is a full 16-byte segment.  Same branch-free acceptance as above.
 // TAIL = true is used from the 4th block on, where only the few unfinished streams still matter: the
 // wave leaves the block as soon as every stream is complete (checked at the 8-candidate flush points).
-template <bool TAIL>
+template <bool TAIL, int SLOTS = 32>
 __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, int16_t *fifo, int16_t *row, int &cnt, int &flushed) {
     bool live = true;
     detail::static_for<0, 112>([&](auto ic) {
@@ -191,11 +191,11 @@ __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, 
             uint32_t v;
             if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
             else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
-            fifo[cnt & 31] = (int16_t)v;
+            fifo[cnt & (SLOTS - 1)] = (int16_t)v;
             cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
             if constexpr (c % 8 == 7) {
                 if (cnt - flushed >= 8) {  // at most 15 pending here, so one flush per check suffices
-                    const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 31));
+                    const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & (SLOTS - 1)));
                     *reinterpret_cast<uint4 *>(row + flushed) = d;
                     flushed += 8;
                 }
@@ -232,6 +232,136 @@ __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t
     while (__any(flushed < 256)) {
         keccak_f1600(s);
         parse_shake128_block_fifo<true>(s, fifo, row, cnt, flushed);
+    }
+}
+
+// Phases A and B of the scratch variant in one routine, so that the stragglers of phase A can ride along
+// with phase B.  After three SHAKE128 blocks 0.83 % of the matrix streams are still a few coefficients
+// short; running a fourth 64-lane permutation for one or two of them costs 12 % of phase A.  The PRF pass
+// of phase B, however, leaves 64 - G*NOISE lanes idle (15 for ML-KEM-768) and runs the very same
+// permutation: the unfinished sponge states (plus their few pending FIFO entries) are parked in LDS,
+// adopted by those idle lanes, permuted for free together with the PRF states, and then parsed from a
+// 16-slot mini FIFO.  With more stragglers than free lanes, or eta1 = 3 (two PRF permutations per pass),
+// the plain fourth-block loop runs instead.  A fifth block (p ~ 1e-32 per stream) falls out of the final loop.
+template <int K, bool TRANSPOSED, int NOISE, int ETA1_COUNT>
+__device__ __forceinline__ void sample_matrix_and_prf(uint8_t *lds_fifo, uint8_t *lds_noise, uint8_t *lds_mini, int16_t *rows,
+                                                      const uint8_t *__restrict__ rho, size_t rho_stride,
+                                                      const uint8_t *__restrict__ seed, size_t seed_stride, size_t item0, size_t n,
+                                                      int lane) {
+    using Gm = Geom<K>;
+    constexpr int STREAMS = Gm::G * NOISE;
+    constexpr int LAST_BASE = ((STREAMS - 1) / 64) * 64, USED_LAST = STREAMS - LAST_BASE, FREE = 64 - USED_LAST;
+    constexpr int MAX_HITCH = FREE < 15 ? FREE : 15;  // mini FIFO #15 is the dummy of the other lanes
+    constexpr bool CAN_HITCH = Params<K>::ETA1 == 2 && MAX_HITCH > 0;
+    constexpr int STASH = 240;                          // bytes per parked stream
+    static_assert(15 * STASH <= Gm::LDS_FIFO, "stash fits in the FIFO area");
+
+    // ---- phase A: three blocks for every stream ----
+    KeccakState s;
+    int cnt, flushed;
+    int16_t *fifo = reinterpret_cast<int16_t *>(lds_fifo + lane * Gm::FIFO_STRIDE);
+    {
+        const bool on = lane < Gm::A_STREAMS;
+        const int g = on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
+        const int i = p / K, j = p % K;
+        size_t item = item0 + g;
+        if (item >= n) item = n - 1;
+        keccak_zero(s);
+        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
+        s.lo[4] = (TRANSPOSED ? (uint32_t)i | ((uint32_t)j << 8) : (uint32_t)j | ((uint32_t)i << 8)) | (kDsShake << 16);
+        s.hi[20] = 0x80000000u;
+        int16_t *row = rows + lane * 256;
+        cnt = on ? 0 : 256;
+        flushed = cnt;
+#pragma unroll 1
+        for (int blk = 0; blk < 3; blk++) {
+            keccak_f1600(s);
+            if (on) parse_shake128_block_fifo<false>(s, fifo, row, cnt, flushed);
+        }
+        const unsigned long long smask0 = __ballot(flushed < 256);
+        if (!CAN_HITCH || __popcll(smask0) > MAX_HITCH) {
+#pragma unroll 1
+            while (__any(flushed < 256)) {
+                keccak_f1600(s);
+                parse_shake128_block_fifo<true>(s, fifo, row, cnt, flushed);
+            }
+        }
+    }
+    const unsigned long long smask = __ballot(flushed < 256);  // wave-uniform; empty unless stragglers hitch-hike
+    const int nstr = __popcll(smask);
+    if (nstr > 0) {
+        const bool mine = (smask >> lane) & 1;
+        uint4 pend = make_uint4(0, 0, 0, 0);
+        if (mine) pend = *reinterpret_cast<const uint4 *>(fifo + (flushed & 31));  // < 8 pending entries, one aligned chunk
+        __syncthreads();  // every pending chunk is in registers before the stash overwrites FIFO rows
+        if (mine) {
+            uint32_t *st = reinterpret_cast<uint32_t *>(lds_fifo + __popcll(smask & ((1ull << lane) - 1)) * STASH);
+#pragma unroll
+            for (int w = 0; w < 25; w++) { st[2 * w] = s.lo[w]; st[2 * w + 1] = s.hi[w]; }
+            st[50] = (uint32_t)cnt; st[51] = (uint32_t)flushed; st[52] = (uint32_t)lane;
+            st[53] = pend.x; st[54] = pend.y; st[55] = pend.z; st[56] = pend.w;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: PRF streams; the last pass adopts the parked streams on its idle lanes ----
+#pragma unroll 1
+    for (int base = 0; base < STREAMS; base += 64) {
+        const int sidx = base + lane;
+        const bool on = sidx < STREAMS;
+        const int g = on ? sidx / NOISE : 0, nonce = on ? sidx % NOISE : 0;
+        size_t item = item0 + g;
+        if (item >= n) item = n - 1;
+        keccak_zero(s);
+        xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(seed + item * seed_stride));
+        s.lo[4] = (uint32_t)nonce | (kDsShake << 8);
+        s.hi[16] = 0x80000000u;
+        const bool adopt_pass = CAN_HITCH && nstr > 0 && base == LAST_BASE;
+        const int tk = lane - USED_LAST;
+        const bool target = adopt_pass && tk >= 0 && tk < nstr;
+        int tcnt = 256, tflushed = 256, tsrc = 0;
+        uint4 pend = make_uint4(0, 0, 0, 0);
+        if (target) {
+            const uint32_t *st = reinterpret_cast<const uint32_t *>(lds_fifo + tk * STASH);
+#pragma unroll
+            for (int w = 0; w < 25; w++) { s.lo[w] = st[2 * w]; s.hi[w] = st[2 * w + 1]; }
+            tcnt = (int)st[50]; tflushed = (int)st[51]; tsrc = (int)st[52];
+            pend = make_uint4(st[53], st[54], st[55], st[56]);
+        }
+        keccak_f1600(s);
+        uint32_t *out = reinterpret_cast<uint32_t *>(lds_noise + (on ? sidx : 0) * Gm::NOISE_STRIDE);
+        if (on) {
+            detail::static_for<0, 16>([&](auto ic) {
+                constexpr int w = decltype(ic)::v;
+                out[2 * w] = s.lo[w];
+                out[2 * w + 1] = s.hi[w];
+            });
+        }
+        if constexpr (Params<K>::ETA1 == 3) {
+            // 192 bytes needed for eta1 = 3 streams: word 16 of this block, then 7 more
+            if (on && nonce < ETA1_COUNT) { out[32] = s.lo[16]; out[33] = s.hi[16]; }
+            if (__any(on && nonce < ETA1_COUNT)) {
+                keccak_f1600(s);
+                if (on && nonce < ETA1_COUNT) {
+                    detail::static_for<0, 7>([&](auto ic) {
+                        constexpr int w = decltype(ic)::v;
+                        out[34 + 2 * w] = s.lo[w];
+                        out[35 + 2 * w] = s.hi[w];
+                    });
+                }
+            }
+        }
+        if (adopt_pass) {  // wave-uniform
+            int16_t *tf = reinterpret_cast<int16_t *>(lds_mini + (target ? tk : 15) * 32);
+            int16_t *trow = rows + tsrc * 256;
+            if (target) *reinterpret_cast<uint4 *>(tf + (tflushed & 15)) = pend;
+            parse_shake128_block_fifo<true, 16>(s, tf, trow, tcnt, tflushed);
+#pragma unroll 1
+            while (__any(tflushed < 256)) {
+                keccak_f1600(s);
+                parse_shake128_block_fifo<true, 16>(s, tf, trow, tcnt, tflushed);
+            }
+        }
     }
 }
 
@@ -472,18 +602,26 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
-    if (!(ABLATE & 1)) {
-        if constexpr (SCRATCH) {
-            __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
-            sample_matrix_scratch<K, true>(lds_a, rows, ek + 384 * K, ek_stride, item0, n, lane);
-            __threadfence_block();  // the rows are in L2 before anybody loads them
-        } else {
-            sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
+    if constexpr (SCRATCH && ABLATE == 0) {
+        __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
+        sample_matrix_and_prf<K, true, Gm::NOISE, K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, ek + 384 * K, ek_stride,
+                                                     r_ws, 32, item0, n, lane);
+        __threadfence_block();  // the rows are in L2 before anybody loads them
+        __syncthreads();
+    } else {
+        if (!(ABLATE & 1)) {
+            if constexpr (SCRATCH) {
+                __syncthreads();
+                sample_matrix_scratch<K, true>(lds_a, rows, ek + 384 * K, ek_stride, item0, n, lane);
+                __threadfence_block();
+            } else {
+                sample_matrix<K, true>(lds_a, ek + 384 * K, ek_stride, item0, n, lane);
+            }
         }
+        __syncthreads();
+        if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
+        __syncthreads();
     }
-    __syncthreads();
-    if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
-    __syncthreads();
 
 #pragma unroll 1
     for (int g = 0; g < ((ABLATE & 4) ? 0 : Gm::G); g++) {
@@ -717,14 +855,16 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     const size_t item0 = grp * Gm::G;
     if constexpr (SCRATCH) {
         __syncthreads();
-        sample_matrix_scratch<K, false>(lds_a, rows, rs_ws, 64, item0, n, lane);
+        sample_matrix_and_prf<K, false, 2 * K, 2 * K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, rs_ws, 64, rs_ws + 32, 64,
+                                                      item0, n, lane);
         __threadfence_block();
+        __syncthreads();
     } else {
         sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
+        __syncthreads();
+        prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
+        __syncthreads();
     }
-    __syncthreads();
-    prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
-    __syncthreads();
 
 #pragma unroll 1
     for (int g = 0; g < Gm::G; g++) {
