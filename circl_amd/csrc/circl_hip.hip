@@ -301,9 +301,30 @@ template <class PerDevice> int shard(size_t n, int device, PerDevice fn) {
 
 // ---- device-resident ML-DSA verify ------------------------------------------------------------
 
-template <int MODE> size_t mldsa_ws_bytes(size_t n) {
+// ML-DSA verify / keygen workspace: per-item intermediates, the ticket counter, and one 64 KB scratch slice
+// (the sampled matrix rows) per resident workgroup of the persistent kernel.
+int dsa_blocks_per_cu() {
+    static const int v = [] {
+        const char *e = getenv("CIRCL_HIP_DSA_BLOCKS_PER_CU");  // tuning aid
+        const int x = e ? atoi(e) : 0;
+        return x >= 1 && x <= kMaxBlocksPerCU ? x : kMaxBlocksPerCU;
+    }();
+    return v;
+}
+template <int MODE> size_t mldsa_groups(size_t n) { return (n + circl::mldsa::DG<MODE>::IT - 1) / circl::mldsa::DG<MODE>::IT; }
+template <int MODE> size_t mldsa_scratch_blocks(size_t n) {
+    return std::min<size_t>(mldsa_groups<MODE>(n), (size_t)cu_count() * dsa_blocks_per_cu());
+}
+template <int MODE> size_t mldsa_item_ws_bytes(size_t n) {
     using G = circl::mldsa::DG<MODE>;
     return up256(n * G::MUW1) + up256(n * circl::mldsa::kBallStateBytes) + up256(n);
+}
+template <int MODE> size_t mldsa_ws_bytes(size_t n) {
+    return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES;
+}
+template <class Kern> unsigned dsa_resident_blocks(Kern kern, int lds_bytes) {
+    const unsigned occ = resident_blocks(kern, lds_bytes);  // cu_count * min(occupancy, kMaxBlocksPerCU)
+    return std::min<unsigned>(occ, (unsigned)(cu_count() * dsa_blocks_per_cu()));
 }
 
 template <int MODE>
@@ -316,6 +337,9 @@ int mldsa_verify_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *
     uint8_t *muw1 = static_cast<uint8_t *>(ws);
     uint8_t *ball = muw1 + up256(n * G::MUW1);
     uint8_t *fail = ball + up256(n * circl::mldsa::kBallStateBytes);
+    unsigned *work = reinterpret_cast<unsigned *>(muw1 + mldsa_item_ws_bytes<MODE>(n));
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -324,8 +348,9 @@ int mldsa_verify_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
-        hipLaunchKernelGGL(circl::mldsa::mldsa_verify_kernel<MODE>, dim3((unsigned)((n + G::IT - 1) / G::IT)), dim3(64), G::LDS_TOTAL, st,
-                           pk, sig, muw1, (const uint8_t *)ball, fail, n);
+        auto kern = circl::mldsa::mldsa_verify_kernel<MODE, 0>;
+        const unsigned vb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, G::LDS_V_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -341,8 +366,12 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     using G = circl::mldsa::DG<MODE>;
     using Kg = circl::mldsa::KG<MODE>;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < 128 * n || !aligned16(ws) || !aligned16(seed32) || !aligned16(pk) || !aligned16(sk)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < mldsa_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(seed32) || !aligned16(pk) || !aligned16(sk))
+        return CIRCL_HIP_EWORKSPACE;
     uint8_t *es = static_cast<uint8_t *>(ws);
+    unsigned *work = reinterpret_cast<unsigned *>(es + mldsa_item_ws_bytes<MODE>(n));
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -350,8 +379,9 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYGEN, st);
-        hipLaunchKernelGGL(circl::mldsa::mldsa_keygen_kernel<MODE>, dim3((unsigned)((n + G::IT - 1) / G::IT)), dim3(64), Kg::LDS_TOTAL, st,
-                           (const uint8_t *)es, pk, sk, n);
+        auto kern = circl::mldsa::mldsa_keygen_kernel<MODE>;
+        const unsigned kb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, Kg::LDS_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Kg::LDS_TOTAL, st, (const uint8_t *)es, pk, sk, scratch, work, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -748,11 +778,11 @@ int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_
     const size_t PK = circl_hip_mldsa_pk_size(param), SK = circl_hip_mldsa_sk_size(param);
     if (!PK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_chunked(dev, cnt, {seed32 + lo * 32}, {32}, {pk + lo * PK, sk + lo * SK}, {PK, SK}, 128,
+        return run_chunked(dev, cnt, {seed32 + lo * 32}, {32}, {pk + lo * PK, sk + lo * SK}, {PK, SK}, 0,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mldsa_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
-                           });
+                           }, circl_hip_mldsa_workspace_size(param, std::min<size_t>(cnt, size_t(1) << 16)));
     });
 }
 

@@ -6,15 +6,19 @@
 //  mldsa_prep_kernel<MODE>    lane = item.  tr = SHAKE256(pk)[:64]; mu = SHAKE256(tr || M')[:64]
 //                             with M' = 0 || len(ctx) || ctx || msg (mldsa65/dilithium.go:115-132);
 //                             first SHAKE256(c~) block for SampleInBall.  -> workspace.
-//  mldsa_verify_kernel<MODE>  one wavefront per workgroup, IT = 64 / (K L) items:
-//    phase 1  per item, one polynomial per wavefront: decode z (norm check), z-hat = NTT(z),
-//             strict hint decoding, c-hat = NTT(SampleInBall(c~)).
-//    phase 2  lane = (item, i, j): ExpandA stream SHAKE128(rho || j || i), 23-bit rejection
-//             (sample.go:92-123).  A is never materialised: each accepted coefficient a_k is
-//             multiplied with z-hat[j][k] at once (the Dilithium NTT splits completely, so MulHat
-//             is coefficient-wise, poly.go:88-92) and added to w[i][k] with an LDS atomic.
-//    phase 3  per (item, i): w - c-hat * NTT(t1 2^13), inverse NTT, UseHint, w1 bit-packing
-//             -> workspace.
+//  mldsa_verify_kernel<MODE>  persistent single-wavefront workgroups, each pulling groups of
+//                             IT = 64 / (K L) items from a ticket counter:
+//    phase A  lane = (item, i, j): ExpandA stream SHAKE128(rho || j || i), 23-bit rejection
+//             (sample.go:92-123), accepted coefficients through a 16-slot LDS FIFO into the
+//             stream's 1 KB row of the workgroup's global scratch slice (L2 / Infinity Cache).
+//    per item, one polynomial per wavefront, everything in registers:
+//    phase 1  decode z (norm check), z-hat[j] = NTT(z[j]), strict hint decoding,
+//             c-hat = NTT(SampleInBall(c~)).
+//    phase 2  w-hat[i] = sum_j A[i][j] o z-hat[j]: the Dilithium NTT splits completely, so MulHat
+//             is coefficient-wise (poly.go:88-92); A rows come back as coalesced 16-byte loads.
+//    phase 3  w - c-hat * NTT(t1 2^13), inverse NTT, UseHint, w1 bit-packing -> workspace.
+//    LDS holds only the FIFOs / the staged signature, the relayout buffer and the hint bitmap
+//    (6.6 KB), so occupancy is set by registers (4 waves per SIMD), not by LDS.
 //  mldsa_final_kernel<MODE>   lane = item.  c' = SHAKE256(mu || w1)[:len(c~)], ok = (c' == c~)
 //                             and no decoding failure.
 #pragma once
@@ -53,8 +57,18 @@ template <int MODE> struct DG {
     static constexpr int LDS_XCH = 1024;
     static constexpr int LDS_HINT = IT * K * 32;       // 256-bit bitmap per polynomial
     static constexpr int LDS_MISC = 256;               // ball block bytes, positions
-    static constexpr int LDS_TOTAL = LDS_ZHAT + LDS_ACC + LDS_XCH + LDS_HINT + LDS_MISC;
+    static constexpr int LDS_TOTAL = LDS_ZHAT + LDS_ACC + LDS_XCH + LDS_HINT + LDS_MISC;  // sign kernels' geometry
+    // verify / keygen kernels: sampled matrix in global scratch
+    static constexpr int FIFO_STRIDE = 80;             // 16 dword slots + pad (bank spread)
+    static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;  // phase A; afterwards the staged z || hint bytes
+    static constexpr int LDS_HINT1 = K * 32;           // one item's hint bitmap
+    static constexpr int LDS_V_TOTAL = LDS_FIFO + LDS_XCH + LDS_HINT1 + LDS_MISC;
+    static constexpr int SCRATCH_BYTES = 64 * 1024;    // 64 rows of 256 dwords per workgroup
 };
+
+#ifndef CIRCL_DSA_WAVES_PER_EU
+#define CIRCL_DSA_WAVES_PER_EU 4
+#endif
 
 constexpr size_t kBallStateBytes = 200;
 
@@ -245,6 +259,97 @@ __device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32
     }
 }
 
+// Scratch variant of ExpandA (used by verification and key generation): lane = (item, i, j) runs the
+// stream SHAKE128(rho || LE16((i << 8) + j)) (mat.go:15-49, sample.go:92-123).  Accepted coefficients go
+// through a 16-slot LDS FIFO and leave four at a time, so that every global store is a full 16-byte
+// segment of the stream's row (row index = lane).  Branch-free acceptance: the candidate is stored at
+// slot cnt and cnt advances only if it is < q.
+template <bool TAIL>
+__device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_t *fifo, uint32_t *row, int &cnt, int &flushed) {
+    bool live = true;
+    detail::static_for<0, 56>([&](auto ic) {
+        constexpr int c = decltype(ic)::v;
+        constexpr int bit = 24 * c, w = bit / 32, sh = bit % 32;
+        auto word = [&](int i) -> uint32_t { return (i & 1) ? s.hi[i >> 1] : s.lo[i >> 1]; };
+        if (!TAIL || live) {
+            uint32_t v;
+            if constexpr (sh <= 8) v = (word(w) >> sh) & 0x7fffffu;
+            else v = alignbit(word(w + 1), word(w), sh) & 0x7fffffu;
+            fifo[cnt & 15] = v;
+            cnt = min(cnt + (v < Q ? 1 : 0), 256);
+            if constexpr (c % 4 == 3) {
+                if (cnt - flushed >= 4) {  // at most 7 pending here, so one flush per check suffices
+                    const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 15));
+                    *reinterpret_cast<uint4 *>(row + flushed) = d;
+                    flushed += 4;
+                }
+                if constexpr (TAIL) live = __any(flushed < 256);  // wave-uniform
+            }
+        }
+    });
+}
+
+template <int MODE>
+__device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *rows, const uint8_t *__restrict__ rho, size_t rho_stride,
+                                                 size_t item0, size_t n, int lane) {
+    using G = DG<MODE>;
+    constexpr int L = G::L;
+    const bool on = lane < G::IT * G::STREAMS;
+    const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
+    const int i = p / L, j = p % L;
+    size_t item = item0 + g;
+    if (item >= n) item = n - 1;
+    KeccakState s;
+    keccak_zero(s);
+    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
+    s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+    s.hi[20] = 0x80000000u;
+    uint32_t *fifo = reinterpret_cast<uint32_t *>(lds_fifo + lane * G::FIFO_STRIDE);
+    uint32_t *row = rows + lane * 256;
+    int cnt = on ? 0 : 256, flushed = cnt;
+    // 256 coefficients need at least 5 blocks of 56 candidates; the acceptance rate is q / 2^23 = 0.999
+#pragma unroll 1
+    for (int blk = 0; blk < 5; blk++) {
+        keccak_f1600(s);
+        if (on) parse23_block_fifo<false>(s, fifo, row, cnt, flushed);
+    }
+#pragma unroll 1
+    while (__any(flushed < 256)) {  // more than 24 rejections in 280 candidates: essentially never
+        keccak_f1600(s);
+        parse23_block_fifo<true>(s, fifo, row, cnt, flushed);
+    }
+}
+
+// One row of the sampled matrix back from scratch, coefficients 4 lane .. 4 lane + 3 (layout L4).
+// Plain loads, so that the compiler may batch and hoist them; the caller runs rows_acquire() between
+// phase A and the first load so that no L1 line left over from the previous group's rows is hit.
+__device__ __forceinline__ void load_row_l4(uint32_t (&a)[4], const uint32_t *rows, int stream, int lane) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(rows + stream * 256 + 4 * lane);
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+}
+// acc += sum_j A[stream0 + j] o vhat[j]: the rows are fetched four at a time ahead of the multiplies, so
+// that their L2 latencies overlap instead of adding up.
+template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&acc)[4], const uint32_t *rows, int stream0, const uint32_t (&vhat)[L][4],
+                                                         int lane) {
+    detail::static_for<0, (L + 3) / 4>([&](auto ic) {
+        constexpr int j0 = 4 * decltype(ic)::v, CNT = L - j0 < 4 ? L - j0 : 4;
+        uint32_t a[CNT][4];
+#pragma unroll
+        for (int j = 0; j < CNT; j++) load_row_l4(a[j], rows, stream0 + j0 + j, lane);
+#pragma unroll
+        for (int j = 0; j < CNT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] += dilithium::mont24(a[j][r], vhat[j0 + j][r]);
+    });
+}
+// Ends phase A: the wave's row stores are out of the CU (L1 is write-through, the release orders them),
+// every lane has arrived, and the acquire at agent scope invalidates the CU's L1 (buffer_inv sc1).
+__device__ __forceinline__ void rows_acquire() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // SampleInBall (sample.go:299-339) followed by the NTT: c-hat * 2^24 in layout L4.
 // `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
 // 8 sign bytes, then bytes b <= i pick the positions.  Lane p keeps bytes p, p+64 and p+128 of the
@@ -314,133 +419,139 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
 
 // ---- kernel V -----------------------------------------------------------------------------------
 
-// ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase 1, bit 1 phase 2, bit 2 phase 3.
+// ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase A, bit 1 phase 1, bit 2 phases 2+3.
+// `scratch` holds gridDim.x slices of DG::SCRATCH_BYTES; `work` is the ticket counter (zeroed by the host)
+// or nullptr for one group per workgroup.
 template <int MODE, int ABLATE = 0>
-__global__ void __launch_bounds__(64) mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig,
-                                                         uint8_t *__restrict__ muw1_ws, const uint8_t *__restrict__ ball_ws,
-                                                         uint8_t *__restrict__ fail_ws, size_t n) {
+__global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
+    mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig, uint8_t *__restrict__ muw1_ws,
+                        const uint8_t *__restrict__ ball_ws, uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ scratch,
+                        unsigned *__restrict__ work, size_t n) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     constexpr int K = P::K, L = P::L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *zhat = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *acc = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT);
-    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC);
-    uint32_t *hintbits = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH);
-    uint8_t *misc = smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH + G::LDS_HINT;
+    uint32_t *stg = reinterpret_cast<uint32_t *>(smem);  // aliases the FIFOs of phase A
+    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_FIFO);
+    uint32_t *hintbits = reinterpret_cast<uint32_t *>(smem + G::LDS_FIFO + G::LDS_XCH);
+    uint8_t *misc = smem + G::LDS_FIFO + G::LDS_XCH + G::LDS_HINT1;
     const int lane = threadIdx.x;
-    const size_t item0 = (size_t)blockIdx.x * G::IT;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
-
-    uint32_t chat[G::IT][4];
-    bool fail[G::IT];
-
-    for (int i = lane; i < G::IT * K * 8; i += 64) hintbits[i] = 0;
-
-    // ------------------------------ phase 1 ------------------------------
-    // The accumulator area is free until phase 2: it stages the (unaligned) z || hint part of the
-    // signature as aligned dwords.
-    uint32_t *stg = acc;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * G::SCRATCH_BYTES);
+    const size_t ngroups = (n + G::IT - 1) / G::IT;
     constexpr int ZH_BYTES = L * G::ZSZ + P::OMEGA + K;
-    static_assert(ZH_BYTES + 8 <= G::LDS_ACC, "staging fits in the accumulator area");
-#pragma unroll
+    static_assert(ZH_BYTES + 8 <= G::LDS_FIFO, "staged z || hint fits in the FIFO area");
+
+#pragma unroll 1
+  for (size_t grp = mlkem::next_group(work, lane, true, ngroups); grp < ngroups; grp = mlkem::next_group(work, lane, false, ngroups)) {
+    const size_t item0 = grp * G::IT;
+    // ------------------------------ phase A ------------------------------
+    __syncthreads();  // the previous group is done with the LDS the FIFOs alias
+    if (!(ABLATE & 1)) expand_a_scratch<MODE>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
+    rows_acquire();
+
+#pragma unroll 1
     for (int g = 0; g < G::IT; g++) {
-        fail[g] = false;
-#pragma unroll
-        for (int r = 0; r < 4; r++) chat[g][r] = 0;
         const size_t item = item0 + g;
-        if (item >= n || (ABLATE & 1)) continue;  // wave-uniform
-        const uint8_t *sg = sig + item * G::SIG;
+        if (item >= n) break;  // wave-uniform
+        // ------------------------------ phase 1 ------------------------------
+        uint32_t zhat[L][4], chat[4] = {0, 0, 0, 0};
         bool bad = false;
-        __syncthreads();
-        stage_unaligned(stg, sg + P::CT, ZH_BYTES, lane);
-        if (lane == 0) stg[(ZH_BYTES + 3) >> 2] = 0;  // slack dword for lds_bits
-        __syncthreads();
-        // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
-        for (int j = 0; j < L; j++) {
-            uint32_t c[4];
+        if (!(ABLATE & 2)) {
+            const uint8_t *sg = sig + item * G::SIG;
+            sample_in_ball_hat<MODE>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // first: z-hat is not live yet
+            __syncthreads();
+            if (lane < K * 8) hintbits[lane] = 0;
+            stage_unaligned(stg, sg + P::CT, ZH_BYTES, lane);
+            if (lane == 0) stg[(ZH_BYTES + 3) >> 2] = 0;  // slack dword for lds_bits
+            __syncthreads();
+            // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t f = lds_bits<G::ZBITS>(stg, j * (G::ZSZ / 4), kyber::idx_l1(lane, r));
-                uint32_t x = G::GAMMA1 - f;
-                x += (uint32_t)((int32_t)x >> 31) & Q;
-                bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
-                c[r] = x;
+            for (int j = 0; j < L; j++) {
+                uint32_t c[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t f = lds_bits<G::ZBITS>(stg, j * (G::ZSZ / 4), kyber::idx_l1(lane, r));
+                    uint32_t x = G::GAMMA1 - f;
+                    x += (uint32_t)((int32_t)x >> 31) & Q;
+                    bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
+                    c[r] = x;
+                }
+                dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) zhat[j][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // z-hat * 2^24
             }
-            dilithium::ntt(c, z, xch, lane);
+            // hints: strict decoding (pack.go:113-141)
+            {
+                const uint8_t *hb = reinterpret_cast<const uint8_t *>(stg) + L * G::ZSZ;
+                uint32_t sop[K];
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                zhat[(g * L + j) * G::PSTRIDE + 4 * lane + r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // z-hat * 2^24
-        }
-        // hints: strict decoding (pack.go:113-141)
-        {
-            const uint8_t *hb = reinterpret_cast<const uint8_t *>(stg) + L * G::ZSZ;
-            uint32_t sop[K];
+                for (int i = 0; i < K; i++) sop[i] = hb[P::OMEGA + i];
 #pragma unroll
-            for (int i = 0; i < K; i++) sop[i] = hb[P::OMEGA + i];
+                for (int i = 0; i < K; i++) bad |= sop[i] > (uint32_t)P::OMEGA || (i > 0 && sop[i] < sop[i - 1]);
+                for (int j0 = 0; j0 < P::OMEGA; j0 += 64) {
+                    const int j = j0 + lane;
+                    if (j < P::OMEGA) {
+                        int poly = 0;
+                        uint32_t start = 0;
 #pragma unroll
-            for (int i = 0; i < K; i++) bad |= sop[i] > (uint32_t)P::OMEGA || (i > 0 && sop[i] < sop[i - 1]);
-            for (int j0 = 0; j0 < P::OMEGA; j0 += 64) {
-                const int j = j0 + lane;
-                if (j < P::OMEGA) {
-                    int poly = 0;
-                    uint32_t start = 0;
-#pragma unroll
-                    for (int i = 0; i < K; i++)
-                        if (sop[i] <= (uint32_t)j) { poly = i + 1; start = sop[i]; }
-                    const uint32_t v = hb[j];
-                    if (poly < K) {
-                        if ((uint32_t)j > start && v <= hb[j - 1]) bad = true;
-                        atomicOr(&hintbits[(g * K + poly) * 8 + (v >> 5)], 1u << (v & 31));
-                    } else if (v != 0) {
-                        bad = true;
+                        for (int i = 0; i < K; i++)
+                            if (sop[i] <= (uint32_t)j) { poly = i + 1; start = sop[i]; }
+                        const uint32_t v = hb[j];
+                        if (poly < K) {
+                            if ((uint32_t)j > start && v <= hb[j - 1]) bad = true;
+                            atomicOr(&hintbits[poly * 8 + (v >> 5)], 1u << (v & 31));
+                        } else if (v != 0) {
+                            bad = true;
+                        }
                     }
                 }
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < L; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) zhat[j][r] = (uint32_t)(lane + j + r);
         }
-        fail[g] = __any(bad);
+        const bool failed = __any(bad);
 
-        sample_in_ball_hat<MODE>(chat[g], ball_ws + item * kBallStateBytes, misc, xch, z, lane);
-    }
-    __syncthreads();
-    // zero the accumulators (they held the staged signature bytes)
-    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
-    __syncthreads();
-
-    // ------------------------------ phase 2 ------------------------------
-    if (!(ABLATE & 2)) expand_a_accumulate<MODE>(zhat, acc, pk, (size_t)G::PK, item0, n, lane);
-    __syncthreads();
-
-    // ------------------------------ phase 3 ------------------------------
-#pragma unroll 1
-    for (int g = 0; g < ((ABLATE & 4) ? 0 : G::IT); g++) {
-        const size_t item = item0 + g;
-        if (item >= n) break;
+        // -------------------------- phases 2 and 3 --------------------------
         uint8_t *w1out = muw1_ws + item * G::MUW1 + 64;
 #pragma unroll 1
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
+            uint32_t acc[4] = {0, 0, 0, 0};
+            mac_rows<L>(acc, rows, g * G::STREAMS + i * L, zhat, lane);  // a * z-hat, < 2q each
             uint32_t t[4], w[4];
+            {
+                // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,
+                // fetched as two aligned dwords (the row is 4-byte aligned), then moved to the NTT's input layout
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + item * G::PK + 32 + 320 * i);
+                const int b = 5 * lane, d = b >> 2;
+                const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
 #pragma unroll
-            for (int r = 0; r < 4; r++) t[r] = get_bits32<10>(pk + item * G::PK + 32 + 320 * i, kyber::idx_l1(lane, r)) << dilithium::D;
+                for (int r = 0; r < 4; r++) t[r] = ((uint32_t)(v >> (10 * r)) & 0x3ffu) << dilithium::D;
+                dilithium::relayout<4, 1>(t, xch, lane);
+            }
             dilithium::ntt(t, z, xch, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t ct1 = dilithium::mont24(dilithium::fold(t[r]), chat[g][r]);  // c-hat * t1-hat, < 3q
-                w[r] = dilithium::fold(acc[(g * K + i) * G::PSTRIDE + 4 * lane + r] + 4 * Q - ct1);
+                const uint32_t ct1 = dilithium::mont24(dilithium::fold(t[r]), chat[r]);  // c-hat * t1-hat, < 3q
+                w[r] = dilithium::fold(acc[r] + 4 * Q - ct1);
             }
             dilithium::invntt(w, z, xch, lane);
             unsigned w1v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
-                const uint32_t hbit = (hintbits[(g * K + i) * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
+                const uint32_t hbit = (hintbits[i * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
                 w1v[r] = dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
             }
             mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
             mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), xch, lane, false);
         }
-        if (lane == 0 && fail[g]) fail_ws[item] = 1;
+        if (lane == 0 && failed) fail_ws[item] = 1;
     }
+  }
 }
 
 // ---- kernel F -----------------------------------------------------------------------------------
@@ -476,7 +587,8 @@ template <int MODE> struct KG {
     static constexpr int NS = G::L + G::K;                            // secret polynomials per item
     static constexpr int S_STRIDE = 264;                              // int8 row + spill slot
     static constexpr int LDS_S = G::IT * NS * S_STRIDE;
-    static constexpr int LDS_TOTAL = G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH + LDS_S;
+    static constexpr int LDS_SEC = LDS_S > G::LDS_FIFO ? LDS_S : G::LDS_FIFO;  // the secrets alias the FIFOs of phase A
+    static constexpr int LDS_TOTAL = LDS_SEC + G::LDS_XCH;
 };
 
 // lane = item: (rho, rho', key) = SHAKE256(seed || K || L)[:128]  (dilithium.go:195-206)
@@ -494,27 +606,34 @@ __global__ void __launch_bounds__(256) mldsa_keygen_seed_kernel(const uint8_t *_
     store_words<0, 16>(reinterpret_cast<uint64_t *>(es_ws + idx * 128), s);
 }
 
-// One wavefront per workgroup, IT items.  phase 1: lane = (item, secret polynomial) samples s1, s2
-// (sample.go:125-175, SHAKE256(rho' || LE16(nonce)), nibble rejection) into LDS as small integers;
-// then s1-hat = NTT(s1) per polynomial, eta-packing of s1, s2 into sk.  phase 2: ExpandA with
-// multiply-accumulate against s1-hat (same code as verification).  phase 3: t = InvNTT(A s1-hat) + s2,
-// Power2Round (field.go:35-52), t1 -> pk, t0 -> sk.
+// Persistent single-wavefront workgroups, IT items per group.  phase A: ExpandA into the global scratch
+// rows (same code as verification).  phase 1a: lane = (item, secret polynomial) samples s1, s2
+// (sample.go:125-175, SHAKE256(rho' || LE16(nonce)), nibble rejection) into LDS as small integers.
+// Then per item, in registers: s1-hat = NTT(s1) per polynomial, eta-packing of s1, s2 into sk;
+// t-hat[i] = sum_j A[i][j] o s1-hat[j]; t = InvNTT(t-hat) + s2, Power2Round (field.go:35-52), t1 -> pk, t0 -> sk.
 template <int MODE>
-__global__ void __launch_bounds__(64) mldsa_keygen_kernel(const uint8_t *__restrict__ es_ws, uint8_t *__restrict__ pk,
-                                                         uint8_t *__restrict__ sk, size_t n) {
+__global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
+    mldsa_keygen_kernel(const uint8_t *__restrict__ es_ws, uint8_t *__restrict__ pk, uint8_t *__restrict__ sk,
+                        uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
     constexpr int K = P::K, L = P::L, NS = Kg::NS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *shat = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *acc = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT);
-    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_ZHAT + G::LDS_ACC);
-    int8_t *sec = reinterpret_cast<int8_t *>(smem + G::LDS_ZHAT + G::LDS_ACC + G::LDS_XCH);
+    int8_t *sec = reinterpret_cast<int8_t *>(smem);  // aliases the FIFOs of phase A
+    uint32_t *xch = reinterpret_cast<uint32_t *>(smem + Kg::LDS_SEC);
     const int lane = threadIdx.x;
-    const size_t item0 = (size_t)blockIdx.x * G::IT;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
-    for (int i = lane; i < G::IT * K * G::PSTRIDE; i += 64) acc[i] = 0;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * G::SCRATCH_BYTES);
+    const size_t ngroups = (n + G::IT - 1) / G::IT;
+
+#pragma unroll 1
+  for (size_t grp = mlkem::next_group(work, lane, true, ngroups); grp < ngroups; grp = mlkem::next_group(work, lane, false, ngroups)) {
+    const size_t item0 = grp * G::IT;
+    // ---- phase A: the matrix ----
+    __syncthreads();
+    expand_a_scratch<MODE>(smem, rows, es_ws, 128, item0, n, lane);
+    rows_acquire();
 
     // ---- phase 1a: sample the secrets, one stream per lane ----
     {
@@ -555,13 +674,14 @@ __global__ void __launch_bounds__(64) mldsa_keygen_kernel(const uint8_t *__restr
     }
     __syncthreads();
 
-    // ---- phase 1b: NTT(s1), pack s1 and s2 ----
 #pragma unroll 1
     for (int g = 0; g < G::IT; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;
-        uint8_t *skp = sk + item * Kg::SK;
-#pragma unroll 1
+        uint8_t *pkp = pk + item * G::PK, *skp = sk + item * Kg::SK;
+        // ---- phase 1b: NTT(s1), pack s1 and s2 ----
+        uint32_t shat[L][4];
+#pragma unroll
         for (int k = 0; k < NS; k++) {
             const int8_t *row = sec + (g * NS + k) * Kg::S_STRIDE;
             unsigned fld[4];
@@ -577,28 +697,17 @@ __global__ void __launch_bounds__(64) mldsa_keygen_kernel(const uint8_t *__restr
             if (k < L) {
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    shat[(g * L + k) * G::PSTRIDE + 4 * lane + r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
+                for (int r = 0; r < 4; r++) shat[k < L ? k : 0][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
             }
         }
-    }
-    __syncthreads();
 
-    // ---- phase 2: t-hat = A s1-hat ----
-    expand_a_accumulate<MODE>(shat, acc, es_ws, 128, item0, n, lane);
-    __syncthreads();
-
-    // ---- phase 3: t = InvNTT(t-hat) + s2, Power2Round, pack ----
-#pragma unroll 1
-    for (int g = 0; g < G::IT; g++) {
-        const size_t item = item0 + g;
-        if (item >= n) break;
-        uint8_t *pkp = pk + item * G::PK, *skp = sk + item * Kg::SK;
+        // ---- phases 2 and 3: t = InvNTT(A s1-hat) + s2, Power2Round, pack ----
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
-            uint32_t w[4];
+            uint32_t w[4] = {0, 0, 0, 0};
+            mac_rows<L>(w, rows, g * G::STREAMS + i * L, shat, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) w[r] = dilithium::fold(acc[(g * K + i) * G::PSTRIDE + 4 * lane + r]);
+            for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
             dilithium::invntt(w, z, xch, lane);
             const int8_t *s2 = sec + (g * NS + L + i) * Kg::S_STRIDE;
             unsigned t1[4], t0[4];
@@ -626,6 +735,7 @@ __global__ void __launch_bounds__(64) mldsa_keygen_kernel(const uint8_t *__restr
             reinterpret_cast<uint32_t *>(skp + 32)[lane] = reinterpret_cast<const uint32_t *>(es_ws + item * 128 + 96)[lane];  // key
         }
     }
+  }
 }
 
 // lane = item: tr = SHAKE256(pk)[:64] -> sk[64:128]  (dilithium.go:257-262)

@@ -3,13 +3,14 @@
     python tests/gpu_microbench.py [logn]
 """
 import ctypes as C
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from circl_amd import _native as nat  # noqa: E402
 from circl_amd import device as cdev  # noqa: E402
 from oracle import orc  # noqa: E402
