@@ -1,14 +1,18 @@
 // dilithium_dev.h -- the Dilithium ring Z_8380417[x]/(x^256+1) on gfx950, one polynomial per
 // wavefront, 4 coefficients per lane.
 //
-// Replaces sign/internal/dilithium {field,ntt,poly}.go and its AVX2 assembler.  The reference
-// uses Montgomery arithmetic with R = 2^32 (field.go:20-24), which on CDNA4 would need
-// quarter-rate 32x32 multiplies.  Every value here is < 2^24, so we use Montgomery arithmetic
-// with R = 2^24 on the full-rate 24-bit multipliers instead (V_MUL_U32_U24 / V_MUL_HI_U32_U24):
-//     mont24(a, b) = a b 2^-24 mod q,   a < 2^24, b < q   ->   result < 2q
-// in 8 VALU instructions.  Twiddles are stored pre-multiplied by 2^24, so a butterfly computes the
-// plain product zeta*b; coefficients are therefore plain residues mod q (no stray Montgomery
-// factor), which is all that the packed outputs of ML-DSA depend on.
+// Replaces sign/internal/dilithium {field,ntt,poly}.go and its AVX2 assembler.  Montgomery arithmetic
+// with R = 2^32 as in the reference (field.go:20-24), on 32-bit halves:
+//     mont32(a, b) = a b 2^-32 mod q  =  hi(a b) - hi(lo(a b) q^-1 * q) + q     (4 multiplies, 2 adds)
+// (the low words of a b and m q are equal, so the high words subtract without a borrow).  On gfx950
+// V_MUL_LO_U32 / V_MUL_HI_U32 issue at the same rate as the 24-bit multiplies (tools/gen_valu_rate.py,
+// profiles/r01_valu_issue_rates.txt), so this is cheaper than a 24-bit Montgomery product, and operands
+// need no pre-reduction: any a < 2^32 with a b < 2^32 q gives a result in (0, 2q).
+// Twiddles are stored pre-multiplied by 2^32 (as ntt.go:19-57 does), so a butterfly computes the plain
+// product zeta*b; coefficients are plain residues mod q (no stray Montgomery factor), which is all that
+// the packed outputs of ML-DSA depend on.  The lazy schedule is the reference's: the forward transform
+// grows by 2q per layer (ntt.go:111-184), the inverse doubles per layer and stays below 512 q < 2^32
+// (ntt.go:191-217).
 //
 // Register layouts L1..L4 are those of kyber_dev.h; the 8 NTT layers (strides 128..1) are done
 // two at a time on register-local pairs, with three re-distributions through 1 KB of LDS.
@@ -31,16 +35,17 @@ constexpr uint32_t cpow(uint64_t b, uint32_t e) {
     }
     return (uint32_t)r;
 }
-constexpr uint32_t R24 = (1u << 24) % Q;                      // 2^24 mod q
-constexpr uint32_t R24SQ = (uint32_t)((uint64_t)R24 * R24 % Q);  // 2^48 mod q
-// q^-1 mod 2^24 (Newton iteration; checked by static_assert below), and its negation
-constexpr uint32_t qinv24() {
+constexpr uint32_t R32 = (uint32_t)((1ull << 32) % Q);           // 2^32 mod q = 4193792 (params.go ROver256 * 256)
+constexpr uint32_t R32SQ = (uint32_t)((uint64_t)R32 * R32 % Q);  // 2^64 mod q = 2365951 (field.go R2)
+// q^-1 mod 2^32 (Newton iteration; checked by static_assert below)
+constexpr uint32_t qinv32() {
     uint32_t x = 1;
     for (int i = 0; i < 6; i++) x = x * (2 - Q * x);
-    return x & 0xffffff;
+    return x;
 }
-constexpr uint32_t NEG_QINV24 = (0x1000000 - qinv24()) & 0xffffff;
-static_assert(((uint64_t)Q * qinv24() & 0xffffff) == 1, "q * qinv == 1 mod 2^24");
+constexpr uint32_t QINV32 = qinv32();
+static_assert((uint32_t)(Q * QINV32) == 1u, "q * qinv == 1 mod 2^32");
+static_assert(R32 == 4193792u && R32SQ == 2365951u, "the reference's Montgomery constants");
 
 CIRCL_HD uint32_t umul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -54,14 +59,24 @@ CIRCL_HD uint32_t umulhi24(uint32_t a, uint32_t b) {  // bits 32..47 of the 48-b
     return (uint32_t)(((uint64_t)(a & 0xffffff) * (uint64_t)(b & 0xffffff)) >> 32);
 }
 
-// a b 2^-24 mod q for a < 2^24, b < 2^24 with a*b < 2^24 * q; result < 2q.
-CIRCL_HD uint32_t mont24(uint32_t a, uint32_t b) {
-    const uint32_t lo = umul24(a, b), hi = umulhi24(a, b);
-    const uint32_t m = kyber::umul24_lowbits<NEG_QINV24>(lo);  // only its low 24 bits are used below
-    const uint32_t mlo = umul24(m, Q), mhi = umulhi24(m, Q);
-    const uint32_t s = lo + mlo;               // low 24 bits are zero by construction
-    const uint32_t top = hi + mhi + (s < lo ? 1u : 0u);
-    return (s >> 24) | (top << 8);
+CIRCL_HD uint32_t umulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+// a b 2^-32 mod q for a b < 2^32 q; result in (0, 2q)  (field.go:20-24 montReduceLe2Q on a 64-bit product)
+CIRCL_HD uint32_t mont32(uint32_t a, uint32_t b) {
+    uint32_t lo = a * b;
+    const uint32_t hi = umulhi32(a, b);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep lo opaque: otherwise LLVM rewrites (a b) qinv as a (b qinv) and hoists b qinv for every
+    // loop-invariant twiddle, doubling the registers the twiddles occupy (spills in the big kernels)
+    asm("" : "+v"(lo));
+#endif
+    const uint32_t m = lo * QINV32;
+    return hi - umulhi32(m, Q) + Q;
 }
 // field.go:5-13 ReduceLe2Q generalised: x < 2^32 -> < 2^24 (and < 2q when x < 2^28)
 CIRCL_HD uint32_t fold(uint32_t x) { return (x & 0x7fffff) + umul24(x >> 23, 8191u); }
@@ -72,7 +87,7 @@ CIRCL_HD uint32_t csubq(uint32_t x) {
 }
 CIRCL_HD uint32_t normalize(uint32_t x) { return csubq(fold(fold(x))); }  // any x < 2^32
 
-// ntt.go:19-57: zeta^brv8(k), here times 2^24 (the reference stores them times 2^32)
+// ntt.go:19-57: zeta^brv8(k) times 2^32
 struct ZetaTable {
     uint32_t v[256];
 };
@@ -81,7 +96,7 @@ constexpr ZetaTable make_zetas() {
     for (int i = 0; i < 256; i++) {
         int brv = 0;
         for (int b = 0; b < 8; b++) brv |= ((i >> b) & 1) << (7 - b);
-        t.v[i] = (uint32_t)((uint64_t)cpow(1753, (uint32_t)brv) * R24 % Q);
+        t.v[i] = (uint32_t)((uint64_t)cpow(1753, (uint32_t)brv) * R32 % Q);
     }
     return t;
 }
@@ -125,17 +140,18 @@ CIRCL_HD LaneZetas load_lane_zetas(int lane) {
     return z;
 }
 
-// Cooley-Tukey: (a, b) -> (a + zb, a - zb); a may be lazy (< 2^31), b any < 2^32.
+// Cooley-Tukey: (a, b) -> (a + zb, a - zb); b any value < 2^32, a grows by at most 2q
 CIRCL_HD void ct(uint32_t &a, uint32_t &b, uint32_t z) {
-    const uint32_t t = mont24(fold(b), z);  // < 2q
+    const uint32_t t = mont32(b, z);  // < 2q
     b = a + (2 * Q - t);
     a = a + t;
 }
-// Gentleman-Sande: (a, b) -> (a + b, z (b - a)); a < 8q (two layers after a fold to < 2^24)
-CIRCL_HD void gs(uint32_t &a, uint32_t &b, uint32_t z) {
-    const uint32_t t = b + (8 * Q - a);
+// Gentleman-Sande, layer with inputs < BOUND q: (a, b) -> (a + b, z (a - b)), outputs < 2 BOUND q and < 2q
+template <uint32_t BOUND> CIRCL_HD void gs(uint32_t &a, uint32_t &b, uint32_t z) {
+    static_assert((uint64_t)2 * BOUND * Q < (1ull << 32), "a - b + BOUND q fits 32 bits");
+    const uint32_t t = b + (BOUND * Q - a);
     a = a + b;
-    b = mont24(fold(t), z);
+    b = mont32(t, z);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -151,7 +167,7 @@ template <int FROM, int TO> __device__ __forceinline__ void relayout(uint32_t (&
     for (int r = 0; r < 4; r++) c[r] = xch[idx(TO, r)];
 }
 
-// Poly.NTT (ntt.go:166-183).  In: layout L1, c < 2^24.  Out: layout L4, c < 17q, plain residues.
+// Poly.NTT (ntt.go:166-183).  In: layout L1, c < 2^32 - 16 q.  Out: layout L4, c < in + 16 q, plain residues.
 __device__ __forceinline__ void ntt(uint32_t (&c)[4], const LaneZetas &z, uint32_t *xch, int lane) {
     const uint32_t z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
     ct(c[0], c[2], z1); ct(c[1], c[3], z1);
@@ -168,31 +184,25 @@ __device__ __forceinline__ void ntt(uint32_t (&c)[4], const LaneZetas &z, uint32
 }
 
 // Exact inverse transform INCLUDING the factor 1/256 (the reference's InvNTT returns R/256 times
-// this, ntt.go:212-216, compensated by its R^-1-carrying MulHat).  In: layout L4, c < 2^24.
-// Out: layout L1, c < 2q.
+// this, ntt.go:212-216, compensated by its R^-1-carrying MulHat).  In: layout L4, c < 2q.
+// Out: layout L1, c < 2q.  No reduction between the layers: values double and stay below 512 q.
 __device__ __forceinline__ void invntt(uint32_t (&c)[4], const LaneZetas &z, uint32_t *xch, int lane) {
-    gs(c[0], c[1], z.i7a); gs(c[2], c[3], z.i7b);
-    gs(c[0], c[2], z.i6); gs(c[1], c[3], z.i6);
+    gs<2>(c[0], c[1], z.i7a); gs<2>(c[2], c[3], z.i7b);
+    gs<4>(c[0], c[2], z.i6); gs<4>(c[1], c[3], z.i6);
     relayout<4, 3>(c, xch, lane);
-#pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = fold(c[r]);
-    gs(c[0], c[1], z.i5a); gs(c[2], c[3], z.i5b);
-    gs(c[0], c[2], z.i4); gs(c[1], c[3], z.i4);
+    gs<8>(c[0], c[1], z.i5a); gs<8>(c[2], c[3], z.i5b);
+    gs<16>(c[0], c[2], z.i4); gs<16>(c[1], c[3], z.i4);
     relayout<3, 2>(c, xch, lane);
-#pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = fold(c[r]);
-    gs(c[0], c[1], z.i3a); gs(c[2], c[3], z.i3b);
-    gs(c[0], c[2], z.i2); gs(c[1], c[3], z.i2);
+    gs<32>(c[0], c[1], z.i3a); gs<32>(c[2], c[3], z.i3b);
+    gs<64>(c[0], c[2], z.i2); gs<64>(c[1], c[3], z.i2);
     relayout<2, 1>(c, xch, lane);
     const uint32_t z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
+    gs<128>(c[0], c[1], z3); gs<128>(c[2], c[3], z2);
+    gs<256>(c[0], c[2], z1); gs<256>(c[1], c[3], z1);
+    // times 256^-1:  mont32(x, 2^32 / 256) = x / 256   (x < 512 q)
+    constexpr uint32_t inv256R = (uint32_t)((uint64_t)cpow(256, Q - 2) * R32 % Q);
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = fold(c[r]);
-    gs(c[0], c[1], z3); gs(c[2], c[3], z2);
-    gs(c[0], c[2], z1); gs(c[1], c[3], z1);
-    // times 256^-1:  mont24(x, 2^24 / 256) = x / 256
-    constexpr uint32_t inv256R = (uint32_t)((uint64_t)cpow(256, Q - 2) * R24 % Q);
-#pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = mont24(fold(c[r]), inv256R);
+    for (int r = 0; r < 4; r++) c[r] = mont32(c[r], inv256R);
 }
 #endif
 

@@ -29,6 +29,7 @@ namespace circl {
 namespace mldsa {
 
 using dilithium::Q;
+using mlkem::rows_acquire;
 using mlkem::store_words;
 using mlkem::xor_words;
 
@@ -227,8 +228,8 @@ template <int D> __device__ __forceinline__ uint32_t lds_bits(const uint32_t *p,
 
 // Phase 2 of verification and of key generation: lane = (item, i, j) runs the ExpandA stream
 // SHAKE128(rho || LE16((i << 8) + j)) (mat.go:15-49, sample.go:92-123) and folds every accepted
-// coefficient a_k straight into acc[item][i][k] += a_k * vhat[item][j][k] (vhat is stored times 2^24,
-// so mont24 yields the plain product).  rho of item t is at rho + t * rho_stride (8-byte aligned).
+// coefficient a_k straight into acc[item][i][k] += a_k * vhat[item][j][k] (vhat is stored times 2^32,
+// so mont32 yields the plain product).  rho of item t is at rho + t * rho_stride (8-byte aligned).
 template <int MODE>
 __device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32_t *acc, const uint8_t *__restrict__ rho,
                                                     size_t rho_stride, size_t item0, size_t n, int lane) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32
         keccak_f1600(s);
         for_each_candidate23(s, [&](uint32_t a) {
             if (a < Q && cnt < 256) {
-                atomicAdd(&arow[cnt], dilithium::mont24(a, zrow[cnt]));  // a * v-hat[j][cnt], < 2q
+                atomicAdd(&arow[cnt], dilithium::mont32(a, zrow[cnt]));  // a * v-hat[j][cnt], < 2q
                 cnt++;
             }
         });
@@ -321,7 +322,7 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
 }
 
 // One row of the sampled matrix back from scratch, coefficients 4 lane .. 4 lane + 3 (layout L4).
-// Plain loads, so that the compiler may batch and hoist them; the caller runs rows_acquire() between
+// Plain loads, so that the compiler may batch and hoist them; the caller runs mlkem::rows_acquire() between
 // phase A and the first load so that no L1 line left over from the previous group's rows is hit.
 __device__ __forceinline__ void load_row_l4(uint32_t (&a)[4], const uint32_t *rows, int stream, int lane) {
     const uint4 v = *reinterpret_cast<const uint4 *>(rows + stream * 256 + 4 * lane);
@@ -339,18 +340,10 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&acc)[4], co
 #pragma unroll
         for (int j = 0; j < CNT; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] += dilithium::mont24(a[j][r], vhat[j0 + j][r]);
+            for (int r = 0; r < 4; r++) acc[r] += dilithium::mont32(a[j][r], vhat[j0 + j][r]);
     });
 }
-// Ends phase A: the wave's row stores are out of the CU (L1 is write-through, the release orders them),
-// every lane has arrived, and the acquire at agent scope invalidates the CU's L1 (buffer_inv sc1).
-__device__ __forceinline__ void rows_acquire() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-// SampleInBall (sample.go:299-339) followed by the NTT: c-hat * 2^24 in layout L4.
+// SampleInBall (sample.go:299-339) followed by the NTT: c-hat * 2^32 in layout L4.
 // `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
 // 8 sign bytes, then bytes b <= i pick the positions.  Lane p keeps bytes p, p+64 and p+128 of the
 // current 136-byte block in registers; one step is three compares + ballots, scalar bit tricks and
@@ -414,7 +407,7 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
     for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
     dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-    for (int r = 0; r < 4; r++) chat[r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
+    for (int r = 0; r < 4; r++) chat[r] = dilithium::mont32(c[r], dilithium::R32SQ);
 }
 
 // ---- kernel V -----------------------------------------------------------------------------------
@@ -479,7 +472,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                 }
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) zhat[j][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);  // z-hat * 2^24
+                for (int r = 0; r < 4; r++) zhat[j][r] = dilithium::mont32(c[r], dilithium::R32SQ);  // z-hat * 2^32
             }
             // hints: strict decoding (pack.go:113-141)
             {
@@ -535,7 +528,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             dilithium::ntt(t, z, xch, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t ct1 = dilithium::mont24(dilithium::fold(t[r]), chat[r]);  // c-hat * t1-hat, < 3q
+                const uint32_t ct1 = dilithium::mont32(t[r], chat[r]);  // c-hat * t1-hat, < 3q
                 w[r] = dilithium::fold(acc[r] + 4 * Q - ct1);
             }
             dilithium::invntt(w, z, xch, lane);
@@ -697,7 +690,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             if (k < L) {
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) shat[k < L ? k : 0][r] = dilithium::mont24(dilithium::fold(c[r]), dilithium::R24SQ);
+                for (int r = 0; r < 4; r++) shat[k < L ? k : 0][r] = dilithium::mont32(c[r], dilithium::R32SQ);
             }
         }
 
@@ -934,7 +927,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                 }
                 dilithium::ntt(yh[l], z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont24(dilithium::fold(yh[l][r]), dilithium::R24SQ);  // y-hat * 2^24
+                for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);  // y-hat * 2^32
             }
             // ---- w = InvNTT(A y-hat), Decompose, w1 packing (dilithium.go:385-398) ----
 #pragma unroll 1
@@ -943,10 +936,10 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
 #pragma unroll
                 for (int j = 0; j < L; j++) {
                     const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * S::A_ROW + 4 * lane);
-                    w[0] += dilithium::mont24(a.x, yh[j][0]);
-                    w[1] += dilithium::mont24(a.y, yh[j][1]);
-                    w[2] += dilithium::mont24(a.z, yh[j][2]);
-                    w[3] += dilithium::mont24(a.w, yh[j][3]);
+                    w[0] += dilithium::mont32(a.x, yh[j][0]);
+                    w[1] += dilithium::mont32(a.y, yh[j][1]);
+                    w[2] += dilithium::mont32(a.z, yh[j][2]);
+                    w[3] += dilithium::mont32(a.w, yh[j][3]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
@@ -988,8 +981,8 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
 #pragma unroll 1
             for (int i = 0; i < K; i++) {
                 const uint4 sv = *reinterpret_cast<const uint4 *>(sec + (L + i) * 256 + 4 * lane);
-                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
-                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                uint32_t t[4] = {dilithium::fold(dilithium::mont32(sv.x, chat[0])), dilithium::fold(dilithium::mont32(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont32(sv.z, chat[2])), dilithium::fold(dilithium::mont32(sv.w, chat[3]))};
                 dilithium::invntt(t, z, xch, lane);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1004,8 +997,8 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
 #pragma unroll 1
             for (int l = 0; l < L; l++) {
                 const uint4 sv = *reinterpret_cast<const uint4 *>(sec + l * 256 + 4 * lane);
-                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
-                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                uint32_t t[4] = {dilithium::fold(dilithium::mont32(sv.x, chat[0])), dilithium::fold(dilithium::mont32(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont32(sv.z, chat[2])), dilithium::fold(dilithium::mont32(sv.w, chat[3]))};
                 dilithium::invntt(t, z, xch, lane);
                 unsigned fld[4];
 #pragma unroll
@@ -1030,8 +1023,8 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
 #pragma unroll 1
             for (int i = 0; i < K; i++) {
                 const uint4 sv = *reinterpret_cast<const uint4 *>(sec + (L + K + i) * 256 + 4 * lane);
-                uint32_t t[4] = {dilithium::fold(dilithium::mont24(sv.x, chat[0])), dilithium::fold(dilithium::mont24(sv.y, chat[1])),
-                                 dilithium::fold(dilithium::mont24(sv.z, chat[2])), dilithium::fold(dilithium::mont24(sv.w, chat[3]))};
+                uint32_t t[4] = {dilithium::fold(dilithium::mont32(sv.x, chat[0])), dilithium::fold(dilithium::mont32(sv.y, chat[1])),
+                                 dilithium::fold(dilithium::mont32(sv.z, chat[2])), dilithium::fold(dilithium::mont32(sv.w, chat[3]))};
                 dilithium::invntt(t, z, xch, lane);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {

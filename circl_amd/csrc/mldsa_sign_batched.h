@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
         }
         dilithium::ntt(yh[l], z, xch, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont24(dilithium::fold(yh[l][r]), dilithium::R24SQ);
+        for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);
     }
     const uint32_t *arows = st.A + item * K * L * 256;
 #pragma unroll 1
@@ -179,10 +179,10 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * 256 + 4 * lane);
-            w[0] += dilithium::mont24(a.x, yh[j][0]);
-            w[1] += dilithium::mont24(a.y, yh[j][1]);
-            w[2] += dilithium::mont24(a.z, yh[j][2]);
-            w[3] += dilithium::mont24(a.w, yh[j][3]);
+            w[0] += dilithium::mont32(a.x, yh[j][0]);
+            w[1] += dilithium::mont32(a.y, yh[j][1]);
+            w[2] += dilithium::mont32(a.z, yh[j][2]);
+            w[3] += dilithium::mont32(a.w, yh[j][3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
@@ -247,10 +247,10 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
     uint32_t *w0 = st.w0 + item * K * 256;
     auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
         const uint4 sv = *reinterpret_cast<const uint4 *>(row + 4 * lane);
-        t[0] = dilithium::fold(dilithium::mont24(sv.x, chat[0]));
-        t[1] = dilithium::fold(dilithium::mont24(sv.y, chat[1]));
-        t[2] = dilithium::fold(dilithium::mont24(sv.z, chat[2]));
-        t[3] = dilithium::fold(dilithium::mont24(sv.w, chat[3]));
+        t[0] = dilithium::fold(dilithium::mont32(sv.x, chat[0]));
+        t[1] = dilithium::fold(dilithium::mont32(sv.y, chat[1]));
+        t[2] = dilithium::fold(dilithium::mont32(sv.z, chat[2]));
+        t[3] = dilithium::fold(dilithium::mont32(sv.w, chat[3]));
         dilithium::invntt(t, z, xch, lane);
     };
     bool bad = false;

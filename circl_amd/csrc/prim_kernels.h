@@ -77,9 +77,8 @@ __global__ void __launch_bounds__(64) dilithium_ntt_kernel(uint32_t *polys, int 
 #pragma unroll
         for (int r = 0; r < 4; r++) c[r] = dilithium::normalize(p[kyber::idx_l4(lane, r)]);
         dilithium::invntt(c, z, xch, lane);
-        constexpr uint32_t R32R24 = (uint32_t)((uint64_t)((1ull << 32) % dilithium::Q) * dilithium::R24 % dilithium::Q);
 #pragma unroll
-        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = dilithium::normalize(dilithium::mont24(dilithium::fold(c[r]), R32R24));
+        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = dilithium::normalize(dilithium::mont32(c[r], dilithium::R32SQ));  // c * 2^32
     }
 }
 

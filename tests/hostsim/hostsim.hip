@@ -94,11 +94,11 @@ void hs_kyber_ntt(int16_t *p, int inverse) {
     }
 }
 
-uint32_t hs_dil_mont24(uint32_t a, uint32_t b) { return dilithium::mont24(a, b); }
+uint32_t hs_dil_mont32(uint32_t a, uint32_t b) { return dilithium::mont32(a, b); }
 uint32_t hs_dil_fold(uint32_t x) { return dilithium::fold(x); }
 uint32_t hs_dil_normalize(uint32_t x) { return dilithium::normalize(x); }
 uint32_t hs_dil_zeta(int i) { return dilithium::zeta(i); }
-uint32_t hs_dil_r24(void) { return dilithium::R24; }
+uint32_t hs_dil_r32(void) { return dilithium::R32; }
 uint32_t hs_dil_use_hint(uint32_t a, uint32_t h, int gamma2_is_88) {
     return gamma2_is_88 ? dilithium::use_hint<95232>(a, h) : dilithium::use_hint<261888>(a, h);
 }

@@ -25,9 +25,9 @@ def hs():
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
                                os.path.join(ROOT, "circl_amd", "csrc"), src, "-o", out])
     L = C.CDLL(out)
-    for f in ("hs_kyber_compress", "hs_kyber_msg_bit", "hs_dil_mont24", "hs_dil_fold", "hs_dil_normalize", "hs_dil_zeta", "hs_dil_r24", "hs_dil_use_hint"):
+    for f in ("hs_kyber_compress", "hs_kyber_msg_bit", "hs_dil_mont32", "hs_dil_fold", "hs_dil_normalize", "hs_dil_zeta", "hs_dil_r32", "hs_dil_use_hint"):
         getattr(L, f).restype = C.c_uint32
-    L.hs_dil_mont24.argtypes = [C.c_uint32, C.c_uint32]
+    L.hs_dil_mont32.argtypes = [C.c_uint32, C.c_uint32]
     L.hs_dil_fold.argtypes = [C.c_uint32]
     L.hs_dil_normalize.argtypes = [C.c_uint32]
     L.hs_dil_use_hint.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
@@ -108,21 +108,24 @@ def test_mulhat_lane_share(hs):
         assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
 
 
-def test_dilithium_mont24_and_zetas(hs):
-    R24 = (1 << 24) % DQ
-    assert hs.hs_dil_r24() == R24
-    z = orc.dilithium_zetas().astype(np.uint64)   # zeta^brv * 2^32
-    inv32 = pow(1 << 32, -1, DQ)
+def test_dilithium_mont32_and_zetas(hs):
+    R32 = (1 << 32) % DQ
+    assert hs.hs_dil_r32() == R32
+    z = orc.dilithium_zetas().astype(np.uint64)   # zeta^brv * 2^32, the reference's table (ntt.go:19-57)
     for i in range(256):
-        assert hs.hs_dil_zeta(i) == int(z[i]) * inv32 % DQ * R24 % DQ
+        assert hs.hs_dil_zeta(i) == int(z[i])
     rng = np.random.default_rng(4)
-    inv24 = pow(1 << 24, -1, DQ)
-    for a, b in zip(rng.integers(0, 1 << 24, 20000), rng.integers(0, DQ, 20000)):
-        r = hs.hs_dil_mont24(int(a), int(b))
-        assert r < 2 * DQ and r % DQ == int(a) * int(b) * inv24 % DQ
+    inv32 = pow(1 << 32, -1, DQ)
+    # contract: a b < 2^32 q  ->  result in (0, 2q)
+    for a, b in zip(rng.integers(0, 1 << 32, 20000, dtype=np.uint64), rng.integers(0, DQ, 20000)):
+        r = hs.hs_dil_mont32(int(a), int(b))
+        assert 0 < r < 2 * DQ and r % DQ == int(a) * int(b) * inv32 % DQ
+    for a, b in zip(rng.integers(0, 36 * DQ, 20000, dtype=np.uint64), rng.integers(0, 2 * DQ, 20000)):  # lazy operands
+        r = hs.hs_dil_mont32(int(a), int(b))
+        assert 0 < r < 2 * DQ and r % DQ == int(a) * int(b) * inv32 % DQ
     for x in rng.integers(0, 1 << 32, 20000, dtype=np.uint64):
         f = hs.hs_dil_fold(int(x))
-        assert f < (1 << 24) and f % DQ == int(x) % DQ
+        assert f < 2 * DQ and f % DQ == int(x) % DQ
         assert hs.hs_dil_normalize(int(x)) == int(x) % DQ
 
 
