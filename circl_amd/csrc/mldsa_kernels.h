@@ -265,7 +265,7 @@ __device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32
 // through a 16-slot LDS FIFO and leave four at a time, so that every global store is a full 16-byte
 // segment of the stream's row (row index = lane).  Branch-free acceptance: the candidate is stored at
 // slot cnt and cnt advances only if it is < q.
-template <bool TAIL>
+template <bool TAIL, bool NOSTORE = false>
 __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_t *fifo, uint32_t *row, int &cnt, int &flushed) {
     bool live = true;
     detail::static_for<0, 56>([&](auto ic) {
@@ -281,7 +281,8 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
             if constexpr (c % 4 == 3) {
                 if (cnt - flushed >= 4) {  // at most 7 pending here, so one flush per check suffices
                     const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 15));
-                    *reinterpret_cast<uint4 *>(row + flushed) = d;
+                    if constexpr (NOSTORE) { if (d.x == 0x7fffffffu) row[0] = d.y; }  // profiling aid: keep the LDS read, drop the store
+                    else *reinterpret_cast<uint4 *>(row + flushed) = d;
                     flushed += 4;
                 }
                 if constexpr (TAIL) live = __any(flushed < 256);  // wave-uniform
@@ -290,7 +291,7 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
     });
 }
 
-template <int MODE>
+template <int MODE, bool NOSTORE = false>
 __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *rows, const uint8_t *__restrict__ rho, size_t rho_stride,
                                                  size_t item0, size_t n, int lane) {
     using G = DG<MODE>;
@@ -312,12 +313,12 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
 #pragma unroll 1
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(s);
-        if (on) parse23_block_fifo<false>(s, fifo, row, cnt, flushed);
+        if (on) parse23_block_fifo<false, NOSTORE>(s, fifo, row, cnt, flushed);
     }
 #pragma unroll 1
     while (__any(flushed < 256)) {  // more than 24 rejections in 280 candidates: essentially never
         keccak_f1600(s);
-        parse23_block_fifo<true>(s, fifo, row, cnt, flushed);
+        parse23_block_fifo<true, NOSTORE>(s, fifo, row, cnt, flushed);
     }
 }
 
@@ -412,7 +413,8 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
 
 // ---- kernel V -----------------------------------------------------------------------------------
 
-// ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase A, bit 1 phase 1, bit 2 phases 2+3.
+// ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase A, bit 1 phase 1, bit 2 phases 2+3,
+// bit 3 drops the row stores of phase A, bit 4 shrinks the row loads of phase 2 to one row (L2 hits).
 // `scratch` holds gridDim.x slices of DG::SCRATCH_BYTES; `work` is the ticket counter (zeroed by the host)
 // or nullptr for one group per workgroup.
 template <int MODE, int ABLATE = 0>
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     const size_t item0 = grp * G::IT;
     // ------------------------------ phase A ------------------------------
     __syncthreads();  // the previous group is done with the LDS the FIFOs alias
-    if (!(ABLATE & 1)) expand_a_scratch<MODE>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
+    if (!(ABLATE & 1)) expand_a_scratch<MODE, (ABLATE & 8) != 0>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
     rows_acquire();
 
 #pragma unroll 1
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
         for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
             uint32_t acc[4] = {0, 0, 0, 0};
-            mac_rows<L>(acc, rows, g * G::STREAMS + i * L, zhat, lane);  // a * z-hat, < 2q each
+            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : g * G::STREAMS + i * L, zhat, lane);  // a * z-hat, < 2q each
             uint32_t t[4], w[4];
             {
                 // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,

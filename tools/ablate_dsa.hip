@@ -49,7 +49,12 @@ template <int MODE> void bench(size_t n) {
         g_bpc = bpc;
         printf("  full            %.3f ms  (%d workgroups/CU)\n", run<MODE, 0>(pk, sig, muw1, ball, fail, n), bpc);
     }
+    g_bpc = 16;
+    printf("  full, no row stores          %.3f ms\n", run<MODE, 8>(pk, sig, muw1, ball, fail, n));
+    printf("  full, row loads hit L2       %.3f ms\n", run<MODE, 16>(pk, sig, muw1, ball, fail, n));
+    printf("  full, neither                %.3f ms\n", run<MODE, 24>(pk, sig, muw1, ball, fail, n));
     printf("  phase A only    %.3f ms\n", run<MODE, 6>(pk, sig, muw1, ball, fail, n));
+    printf("  phase A only, no row stores  %.3f ms\n", run<MODE, 14>(pk, sig, muw1, ball, fail, n));
     printf("  phase 1 only    %.3f ms\n", run<MODE, 5>(pk, sig, muw1, ball, fail, n));
     printf("  phases 2+3 only %.3f ms\n", run<MODE, 3>(pk, sig, muw1, ball, fail, n));
     printf("  nothing         %.3f ms\n", run<MODE, 7>(pk, sig, muw1, ball, fail, n));
