@@ -95,6 +95,25 @@ def load_traffic():
         return None
 
 
+def valu_issue(batch, launch_ms):
+    """VALU issue figures of the dominant kernel: instruction count from the committed SQ_INSTS_VALU pass
+    (profiles/valu.json, per 2^20 items), rate from this run's launch time.  The bound that matters for this
+    integer path: cycles per wave-instruction per SIMD against the 2.3 (fast class) .. 4.2 (slow
+    class) measured by tools/gen_valu_rate.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
+            insts = json.load(f)["mlkem768_encrypt_valu_insts_per_launch_2p20"] * batch / (1 << 20)
+    except Exception:
+        return None
+    if not launch_ms:
+        return None
+    simds, nominal_hz = 1024, 2.4e9
+    per_s = insts / (launch_ms * 1e-3)
+    return {"wave_insts_per_launch": insts, "achieved_Ginst_per_s": per_s / 1e9,
+            "cycles_per_inst_per_simd_at_2.4GHz": simds * nominal_hz / per_s,
+            "keccak_mix_floor_cycles_per_inst": 3.3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +183,7 @@ def main():
                 "algorithmic_bytes_per_launch": B * BYTES_PER_OP,
                 "avg_launch_ms": enc_avg_ms, "launches": enc_n,
                 "hash_kernel_avg_ms": hash_ms / max(hash_n, 1),
+                "valu": valu_issue(B, enc_avg_ms),
                 "note": "integer-VALU bound (Keccak-f[1600] as 2x u32 bit ops, Z_3329 Montgomery in 32-bit lanes), not HBM bound; "
                         "traffic is L2<->fabric bytes incl. the Infinity-Cache-resident matrix scratch: see DESIGN.md 4.4/5",
             },

@@ -24,8 +24,16 @@ for f in glob.glob("gpurun_out/sq/g*/*counter_collection.csv"):
         if "mlkem" not in k: continue
         k = k.split("(")[0][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+out = {}
 for k, d in agg.items():
     print(k)
     for c, v in sorted(d.items()):
         v = sorted(v); print(f"   {c:28s} median {v[len(v)//2]:.4e}  n={len(v)}")
+    if "mlkem_encrypt_kernel<3" in k:
+        med = lambda c: sorted(d[c])[len(d[c]) // 2]
+        out = {"mlkem768_encrypt_valu_insts_per_launch_2p20": med("SQ_INSTS_VALU"), "salu": med("SQ_INSTS_SALU"), "lds": med("SQ_INSTS_LDS"),
+               "grbm_gui_active_per_xcd": med("GRBM_GUI_ACTIVE") / 8, "wave_quad_cycles": med("SQ_WAVE_CYCLES"),
+               "method": "rocprofv3 --pmc SQ_* (own passes, kernel-trace only), median over the launches of bench.py --steps 2; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES counts in units of 4 cycles"}
+json.dump(out, open("gpurun_out/sq/valu.json", "w"), indent=1)
 PY
