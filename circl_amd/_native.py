@@ -18,6 +18,8 @@ SYMBOLS = [
     "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
     "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
     "circl_hip_mlkem_keygen_dev",
+    "circl_hip_kyber_keygen", "circl_hip_kyber_encaps", "circl_hip_kyber_decaps",
+    "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
     "circl_hip_keccak_f1600", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_dilithium_ntt",
     "circl_hip_shake", "circl_hip_xof", "circl_hip_alloc_host", "circl_hip_free_host",
@@ -84,6 +86,12 @@ def lib():
         L.circl_hip_mlkem_encaps_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_kyber_keygen.argtypes = [i, vp, vp, vp, sz, i]
+        L.circl_hip_kyber_encaps.argtypes = [i, vp, vp, vp, vp, sz, i]
+        L.circl_hip_kyber_decaps.argtypes = [i, vp, vp, vp, sz, i]
+        L.circl_hip_kyber_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_kyber_encaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_kyber_decaps_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_sign.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_sign_internal.argtypes = [i, vp, vp, vp, vp, vp, sz, i]

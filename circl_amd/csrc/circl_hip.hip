@@ -108,8 +108,9 @@ template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
 }
 
 size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
-// ML-KEM workspace: 128 B per item + one 32 KB scratch slice per resident workgroup
-size_t kem_ws_bytes(size_t n) { return up256(128 * n) + 256 + max_resident_blocks() * 64 * 512; }
+// ML-KEM workspace: 129 B per item + one 32 KB scratch slice per resident workgroup
+constexpr size_t kKemWsPerItem = 129;  // four 32-byte slots + one status byte (round-3 decapsulation has no caller-side status)
+size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + 256 + max_resident_blocks() * 64 * 512; }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -117,51 +118,65 @@ int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 102
 
 // ---- device-resident ML-KEM ---------------------------------------------------------------
 
-template <int K>
+// R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:105-154): m = H(seed), lenient key decoding, K = KDF(K' || H(ct)).
+template <int K, bool R3 = false>
 int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
                     void *ws, size_t ws_bytes, hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
         return CIRCL_HIP_EWORKSPACE;
-    uint8_t *r_ws = static_cast<uint8_t *>(ws);
-    unsigned *work = reinterpret_cast<unsigned *>(r_ws + up256(128 * n));
-    uint8_t *scratch = r_ws + up256(128 * n) + 256;
+    uint8_t *r_ws = static_cast<uint8_t *>(ws), *m_ws = r_ws + 32 * n;
+    unsigned *work = reinterpret_cast<unsigned *>(r_ws + up256(kKemWsPerItem * n));
+    uint8_t *scratch = r_ws + up256(kKemWsPerItem * n) + 256;
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
+        if (R3) hipLaunchKernelGGL(circl::mlkem::kyber_r3_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, m_ws, n);
+        else hipLaunchKernelGGL(circl::mlkem::mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
     }
     {
-        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::ENCAPS, 0, true>;
+        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, R3 ? circl::mlkem::ENCAPS_LENIENT : circl::mlkem::ENCAPS, 0, true>;
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, work, n);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, R3 ? (const uint8_t *)m_ws : m, (const uint8_t *)r_ws,
+                           ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, work, n);
+    }
+    if (R3) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::kyber_r3_finish_kernel<K>, dim3(hb), dim3(256), 0, st, (const uint8_t *)ct, ss, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
 
-template <int K>
+// R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:156-197): no private-key check, K = KDF((ct' == ct ? K'' : z) || H(ct));
+// `status` may then be null (an n-byte slot of the workspace is used).
+template <int K, bool R3 = false>
 int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t ws_bytes,
                     hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *mprime = static_cast<uint8_t *>(ws), *r_ws = mprime + 32 * n, *kbar = mprime + 64 * n, *ssrej = mprime + 96 * n;
-    unsigned *work = reinterpret_cast<unsigned *>(mprime + up256(128 * n));
-    uint8_t *scratch = mprime + up256(128 * n) + 256;
+    if (R3) status = mprime + 128 * n;
+    unsigned *work = reinterpret_cast<unsigned *>(mprime + up256(kKemWsPerItem * n));
+    uint8_t *scratch = mprime + up256(kKemWsPerItem * n) + 256;
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
         hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, ct, mprime, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dk, ct,
-                           (const uint8_t *)mprime, kbar, r_ws, ssrej, status, n);
+        if (R3)
+            hipLaunchKernelGGL(circl::mlkem::kyber_r3_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (const uint8_t *)mprime, kbar, r_ws,
+                               ssrej, status, n);
+        else
+            hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, ct, (const uint8_t *)mprime, kbar, r_ws,
+                               ssrej, status, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -171,23 +186,27 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
                            (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej,
                            scratch, work, n);
     }
+    if (R3) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::kyber_r3_finish_kernel<K>, dim3(hb), dim3(256), 0, st, ct, ss, n);
+    }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
 
-template <int K>
+template <int K, bool R3 = false>
 int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
     using Gm = circl::mlkem::Geom<K>;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *rs = static_cast<uint8_t *>(ws);
-    unsigned *work = reinterpret_cast<unsigned *>(rs + up256(128 * n));
-    uint8_t *scratch = rs + up256(128 * n) + 256;
+    unsigned *work = reinterpret_cast<unsigned *>(rs + up256(kKemWsPerItem * n));
+    uint8_t *scratch = rs + up256(kKemWsPerItem * n) + 256;
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_keygen_seed_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, rs, n);
+        hipLaunchKernelGGL((circl::mlkem::mlkem_keygen_seed_kernel<K, R3>), dim3(hb), dim3(256), 0, st, seed64, rs, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
@@ -679,7 +698,7 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_chunked(dev, cnt, {ek + lo * EK, m + lo * 32}, {EK, 32},
-                           {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, 128,
+                           {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, kKemWsPerItem,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_encaps_dev(param, in[0], in[1], out[0], out[1], out[2], c, ws, wsb, st);
@@ -716,7 +735,7 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_chunked(dev, cnt, {dk + lo * DK, ct + lo * CT}, {DK, CT}, {ss + lo * 32, status ? status + lo : nullptr}, {32, 1},
-                           128,
+                           kKemWsPerItem,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_decaps_dev(param, in[0], in[1], out[0], out[1], c, ws, wsb, st);
@@ -728,10 +747,76 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, 128,
+        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, kKemWsPerItem,
                            [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb,
                                hipStream_t st) {
                                return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
+                           }, 256 + max_resident_blocks() * 64 * 512);
+    });
+}
+
+// ---- round-3 Kyber (kem/kyber/kyber{512,768,1024}), SURVEY 8f row f3 ------------------------------------
+
+int circl_hip_kyber_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk, size_t n, void *d_ws, size_t ws_bytes,
+                               void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return keygen_dev_impl<2, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    case 3: return keygen_dev_impl<3, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    case 4: return keygen_dev_impl<4, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_kyber_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_seed32, uint8_t *d_ct, uint8_t *d_ss, size_t n, void *d_ws,
+                               size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return encaps_dev_impl<2, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    case 3: return encaps_dev_impl<3, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    case 4: return encaps_dev_impl<4, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_kyber_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, size_t n, void *d_ws, size_t ws_bytes,
+                               void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return decaps_dev_impl<2, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    case 3: return decaps_dev_impl<3, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    case 4: return decaps_dev_impl<4, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_kyber_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {seed64 + lo * 64}, {64}, {ek + lo * EK, dk + lo * DK}, {EK, DK}, kKemWsPerItem,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb, hipStream_t st) {
+                               return circl_hip_kyber_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
+                           }, 256 + max_resident_blocks() * 64 * 512);
+    });
+}
+int circl_hip_kyber_encaps(int param, const uint8_t *ek, const uint8_t *seed32, uint8_t *ct, uint8_t *ss, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {ek + lo * EK, seed32 + lo * 32}, {EK, 32}, {ct + lo * CT, ss + lo * 32}, {CT, 32}, kKemWsPerItem,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb, hipStream_t st) {
+                               return circl_hip_kyber_encaps_dev(param, in[0], in[1], out[0], out[1], c, ws, wsb, st);
+                           }, 256 + max_resident_blocks() * 64 * 512);
+    });
+}
+int circl_hip_kyber_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_chunked(dev, cnt, {dk + lo * DK, ct + lo * CT}, {DK, CT}, {ss + lo * 32}, {32}, kKemWsPerItem,
+                           [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb, hipStream_t st) {
+                               return circl_hip_kyber_decaps_dev(param, in[0], in[1], out[0], c, ws, wsb, st);
                            }, 256 + max_resident_blocks() * 64 * 512);
     });
 }

@@ -126,6 +126,79 @@ __global__ void __launch_bounds__(256) mlkem_hash_kernel(const uint8_t *__restri
     }
 }
 
+// ---- round-3 Kyber hashing (kem/kyber/kyber768/kyber.go), SURVEY 8f row f3 ---------------------
+
+// lane = item: m = H(seed) ("the hash of shame", kyber.go:131-135), (K', r) = G(m || H(pk)) (:137-142).
+// K' -> ss (replaced by kyber_r3_finish_kernel once the ciphertext exists), r and m -> workspace.
+template <int K>
+__global__ void __launch_bounds__(256) kyber_r3_hash_kernel(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ seed,
+                                                            uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws,
+                                                            uint8_t *__restrict__ m_ws, size_t n) {
+    using Gm = Geom<K>;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    KeccakState h, g;
+    sha3_256_words<4>(g, reinterpret_cast<const uint64_t *>(seed + idx * 32));  // m in words 0..3 of g
+    sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek + idx * Gm::EK));
+    if (live) store_words<0, 4>(reinterpret_cast<uint64_t *>(m_ws + idx * 32), g);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { g.lo[4 + i] = h.lo[i]; g.hi[4 + i] = h.hi[i]; }
+#pragma unroll
+    for (int i = 8; i < 25; i++) { g.lo[i] = 0; g.hi[i] = 0; }
+    g.lo[8] = kDsSha3;
+    g.hi[8] = 0x80000000u;
+    keccak_f1600(g);
+    if (live) {
+        store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
+        store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
+    }
+}
+
+// lane = item: ss = KDF(ss || H(ct)) = SHAKE256(ss || SHA3-256(ct))[:32]  (kyber.go:147-154, :179-196)
+template <int K>
+__global__ void __launch_bounds__(256) kyber_r3_finish_kernel(const uint8_t *__restrict__ ct, uint8_t *__restrict__ ss, size_t n) {
+    using Gm = Geom<K>;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    KeccakState h, g;
+    sha3_256_words<Gm::CT / 8>(h, reinterpret_cast<const uint64_t *>(ct + idx * Gm::CT));
+    keccak_zero(g);
+    xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(ss + idx * 32));
+#pragma unroll
+    for (int i = 0; i < 4; i++) { g.lo[4 + i] = h.lo[i]; g.hi[4 + i] = h.hi[i]; }
+    g.lo[8] = kDsShake;
+    g.hi[16] = 0x80000000u;
+    keccak_f1600(g);
+    if (live) store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
+}
+
+// lane = item: (K'', r') = G(m' || H(pk) as stored in the private key) (kyber.go:168-173); the re-encryption
+// kernel then selects K'' (ct' == ct) or z (:184-189) and kyber_r3_finish_kernel applies the KDF.
+template <int K>
+__global__ void __launch_bounds__(256) kyber_r3_decaps_hash_kernel(const uint8_t *__restrict__ dk, const uint8_t *__restrict__ mprime_ws,
+                                                                   uint8_t *__restrict__ kbar_ws, uint8_t *__restrict__ r_ws,
+                                                                   uint8_t *__restrict__ z_ws, uint8_t *__restrict__ status, size_t n) {
+    using Gm = Geom<K>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const uint8_t *dkp = dk + idx * Gm::DK;
+    KeccakState g;
+    keccak_zero(g);
+    xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(mprime_ws + idx * 32));
+    xor_words<4, 4>(g, reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32));
+    g.lo[8] = kDsSha3;
+    g.hi[8] = 0x80000000u;
+    keccak_f1600(g);
+    store_words<0, 4>(reinterpret_cast<uint64_t *>(kbar_ws + idx * 32), g);
+    store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
+    const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
+#pragma unroll
+    for (int i = 0; i < 4; i++) reinterpret_cast<uint64_t *>(z_ws + idx * 32)[i] = zw[i];
+    status[idx] = 0;  // round-3 private keys are not checked (kyber.go:215-232)
+}
+
 // ---- phase A: matrix expansion --------------------------------------------------------------
 
 // Parse one squeezed SHAKE128 block (21 words = 56 three-byte groups = 112 candidates, t1 then
@@ -580,7 +653,7 @@ __device__ __forceinline__ size_t next_group(unsigned *work, int lane, bool firs
 
 // ---- kernel 2: K-PKE.Encrypt ------------------------------------------------------------------
 
-enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
+enum EncryptMode { ENCAPS = 0, REENCRYPT = 1, ENCAPS_LENIENT = 2 };
 
 // ENCAPS   : ek rows of stride EK, canonical check, ciphertext stored, status written.
 // REENCRYPT: decapsulation's second half (kyber.go:158-181).  `ek` points at the ek embedded in dk
@@ -588,6 +661,8 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1 };
 //            m = m', r = r' come from the workspace; ct' is compared with ct instead of stored and
 //            ss = (ct == ct') ? K' : J(z || ct), both candidates parked in the workspace by
 //            mlkem_decaps_hash_kernel.  Items whose status is already non-zero get ss = 0.
+// ENCAPS_LENIENT: round-3 Kyber's encapsulation (kem/kyber/kyber768/kyber.go:248-262): as ENCAPS, but
+//            coefficients >= q of the key are reduced instead of rejected and ss / status are left alone.
 // ABLATE is a profiling aid (tools/ablate.hip): bit 0 skips phase A, bit 1 phase B, bit 2 phase C.
 // SCRATCH selects where the sampled matrix lives between phase A and phase C: the workgroup's slice of
 // a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
@@ -652,7 +727,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 else th[j][r] = kyber::csubq(th[j][r]);  // 12-bit value < 2q: Normalize == csubq
             }
         }
-        const bool reject = MODE == ENCAPS ? __any(bad) : false;
+        const bool reject = MODE == ENCAPS ? __any(bad) : false;  // ENCAPS_LENIENT and REENCRYPT reduce instead
 
         // r-hat = NTT(CBD_eta1(PRF(r, j))), Barrett-reduced (cpapke.go:142-144), layout L4
         int rh[K][4];
@@ -719,7 +794,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         if (MODE == ENCAPS) {
             if (lane == 0) status[item] = reject ? 1 : 0;
             if (reject && lane < 8) reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = 0;
-        } else {
+        } else if (MODE == REENCRYPT) {
             // subtle.ConstantTimeCopy(ConstantTimeCompare(ct, ct'), ss2, K')  -- a lane-wise select here
             const bool mismatch = __any(differs);
             const bool dead = status[item] != 0;
@@ -830,14 +905,15 @@ __global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *_
 
 // lane = item: (rho, sigma) = G(d || K) (cpapke.go:72-79 with the FIPS 203 domain byte,
 // pke/kyber/kyber768/kyber.go:77-86) -> workspace (rho 32 B, sigma 32 B per item).
-template <int K>
+// R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:60-82): G(d) without the domain byte.
+template <int K, bool R3 = false>
 __global__ void __launch_bounds__(256) mlkem_keygen_seed_kernel(const uint8_t *__restrict__ seed64, uint8_t *__restrict__ rs_ws, size_t n) {
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState g;
     keccak_zero(g);
     xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(seed64 + idx * 64));
-    g.lo[4] = (uint32_t)K | (kDsSha3 << 8);
+    g.lo[4] = R3 ? kDsSha3 : ((uint32_t)K | (kDsSha3 << 8));
     g.hi[8] = 0x80000000u;
     keccak_f1600(g);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(rs_ws + idx * 64), g);

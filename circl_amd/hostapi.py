@@ -56,6 +56,38 @@ def mlkem_keygen(param, seeds, device=0):
     return ek, dk
 
 
+# round-3 Kyber (kem/kyber/kyber{512,768,1024}): no per-item failures
+def kyber_keygen(param, seeds, device=0):
+    EK, DK, _ = KEM_SIZES[param]
+    seeds = _u8(seeds, 64)
+    n = len(seeds)
+    ek = np.empty((n, EK), np.uint8)
+    dk = np.empty((n, DK), np.uint8)
+    nat.check(nat.lib().circl_hip_kyber_keygen(param, _p(seeds), _p(ek), _p(dk), n, device), "kyber_keygen")
+    return ek, dk
+
+
+def kyber_encaps(param, ek, seeds, device=0):
+    EK, _, CT = KEM_SIZES[param]
+    ek, seeds = _u8(ek, EK), _u8(seeds, 32)
+    n = len(ek)
+    assert len(seeds) == n
+    ct = np.empty((n, CT), np.uint8)
+    ss = np.empty((n, 32), np.uint8)
+    nat.check(nat.lib().circl_hip_kyber_encaps(param, _p(ek), _p(seeds), _p(ct), _p(ss), n, device), "kyber_encaps")
+    return ct, ss
+
+
+def kyber_decaps(param, dk, ct, device=0):
+    _, DK, CT = KEM_SIZES[param]
+    dk, ct = _u8(dk, DK), _u8(ct, CT)
+    n = len(dk)
+    assert len(ct) == n
+    ss = np.empty((n, 32), np.uint8)
+    nat.check(nat.lib().circl_hip_kyber_decaps(param, _p(dk), _p(ct), _p(ss), n, device), "kyber_decaps")
+    return ss
+
+
 def _blob(items):
     off = np.zeros(len(items) + 1, np.uint64)
     if len(items):

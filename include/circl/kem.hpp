@@ -24,6 +24,7 @@
 // batches of distinct keys.  Every operation runs on the GPU: there is no CPU path.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -68,7 +69,8 @@ class PrivateKey {
 
 class Scheme {
   public:
-    Scheme(int param, const char *name) : param_(param), name_(name) {}
+    // round3 = the pre-standard Kyber of kem/kyber/kyber{512,768,1024} (no key validation, different hashing)
+    Scheme(int param, const char *name, bool round3 = false) : param_(param), name_(name), r3_(round3) {}
     std::string Name() const { return name_; }
     int PublicKeySize() const { return (int)circl_hip_mlkem_ek_size(param_); }
     int PrivateKeySize() const { return (int)circl_hip_mlkem_dk_size(param_); }
@@ -82,13 +84,15 @@ class Scheme {
         if ((int)seed.size() != SeedSize()) throw std::invalid_argument("seed must be of length KeySeedSize");
         PublicKey pk{this, Bytes(PublicKeySize())};
         PrivateKey sk{this, Bytes(PrivateKeySize())};
-        check(circl_hip_mlkem_keygen(param_, seed.data(), pk.packed.data(), sk.packed.data(), 1, dev1()));
+        check(r3_ ? circl_hip_kyber_keygen(param_, seed.data(), pk.packed.data(), sk.packed.data(), 1, dev1())
+                  : circl_hip_mlkem_keygen(param_, seed.data(), pk.packed.data(), sk.packed.data(), 1, dev1()));
         return {pk, sk};
     }
     std::pair<PublicKey, PrivateKey> GenerateKeyPair() const { return DeriveKeyPair(random_bytes(SeedSize())); }
 
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
         if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
+        if (r3_) return PublicKey{this, buf};  // kem/kyber/kyber768/kyber.go:248-262: non-canonical encodings are accepted
         // canonical check == cpapke.go:45-55; done on the device by an encapsulation's status byte
         Bytes ct(CiphertextSize()), ss(32), m(32, 0);
         uint8_t st = 0;
@@ -98,6 +102,7 @@ class Scheme {
     }
     PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
         if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
+        if (r3_) return PrivateKey{this, buf};  // kyber.go:215-232: no hash check
         Bytes ct(CiphertextSize(), 0), ss(32);
         uint8_t st = 0;
         check(circl_hip_mlkem_decaps(param_, buf.data(), ct.data(), ss.data(), &st, 1, dev1()));
@@ -110,7 +115,8 @@ class Scheme {
         if ((int)seed.size() != EncapsulationSeedSize()) throw ErrSeedSize();
         Bytes ct(CiphertextSize()), ss(32);
         uint8_t st = 0;
-        check(circl_hip_mlkem_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (r3_) check(circl_hip_kyber_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), 1, dev1()));
+        else check(circl_hip_mlkem_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), &st, 1, dev1()));
         if (st) throw ErrPubKey();
         return {ct, ss};
     }
@@ -122,7 +128,8 @@ class Scheme {
         if ((int)ct.size() != CiphertextSize()) throw ErrCiphertextSize();
         Bytes ss(32);
         uint8_t st = 0;
-        check(circl_hip_mlkem_decaps(param_, sk.packed.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        if (r3_) check(circl_hip_kyber_decaps(param_, sk.packed.data(), ct.data(), ss.data(), 1, dev1()));
+        else check(circl_hip_mlkem_decaps(param_, sk.packed.data(), ct.data(), ss.data(), &st, 1, dev1()));
         if (st) throw ErrPrivKey();
         return ss;
     }
@@ -130,18 +137,29 @@ class Scheme {
     // ---- batch API (new; rows are MarshalBinary-form keys) -------------------------------------
     // status[i]: 0 ok, 1 = ErrPubKey, 2 = ErrPrivKey; failed items have zeroed outputs.
     void EncapsulateBatch(const uint8_t *eks, const uint8_t *seeds, uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
-        check(circl_hip_mlkem_encaps(param_, eks, seeds, cts, sss, status, n, device));
+        if (r3_) {
+            check(circl_hip_kyber_encaps(param_, eks, seeds, cts, sss, n, device));
+            if (status) std::fill(status, status + n, (uint8_t)0);
+        } else {
+            check(circl_hip_mlkem_encaps(param_, eks, seeds, cts, sss, status, n, device));
+        }
     }
     void DecapsulateBatch(const uint8_t *dks, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
-        check(circl_hip_mlkem_decaps(param_, dks, cts, sss, status, n, device));
+        if (r3_) {
+            check(circl_hip_kyber_decaps(param_, dks, cts, sss, n, device));
+            if (status) std::fill(status, status + n, (uint8_t)0);
+        } else {
+            check(circl_hip_mlkem_decaps(param_, dks, cts, sss, status, n, device));
+        }
     }
     void DeriveKeyPairBatch(const uint8_t *seeds64, uint8_t *eks, uint8_t *dks, size_t n) const {
-        check(circl_hip_mlkem_keygen(param_, seeds64, eks, dks, n, device));
+        check(r3_ ? circl_hip_kyber_keygen(param_, seeds64, eks, dks, n, device) : circl_hip_mlkem_keygen(param_, seeds64, eks, dks, n, device));
     }
 
   private:
     int param_;
     const char *name_;
+    bool r3_;
     int dev1() const { return device < 0 ? 0 : device; }
     static void check(int rc) {
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("error ") + std::to_string(rc) + " " + circl_hip_last_error());
@@ -162,7 +180,8 @@ inline PublicKey PrivateKey::Public() const {
 // kem/schemes/schemes.go:35-75
 inline const Scheme *ByName(const std::string &name) {
     static const Scheme s512(512, "ML-KEM-512"), s768(768, "ML-KEM-768"), s1024(1024, "ML-KEM-1024");
-    for (const Scheme *s : {&s512, &s768, &s1024})
+    static const Scheme k512(512, "Kyber512", true), k768(768, "Kyber768", true), k1024(1024, "Kyber1024", true);
+    for (const Scheme *s : {&s512, &s768, &s1024, &k512, &k768, &k1024})
         if (s->Name() == name) return s;
     return nullptr;
 }

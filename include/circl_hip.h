@@ -93,6 +93,31 @@ int circl_hip_mlkem_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_
 int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- round-3 Kyber ------------------------------------------------------
+ * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in
+ * kem/schemes).  param 512 | 768 | 1024; key and ciphertext sizes are those of ML-KEM.  Differences from
+ * ML-KEM (kem/kyber/kyber768/kyber.go):
+ *   keygen  scheme.DeriveKeyPair(seed64): G(d) without the domain byte                          :60-82
+ *   encaps  scheme.EncapsulateDeterministically(pk, seed32): m = H(seed); (K',r) = G(m || H(pk));
+ *           K = KDF(K' || H(ct)); key coefficients >= q are reduced, never rejected   :105-154, :248-262
+ *   decaps  scheme.Decapsulate(sk, ct): K = KDF((ct' == ct ? K'' : z) || H(ct)); the private key is
+ *           not checked                                                               :156-197, :215-232
+ * so none of the three has a per-item failure.  Workspace of the _dev variants:
+ * circl_hip_mlkem_workspace_size(param, n). */
+int circl_hip_kyber_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n,
+                           int device);
+int circl_hip_kyber_encaps(int param, const uint8_t *ek, const uint8_t *seed32, uint8_t *ct,
+                           uint8_t *ss, size_t n, int device);
+int circl_hip_kyber_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, size_t n,
+                           int device);
+int circl_hip_kyber_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk,
+                               size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+int circl_hip_kyber_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_seed32, uint8_t *d_ct,
+                               uint8_t *d_ss, size_t n, void *d_workspace, size_t workspace_bytes,
+                               void *stream);
+int circl_hip_kyber_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss,
+                               size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- ML-DSA verify ----------------------------------------------------------------------
  * scheme.UnmarshalBinaryPublicKey(pk_i) + scheme.Verify(pk_i, msg_i, sig_i, &SignatureOpts{Context: ctx_i})
  * (sign/mldsa/mldsa65/dilithium.go:305-327 -> :115-132 -> internal/dilithium.go:273-332).

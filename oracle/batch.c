@@ -7,7 +7,7 @@
 #include <string.h>
 
 typedef struct job {
-    int kind, param;
+    int kind, param, r3; /* r3: round-3 Kyber instead of ML-KEM */
     size_t lo, hi;
     const uint8_t *a, *b, *c, *d, *e;
     const uint64_t *off1, *off2;
@@ -23,13 +23,16 @@ static void *run(void *arg) {
         size_t ek = orc_mlkem_ek_size(p), dk = orc_mlkem_dk_size(p), ct = orc_mlkem_ct_size(p);
         for (size_t i = j->lo; i < j->hi; i++) {
             if (j->kind == J_KEM_KEYGEN) {
-                orc_mlkem_keygen(p, j->a + 64 * i, j->o1 + ek * i, j->o2 + dk * i);
+                if (j->r3) orc_kyber_r3_keygen(p, j->a + 64 * i, j->o1 + ek * i, j->o2 + dk * i);
+                else orc_mlkem_keygen(p, j->a + 64 * i, j->o1 + ek * i, j->o2 + dk * i);
             } else if (j->kind == J_KEM_ENCAPS) {
-                int r = orc_mlkem_encaps(p, j->a + ek * i, j->b + 32 * i, j->o1 + ct * i, j->o2 + 32 * i);
+                int r = j->r3 ? orc_kyber_r3_encaps(p, j->a + ek * i, j->b + 32 * i, j->o1 + ct * i, j->o2 + 32 * i)
+                              : orc_mlkem_encaps(p, j->a + ek * i, j->b + 32 * i, j->o1 + ct * i, j->o2 + 32 * i);
                 if (r) { memset(j->o1 + ct * i, 0, ct); memset(j->o2 + 32 * i, 0, 32); }
                 if (j->st) j->st[i] = (uint8_t)r;
             } else {
-                int r = orc_mlkem_decaps(p, j->a + dk * i, j->b + ct * i, j->o1 + 32 * i);
+                int r = j->r3 ? orc_kyber_r3_decaps(p, j->a + dk * i, j->b + ct * i, j->o1 + 32 * i)
+                              : orc_mlkem_decaps(p, j->a + dk * i, j->b + ct * i, j->o1 + 32 * i);
                 if (r) memset(j->o1 + 32 * i, 0, 32);
                 if (j->st) j->st[i] = (uint8_t)r;
             }
@@ -86,6 +89,21 @@ int orc_mlkem_decaps_batch(int param, const uint8_t *dk, const uint8_t *ct, uint
                            uint8_t *status, size_t n, int threads) {
     if (!orc_mlkem_ek_size(param)) return -1;
     job j = {.kind = J_KEM_DECAPS, .param = param, .a = dk, .b = ct, .o1 = ss, .st = status};
+    return fan(&j, n, threads);
+}
+int orc_kyber_r3_keygen_batch(int param, const uint8_t *seed, uint8_t *ek, uint8_t *dk, size_t n, int threads) {
+    if (!orc_mlkem_ek_size(param)) return -1;
+    job j = {.kind = J_KEM_KEYGEN, .param = param, .r3 = 1, .a = seed, .o1 = ek, .o2 = dk};
+    return fan(&j, n, threads);
+}
+int orc_kyber_r3_encaps_batch(int param, const uint8_t *ek, const uint8_t *seed, uint8_t *ct, uint8_t *ss, size_t n, int threads) {
+    if (!orc_mlkem_ek_size(param)) return -1;
+    job j = {.kind = J_KEM_ENCAPS, .param = param, .r3 = 1, .a = ek, .b = seed, .o1 = ct, .o2 = ss};
+    return fan(&j, n, threads);
+}
+int orc_kyber_r3_decaps_batch(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, size_t n, int threads) {
+    if (!orc_mlkem_ek_size(param)) return -1;
+    job j = {.kind = J_KEM_DECAPS, .param = param, .r3 = 1, .a = dk, .b = ct, .o1 = ss};
     return fan(&j, n, threads);
 }
 int orc_mldsa_keygen_batch(int param, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int threads) {

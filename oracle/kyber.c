@@ -458,6 +458,63 @@ int orc_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t ss
     return 0;
 }
 
+/* ---- kem/kyber/kyber768/kyber.go: round-3 Kyber ("Kyber512/768/1024"), SURVEY 8f row f3 ---- */
+
+/* kyber.go:60-82 NewKeyFromSeed: the K-PKE seed carries no domain byte (cpapke.go:66-76); same dk layout */
+int orc_kyber_r3_keygen(int param, const uint8_t seed[64], uint8_t *ek, uint8_t *dk) {
+    kparams P;
+    if (kyber_params(param, &P)) return -1;
+    if (!zetas_ready) zetas_init();
+    int K = P.k;
+    kpke_keygen(ek, dk, seed, 32, &P);
+    memcpy(dk + 384 * K, ek, (size_t)(384 * K + 32));
+    orc_sha3_256(dk + 768 * K + 32, ek, (size_t)(384 * K + 32));
+    memcpy(dk + 768 * K + 64, seed + 32, 32);
+    return 0;
+}
+
+/* kyber.go:248-262 PublicKey.Unpack (no canonical check: coefficients are reduced, H(pk) binds the raw
+ * bytes) then kyber.go:105-154 EncapsulateTo: m = H(seed); (K', r) = G(m || H(pk)); c = Enc(pk, m, r);
+ * K = KDF(K' || H(c)). */
+int orc_kyber_r3_encaps(int param, const uint8_t *ek, const uint8_t seed[32], uint8_t *ct, uint8_t ss[32]) {
+    kparams P;
+    if (kyber_params(param, &P)) return -1;
+    if (!zetas_ready) zetas_init();
+    int K = P.k;
+    size_t ctsz = (size_t)(32 * (P.du * K + P.dv));
+    uint8_t g_in[64], kr[64];
+    orc_sha3_256(g_in, seed, 32);
+    orc_sha3_256(g_in + 32, ek, (size_t)(384 * K + 32));
+    orc_sha3_512(kr, g_in, 64);
+    kpke_encrypt(ct, ek, g_in, kr + 32, &P);
+    orc_sha3_256(kr + 32, ct, ctsz);
+    orc_shake256(ss, 32, kr, 64);
+    return 0;
+}
+
+/* kyber.go:215-232 PrivateKey.Unpack (no hash check) then kyber.go:156-197 DecapsulateTo */
+int orc_kyber_r3_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t ss[32]) {
+    kparams P;
+    if (kyber_params(param, &P)) return -1;
+    if (!zetas_ready) zetas_init();
+    int K = P.k;
+    size_t ctsz = (size_t)(32 * (P.du * K + P.dv));
+    const uint8_t *ek = dk + 384 * K, *hpk = dk + 768 * K + 32, *z = dk + 768 * K + 64;
+    uint8_t g_in[64], kr2[64], ct2[1568];
+    kpke_decrypt(g_in, dk, ct, &P);
+    memcpy(g_in + 32, hpk, 32);
+    orc_sha3_512(kr2, g_in, 64);
+    kpke_encrypt(ct2, ek, g_in, kr2 + 32, &P);
+    orc_sha3_256(kr2 + 32, ct, ctsz);
+    /* subtle.ConstantTimeCopy(1 - ConstantTimeCompare(ct, ct2), kr2[:32], z) */
+    uint8_t diff = 0;
+    for (size_t i = 0; i < ctsz; i++) diff |= (uint8_t)(ct[i] ^ ct2[i]);
+    uint8_t mask = (uint8_t)(((uint32_t)diff - 1) >> 8); /* 0xff when equal */
+    for (int i = 0; i < 32; i++) kr2[i] = (uint8_t)((kr2[i] & mask) | (z[i] & ~mask));
+    orc_shake256(ss, 32, kr2, 64);
+    return 0;
+}
+
 /* ---- primitives exposed for the unit-level parity tests ------------------ */
 
 void orc_kyber_ntt(int16_t p[256]) { if (!zetas_ready) zetas_init(); poly_ntt((poly *)p); }

@@ -32,6 +32,13 @@ int orc_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t ss
 
 /* batch forms, `threads` pthreads over contiguous slices; status[n] per item.
  * On a per-item error the item's outputs are zero-filled. */
+/* round-3 Kyber (kem/kyber/kyber{512,768,1024}): same sizes as ML-KEM, different hashing; never fails */
+int orc_kyber_r3_keygen(int param, const uint8_t seed[64], uint8_t *ek, uint8_t *dk);
+int orc_kyber_r3_encaps(int param, const uint8_t *ek, const uint8_t seed[32], uint8_t *ct, uint8_t ss[32]);
+int orc_kyber_r3_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t ss[32]);
+int orc_kyber_r3_keygen_batch(int param, const uint8_t *seed, uint8_t *ek, uint8_t *dk, size_t n, int threads);
+int orc_kyber_r3_encaps_batch(int param, const uint8_t *ek, const uint8_t *seed, uint8_t *ct, uint8_t *ss, size_t n, int threads);
+int orc_kyber_r3_decaps_batch(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, size_t n, int threads);
 int orc_mlkem_keygen_batch(int param, const uint8_t *seed, uint8_t *ek, uint8_t *dk, size_t n, int threads);
 int orc_mlkem_encaps_batch(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss,
                            uint8_t *status, size_t n, int threads);

@@ -138,6 +138,42 @@ def mlkem_decaps(param, dk, ct, threads=None):
     return ss, st
 
 
+# ---------------- round-3 Kyber (kem/kyber/kyber{512,768,1024}) ----------------
+def kyber_r3_keygen(param, seeds, threads=None):
+    """seeds: (n,64) uint8 -> ek (n,EK), dk (n,DK); param 512 | 768 | 1024"""
+    EK, DK, _ = KEM_SIZES[param]
+    seeds = _u8(seeds).reshape(-1, 64)
+    n = len(seeds)
+    ek = np.zeros((n, EK), np.uint8)
+    dk = np.zeros((n, DK), np.uint8)
+    assert lib().orc_kyber_r3_keygen_batch(param, _p(seeds), _p(ek), _p(dk), C.c_size_t(n), threads or ncpu()) == 0
+    return ek, dk
+
+
+def kyber_r3_encaps(param, ek, seeds, threads=None):
+    """-> ct (n,CT), ss (n,32); never fails (non-canonical keys are reduced)"""
+    EK, _, CT = KEM_SIZES[param]
+    ek = _u8(ek).reshape(-1, EK)
+    seeds = _u8(seeds).reshape(-1, 32)
+    n = len(ek)
+    assert len(seeds) == n
+    ct = np.zeros((n, CT), np.uint8)
+    ss = np.zeros((n, 32), np.uint8)
+    assert lib().orc_kyber_r3_encaps_batch(param, _p(ek), _p(seeds), _p(ct), _p(ss), C.c_size_t(n), threads or ncpu()) == 0
+    return ct, ss
+
+
+def kyber_r3_decaps(param, dk, ct, threads=None):
+    _, DK, CT = KEM_SIZES[param]
+    dk = _u8(dk).reshape(-1, DK)
+    ct = _u8(ct).reshape(-1, CT)
+    n = len(dk)
+    assert len(ct) == n
+    ss = np.zeros((n, 32), np.uint8)
+    assert lib().orc_kyber_r3_decaps_batch(param, _p(dk), _p(ct), _p(ss), C.c_size_t(n), threads or ncpu()) == 0
+    return ss
+
+
 # Kyber ring primitives (single polynomial, int16[256])
 def _poly16(p):
     a = np.array(p, dtype=np.int16).copy()

@@ -177,3 +177,73 @@ def test_decaps_large_batch_matches_encaps():
     idx = rng.choice(n, 2048, replace=False)
     want, _ = orc.mlkem_decaps(768, dk[idx], ct[idx])
     assert (ss2[idx] == want).all()
+
+
+# ---- round-3 Kyber (kem/kyber/kyber{512,768,1024}), SURVEY 8f row f3 ----
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,want", [
+    # kem/kyber/kat_test.go:25-27, replayed through the HIP path (the 100 DRBG-derived seeds form one batch)
+    ("Kyber1024", "89248f2f33f7f4f7051729111f3049c409a933ec904aedadf035f30fa5646cd5"),
+    ("Kyber768", "a1e122cad3c24bc51622e4c242d8b8acbcd3f618fee4220400605ca8f9ea02c2"),
+    ("Kyber512", "e9c2bd37133fcb40772f81559f14b1f58dccd1c816701be9ba6214d43baf4547"),
+])
+def test_round3_kyber_kat_transcript_hash_on_gpu(name, want):
+    import hashlib
+    from drbg import DRBG
+    p = int(name[len("Kyber"):])
+    g = DRBG(bytes(range(48)))
+    seeds, kseeds, eseeds = [], [], []
+    for i in range(100):
+        seed = g.fill(48)
+        g2 = DRBG(seed)
+        seeds.append(seed)
+        kseeds.append(g2.fill(32) + g2.fill(32))
+        eseeds.append(g2.fill(32))
+    ks = np.frombuffer(b"".join(kseeds), dtype=np.uint8).reshape(100, 64)
+    es = np.frombuffer(b"".join(eseeds), dtype=np.uint8).reshape(100, 32)
+    ek, dk = hostapi.kyber_keygen(p, ks)
+    ct, ss = hostapi.kyber_encaps(p, ek, es)
+    ss2 = hostapi.kyber_decaps(p, dk, ct)
+    assert (ss == ss2).all()
+    f = hashlib.sha256()
+    f.update(("# %s\n\n" % name).encode())
+    for i in range(100):
+        f.update(b"count = %d\n" % i)
+        f.update(b"seed = %s\n" % seeds[i].hex().upper().encode())
+        f.update(b"pk = %s\n" % ek[i].tobytes().hex().upper().encode())
+        f.update(b"sk = %s\n" % dk[i].tobytes().hex().upper().encode())
+        f.update(b"ct = %s\n" % ct[i].tobytes().hex().upper().encode())
+        f.update(b"ss = %s\n\n" % ss[i].tobytes().hex().upper().encode())
+    assert f.hexdigest() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("param", [512, 768, 1024])
+def test_round3_kyber_matches_oracle_incl_rejection_and_lenient_keys(param):
+    rng = np.random.default_rng(param + 3)
+    n = 777   # ragged: not a multiple of any group size
+    seeds = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ek, dk = hostapi.kyber_keygen(param, seeds)
+    ek_o, dk_o = orc.kyber_r3_keygen(param, seeds)
+    assert (ek == ek_o).all() and (dk == dk_o).all()
+    # non-canonical keys: add q to the first coefficient where it still fits 12 bits (kyber.go:248-262: accepted)
+    ek2 = ek.copy()
+    for i in range(0, n, 3):
+        c0 = int(ek2[i, 0]) | ((int(ek2[i, 1]) & 15) << 8)
+        if c0 + 3329 < 4096:
+            c1 = c0 + 3329
+            ek2[i, 0] = c1 & 255
+            ek2[i, 1] = (ek2[i, 1] & 0xf0) | (c1 >> 8)
+    es = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct, ss = hostapi.kyber_encaps(param, ek2, es)
+    ct_o, ss_o = orc.kyber_r3_encaps(param, ek2, es)
+    assert (ct == ct_o).all() and (ss == ss_o).all()
+    # decapsulation of honest and of tampered ciphertexts (implicit rejection, kyber.go:184-196)
+    ct_h, ss_h = hostapi.kyber_encaps(param, ek, es)
+    bad = ct_h.copy()
+    bad[::2, 7] ^= 0x40
+    got = hostapi.kyber_decaps(param, dk, bad)
+    want = orc.kyber_r3_decaps(param, dk, bad)
+    assert (got == want).all()
+    assert (got[1::2] == ss_h[1::2]).all() and not (got[::2] == ss_h[::2]).all(axis=1).any()

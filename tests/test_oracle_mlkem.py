@@ -138,6 +138,62 @@ def test_kat_transcript_hash(name, want):
     assert f.hexdigest() == want
 
 
+@pytest.mark.parametrize("name,want", [
+    # kem/kyber/kat_test.go:25-27 -- round-3 Kyber
+    ("Kyber1024", "89248f2f33f7f4f7051729111f3049c409a933ec904aedadf035f30fa5646cd5"),
+    ("Kyber768", "a1e122cad3c24bc51622e4c242d8b8acbcd3f618fee4220400605ca8f9ea02c2"),
+    ("Kyber512", "e9c2bd37133fcb40772f81559f14b1f58dccd1c816701be9ba6214d43baf4547"),
+])
+def test_kat_transcript_hash_round3_kyber(name, want):
+    # kem/kyber/kat_test.go:42-94; the reference implementation calls randombytes twice for the key seed
+    p = int(name[len("Kyber"):])
+    g = DRBG(bytes(range(48)))
+    f = hashlib.sha256()
+    f.update(("# %s\n\n" % name).encode())
+    for i in range(100):
+        seed = g.fill(48)
+        f.update(b"count = %d\n" % i)
+        f.update(b"seed = %s\n" % seed.hex().upper().encode())
+        g2 = DRBG(seed)
+        kseed = g2.fill(32) + g2.fill(32)
+        eseed = g2.fill(32)
+        ek, dk = orc.kyber_r3_keygen(p, kseed, threads=1)
+        ct, ss = orc.kyber_r3_encaps(p, ek, eseed, threads=1)
+        ss2 = orc.kyber_r3_decaps(p, dk, ct, threads=1)
+        assert (ss == ss2).all()
+        f.update(b"pk = %s\n" % ek.tobytes().hex().upper().encode())
+        f.update(b"sk = %s\n" % dk.tobytes().hex().upper().encode())
+        f.update(b"ct = %s\n" % ct.tobytes().hex().upper().encode())
+        f.update(b"ss = %s\n\n" % ss.tobytes().hex().upper().encode())
+    assert f.hexdigest() == want
+
+
+def test_round3_kyber_implicit_rejection_and_lenient_keys():
+    # kem/kyber/kyber768/kyber.go:184-196: a modified ciphertext yields KDF(z || H(c)), no error;
+    # :248-262: coefficients in {q..4095} of a public key are accepted and reduced
+    rng = np.random.default_rng(11)
+    ek, dk = orc.kyber_r3_keygen(768, rng.integers(0, 256, (4, 64), dtype=np.uint8))
+    ct, ss = orc.kyber_r3_encaps(768, ek, rng.integers(0, 256, (4, 32), dtype=np.uint8))
+    bad = ct.copy()
+    bad[:, 5] ^= 1
+    ssb = orc.kyber_r3_decaps(768, dk, bad)
+    for i in range(4):
+        z = dk[i, 2400 - 32:].tobytes()
+        want = orc.sponge(z + orc.sha3_256(bad[i].tobytes()), 32, 136, 0x1f)
+        assert ssb[i].tobytes() == want and ssb[i].tobytes() != ss[i].tobytes()
+    # first coefficient of the key +q (still < 4096 when the coefficient is < 767): different bytes, same ring element
+    ek2 = ek.copy()
+    for i in range(4):
+        c0 = int(ek2[i, 0]) | ((int(ek2[i, 1]) & 15) << 8)
+        if c0 + 3329 < 4096:
+            c1 = c0 + 3329
+            ek2[i, 0] = c1 & 255
+            ek2[i, 1] = (ek2[i, 1] & 0xf0) | (c1 >> 8)
+    seeds = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    ct2, ss2 = orc.kyber_r3_encaps(768, ek2, seeds)   # must not fail
+    assert ct2.shape == (4, 1088)
+
+
 # ---- algebraic properties the reference re-checks (ntt_test.go, poly_test.go) ----
 
 def _rand_abs_le_q(rng):
