@@ -418,6 +418,9 @@ int mldsa_verify_dev_any(int param, const uint8_t *pk, const uint8_t *sig, const
     case 44: return mldsa_verify_dev_impl<44>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
     case 65: return mldsa_verify_dev_impl<65>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
     case 87: return mldsa_verify_dev_impl<87>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 2: return mldsa_verify_dev_impl<2>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 3: return mldsa_verify_dev_impl<3>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 5: return mldsa_verify_dev_impl<5>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
     }
     return CIRCL_HIP_EPARAM;
 }
@@ -591,6 +594,9 @@ int mldsa_sign_dev_any(int param, const uint8_t *sk, const uint8_t *msg_blob, co
     case 44: return mldsa_sign_dev_impl<44>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
     case 65: return mldsa_sign_dev_impl<65>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
     case 87: return mldsa_sign_dev_impl<87>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 2: return mldsa_sign_dev_impl<2>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 3: return mldsa_sign_dev_impl<3>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 5: return mldsa_sign_dev_impl<5>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
     }
     return CIRCL_HIP_EPARAM;
 }
@@ -600,6 +606,9 @@ size_t mldsa_sign_ws_any(int param, size_t n) {
     case 44: return mldsa_sign_ws_bytes<44>(n);
     case 65: return mldsa_sign_ws_bytes<65>(n);
     case 87: return mldsa_sign_ws_bytes<87>(n);
+    case 2: return mldsa_sign_ws_bytes<2>(n);
+    case 3: return mldsa_sign_ws_bytes<3>(n);
+    case 5: return mldsa_sign_ws_bytes<5>(n);
     }
     return 0;
 }
@@ -674,9 +683,14 @@ size_t circl_hip_mlkem_ct_size(int param) {
     }
     return 0;
 }
-size_t circl_hip_mldsa_pk_size(int param) { return param == 44 ? 1312 : param == 65 ? 1952 : param == 87 ? 2592 : 0; }
-size_t circl_hip_mldsa_sig_size(int param) { return param == 44 ? 2420 : param == 65 ? 3309 : param == 87 ? 4627 : 0; }
-size_t circl_hip_mldsa_sk_size(int param) { return param == 44 ? 2560 : param == 65 ? 4032 : param == 87 ? 4896 : 0; }
+// 44 / 65 / 87 = ML-DSA; 2 / 3 / 5 = round-3 Dilithium2/3/5 (32-byte tr and c~)
+size_t circl_hip_mldsa_pk_size(int param) { return param == 44 || param == 2 ? 1312 : param == 65 || param == 3 ? 1952 : param == 87 || param == 5 ? 2592 : 0; }
+size_t circl_hip_mldsa_sig_size(int param) {
+    return param == 44 || param == 2 ? 2420 : param == 65 ? 3309 : param == 3 ? 3293 : param == 87 ? 4627 : param == 5 ? 4595 : 0;
+}
+size_t circl_hip_mldsa_sk_size(int param) {
+    return param == 44 ? 2560 : param == 2 ? 2528 : param == 65 ? 4032 : param == 3 ? 4000 : param == 87 ? 4896 : param == 5 ? 4864 : 0;
+}
 
 size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? kem_ws_bytes(n) : 0; }
 
@@ -826,6 +840,9 @@ size_t circl_hip_mldsa_workspace_size(int param, size_t n) {
     case 44: return mldsa_ws_bytes<44>(n);
     case 65: return mldsa_ws_bytes<65>(n);
     case 87: return mldsa_ws_bytes<87>(n);
+    case 2: return mldsa_ws_bytes<2>(n);
+    case 3: return mldsa_ws_bytes<3>(n);
+    case 5: return mldsa_ws_bytes<5>(n);
     }
     return 0;
 }
@@ -855,6 +872,9 @@ int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk
     case 44: return mldsa_keygen_dev_impl<44>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
     case 65: return mldsa_keygen_dev_impl<65>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
     case 87: return mldsa_keygen_dev_impl<87>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    case 2: return mldsa_keygen_dev_impl<2>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    case 3: return mldsa_keygen_dev_impl<3>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
+    case 5: return mldsa_keygen_dev_impl<5>(d_seed32, d_pk, d_sk, n, d_ws, ws_bytes, st);
     }
     return CIRCL_HIP_EPARAM;
 }

@@ -34,9 +34,16 @@ using mlkem::store_words;
 using mlkem::xor_words;
 
 template <int MODE> struct DP;
-template <> struct DP<44> { static constexpr int K = 4, L = 4, ETA = 2, TAU = 39, OMEGA = 80, G1BITS = 17, CT = 32; static constexpr uint32_t GAMMA2 = 95232; };
-template <> struct DP<65> { static constexpr int K = 6, L = 5, ETA = 4, TAU = 49, OMEGA = 55, G1BITS = 19, CT = 48; static constexpr uint32_t GAMMA2 = 261888; };
-template <> struct DP<87> { static constexpr int K = 8, L = 7, ETA = 2, TAU = 60, OMEGA = 75, G1BITS = 19, CT = 64; static constexpr uint32_t GAMMA2 = 261888; };
+// MODE 44 / 65 / 87 = ML-DSA (sign/mldsa/mldsa*/internal/params.go); MODE 2 / 3 / 5 = round-3 Dilithium2/3/5
+// (sign/dilithium/mode*/internal/params.go): NIST = false, 32-byte tr and c~.  NIST selects the ML-DSA domain
+// separation: K, L appended to the key seed (dilithium.go:191-193), rnd in rho'' (:360-362), and the ctx-prefixed
+// message of the outer package (mldsa65/dilithium.go:115-132; round 3 hashes the bare message, mode3/dilithium.go:54-75).
+template <> struct DP<44> { static constexpr int K = 4, L = 4, ETA = 2, TAU = 39, OMEGA = 80, G1BITS = 17, CT = 32, TR = 64; static constexpr bool NIST = true; static constexpr uint32_t GAMMA2 = 95232; };
+template <> struct DP<65> { static constexpr int K = 6, L = 5, ETA = 4, TAU = 49, OMEGA = 55, G1BITS = 19, CT = 48, TR = 64; static constexpr bool NIST = true; static constexpr uint32_t GAMMA2 = 261888; };
+template <> struct DP<87> { static constexpr int K = 8, L = 7, ETA = 2, TAU = 60, OMEGA = 75, G1BITS = 19, CT = 64, TR = 64; static constexpr bool NIST = true; static constexpr uint32_t GAMMA2 = 261888; };
+template <> struct DP<2> { static constexpr int K = 4, L = 4, ETA = 2, TAU = 39, OMEGA = 80, G1BITS = 17, CT = 32, TR = 32; static constexpr bool NIST = false; static constexpr uint32_t GAMMA2 = 95232; };
+template <> struct DP<3> { static constexpr int K = 6, L = 5, ETA = 4, TAU = 49, OMEGA = 55, G1BITS = 19, CT = 32, TR = 32; static constexpr bool NIST = false; static constexpr uint32_t GAMMA2 = 261888; };
+template <> struct DP<5> { static constexpr int K = 8, L = 7, ETA = 2, TAU = 60, OMEGA = 75, G1BITS = 19, CT = 32, TR = 32; static constexpr bool NIST = false; static constexpr uint32_t GAMMA2 = 261888; };
 
 template <int MODE> struct DG {
     using P = DP<MODE>;
@@ -89,8 +96,10 @@ template <int NWORDS> __device__ __forceinline__ void sponge17_words(KeccakState
 }
 
 // mu = SHAKE256(tr || M')[:64] with M' = 0 || len(ctx) || ctx || msg (mldsa65/dilithium.go:115-132;
-// internal = the ACVP interface without the prefix).  On entry words 0..7 of h hold tr and the rest is
-// zero; on exit words 0..7 hold mu.  One sponge per lane, message lengths may differ per lane.
+// internal = the ACVP interface without the prefix).  On entry words 0..TRW-1 of h hold tr (TRW = 8, or 4 for
+// round-3 Dilithium) and the rest is zero; on exit words 0..7 hold mu.  One sponge per lane, message lengths
+// may differ per lane.
+template <int TRW>
 __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const uint8_t *mp, size_t mlen, const uint8_t *cp,
                                                            size_t clen, int internal) {
     const size_t pre = internal ? 0 : 2;
@@ -106,20 +115,21 @@ __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const
         }
         return mp[k];
     };
-    // first block: words 0..7 hold tr, words 8..16 the first 72 bytes of M'
+    // first block: words 0..TRW-1 hold tr, words TRW..16 the first FIRST bytes of M'
+    constexpr size_t FIRST = 136 - 8 * TRW;
     size_t pos = 0;  // M' bytes consumed
     bool done = false;
     {
-        detail::static_for<8, 17>([&](auto ic) {
+        detail::static_for<TRW, 17>([&](auto ic) {
             constexpr int w = decltype(ic)::v;
             uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v |= mbyte(8 * (size_t)(w - 8) + b) << (8 * b);
+            for (int b = 0; b < 8; b++) v |= mbyte(8 * (size_t)(w - TRW) + b) << (8 * b);
             h.lo[w] ^= (uint32_t)v;
             h.hi[w] ^= (uint32_t)(v >> 32);
         });
-        if (total < 72) { done = true; h.hi[16] ^= 0x80000000u; }
+        if (total < FIRST) { done = true; h.hi[16] ^= 0x80000000u; }
         keccak_f1600(h);
-        pos = 72;
+        pos = FIRST;
     }
     while (!done) {
         detail::static_for<0, 17>([&](auto ic) {
@@ -148,17 +158,18 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState s;
-    // tr = SHAKE256(pk)[:64]  (dilithium.go:123-125)
+    if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
+    // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125)
     sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
     KeccakState h;
     keccak_zero(h);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+    for (int i = 0; i < P::TR / 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
     const uint8_t *mp = msg_blob + msg_off[idx];
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze(h, mp, mlen, cp, clen, internal);
+    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), h);  // mu
     // SampleInBall's sponge: SHAKE256(c~), first block (sample.go:299-306); the whole state is
     // parked so that the verify kernel can squeeze further blocks in the (rare) case it must.
@@ -578,7 +589,8 @@ template <int MODE> struct KG {
     using P = DP<MODE>;
     static constexpr int ETABITS = P::ETA == 2 ? 3 : 4;              // params.go DoubleEtaBits
     static constexpr int ETASZ = 32 * ETABITS;
-    static constexpr int SK = 32 + 32 + 64 + ETASZ * (G::L + G::K) + 416 * G::K;
+    static constexpr int SKHDR = 32 + 32 + P::TR;                     // rho || key || tr
+    static constexpr int SK = SKHDR + ETASZ * (G::L + G::K) + 416 * G::K;
     static constexpr int NS = G::L + G::K;                            // secret polynomials per item
     static constexpr int S_STRIDE = 264;                              // int8 row + spill slot
     static constexpr int LDS_S = G::IT * NS * S_STRIDE;
@@ -595,7 +607,7 @@ __global__ void __launch_bounds__(256) mldsa_keygen_seed_kernel(const uint8_t *_
     KeccakState s;
     keccak_zero(s);
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(seed32 + idx * 32));
-    s.lo[4] = (uint32_t)P::K | ((uint32_t)P::L << 8) | (kDsShake << 16);
+    s.lo[4] = P::NIST ? ((uint32_t)P::K | ((uint32_t)P::L << 8) | (kDsShake << 16)) : kDsShake;  // dilithium.go:191-193
     s.hi[16] = 0x80000000u;
     keccak_f1600(s);
     store_words<0, 16>(reinterpret_cast<uint64_t *>(es_ws + idx * 128), s);
@@ -688,7 +700,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                 c[r] = v < 0 ? Q + v : (uint32_t)v;
             }
             mlkem::stage_bits_l1<Kg::ETABITS>(xch, fld, lane);
-            mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + 128 + Kg::ETASZ * k), xch, lane, false);
+            mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * k), xch, lane, false);
             if (k < L) {
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
@@ -721,7 +733,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             mlkem::stage_bits_l1<10>(xch, t1, lane);
             mlkem::store_staged<10>(reinterpret_cast<uint32_t *>(pkp + 32 + 320 * i), xch, lane, false);
             mlkem::stage_bits_l1<13>(xch, t0, lane);
-            mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + 128 + Kg::ETASZ * NS + 416 * i), xch, lane, false);
+            mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * NS + 416 * i), xch, lane, false);
         }
         if (lane < 8) {
             const uint32_t r = reinterpret_cast<const uint32_t *>(es_ws + item * 128)[lane];
@@ -741,7 +753,7 @@ __global__ void __launch_bounds__(256) mldsa_keygen_finish_kernel(const uint8_t 
     if (idx >= n) return;
     KeccakState s;
     sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
-    store_words<0, 8>(reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64), s);
+    store_words<0, DP<MODE>::TR / 8>(reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64), s);
 }
 
 // ---- signing (sign/mldsa/mldsa65/internal/dilithium.go:340-470 SignTo) ------
@@ -780,25 +792,28 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
                                                               int internal, uint8_t *__restrict__ mr_ws, size_t n) {
     using Kg = KG<MODE>;
+    using P = DP<MODE>;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
     const uint8_t *skp = sk + idx * Kg::SK;
     KeccakState h;
     keccak_zero(h);
-    xor_words<0, 8>(h, reinterpret_cast<const uint64_t *>(skp + 64));  // tr
+    xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(skp + 64));  // tr
     const uint8_t *mp = msg_blob + msg_off[idx];
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze(h, mp, mlen, cp, clen, internal);
+    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128), h);  // mu
     KeccakState s;
     keccak_zero(s);
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(skp + 32));          // key
-    xor_words<4, 4>(s, reinterpret_cast<const uint64_t *>(rnd + idx * 32));    // rnd (zero = deterministic)
+    constexpr int MU0 = P::NIST ? 8 : 4;                                       // round 3: rho'' = CRH(key || mu), no rnd (dilithium.go:357-364)
+    if constexpr (P::NIST) xor_words<4, 4>(s, reinterpret_cast<const uint64_t *>(rnd + idx * 32));  // rnd (zero = deterministic)
 #pragma unroll
-    for (int i = 0; i < 8; i++) { s.lo[8 + i] = h.lo[i]; s.hi[8 + i] = h.hi[i]; }
-    s.lo[16] ^= kDsShake;
+    for (int i = 0; i < 8; i++) { s.lo[MU0 + i] = h.lo[i]; s.hi[MU0 + i] = h.hi[i]; }
+    s.lo[MU0 + 8] ^= kDsShake;
     s.hi[16] ^= 0x80000000u;
     keccak_f1600(s);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), s);  // rho''
@@ -873,8 +888,8 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
                 int v;
-                if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (128 + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
-                else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (128 + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
+                if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (Kg::SKHDR + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
+                else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (Kg::SKHDR + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
                 c[r] = v < 0 ? Q + v : (uint32_t)v;
             }
             dilithium::ntt(c, z, xch, lane);

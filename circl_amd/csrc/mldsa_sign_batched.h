@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
         for (int r = 0; r < 4; r++) {
             const int nidx = kyber::idx_l1(lane, r);
             int v;
-            if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (128 + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
-            else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (128 + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
+            if (k < L + K) v = P::ETA - (int)gbits<Kg::ETABITS>(sk32 + (Kg::SKHDR + Kg::ETASZ * k) / 4, nidx, Kg::ETASZ / 4);
+            else v = (1 << (dilithium::D - 1)) - (int)gbits<13>(sk32 + (Kg::SKHDR + Kg::ETASZ * (L + K) + 416 * (k - L - K)) / 4, nidx, 104);
             c[r] = v < 0 ? Q + v : (uint32_t)v;
         }
         dilithium::ntt(c, z, xch, lane);

@@ -6,8 +6,9 @@ import numpy as np
 from . import _native as nat
 
 KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
-DSA_SIZES = {44: (1312, 2420), 65: (1952, 3309), 87: (2592, 4627)}  # pk, sig
-DSA_SK_SIZES = {44: 2560, 65: 4032, 87: 4896}
+# pk, sig; 2 / 3 / 5 = round-3 Dilithium2/3/5 (sign/dilithium/mode{2,3,5}): no context, deterministic, 32-byte tr and c~
+DSA_SIZES = {44: (1312, 2420), 65: (1952, 3309), 87: (2592, 4627), 2: (1312, 2420), 3: (1952, 3293), 5: (2592, 4595)}
+DSA_SK_SIZES = {44: 2560, 65: 4032, 87: 4896, 2: 2528, 3: 4000, 5: 4864}
 
 
 def _u8(x, cols):

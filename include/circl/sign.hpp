@@ -30,6 +30,7 @@ struct ErrTypeMismatch : std::runtime_error { ErrTypeMismatch() : std::runtime_e
 struct ErrPubKeySize : std::runtime_error { ErrPubKeySize() : std::runtime_error("sign: wrong size for public key") {} };
 struct ErrPrivKeySize : std::runtime_error { ErrPrivKeySize() : std::runtime_error("sign: wrong size for private key") {} };
 struct ErrContextTooLong : std::runtime_error { ErrContextTooLong() : std::runtime_error("sign: context string too long") {} };
+struct ErrContextNotSupported : std::runtime_error { ErrContextNotSupported() : std::runtime_error("context not supported") {} };  // sign/sign.go:113-115
 struct ErrDevice : std::runtime_error { using std::runtime_error::runtime_error; };
 
 struct SignatureOpts {
@@ -56,7 +57,8 @@ class Scheme {
     int SignatureSize() const { return (int)circl_hip_mldsa_sig_size(param_); }
     int PrivateKeySize() const { return (int)circl_hip_mldsa_sk_size(param_); }
     int SeedSize() const { return 32; }
-    bool SupportsContext() const { return true; }
+    // round-3 Dilithium2/3/5 (param 2 / 3 / 5) has no context: sign/dilithium/mode3/dilithium.go:213-215, :232-234, :249-251
+    bool SupportsContext() const { return param_ > 5; }
     int device = 0;
 
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
@@ -77,6 +79,7 @@ class Scheme {
     Bytes Sign(const PrivateKey &sk, const Bytes &msg, const SignatureOpts *opts = nullptr) const {
         if (sk.scheme != this) throw ErrTypeMismatch();
         const std::string ctx = opts ? opts->Context : std::string();
+        if (!SupportsContext() && !ctx.empty()) throw ErrContextNotSupported();
         if (ctx.size() > 255) throw ErrContextTooLong();
         const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
         const uint8_t pad = 0;
@@ -89,6 +92,7 @@ class Scheme {
         if (pk.scheme != this) throw ErrTypeMismatch();
         if ((int)sig.size() != SignatureSize()) return false;  // internal/dilithium.go:90-93
         const std::string ctx = opts ? opts->Context : std::string();
+        if (!SupportsContext() && !ctx.empty()) throw ErrContextNotSupported();
         if (ctx.size() > 255) return false;                    // dilithium.go:116-118
         const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
         const uint8_t pad = 0;
@@ -128,7 +132,8 @@ class Scheme {
 // sign/schemes/schemes.go:31-74
 inline const Scheme *ByName(const std::string &name) {
     static const Scheme s44(44, "ML-DSA-44"), s65(65, "ML-DSA-65"), s87(87, "ML-DSA-87");
-    for (const Scheme *s : {&s44, &s65, &s87})
+    static const Scheme d2(2, "Dilithium2"), d3(3, "Dilithium3"), d5(5, "Dilithium5");
+    for (const Scheme *s : {&s44, &s65, &s87, &d2, &d3, &d5})
         if (s->Name() == name) return s;
     return nullptr;
 }

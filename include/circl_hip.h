@@ -118,7 +118,14 @@ int circl_hip_kyber_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_
 int circl_hip_kyber_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* ---- ML-DSA verify ----------------------------------------------------------------------
+/* ---- ML-DSA (param 44 | 65 | 87) and round-3 Dilithium2/3/5 (param 2 | 3 | 5) ----
+ * Every circl_hip_mldsa_* entry point below also accepts param 2, 3 or 5 = sign/dilithium/mode{2,3,5}: the same
+ * lattice, 32-byte tr and c~ (sign/dilithium/mode3/internal/params.go:5-18), key seed hashed without the K, L domain
+ * bytes (internal/dilithium.go:191-193), mu = CRH(tr || msg) without a context prefix (mode3/dilithium.go:54-75) and
+ * deterministic signing (no rnd, internal/dilithium.go:360-362).  For these modes contexts must be empty / NULL
+ * (the reference panics with sign.ErrContextNotSupported) and rnd is ignored.
+ *
+ * ---- ML-DSA verify ----------------------------------------------------------------------
  * scheme.UnmarshalBinaryPublicKey(pk_i) + scheme.Verify(pk_i, msg_i, sig_i, &SignatureOpts{Context: ctx_i})
  * (sign/mldsa/mldsa65/dilithium.go:305-327 -> :115-132 -> internal/dilithium.go:273-332).
  * Messages / contexts are blobs with n+1 offsets; ctx_blob may be NULL (all contexts empty).

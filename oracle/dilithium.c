@@ -26,14 +26,20 @@ typedef struct {
     int k, l, eta, deta_bits, omega, tau, gamma1_bits;
     uint32_t gamma2;
     int ctilde;
+    int tr;   /* TRSize: 64 for ML-DSA, 32 for round-3 Dilithium */
+    int nist; /* params.go NIST flag: ML-DSA domain separation in keygen, rnd in signing */
 } dparams;
 
 static int dil_params(int param, dparams *p) {
     /* sign/mldsa/mldsa{44,65,87}/internal/params.go:5-18 */
     switch (param) {
-    case 44: *p = (dparams){4, 4, 2, 3, 80, 39, 17, 95232, 32}; return 0;
-    case 65: *p = (dparams){6, 5, 4, 4, 55, 49, 19, 261888, 48}; return 0;
-    case 87: *p = (dparams){8, 7, 2, 3, 75, 60, 19, 261888, 64}; return 0;
+    case 44: *p = (dparams){4, 4, 2, 3, 80, 39, 17, 95232, 32, 64, 1}; return 0;
+    case 65: *p = (dparams){6, 5, 4, 4, 55, 49, 19, 261888, 48, 64, 1}; return 0;
+    case 87: *p = (dparams){8, 7, 2, 3, 75, 60, 19, 261888, 64, 64, 1}; return 0;
+    /* round-3 Dilithium2/3/5: sign/dilithium/mode{2,3,5}/internal/params.go:5-18 */
+    case 2: *p = (dparams){4, 4, 2, 3, 80, 39, 17, 95232, 32, 32, 0}; return 0;
+    case 3: *p = (dparams){6, 5, 4, 4, 55, 49, 19, 261888, 32, 32, 0}; return 0;
+    case 5: *p = (dparams){8, 7, 2, 3, 75, 60, 19, 261888, 32, 32, 0}; return 0;
     }
     return -1;
 }
@@ -43,7 +49,7 @@ static int dil_params(int param, dparams *p) {
 #define P_LEGAMMA1_SZ(P) (((P)->gamma1_bits + 1) * DN / 8)
 #define P_W1_SZ(P) (DN * (23 - (P)->gamma1_bits) / 8)
 #define P_PK_SZ(P) (32 + 320 * (P)->k)
-#define P_SK_SZ(P) (32 + 32 + 64 + P_LEQETA_SZ(P) * ((P)->l + (P)->k) + 416 * (P)->k)
+#define P_SK_SZ(P) (32 + 32 + (P)->tr + P_LEQETA_SZ(P) * ((P)->l + (P)->k) + 416 * (P)->k)
 #define P_SIG_SZ(P) ((P)->l * P_LEGAMMA1_SZ(P) + (P)->omega + (P)->k + (P)->ctilde)
 
 /* ---- field.go ---------------------------------------------------------- */
@@ -372,7 +378,7 @@ int orc_mldsa_keygen(int param, const uint8_t seed[32], uint8_t *pk, uint8_t *sk
     memcpy(in, seed, 32);
     in[32] = (uint8_t)P.k;
     in[33] = (uint8_t)P.l;
-    orc_shake256(eseed, 128, in, 34);
+    orc_shake256(eseed, 128, in, P.nist ? 34 : 32); /* dilithium.go:189-195 */
     const uint8_t *rho = eseed, *sseed = eseed + 32, *key = eseed + 96;
     mat_derive(sk.A, rho, &P);
     for (int i = 0; i < P.l; i++) dpoly_leqeta(&sk.s1[i], sseed, (uint16_t)i, &P);
@@ -390,11 +396,11 @@ int orc_mldsa_keygen(int param, const uint8_t seed[32], uint8_t *pk, uint8_t *sk
     memcpy(pk, rho, 32);
     for (int i = 0; i < P.k; i++) pack_t1(pk + 32 + 320 * i, &t1[i]);
     uint8_t tr[64];
-    orc_shake256(tr, 64, pk, (size_t)P_PK_SZ(&P));
+    orc_shake256(tr, (size_t)P.tr, pk, (size_t)P_PK_SZ(&P));
     uint8_t *o = skbuf;
     memcpy(o, rho, 32); o += 32;
     memcpy(o, key, 32); o += 32;
-    memcpy(o, tr, 64); o += 64;
+    memcpy(o, tr, (size_t)P.tr); o += P.tr;
     for (int i = 0; i < P.l; i++, o += P_LEQETA_SZ(&P)) pack_leqeta(o, &sk.s1[i], &P);
     for (int i = 0; i < P.k; i++, o += P_LEQETA_SZ(&P)) pack_leqeta(o, &sk.s2[i], &P);
     for (int i = 0; i < P.k; i++, o += 416) pack_t0(o, &t0[i]);
@@ -405,8 +411,8 @@ int orc_mldsa_keygen(int param, const uint8_t seed[32], uint8_t *pk, uint8_t *sk
 static void sk_unpack(dsk *sk, const uint8_t *buf, const dparams *P) {
     memcpy(sk->rho, buf, 32);
     memcpy(sk->key, buf + 32, 32);
-    memcpy(sk->tr, buf + 64, 64);
-    const uint8_t *o = buf + 128;
+    memcpy(sk->tr, buf + 64, (size_t)P->tr);
+    const uint8_t *o = buf + 64 + P->tr;
     for (int i = 0; i < P->l; i++, o += P_LEQETA_SZ(P)) unpack_leqeta(&sk->s1[i], o, P);
     for (int i = 0; i < P->k; i++, o += P_LEQETA_SZ(P)) unpack_leqeta(&sk->s2[i], o, P);
     for (int i = 0; i < P->k; i++, o += 416) unpack_t0(&sk->t0[i], o);
@@ -438,12 +444,12 @@ int orc_mldsa_sign(int param, const uint8_t *skbuf, const uint8_t *msg, size_t m
     uint8_t mu[64], rhop[64], w1p[192 * 8], ct[64];
     orc_sponge h;
     orc_sponge_init(&h, ORC_SHAKE256_RATE, ORC_DS_SHAKE);
-    orc_sponge_absorb(&h, sk.tr, 64);
-    absorb_msg(&h, msg, msglen, ctx, ctxlen, internal);
+    orc_sponge_absorb(&h, sk.tr, (size_t)P.tr);
+    absorb_msg(&h, msg, msglen, ctx, ctxlen, internal || !P.nist); /* round 3: mu = CRH(tr || msg), mode3/dilithium.go:54-66 */
     orc_sponge_squeeze(&h, mu, 64);
     orc_sponge_init(&h, ORC_SHAKE256_RATE, ORC_DS_SHAKE);
     orc_sponge_absorb(&h, sk.key, 32);
-    orc_sponge_absorb(&h, rnd, 32);
+    if (P.nist) orc_sponge_absorb(&h, rnd, 32); /* dilithium.go:360-362 */
     orc_sponge_absorb(&h, mu, 64);
     orc_sponge_squeeze(&h, rhop, 64);
 
@@ -520,13 +526,14 @@ int orc_mldsa_verify(int param, const uint8_t *pkbuf, const uint8_t *msg, size_t
     dparams P;
     if (dil_params(param, &P)) return -1;
     if (!dz_ready) dz_init();
+    if (!P.nist) internal = 1; /* round 3 hashes the bare message: mode3/dilithium.go:68-75 */
     if (!internal && ctxlen > 255) return 0; /* mldsa65/dilithium.go:116-118 */
     if (siglen != (size_t)P_SIG_SZ(&P)) return 0;
     static __thread dpk pk;
     memcpy(pk.rho, pkbuf, 32);
     for (int i = 0; i < P.k; i++) unpack_t1(&pk.t1[i], pkbuf + 32 + 320 * i);
     mat_derive(pk.A, pk.rho, &P);
-    orc_shake256(pk.tr, 64, pkbuf, (size_t)P_PK_SZ(&P));
+    orc_shake256(pk.tr, (size_t)P.tr, pkbuf, (size_t)P_PK_SZ(&P));
 
     dpoly z[7], hint[8], ch, az, t, w1;
     const uint8_t *o = sig + P.ctilde;
@@ -539,7 +546,7 @@ int orc_mldsa_verify(int param, const uint8_t *pkbuf, const uint8_t *msg, size_t
     uint8_t mu[64], w1p[192 * 8], cp[64];
     orc_sponge h;
     orc_sponge_init(&h, ORC_SHAKE256_RATE, ORC_DS_SHAKE);
-    orc_sponge_absorb(&h, pk.tr, 64);
+    orc_sponge_absorb(&h, pk.tr, (size_t)P.tr);
     absorb_msg(&h, msg, msglen, ctx, ctxlen, internal);
     orc_sponge_squeeze(&h, mu, 64);
 

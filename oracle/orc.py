@@ -15,7 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liborc.so")
 
 KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
-DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 4627)}  # pk, sk, sig
+DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 4627),  # pk, sk, sig
+             # round-3 Dilithium2/3/5 (sign/dilithium/mode{2,3,5}): tr is 32 bytes, c~ is 32 bytes
+             2: (1312, 2528, 2420), 3: (1952, 4000, 3293), 5: (2592, 4864, 4595)}
 
 
 def build(force=False):

@@ -103,6 +103,22 @@ int main() {
         REQUIRE(throws<sign::ErrContextTooLong>([&] { s->Sign(gsk, msg, &longctx); }));
         REQUIRE(throws<std::invalid_argument>([&] { s->DeriveKey(shortsig); }));
     }
+    // round-3 Dilithium2/3/5 (sign/dilithium/mode{2,3,5}/dilithium.go:213-255): no context support
+    for (const char *name : {"Dilithium2", "Dilithium3", "Dilithium5"}) {
+        const sign::Scheme *s = sign::ByName(name);
+        REQUIRE(s && s->Name() == name && !s->SupportsContext());
+        sign::Bytes seed(s->SeedSize(), 9), msg{4, 5, 6, 7};
+        auto [pk, sk] = s->DeriveKey(seed);
+        REQUIRE((int)pk.MarshalBinary().size() == s->PublicKeySize() && (int)sk.MarshalBinary().size() == s->PrivateKeySize());
+        sign::Bytes sg = s->Sign(sk, msg);
+        REQUIRE((int)sg.size() == s->SignatureSize() && sg == s->Sign(sk, msg));
+        REQUIRE(s->Verify(pk, msg, sg));
+        sign::Bytes msg2 = msg; msg2[1] ^= 1;
+        REQUIRE(!s->Verify(pk, msg2, sg));
+        sign::SignatureOpts ctx{"x"};
+        REQUIRE(throws<sign::ErrContextNotSupported>([&] { s->Sign(sk, msg, &ctx); }));
+        REQUIRE(throws<sign::ErrContextNotSupported>([&] { s->Verify(pk, msg, sg, &ctx); }));
+    }
     std::printf("OK\n");
     return 0;
 }

@@ -201,3 +201,70 @@ def test_wycheproof_sign_on_device(name):
     sig = hostapi.mldsa_sign(PARAMS[name], b"".join(sks), msgs, ctxs)
     got = [hashlib.sha256(sig[i].tobytes()).hexdigest() for i in range(len(want))]
     assert got == want and len(want) >= 100
+
+
+# ---- KAT transcripts and round-3 Dilithium2/3/5 (sign/dilithium/mode{2,3,5}) ----
+
+@pytest.mark.parametrize("name,param,want", [
+    # sign/dilithium/kat_test.go:25-35 replayed through the HIP path (keygen, deterministic sign, verify)
+    ("Dilithium2", 2, "38ed991c5ca11e39ab23945ca37af89e059d16c5474bf8ba96b15cb4e948af2a"),
+    ("Dilithium3", 3, "8196b32212753f525346201ffec1c7a0a852596fa0b57bd4e2746231dab44d55"),
+    ("Dilithium5", 5, "7ded97a6e6c809b43b54c248171d7504fa6a0cab651bf288bb00034782667481"),
+    ("ML-DSA-44", 44, "14f92c48abc0d63ea263cce3c83183c8360c6ede7cbd5b65bd7c6f31e38f0ea5"),
+    ("ML-DSA-65", 65, "595a8eff6988159c94eb5398294458c5d27d21c994fb64cadbee339173abcf63"),
+    ("ML-DSA-87", 87, "35e2ce3d88b3311517bf8d41aa2cd24aa0fbda2bb8052ca8af4ad8d7c7344074"),
+])
+def test_kat_transcript_hash_on_gpu(name, param, want):
+    import hashlib
+    from drbg import DRBG
+    name_in_kat = {"ML-DSA-44": "Dilithium2", "ML-DSA-65": "Dilithium3", "ML-DSA-87": "Dilithium5"}.get(name, name)
+    g = DRBG(bytes(range(48)))
+    seeds, msgs, eseeds = [], [], []
+    for i in range(100):
+        seed = g.fill(48)
+        msgs.append(g.fill(33 * (i + 1)))
+        seeds.append(seed)
+        eseeds.append(DRBG(seed).fill(32))
+    pk, sk = hostapi.mldsa_keygen(param, np.frombuffer(b"".join(eseeds), np.uint8).reshape(100, 32))
+    sig = hostapi.mldsa_sign(param, sk, msgs)
+    assert hostapi.mldsa_verify(param, pk, sig, msgs).all()
+    f = hashlib.sha256()
+    f.update(("# %s\n\n" % name_in_kat).encode())
+    for i in range(100):
+        f.update(b"count = %d\n" % i)
+        f.update(b"seed = %s\n" % seeds[i].hex().upper().encode())
+        f.update(b"mlen = %d\n" % len(msgs[i]))
+        f.update(b"msg = %s\n" % msgs[i].hex().upper().encode())
+        f.update(b"pk = %s\n" % pk[i].tobytes().hex().upper().encode())
+        f.update(b"sk = %s\n" % sk[i].tobytes().hex().upper().encode())
+        f.update(b"smlen = %d\n" % (len(msgs[i]) + sig.shape[1]))
+        f.update(b"sm = %s%s\n\n" % (sig[i].tobytes().hex().upper().encode(), msgs[i].hex().upper().encode()))
+    assert f.hexdigest() == want
+
+
+@pytest.mark.parametrize("param", [2, 3, 5])
+def test_round3_dilithium_matches_oracle_with_corruptions(param):
+    rng = np.random.default_rng(100 + param)
+    n = 131
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = hostapi.mldsa_keygen(param, seeds)
+    pk_o, sk_o = orc.mldsa_keygen(param, seeds)
+    assert (pk == pk_o).all() and (sk == sk_o).all()
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sig = hostapi.mldsa_sign(param, sk, msgs)
+    assert (sig == orc.mldsa_sign(param, sk, msgs)).all()
+    SIG = sig.shape[1]
+    bad = sig.copy()
+    for i in range(0, n, 4):
+        kind = (i // 4) % 4
+        if kind == 0:
+            bad[i, int(rng.integers(0, 32))] ^= 1          # c~ (32 bytes in round 3)
+        elif kind == 1:
+            bad[i, 32 + int(rng.integers(0, 600))] ^= 0x40  # z
+        elif kind == 2:
+            bad[i, SIG - 1] = 0xFF                          # hint switch-over point > omega
+        else:
+            msgs[i] = msgs[i] + b"x"
+    ok = hostapi.mldsa_verify(param, pk, bad, msgs)
+    assert ok.tolist() == orc.mldsa_verify(param, pk, bad, msgs).tolist()
+    assert ok[[i for i in range(n) if i % 4]].all() and not ok[::4].any()

@@ -141,3 +141,42 @@ def test_wycheproof_sign(name):
         assert hashlib.sha256(sig).hexdigest() == t["sig_sha256"], (t["id"], t["comment"])
         n += 1
     assert n >= 100
+
+
+@pytest.mark.parametrize("name,param,want", [
+    # sign/dilithium/kat_test.go:25-35: SHA-256 over 100 keygen + deterministic-sign transcripts
+    ("Dilithium2", 2, "38ed991c5ca11e39ab23945ca37af89e059d16c5474bf8ba96b15cb4e948af2a"),
+    ("Dilithium3", 3, "8196b32212753f525346201ffec1c7a0a852596fa0b57bd4e2746231dab44d55"),
+    ("Dilithium5", 5, "7ded97a6e6c809b43b54c248171d7504fa6a0cab651bf288bb00034782667481"),
+    ("ML-DSA-44", 44, "14f92c48abc0d63ea263cce3c83183c8360c6ede7cbd5b65bd7c6f31e38f0ea5"),
+    ("ML-DSA-65", 65, "595a8eff6988159c94eb5398294458c5d27d21c994fb64cadbee339173abcf63"),
+    ("ML-DSA-87", 87, "35e2ce3d88b3311517bf8d41aa2cd24aa0fbda2bb8052ca8af4ad8d7c7344074"),
+])
+def test_kat_transcript_hash(name, param, want):
+    import hashlib
+    from drbg import DRBG
+    name_in_kat = {"ML-DSA-44": "Dilithium2", "ML-DSA-65": "Dilithium3", "ML-DSA-87": "Dilithium5"}.get(name, name)
+    g = DRBG(bytes(range(48)))
+    f = hashlib.sha256()
+    f.update(("# %s\n\n" % name_in_kat).encode())
+    seeds, msgs, eseeds = [], [], []
+    for i in range(100):
+        seed = g.fill(48)
+        msgs.append(g.fill(33 * (i + 1)))
+        seeds.append(seed)
+        eseeds.append(DRBG(seed).fill(32))
+    pk, sk = orc.mldsa_keygen(param, np.frombuffer(b"".join(eseeds), np.uint8).reshape(100, 32))
+    sig = orc.mldsa_sign(param, sk, msgs)   # empty context, rnd = 0: deterministic (mldsa65/dilithium.go:56-99 with nil opts)
+    ok = orc.mldsa_verify(param, pk, sig, msgs)
+    assert ok.all()
+    sig_size = orc.DSA_SIZES[param][2]
+    for i in range(100):
+        f.update(b"count = %d\n" % i)
+        f.update(b"seed = %s\n" % seeds[i].hex().upper().encode())
+        f.update(b"mlen = %d\n" % len(msgs[i]))
+        f.update(b"msg = %s\n" % msgs[i].hex().upper().encode())
+        f.update(b"pk = %s\n" % pk[i].tobytes().hex().upper().encode())
+        f.update(b"sk = %s\n" % sk[i].tobytes().hex().upper().encode())
+        f.update(b"smlen = %d\n" % (len(msgs[i]) + sig_size))
+        f.update(b"sm = %s%s\n\n" % (sig[i].tobytes().hex().upper().encode(), msgs[i].hex().upper().encode()))
+    assert f.hexdigest() == want
