@@ -22,7 +22,7 @@ SYMBOLS = [
     "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
     "circl_hip_keccak_f1600", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_dilithium_ntt",
-    "circl_hip_shake", "circl_hip_xof", "circl_hip_alloc_host", "circl_hip_free_host",
+    "circl_hip_shake", "circl_hip_xof", "circl_hip_k12", "circl_hip_alloc_host", "circl_hip_free_host",
     "circl_hip_profile_enable", "circl_hip_profile_read",
 ]
 
@@ -106,6 +106,7 @@ def lib():
         L.circl_hip_dilithium_ntt.argtypes = [vp, sz, i, i]
         L.circl_hip_shake.argtypes = [i, i, vp, sz, vp, sz, sz, i]
         L.circl_hip_xof.argtypes = [i, i, i, vp, vp, vp, sz, sz, i]
+        L.circl_hip_k12.argtypes = [vp, vp, vp, vp, vp, sz, sz, i]
         L.circl_hip_profile_enable.argtypes = [i]
         L.circl_hip_profile_read.argtypes = [i, vp, vp]
         _lib = L

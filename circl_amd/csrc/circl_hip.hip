@@ -1074,6 +1074,91 @@ int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const ui
     return CIRCL_HIP_OK;
 }
 
+// KangarooTwelve draft -10 (xof/k12/k12.go), n independent computations.  Tree hashing maps onto the batched
+// sponge service as two or three TurboSHAKE128 batches: every 8192-byte leaf of every long message (D = 0x0B,
+// k12.go:136-160), then the final nodes of the long messages (D = 0x06, :141-142, :383-395) and the short
+// messages (|M| + |C| + |length_encode(|C|)| <= 8192, D = 0x07, :60-66).
+namespace {
+void k12_length_encode(std::vector<uint8_t> &v, uint64_t x) {  // k12.go:333-342
+    uint8_t be[8];
+    int nz = 0;
+    for (int i = 0; i < 8; i++) be[i] = (uint8_t)(x >> (56 - 8 * i));
+    while (nz < 8 && be[nz] == 0) nz++;
+    v.insert(v.end(), be + nz, be + 8);
+    v.push_back((uint8_t)(8 - nz));
+}
+}  // namespace
+
+int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *out,
+                  size_t outlen, size_t n, int device) {
+    constexpr size_t CHUNK = 8192;
+    if (outlen == 0) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    // S_i = M_i || C_i || length_encode(|C_i|), first chunks and leaves gathered separately
+    std::vector<uint8_t> leaves, tail;
+    std::vector<uint64_t> leaf_off{0};
+    std::vector<std::vector<uint8_t>> head(n);   // S_0 of each message (whole S for short ones)
+    std::vector<size_t> nleaves(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *m = msg_blob + msg_off[i];
+        const size_t ml = (size_t)(msg_off[i + 1] - msg_off[i]);
+        const uint8_t *c = ctx_blob ? ctx_blob + ctx_off[i] : nullptr;
+        const size_t cl = ctx_blob ? (size_t)(ctx_off[i + 1] - ctx_off[i]) : 0;
+        tail.clear();
+        if (cl) tail.insert(tail.end(), c, c + cl);
+        k12_length_encode(tail, cl);
+        const size_t total = ml + tail.size();
+        auto byte_range = [&](size_t lo, size_t hi, std::vector<uint8_t> &dst) {  // S[lo, hi)
+            if (lo < ml) dst.insert(dst.end(), m + lo, m + std::min(hi, ml));
+            if (hi > ml) dst.insert(dst.end(), tail.begin() + (std::max(lo, ml) - ml), tail.begin() + (hi - ml));
+        };
+        byte_range(0, std::min(total, CHUNK), head[i]);
+        for (size_t off = CHUNK; off < total; off += CHUNK) {
+            byte_range(off, std::min(total, off + CHUNK), leaves);
+            leaf_off.push_back(leaves.size());
+            nleaves[i]++;
+        }
+    }
+    const size_t total_leaves = leaf_off.size() - 1;
+    std::vector<uint8_t> cv(32 * total_leaves);
+    if (total_leaves) {
+        leaves.resize(leaves.size() + 16);
+        const int rc = circl_hip_xof(168, 0x0B, 12, leaves.data(), leaf_off.data(), cv.data(), 32, total_leaves, device);
+        if (rc) return rc;
+    }
+    // final nodes: long and short messages go out as two batches (different domain bytes)
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<uint8_t> blob;
+        std::vector<uint64_t> off{0};
+        std::vector<size_t> idx;
+        size_t cvpos = 0;
+        for (size_t i = 0; i < n; i++) {
+            const bool is_long = nleaves[i] != 0;
+            if (is_long == (pass == 0)) {
+                blob.insert(blob.end(), head[i].begin(), head[i].end());
+                if (is_long) {
+                    static const uint8_t sep[8] = {3, 0, 0, 0, 0, 0, 0, 0};
+                    blob.insert(blob.end(), sep, sep + 8);
+                    blob.insert(blob.end(), cv.begin() + 32 * cvpos, cv.begin() + 32 * (cvpos + nleaves[i]));
+                    k12_length_encode(blob, nleaves[i]);
+                    blob.push_back(0xff);
+                    blob.push_back(0xff);
+                }
+                off.push_back(blob.size());
+                idx.push_back(i);
+            }
+            cvpos += nleaves[i];
+        }
+        if (idx.empty()) continue;
+        blob.resize(blob.size() + 16);
+        std::vector<uint8_t> res(outlen * idx.size());
+        const int rc = circl_hip_xof(168, pass == 0 ? 0x06 : 0x07, 12, blob.data(), off.data(), res.data(), outlen, idx.size(), device);
+        if (rc) return rc;
+        for (size_t k = 0; k < idx.size(); k++) std::memcpy(out + idx[k] * outlen, &res[k * outlen], outlen);
+    }
+    return CIRCL_HIP_OK;
+}
+
 void *circl_hip_alloc_host(size_t bytes) {
     void *p = nullptr;
     if (ndev() <= 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -197,3 +197,17 @@ def xof(rate, ds, msgs, outlen, rounds=24, device=0):
     out = np.empty((n, outlen), np.uint8)
     nat.check(nat.lib().circl_hip_xof(rate, ds, rounds, _p(mb), _p(mo), _p(out), outlen, n, device), "xof")
     return out
+
+
+def k12(msgs, outlen, ctxs=None, device=0):
+    """KangarooTwelve draft -10 of every message (xof/k12 Draft10Sum) -> (n, outlen)"""
+    n = len(msgs)
+    mb, mo = _blob(msgs)
+    out = np.empty((n, outlen), np.uint8)
+    if ctxs is None:
+        rc = nat.lib().circl_hip_k12(_p(mb), _p(mo), None, None, _p(out), outlen, n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_k12(_p(mb), _p(mo), _p(cb), _p(co), _p(out), outlen, n, device)
+    nat.check(rc, "k12")
+    return out

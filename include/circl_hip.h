@@ -202,6 +202,12 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
  * (TurboSHAKE128/256 with domain byte `ds` in 0x01..0x7f), every output `outlen` bytes. */
 int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const uint64_t *in_off,
                   uint8_t *out, size_t outlen, size_t n, int device);
+/* KangarooTwelve draft -10, n independent computations: xof/k12/k12.go Draft10Sum(hash, msg_i, ctx_i)
+ * (and xof.New(xof.K12D10) for an empty context, xof/xof.go:61-64).  Messages and contexts are blobs with
+ * n+1 offsets; ctx_blob may be NULL (all contexts empty); every output is `outlen` bytes.  Leaves and final
+ * nodes run as TurboSHAKE128 batches on the device. */
+int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                  const uint64_t *ctx_off, uint8_t *out, size_t outlen, size_t n, int device);
 
 /* ---- kernel-level profiling (used by bench.py for the roofline figures) --------------------
  * While enabled, every *_dev call brackets each kernel it enqueues with HIP events recorded on

@@ -99,3 +99,29 @@ def test_xof_service_variable_length_and_turboshake():
     tm = hostapi.xof(136, 0x0B, msgs[:50], 64, rounds=12)
     for i in range(50):
         assert tm[i].tobytes() == orc.sponge_rounds(msgs[i], 64, 136, 0x0B, 12)
+
+
+# ---- KangarooTwelve (xof/k12) ----
+
+@pytest.mark.gpu
+def test_k12_id_vectors_and_oracle():
+    from test_oracle_k12 import BIG, VECTORS, ptn
+    from oracle import k12 as ok12
+    # xof/k12/k12_test.go:46-70, all vectors of one output length in one batch each
+    for outlen in (32, 16):
+        vs = [v for v in VECTORS if v[2] == outlen]
+        got = hostapi.k12([v[0] for v in vs], outlen, [v[1] for v in vs])
+        assert [g.tobytes().hex() for g in got] == [v[3] for v in vs]
+    # the 24 MB vector (k12_test.go:59): 2946 leaves in one TurboSHAKE128 batch
+    assert hostapi.k12([ptn(BIG[0])], 32)[0].tobytes().hex() == BIG[1]
+    # random lengths around the chunk boundaries, with and without contexts, long outputs
+    rng = np.random.default_rng(12)
+    lens = [0, 1, 167, 168, 169, 8190, 8191, 8192, 8193, 16383, 16384, 16385, 40000, 100000]
+    msgs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    ctxs = [rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes() for _ in lens]
+    got = hostapi.k12(msgs, 200, ctxs)
+    for g, m, c in zip(got, msgs, ctxs):
+        assert g.tobytes() == ok12.k12(m, c, 200)
+    got = hostapi.k12(msgs, 64)
+    for g, m in zip(got, msgs):
+        assert g.tobytes() == ok12.k12(m, b"", 64)
