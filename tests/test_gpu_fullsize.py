@@ -128,3 +128,56 @@ def test_two_streams_concurrently():
     for k in range(2):
         ct0, ss0, _ = orc.mlkem_encaps(768, inputs[k][0], inputs[k][1])
         assert (inputs[k][4].ct.cpu().numpy() == ct0).all() and (inputs[k][4].ss.cpu().numpy() == ss0).all()
+
+
+def test_mixed_mlkem1024_and_mldsa87_concurrently():
+    # configs[4] shape per GPU (2^20 mixed items over 8 GPUs = 2^17 per device): 2^16 ML-KEM-1024 encapsulations and
+    # 2^16 ML-DSA-87 verifications submitted on two streams at once, each half checked as in the tests above
+    import torch
+    from circl_amd import _native as nat
+    from circl_amd import device as cdev
+    from oracle import orc
+    L = nat.lib()
+    n, pool = 1 << 16, 1 << 8
+    rng = np.random.default_rng(55)
+    pk, sk = orc.mldsa_keygen(87, rng.integers(0, 256, (pool, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(pool)]
+    sig = orc.mldsa_sign(87, sk, msgs)
+    want = np.ones(pool, np.uint8)
+    bad = rng.choice(pool, pool // 16, replace=False)
+    for i in bad:
+        sig[i, 64 + int(rng.integers(0, 2000))] ^= 8
+    want[bad] = 0
+    reps = n // pool
+    d_pk = torch.from_numpy(np.tile(pk, (reps, 1))).cuda()
+    d_sig = torch.from_numpy(np.tile(sig, (reps, 1))).cuda()
+    d_msg = torch.from_numpy(np.frombuffer(b"".join(msgs) * reps + b"\0" * 16, np.uint8).copy()).cuda()
+    d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+    ok = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wsb = L.circl_hip_mldsa_workspace_size(87, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(56)
+    seeds = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    m = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    eng = cdev.MLKEMDevice(1024, n)
+    ek, dk = eng.keygen(seeds)
+    ct = torch.empty((n, 1568), dtype=torch.uint8, device="cuda")
+    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    s_kem, s_dsa = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):
+        with torch.cuda.stream(s_kem):
+            eng.encaps(ek, m, ct, ss)
+        rc = L.circl_hip_mldsa_verify_dev(87, d_pk.data_ptr(), d_sig.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), None, None,
+                                          ok.data_ptr(), n, ws.data_ptr(), wsb, C.c_void_p(s_dsa.cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    assert (ok.cpu().numpy() == np.tile(want, reps)).all()
+    ss2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    eng.decaps(dk, ct, ss2)
+    torch.cuda.synchronize()
+    assert bool((ss == ss2).all()) and int(eng.status.sum()) == 0
+    idx = np.random.default_rng(2).choice(n, 1 << 10, replace=False)
+    ti = torch.from_numpy(idx).cuda()
+    ct0, ss0, _ = orc.mlkem_encaps(1024, ek[ti].cpu().numpy(), m[ti].cpu().numpy())
+    assert (ct0 == ct[ti].cpu().numpy()).all() and (ss0 == ss[ti].cpu().numpy()).all()
