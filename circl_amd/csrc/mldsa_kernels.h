@@ -58,14 +58,9 @@ template <int MODE> struct DG {
     static constexpr uint32_t BETA = P::TAU * P::ETA;
     static constexpr int STREAMS = K * L;
     static constexpr int IT = 64 / STREAMS;            // items per workgroup
-    static constexpr int PSTRIDE = 257;                // dwords per polynomial in LDS (bank spread)
     static constexpr int MUW1 = 64 + K * W1SZ;         // bytes of mu || w1 per item in the workspace
-    static constexpr int LDS_ZHAT = IT * L * PSTRIDE * 4;
-    static constexpr int LDS_ACC = IT * K * PSTRIDE * 4;
     static constexpr int LDS_XCH = 1024;
-    static constexpr int LDS_HINT = IT * K * 32;       // 256-bit bitmap per polynomial
     static constexpr int LDS_MISC = 256;               // ball block bytes, positions
-    static constexpr int LDS_TOTAL = LDS_ZHAT + LDS_ACC + LDS_XCH + LDS_HINT + LDS_MISC;  // sign kernels' geometry
     // verify / keygen kernels: sampled matrix in global scratch
     static constexpr int FIFO_STRIDE = 80;             // 16 dword slots + pad (bank spread)
     static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;  // phase A; afterwards the staged z || hint bytes
@@ -237,41 +232,7 @@ template <int D> __device__ __forceinline__ uint32_t lds_bits(const uint32_t *p,
     return (sh ? alignbit(hi, lo, (uint32_t)sh) : lo) & ((1u << D) - 1);
 }
 
-// Phase 2 of verification and of key generation: lane = (item, i, j) runs the ExpandA stream
-// SHAKE128(rho || LE16((i << 8) + j)) (mat.go:15-49, sample.go:92-123) and folds every accepted
-// coefficient a_k straight into acc[item][i][k] += a_k * vhat[item][j][k] (vhat is stored times 2^32,
-// so mont32 yields the plain product).  rho of item t is at rho + t * rho_stride (8-byte aligned).
-template <int MODE>
-__device__ __forceinline__ void expand_a_accumulate(const uint32_t *vhat, uint32_t *acc, const uint8_t *__restrict__ rho,
-                                                    size_t rho_stride, size_t item0, size_t n, int lane) {
-    using G = DG<MODE>;
-    constexpr int K = G::K, L = G::L;
-    const bool on = lane < G::IT * G::STREAMS;
-    const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
-    const int i = p / L, j = p % L;
-    size_t item = item0 + g;
-    if (item >= n) item = n - 1;
-    KeccakState s;
-    keccak_zero(s);
-    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
-    s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
-    s.hi[20] = 0x80000000u;
-    const uint32_t *zrow = vhat + (g * L + j) * G::PSTRIDE;
-    uint32_t *arow = acc + (g * K + i) * G::PSTRIDE;
-    int cnt = on ? 0 : 256;
-#pragma unroll 1
-    for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
-        keccak_f1600(s);
-        for_each_candidate23(s, [&](uint32_t a) {
-            if (a < Q && cnt < 256) {
-                atomicAdd(&arow[cnt], dilithium::mont32(a, zrow[cnt]));  // a * v-hat[j][cnt], < 2q
-                cnt++;
-            }
-        });
-    }
-}
-
-// Scratch variant of ExpandA (used by verification and key generation): lane = (item, i, j) runs the
+// ExpandA for verification and key generation: lane = (item, i, j) runs the
 // stream SHAKE128(rho || LE16((i << 8) + j)) (mat.go:15-49, sample.go:92-123).  Accepted coefficients go
 // through a 16-slot LDS FIFO and leave four at a time, so that every global store is a full 16-byte
 // segment of the stream's row (row index = lane).  Branch-free acceptance: the candidate is stored at

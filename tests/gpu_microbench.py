@@ -107,6 +107,34 @@ def dsa(param, n, pool=1 << 11):
     print("   kernel ms: prep+final %.3f  verify %.3f" % (cdev.profile_read("mldsa_hash")[0], cdev.profile_read("mldsa_verify")[0]))
 
 
+def latency_curve(param=768):
+    """Device-resident ML-KEM encapsulation latency and rate against the batch size (stream-ordered, one call per sample);
+    plus the wall-clock latency of a batch of one through the host-buffer ABI."""
+    from circl_amd import hostapi
+    rng = np.random.default_rng(1)
+    for logn in (0, 6, 10, 12, 14, 16, 18, 20):
+        n = 1 << logn
+        eng = cdev.MLKEMDevice(param, n)
+        seeds = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
+        ek, dk = eng.keygen(seeds)
+        m = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).cuda()
+        ct = torch.empty((n, eng.CT), dtype=torch.uint8, device="cuda")
+        ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+        ms = timeit(lambda: eng.encaps(ek, m, ct, ss), 20 if n < (1 << 18) else 5)
+        print(f"ML-KEM-{param} encaps  n=2^{logn:<2d}: {ms * 1e3:10.1f} us per call -> {n / ms * 1e3:.3e}/s")
+    ek1, _ = orc.mlkem_keygen(param, rng.integers(0, 256, (1, 64), dtype=np.uint8))
+    m1 = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    hostapi.mlkem_encaps(param, ek1, m1)
+    t = time.perf_counter()
+    for _ in range(50):
+        hostapi.mlkem_encaps(param, ek1, m1)
+    print(f"ML-KEM-{param} encaps  n=1 through the host-buffer ABI (H2D + 2 kernels + D2H + sync): {(time.perf_counter() - t) / 50 * 1e6:.0f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "latency":
+    latency_curve()
+    sys.exit(0)
+
 if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "host"):
     logn = int(sys.argv[1]) if len(sys.argv) > 1 else 18
     for p in (768, 512, 1024):
