@@ -28,6 +28,10 @@ const AllDevices = -1
 
 var params = map[string]C.int{"ML-KEM-512": 512, "ML-KEM-768": 768, "ML-KEM-1024": 1024}
 
+// round-3 Kyber (kem/kyber/kyber{512,768,1024}) goes through circl_hip_kyber_*: same sizes, different hashing,
+// no per-item failure (kem/kyber/kyber768/kyber.go:215-262).
+var paramsRound3 = map[string]C.int{"Kyber512": 512, "Kyber768": 768, "Kyber1024": 1024}
+
 func status(code C.int, where string) error {
 	if code == 0 {
 		return nil
@@ -60,7 +64,8 @@ func ptr(b []byte) *C.uint8_t {
 // errs[i] is nil, kem.ErrPubKey, ... per item; the Go slices are only borrowed for the call.
 func EncapsulateBatch(s kem.Scheme, eks, seeds []byte, device int) (cts, sss []byte, errs []error, err error) {
 	p, ok := params[s.Name()]
-	if !ok {
+	p3, ok3 := paramsRound3[s.Name()]
+	if !ok && !ok3 {
 		return nil, nil, nil, kem.ErrTypeMismatch
 	}
 	if len(eks)%s.PublicKeySize() != 0 {
@@ -73,7 +78,12 @@ func EncapsulateBatch(s kem.Scheme, eks, seeds []byte, device int) (cts, sss []b
 	cts = make([]byte, n*s.CiphertextSize())
 	sss = make([]byte, n*s.SharedKeySize())
 	st := make([]byte, n)
-	if err = status(C.circl_hip_mlkem_encaps(p, ptr(eks), ptr(seeds), ptr(cts), ptr(sss), ptr(st), C.size_t(n), C.int(device)), "encaps"); err != nil {
+	if ok3 {
+		err = status(C.circl_hip_kyber_encaps(p3, ptr(eks), ptr(seeds), ptr(cts), ptr(sss), C.size_t(n), C.int(device)), "kyber encaps")
+	} else {
+		err = status(C.circl_hip_mlkem_encaps(p, ptr(eks), ptr(seeds), ptr(cts), ptr(sss), ptr(st), C.size_t(n), C.int(device)), "encaps")
+	}
+	if err != nil {
 		return nil, nil, nil, err
 	}
 	errs = make([]error, n)
@@ -87,7 +97,8 @@ func EncapsulateBatch(s kem.Scheme, eks, seeds []byte, device int) (cts, sss []b
 // (kyber.go:398-407, :376-386).  An invalid ciphertext is not an error (implicit rejection).
 func DecapsulateBatch(s kem.Scheme, dks, cts []byte, device int) (sss []byte, errs []error, err error) {
 	p, ok := params[s.Name()]
-	if !ok {
+	p3, ok3 := paramsRound3[s.Name()]
+	if !ok && !ok3 {
 		return nil, nil, kem.ErrTypeMismatch
 	}
 	if len(dks)%s.PrivateKeySize() != 0 {
@@ -99,7 +110,12 @@ func DecapsulateBatch(s kem.Scheme, dks, cts []byte, device int) (sss []byte, er
 	}
 	sss = make([]byte, n*s.SharedKeySize())
 	st := make([]byte, n)
-	if err = status(C.circl_hip_mlkem_decaps(p, ptr(dks), ptr(cts), ptr(sss), ptr(st), C.size_t(n), C.int(device)), "decaps"); err != nil {
+	if ok3 {
+		err = status(C.circl_hip_kyber_decaps(p3, ptr(dks), ptr(cts), ptr(sss), C.size_t(n), C.int(device)), "kyber decaps")
+	} else {
+		err = status(C.circl_hip_mlkem_decaps(p, ptr(dks), ptr(cts), ptr(sss), ptr(st), C.size_t(n), C.int(device)), "decaps")
+	}
+	if err != nil {
 		return nil, nil, err
 	}
 	errs = make([]error, n)
@@ -112,7 +128,8 @@ func DecapsulateBatch(s kem.Scheme, dks, cts []byte, device int) (sss []byte, er
 // DeriveKeyPairBatch is n times scheme.DeriveKeyPair (kyber.go:340-345); seeds are [n][SeedSize].
 func DeriveKeyPairBatch(s kem.Scheme, seeds []byte, device int) (eks, dks []byte, err error) {
 	p, ok := params[s.Name()]
-	if !ok {
+	p3, ok3 := paramsRound3[s.Name()]
+	if !ok && !ok3 {
 		return nil, nil, kem.ErrTypeMismatch
 	}
 	if len(seeds)%s.SeedSize() != 0 {
@@ -121,6 +138,10 @@ func DeriveKeyPairBatch(s kem.Scheme, seeds []byte, device int) (eks, dks []byte
 	n := len(seeds) / s.SeedSize()
 	eks = make([]byte, n*s.PublicKeySize())
 	dks = make([]byte, n*s.PrivateKeySize())
-	err = status(C.circl_hip_mlkem_keygen(p, ptr(seeds), ptr(eks), ptr(dks), C.size_t(n), C.int(device)), "keygen")
+	if ok3 {
+		err = status(C.circl_hip_kyber_keygen(p3, ptr(seeds), ptr(eks), ptr(dks), C.size_t(n), C.int(device)), "kyber keygen")
+	} else {
+		err = status(C.circl_hip_mlkem_keygen(p, ptr(seeds), ptr(eks), ptr(dks), C.size_t(n), C.int(device)), "keygen")
+	}
 	return
 }

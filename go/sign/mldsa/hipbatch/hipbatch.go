@@ -18,7 +18,9 @@ import (
 	"github.com/cloudflare/circl/sign"
 )
 
-var params = map[string]C.int{"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87}
+// ML-DSA, and the round-3 Dilithium modes of sign/dilithium/mode{2,3,5} (param 2 / 3 / 5 of the same C entry points:
+// contexts must be empty, signing is deterministic; sign/dilithium/mode3/dilithium.go:213-255).
+var params = map[string]C.int{"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87, "Dilithium2": 2, "Dilithium3": 3, "Dilithium5": 5}
 
 // VerifyBatch is n times scheme.UnmarshalBinaryPublicKey + scheme.Verify(pk, msg, sig, &opts)
 // (sign/mldsa/mldsa65/dilithium.go:305-343).  Signatures of the wrong length and contexts longer
