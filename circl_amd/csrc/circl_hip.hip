@@ -513,7 +513,12 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     S.count = reinterpret_cast<uint32_t *>(p); p += 256;
     unsigned *tail_work = reinterpret_cast<unsigned *>(p);          // persistent-kernel ticket counter
     uint8_t *tail_scratch = p + 256;
-    const uint32_t tail_threshold = (uint32_t)cu_count() * kSignBlocksPerCU;  // one resident wave per leftover item
+    static const uint32_t tail_mult = [] {  // tuning aid: CIRCL_HIP_SIGN_TAIL = leftover items per CU handed to the persistent kernel
+        const char *e = getenv("CIRCL_HIP_SIGN_TAIL");
+        const int x = e ? atoi(e) : 0;
+        return (uint32_t)(x >= 1 && x <= 1024 ? x : 4);  // measured optimum (tools/sign_tail_sweep.sh): 4 leftover items per CU
+    }();
+    const uint32_t tail_threshold = (uint32_t)cu_count() * tail_mult;
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
