@@ -604,6 +604,24 @@ template <int D> __device__ __forceinline__ void store_staged(uint32_t *dst, con
         if (w < WORDS) dst[w] = zero ? 0u : stage[w];
     }
 }
+// The same comparison with the reference words fetched ahead of time (RefWords<D>::load at the top of the
+// polynomial's iteration): the global-load latency then hides behind the MulHat / InvNTT work instead of sitting
+// at the end of every polynomial of a re-encryption.
+template <int D> struct RefWords {
+    static constexpr int WORDS = 8 * D, N = (WORDS + 63) / 64;
+    uint32_t w[N];
+    __device__ __forceinline__ void load(const uint32_t *ref, int lane) {
+#pragma unroll
+        for (int k = 0; k < N; k++) w[k] = (64 * k + lane < WORDS) ? ref[64 * k + lane] : 0u;
+    }
+    __device__ __forceinline__ bool differs(const uint32_t *stage, int lane) const {
+        bool diff = false;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            if (64 * k + lane < WORDS) diff |= w[k] != stage[64 * k + lane];
+        return diff;
+    }
+};
 template <int D> __device__ __forceinline__ bool staged_differs(const uint32_t *ref, const uint32_t *stage, int lane) {
     constexpr int WORDS = 8 * D;
     bool diff = false;
@@ -748,6 +766,9 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         // u[i] = InvNTT(sum_j A^T[i][j] * r-hat[j]) + e1[i]  (cpapke.go:150-164), compressed to du bits
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i);
+            RefWords<P::DU> ref;
+            if (MODE == REENCRYPT) ref.load(dst, lane);
             int acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < K; j++) {
@@ -765,12 +786,14 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 cv[r] = kyber::compress_coeff<P::DU>(kyber::normalize(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r))));
             uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
             stage_bits_l1<P::DU>(stage, cv, lane);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i);
-            if (MODE == REENCRYPT) differs |= staged_differs<P::DU>(dst, stage, lane);
+            if (MODE == REENCRYPT) differs |= ref.differs(stage, lane);
             else store_staged<P::DU>(dst, stage, lane, reject);
         }
         // v = InvNTT(<t-hat, r-hat>) + e2 + Decompress_q(m, 1)  (cpapke.go:167-173), dv bits
         {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * K);
+            RefWords<P::DV> ref;
+            if (MODE == REENCRYPT) ref.load(dst, lane);
             int acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < K; j++) kyber::mulhat_acc_packed(acc, kyber::pack16(th[j][0], th[j][1]), kyber::pack16(th[j][2], th[j][3]), rop[j]);
@@ -787,8 +810,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             }
             uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
             stage_bits_l1<P::DV>(stage, cv, lane);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * K);
-            if (MODE == REENCRYPT) differs |= staged_differs<P::DV>(dst, stage, lane);
+            if (MODE == REENCRYPT) differs |= ref.differs(stage, lane);
             else store_staged<P::DV>(dst, stage, lane, reject);
         }
         if (MODE == ENCAPS) {
