@@ -75,7 +75,10 @@ struct ProfScope {
 };
 
 // ---- persistent-launch geometry for the scratch-based kernels ---------------------------------
-constexpr int kMaxBlocksPerCU = 16;  // 4 single-wave workgroups per SIMD
+#ifndef CIRCL_MAX_BLOCKS_PER_CU
+#define CIRCL_MAX_BLOCKS_PER_CU 16  // 4 single-wave workgroups per SIMD
+#endif
+constexpr int kMaxBlocksPerCU = CIRCL_MAX_BLOCKS_PER_CU;
 int g_cu_count = 0;
 
 int cu_count() {
