@@ -66,13 +66,20 @@ __global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__res
     s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
     uint32_t *row = st.A + (item * K * L + p) * 256;
-    int cnt = on ? 0 : 256;
+    // accepted coefficients leave through a per-lane 16-slot LDS FIFO, four at a time (16-byte stores), with the
+    // branch-free acceptance of the verify kernel's ExpandA (parse23_block_fifo)
+    __shared__ __attribute__((aligned(16))) uint8_t fifo_lds[256 * DG<MODE>::FIFO_STRIDE];
+    uint32_t *fifo = reinterpret_cast<uint32_t *>(fifo_lds + threadIdx.x * DG<MODE>::FIFO_STRIDE);
+    int cnt = on ? 0 : 256, flushed = cnt;
 #pragma unroll 1
-    for (int blk = 0; blk < 5 || __any(cnt < 256); blk++) {
+    for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(s);
-        for_each_candidate23(s, [&](uint32_t a) {
-            if (a < Q && cnt < 256) row[cnt++] = a;
-        });
+        if (on) parse23_block_fifo<false>(s, fifo, row, cnt, flushed);
+    }
+#pragma unroll 1
+    while (__any(flushed < 256)) {
+        keccak_f1600(s);
+        parse23_block_fifo<true>(s, fifo, row, cnt, flushed);
     }
 }
 
