@@ -486,7 +486,8 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
     using S = circl::mldsa::SG<MODE>;
     using B = circl::mldsa::SB<MODE>;
     const size_t persistent = up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
-    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 3 + up256(n) + 256;
+    const size_t tail_units = (size_t)cu_count() * kSignBlocksPerCU;  // speculative tail: best[] and one parked signature per unit
+    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 3 + up256(n) + 256 + up256(4 * tail_units) + tail_units * S::SPEC_STRIDE;
     return n < kSignBatchedMin ? persistent : persistent + batched;  // the batched path finishes its tail persistently
 }
 
@@ -516,10 +517,13 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     S.count = reinterpret_cast<uint32_t *>(p); p += 256;
     unsigned *tail_work = reinterpret_cast<unsigned *>(p);          // persistent-kernel ticket counter
     uint8_t *tail_scratch = p + 256;
+    const size_t tail_units = (size_t)cu_count() * kSignBlocksPerCU;
+    uint32_t *tail_best = reinterpret_cast<uint32_t *>(tail_scratch + tail_units * SG<MODE>::SCRATCH_BYTES);
+    uint8_t *tail_spec = reinterpret_cast<uint8_t *>(tail_best) + up256(4 * tail_units);
     static const uint32_t tail_mult = [] {  // tuning aid: CIRCL_HIP_SIGN_TAIL = leftover items per CU handed to the persistent kernel
         const char *e = getenv("CIRCL_HIP_SIGN_TAIL");
         const int x = e ? atoi(e) : 0;
-        return (uint32_t)(x >= 1 && x <= 1024 ? x : 4);  // measured optimum (tools/sign_tail_sweep.sh): 4 leftover items per CU
+        return (uint32_t)(x >= 1 && x <= 1024 ? x : 2);  // measured optimum (tools/sign_tail_sweep.sh): 2 leftover items per CU
     }();
     const uint32_t tail_threshold = (uint32_t)cu_count() * tail_mult;
     const unsigned nb256 = (unsigned)((n + 255) / 256);
@@ -543,9 +547,17 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         if (upper <= tail_threshold) {
             // few items left: rounds would be launch-bound, so every leftover item gets its own wavefront, which
             // runs that item's remaining rejection iterations to the end (continuing its nonce sequence)
+            // The tail's duration is the unluckiest item's ~30 sequential attempts, with most of the chip idle: when the
+            // resident slots allow, 2, 4 or 8 wavefronts share an item and try its attempts in parallel (first success wins).
+            const unsigned spec_w = (size_t)upper * 8 <= tail_units ? 8u : (size_t)upper * 4 <= tail_units ? 4u : (size_t)upper * 2 <= tail_units ? 2u : 1u;
             HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
-            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3(upper), dim3(64), SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig,
-                               tail_scratch, tail_work, (const uint32_t *)S.list[cur], (const uint32_t *)S.attempts, (size_t)upper);
+            if (spec_w > 1) HIP_TRY(hipMemsetAsync(tail_best, 0xff, 4 * (size_t)upper, st));
+            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>((size_t)upper * spec_w, tail_units)), dim3(64),
+                               SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[cur],
+                               (const uint32_t *)S.attempts, (size_t)upper, spec_w, tail_best, tail_spec);
+            if (spec_w > 1)
+                hipLaunchKernelGGL(sign_tail_commit_kernel<MODE>, dim3(upper), dim3(64), 0, st, (const uint32_t *)S.list[cur],
+                                   (const uint32_t *)S.attempts, (const uint32_t *)tail_best, (const uint8_t *)tail_spec, sig, spec_w);
             break;
         }
         hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3((unsigned)(((size_t)upper * L + 255) / 256)), dim3(256), 0, st, S, cur);
@@ -588,7 +600,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         const unsigned blocks = (unsigned)std::min<size_t>(n, (size_t)cu_count() * occ);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

@@ -744,6 +744,7 @@ template <int MODE> struct SG {
     static constexpr int LDS_XCH = 1024;
     static constexpr int LDS_MISC = 256;                                // ball block (200 B)
     static constexpr int LDS_TOTAL = LDS_Y + LDS_W0 + LDS_W1 + LDS_MUW1 + LDS_Z + LDS_H + LDS_XCH + LDS_MISC;
+    static constexpr int SPEC_STRIDE = (G::SIG + 15) & ~15;                // one parked signature of the speculative tail
 };
 
 // lane = item: mu = H(tr || M'), rho'' = H(key || rnd || mu)[:64]  (dilithium.go:355-368) -> workspace
@@ -791,7 +792,8 @@ template <int MODE>
 __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ mr_ws,
                                                        uint8_t *__restrict__ sig, uint8_t *__restrict__ scratch,
                                                        unsigned *__restrict__ work, const uint32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ attempts, size_t n) {
+                                                       const uint32_t *__restrict__ attempts, size_t n, unsigned spec_w,
+                                                       uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
@@ -811,10 +813,17 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
     const int lane = threadIdx.x;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
 
-#pragma unroll 1
     // `list` (optional) names the n items to sign and `attempts` how many rejection rounds each of them
     // has already been through (the tail of mldsa_sign_batched); otherwise items are 0..n-1 from scratch.
-    for (size_t t = mlkem::next_group(work, lane, true, n); t < n; t = mlkem::next_group(work, lane, false, n)) {
+    // spec_w > 1 (tail only): spec_w wavefronts share an item and try its attempts a0 + w, a0 + w + spec_w, ...
+    // in parallel.  The signature of the reference is the one of the FIRST successful attempt, so every success
+    // lowers best[t] (atomicMin), a wave gives up once its next attempt lies beyond best[t], successful waves park
+    // their signature in slot (t, w) of spec_sig, and sign_tail_commit_kernel copies the winner's slot out.
+    const size_t units = n * spec_w;
+#pragma unroll 1
+    for (size_t u = mlkem::next_group(work, lane, true, units); u < units; u = mlkem::next_group(work, lane, false, units)) {
+        const size_t t = u / spec_w;
+        const unsigned spec_class = (unsigned)(u % spec_w);
         const size_t item = list ? list[t] : t;
         const uint8_t *skp = sk + item * Kg::SK;
         const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
@@ -865,11 +874,17 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
 
-        unsigned nonce = attempts ? attempts[item] * L : 0;
-        bool accepted = false;
+        unsigned attempt = (attempts ? attempts[item] : 0) + spec_class - spec_w;  // pre-decremented (wraps)
+        bool accepted = false, lost = false;
         KeccakState cs;  // c~ sponge (uniform across lanes)
 #pragma unroll 1
         while (!accepted) {
+            attempt += spec_w;
+            if (spec_w > 1 && attempt > __hip_atomic_load(&best[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {  // wave-uniform
+                lost = true;
+                break;
+            }
+            const unsigned nonce = attempt * L;
             // ---- y = ExpandMask(rho'', nonce) (sample.go:178-196): lane l < L squeezes L streams ----
             {
                 const bool on = lane < L;
@@ -890,7 +905,6 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                         });
                     }
                 }
-                nonce += L;
             }
             __syncthreads();
             // ---- y-hat ----
@@ -1025,15 +1039,32 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
             if (__any(bad) || pop > (unsigned)P::OMEGA) continue;
             accepted = true;
         }
+        if (lost) continue;  // another wave of this item succeeded at an earlier attempt
+        if (spec_w > 1 && lane == 0) atomicMin(&best[t], attempt);
         // ---- sig = c~ || z || hints (dilithium.go:84-88), byte-wise because rows are unaligned ----
         __syncthreads();
-        uint8_t *sg = sig + item * G::SIG;
+        uint8_t *sg = spec_w > 1 ? spec_sig + (t * spec_w + spec_class) * S::SPEC_STRIDE : sig + item * G::SIG;
         if (lane == 0) store_words<0, P::CT / 8>(reinterpret_cast<uint64_t *>(misc), cs);
         __syncthreads();
         for (int b = lane; b < P::CT; b += 64) sg[b] = misc[b];
         for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
         for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
     }
+}
+
+// Speculative tail of batch signing: workgroup t copies the signature of item list[t]'s first successful attempt
+// (best[t], found by class (best[t] - attempts[item]) mod spec_w) from its parking slot to the output row.
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_tail_commit_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ attempts,
+                                                             const uint32_t *__restrict__ best, const uint8_t *__restrict__ spec_sig,
+                                                             uint8_t *__restrict__ sig, unsigned spec_w) {
+    using G = DG<MODE>;
+    const size_t t = blockIdx.x;
+    const size_t item = list[t];
+    const unsigned cls = (best[t] - attempts[item]) % spec_w;
+    const uint8_t *src = spec_sig + (t * spec_w + cls) * SG<MODE>::SPEC_STRIDE;
+    uint8_t *dst = sig + item * G::SIG;
+    for (int b = threadIdx.x; b < G::SIG; b += 64) dst[b] = src[b];
 }
 
 }  // namespace mldsa

@@ -1,2 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for t in 2 4 8 16 32 64; do echo "== tail $t"; CIRCL_HIP_SIGN_TAIL=$t python tests/gpu_microbench.py 18 2>&1 | grep "DSA-65 sign"; CIRCL_HIP_SIGN_TAIL=$t python tests/gpu_microbench.py 16 2>&1 | grep "DSA-65 sign"; done
+for t in 1 2; do echo "== tail $t per CU"; for p in 65 44 87; do CIRCL_HIP_SIGN_TAIL=$t python - <<PY 2>&1 | grep sign
+import sys; sys.argv=["x","18"]
+exec(open("tests/gpu_microbench.py").read().split('if __name__ == "__main__"')[0])
+dsa($p, 1 << 16)
+PY
+done; done
