@@ -9,13 +9,17 @@
 //                            shared secret K and parks r (32 B / item) in the workspace.
 //                            64 independent sponges per wavefront, states in registers.
 //
-//  mlkem_encrypt_kernel<K>   one wavefront per workgroup, G = 64 / K^2 items per workgroup:
+//  mlkem_encrypt_kernel<K>   persistent single-wavefront workgroups pull groups of G = 64 / K^2 items from a
+//                            ticket counter:
 //    phase A  lane = (item, i, j): SHAKE128(rho || i || j) rejection sampling of the K^2
 //             matrix polynomials of G items at once (sample.go:192-236, mat.go:13-74 with
-//             transpose=true), accepted coefficients streamed into LDS.  A^T never touches
-//             HBM and lives only until phase C of the same workgroup consumed it.
+//             transpose=true); accepted coefficients go through a per-lane LDS FIFO into the
+//             stream's 512-byte row of the workgroup's global scratch slice (L2 / Infinity Cache
+//             resident, reused by every group).  An LDS-resident variant (template flag) is kept
+//             for A/B measurements.
 //    phase B  lane = (item, nonce): SHAKE256(r || nonce) PRF blocks for the 2K+1 noise
-//             polynomials (sample.go:31-95), raw bytes into LDS.
+//             polynomials (sample.go:31-95), raw bytes into LDS; its idle lanes adopt the few
+//             matrix streams that need a fourth block (sample_matrix_and_prf).
 //    phase C  the wave walks its G items; per item it is K-PKE.Encrypt (cpapke.go:137-181)
 //             with one polynomial per wavefront: CBD, 3 forward NTTs, K(K+1) lazy MulHat
 //             accumulations, K+1 inverse NTTs, compress and bit-pack straight to HBM.
