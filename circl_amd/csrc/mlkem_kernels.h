@@ -57,7 +57,12 @@ template <int K> struct Geom {
     static constexpr int NOISE_BYTES = 64 * P::ETA1;     // eta1 stream length (eta2 streams use 128)
     static constexpr int NOISE_STRIDE = NOISE_BYTES + 8; // breaks the power-of-two bank stride
     static constexpr int LDS_A = A_STREAMS * A_STRIDE;
-    static constexpr int LDS_NOISE = G * NOISE * NOISE_STRIDE;
+    // ML-KEM-512 packs 16 items into a group (64 / K^2) and its eta1 = 3 streams are 192 bytes long: the noise of a whole
+    // group would be 16 KB of LDS (2.25 waves per SIMD).  Its PRF therefore runs in two halves of GH = 8 items, each
+    // consumed by phase C before the next is produced; the other parameter sets do the whole group at once.
+    static constexpr int HALVES = K == 2 ? 2 : 1;
+    static constexpr int GH = G / HALVES;
+    static constexpr int LDS_NOISE = GH * NOISE * NOISE_STRIDE;
     static constexpr int LDS_XCH = 512;
     static constexpr int LDS_TOTAL = LDS_A + LDS_NOISE + LDS_XCH;
     // "scratch" variant: the sampled matrix goes through a per-workgroup global scratch (L2 / Infinity
@@ -477,16 +482,17 @@ __device__ __forceinline__ void rows_acquire() {
 // SHAKE256(seed || nonce) -> 128 bytes (eta=2) or 192 bytes (eta=3) written to LDS.  NOISE streams
 // per item; the first ETA1_COUNT of them use eta1, the rest eta2 = 2.  The seed of item t is at
 // seed + t * seed_stride.
-template <int K, int NOISE, int ETA1_COUNT>
+// Items g0 .. g0 + GCOUNT - 1 of the group; stream s of that range goes to slot s of the noise area.
+template <int K, int NOISE, int ETA1_COUNT, int GCOUNT = Geom<K>::G>
 __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *__restrict__ seed, size_t seed_stride,
-                                            size_t item0, size_t n, int lane) {
+                                            size_t item0, size_t n, int lane, int g0 = 0) {
     using Gm = Geom<K>;
-    constexpr int STREAMS = Gm::G * NOISE;
+    constexpr int STREAMS = GCOUNT * NOISE;
 #pragma unroll 1
     for (int base = 0; base < STREAMS; base += 64) {
         const int sidx = base + lane;
         const bool on = sidx < STREAMS;
-        const int g = on ? sidx / NOISE : 0, nonce = on ? sidx % NOISE : 0;
+        const int g = g0 + (on ? sidx / NOISE : 0), nonce = on ? sidx % NOISE : 0;
         size_t item = item0 + g;
         if (item >= n) item = n - 1;
         KeccakState s;
@@ -709,7 +715,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
-    if constexpr (SCRATCH && ABLATE == 0) {
+    if constexpr (SCRATCH && ABLATE == 0 && Gm::HALVES == 1) {
         __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
         sample_matrix_and_prf<K, true, Gm::NOISE, K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, ek + 384 * K, ek_stride,
                                                      r_ws, 32, item0, n, lane);
@@ -726,16 +732,25 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             }
         }
         __syncthreads();
-        if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
-        __syncthreads();
+        if constexpr (Gm::HALVES == 1) {
+            if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane);
+            __syncthreads();
+        }
     }
 
 #pragma unroll 1
     for (int g = 0; g < ((ABLATE & 4) ? 0 : Gm::G); g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
+        if constexpr (Gm::HALVES > 1) {
+            if (g % Gm::GH == 0) {  // this half's PRF streams replace the consumed ones of the previous half
+                __syncthreads();
+                if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K, Gm::GH>(lds_noise, r_ws, 32, item0, n, lane, g);
+                __syncthreads();
+            }
+        }
         const uint8_t *ekp = ek + item * ek_stride;
-        const uint8_t *noise = lds_noise + g * Gm::NOISE * Gm::NOISE_STRIDE;
+        const uint8_t *noise = lds_noise + (g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
 
         // t-hat (12-bit codec) in layout L4; ENCAPS applies UnpackMLKEM's range check
         int th[K][4];
@@ -965,24 +980,39 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
-    if constexpr (SCRATCH) {
+    if constexpr (SCRATCH && Gm::HALVES == 1) {
         __syncthreads();
         sample_matrix_and_prf<K, false, 2 * K, 2 * K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, rs_ws, 64, rs_ws + 32, 64,
                                                       item0, n, lane);
         __threadfence_block();
         __syncthreads();
     } else {
-        sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
+        if constexpr (SCRATCH) {
+            __syncthreads();
+            sample_matrix_scratch<K, false>(lds_a, rows, rs_ws, 64, item0, n, lane);
+            __threadfence_block();
+        } else {
+            sample_matrix<K, false>(lds_a, rs_ws, 64, item0, n, lane);
+        }
         __syncthreads();
-        prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
-        __syncthreads();
+        if constexpr (Gm::HALVES == 1) {
+            prf_streams<K, 2 * K, 2 * K>(lds_noise, rs_ws + 32, 64, item0, n, lane);
+            __syncthreads();
+        }
     }
 
 #pragma unroll 1
     for (int g = 0; g < Gm::G; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;
-        const uint8_t *noise = lds_noise + g * (2 * K) * Gm::NOISE_STRIDE;
+        if constexpr (Gm::HALVES > 1) {
+            if (g % Gm::GH == 0) {
+                __syncthreads();
+                prf_streams<K, 2 * K, 2 * K, Gm::GH>(lds_noise, rs_ws + 32, 64, item0, n, lane, g);
+                __syncthreads();
+            }
+        }
+        const uint8_t *noise = lds_noise + (g % Gm::GH) * (2 * K) * Gm::NOISE_STRIDE;
         uint8_t *ekp = ek + item * Gm::EK, *dkp = dk + item * Gm::DK;
         int sh[K][4];
 #pragma unroll
