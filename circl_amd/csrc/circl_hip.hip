@@ -539,14 +539,37 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((n * K * L + 255) / 256)), dim3(256), 0, st, sk, S, n);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n);
     }
+    // The host needs the number of unsigned items only to size the next round's grids, and the kernels bound themselves
+    // with the device-side count, so it runs one round ahead: round r is launched with the count read back after round
+    // r - 2 (an over-estimate, the list only shrinks) while round r - 1 still executes, and the read-back of round r - 1
+    // has arrived by the time round r + 1 is enqueued.  Only the hand-over to the tail kernel needs the exact count.
+    static uint32_t *pinned[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return CIRCL_HIP_ENODEV;
+    if (!pinned[dev]) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned[dev]), 256, hipHostMallocDefault));
+    volatile uint32_t *h_count = pinned[dev];  // [0], [1]: counts after even / odd rounds
+    hipEvent_t ev[2];
+    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } guard{ev};
     int cur = 0;
-    uint32_t upper = (uint32_t)n;
+    uint32_t upper = (uint32_t)n;   // bound on the current list's length
+    bool exact = true;              // upper is the exact length
+    int pending = 0;                // read-backs in flight: rounds (round - pending) .. (round - 1)
     for (int round = 0; upper > 0; round++) {
         if (round > 4096) { g_err = "mldsa sign: rejection loop did not terminate"; return CIRCL_HIP_EHIP; }
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        if (upper <= tail_threshold + tail_threshold / 2 && !exact) {  // close to the hand-over: get the exact count
+            HIP_TRY(hipStreamSynchronize(st));
+            upper = h_count[(round - 1) & 1];
+            exact = true;
+            pending = 0;
+            if (upper == 0) break;
+        }
         if (upper <= tail_threshold) {
-            // few items left: rounds would be launch-bound, so every leftover item gets its own wavefront, which
-            // runs that item's remaining rejection iterations to the end (continuing its nonce sequence)
+            // few items left: rounds would be launch-bound, so every leftover item gets its own wavefront(s), which
+            // run that item's remaining rejection iterations to the end (continuing its nonce sequence).
             // The tail's duration is the unluckiest item's ~30 sequential attempts, with most of the chip idle: when the
             // resident slots allow, 2, 4 or 8 wavefronts share an item and try its attempts in parallel (first success wins).
             const unsigned spec_w = (size_t)upper * 8 <= tail_units ? 8u : (size_t)upper * 4 <= tail_units ? 4u : (size_t)upper * 2 <= tail_units ? 2u : 1u;
@@ -567,9 +590,19 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
         hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
         cur ^= 1;
-        HIP_TRY(hipMemcpyAsync(&upper, S.count + cur, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(&h_count[round & 1]), S.count + cur, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ev[round & 1], st));
+        pending++;
+        if (pending == 2) {  // the count after round - 1 has long arrived: it bounds the list of round + 1
+            HIP_TRY(hipEventSynchronize(ev[(round - 1) & 1]));
+            upper = h_count[(round - 1) & 1];
+            exact = false;
+            pending = 1;
+        }
+        // (with pending == 1, i.e. right after an exact count, `upper` stays the bound for one more round)
+        else exact = false;
     }
+    HIP_TRY(hipStreamSynchronize(st));  // the pinned slots and events are reused by the next call
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
