@@ -154,6 +154,36 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     return CIRCL_HIP_OK;
 }
 
+// Shared-key encapsulation: one ek for all n items (the reference's BenchmarkEncapsulate shape; SURVEY 8d "secondary
+// input").  H(ek) and A^T are computed once (per launch / per resident workgroup), leaving 8 permutations per item.
+template <int K>
+int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws,
+                           size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+        return CIRCL_HIP_EWORKSPACE;
+    uint8_t *r_ws = static_cast<uint8_t *>(ws), *h_ws = r_ws + 32 * n;
+    unsigned *work = reinterpret_cast<unsigned *>(r_ws + up256(kKemWsPerItem * n));
+    uint8_t *scratch = r_ws + up256(kKemWsPerItem * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_hek_kernel<K>, dim3(1), dim3(64), 0, st, ek, h_ws);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)h_ws, m, ss,
+                           r_ws, n);
+    }
+    {
+        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::ENCAPS, 0, true, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)0, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, scratch, work, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
 // R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:156-197): no private-key check, K = KDF((ct' == ct ? K'' : z) || H(ct));
 // `status` may then be null (an n-byte slot of the workspace is used).
 template <int K, bool R3 = false>
@@ -819,6 +849,37 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
                                hipStream_t st) {
                                return circl_hip_mlkem_keygen_dev(param, in[0], out[0], out[1], c, ws, wsb, st);
                            }, 256 + max_resident_blocks() * 64 * 512);
+    });
+}
+
+int circl_hip_mlkem_encaps_shared_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status,
+                                      size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return encaps_shared_dev_impl<2>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 3: return encaps_shared_dev_impl<3>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 4: return encaps_shared_dev_impl<4>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                                  int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        // the key travels as a one-row input that is not advanced with the chunk: stage it behind the per-item arrays
+        HIP_TRY(hipSetDevice(dev));
+        uint8_t *d_ek = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_ek), up256(EK)));
+        int rc = hipMemcpy(d_ek, ek, EK, hipMemcpyHostToDevice) == hipSuccess ? CIRCL_HIP_OK : CIRCL_HIP_EHIP;
+        if (rc == CIRCL_HIP_OK)
+            rc = run_chunked(dev, cnt, {m + lo * 32}, {32}, {ct + lo * CT, ss + lo * 32, status ? status + lo : nullptr}, {CT, 32, 1}, kKemWsPerItem,
+                             [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb, hipStream_t st) {
+                                 return circl_hip_mlkem_encaps_shared_dev(param, d_ek, in[0], out[0], out[1], out[2], c, ws, wsb, st);
+                             }, 256 + max_resident_blocks() * 64 * 512);
+        (void)hipFree(d_ek);
+        return rc;
     });
 }
 

@@ -71,6 +71,12 @@ template <int K> struct Geom {
     static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;
     static constexpr int LDS_SCRATCH_TOTAL = (LDS_FIFO > LDS_NOISE + LDS_XCH) ? LDS_FIFO : LDS_NOISE + LDS_XCH;
     static constexpr int SCRATCH_BYTES = 64 * 512;       // per resident workgroup
+    // shared-key encapsulation (one ek for the whole batch: the shape of the reference's BenchmarkEncapsulate,
+    // kem/schemes/schemes_test.go:28-38): the matrix is sampled once per workgroup, a group is GS items whose
+    // 2K+1 PRF streams fill one 64-lane pass
+    static constexpr int GS = K == 2 ? 8 : 64 / NOISE;
+    static constexpr int LDS_NOISE_SHARED = GS * NOISE * NOISE_STRIDE;
+    static constexpr int LDS_SHARED_TOTAL = (LDS_FIFO > LDS_NOISE_SHARED + LDS_XCH) ? LDS_FIFO : LDS_NOISE_SHARED + LDS_XCH;
 };
 
 // ---- little helpers -------------------------------------------------------------------------
@@ -133,6 +139,29 @@ __global__ void __launch_bounds__(256) mlkem_hash_kernel(const uint8_t *__restri
         store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
         store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
     }
+}
+
+// ---- shared-key encapsulation: H(ek) once, then (K, r) = G(m || H(ek)) per item ------------------
+
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_hek_kernel(const uint8_t *__restrict__ ek, uint8_t *__restrict__ h_ws) {
+    KeccakState h;
+    sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek));
+    if (threadIdx.x == 0) store_words<0, 4>(reinterpret_cast<uint64_t *>(h_ws), h);
+}
+__global__ void __launch_bounds__(256) mlkem_g_shared_kernel(const uint8_t *__restrict__ h_ws, const uint8_t *__restrict__ m,
+                                                             uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    KeccakState g;
+    keccak_zero(g);
+    xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(m + idx * 32));
+    xor_words<4, 4>(g, reinterpret_cast<const uint64_t *>(h_ws));
+    g.lo[8] = kDsSha3;
+    g.hi[8] = 0x80000000u;
+    keccak_f1600(g);
+    store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
+    store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
 }
 
 // ---- round-3 Kyber hashing (kem/kyber/kyber768/kyber.go), SURVEY 8f row f3 ---------------------
@@ -287,11 +316,11 @@ __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, 
     });
 }
 
-template <int K, bool TRANSPOSED>
+template <int K, bool TRANSPOSED, int GA = Geom<K>::G>
 __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t *rows, const uint8_t *__restrict__ rho,
                                                       size_t rho_stride, size_t item0, size_t n, int lane) {
     using Gm = Geom<K>;
-    const bool on = lane < Gm::A_STREAMS;
+    const bool on = lane < GA * Gm::PAIRS;
     const int g = on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
     const int i = p / K, j = p % K;
     size_t item = item0 + g;
@@ -695,7 +724,9 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1, ENCAPS_LENIENT = 2 };
 // SCRATCH selects where the sampled matrix lives between phase A and phase C: the workgroup's slice of
 // a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
 // or LDS (one group per workgroup; kept for A/B measurements).
-template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true>
+// SHARED (ENCAPS, scratch variant only): every item uses the key at `ek` (ek_stride = 0); A^T is sampled once per
+// workgroup before the group loop and groups are GS items.
+template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true, bool SHARED = false>
 __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
@@ -706,16 +737,27 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
-    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + Gm::LDS_NOISE);
+    static_assert(!SHARED || (SCRATCH && MODE == ENCAPS && ABLATE == 0), "shared-key mode");
+    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE));
     int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
-    const size_t ngroups = (n + Gm::G - 1) / Gm::G;
+    constexpr int GI = SHARED ? Gm::GS : Gm::G;  // items per group
+    const size_t ngroups = (n + GI - 1) / GI;
+    if constexpr (SHARED) {
+        sample_matrix_scratch<K, true, 1>(lds_a, rows, ek + 384 * K, 0, 0, 1, lane);  // rows 0 .. K^2 - 1, once
+        __threadfence_block();
+        __syncthreads();
+    }
 
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
-    const size_t item0 = grp * Gm::G;
-    if constexpr (SCRATCH && ABLATE == 0 && Gm::HALVES == 1) {
+    const size_t item0 = grp * GI;
+    if constexpr (SHARED) {
+        __syncthreads();  // phase C of the previous group is done with the noise
+        prf_streams<K, Gm::NOISE, K, Gm::GS>(lds_noise, r_ws, 32, item0, n, lane);
+        __syncthreads();
+    } else if constexpr (SCRATCH && ABLATE == 0 && Gm::HALVES == 1) {
         __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
         sample_matrix_and_prf<K, true, Gm::NOISE, K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, ek + 384 * K, ek_stride,
                                                      r_ws, 32, item0, n, lane);
@@ -739,10 +781,10 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     }
 
 #pragma unroll 1
-    for (int g = 0; g < ((ABLATE & 4) ? 0 : Gm::G); g++) {
+    for (int g = 0; g < ((ABLATE & 4) ? 0 : GI); g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
-        if constexpr (Gm::HALVES > 1) {
+        if constexpr (Gm::HALVES > 1 && !SHARED) {
             if (g % Gm::GH == 0) {  // this half's PRF streams replace the consumed ones of the previous half
                 __syncthreads();
                 if (!(ABLATE & 2)) prf_streams<K, Gm::NOISE, K, Gm::GH>(lds_noise, r_ws, 32, item0, n, lane, g);
@@ -750,7 +792,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             }
         }
         const uint8_t *ekp = ek + item * ek_stride;
-        const uint8_t *noise = lds_noise + (g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
+        const uint8_t *noise = lds_noise + (SHARED ? g : g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
 
         // t-hat (12-bit codec) in layout L4; ENCAPS applies UnpackMLKEM's range check
         int th[K][4];
@@ -792,7 +834,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 uint32_t a01, a23;
-                if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, (g * K + i) * K + j, lane);
+                if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, SHARED ? i * K + j : (g * K + i) * K + j, lane);
                 else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, (g * K + i) * K + j, lane);
                 kyber::mulhat_acc_packed(acc, a01, a23, rop[j]);
             }

@@ -57,6 +57,19 @@ def mlkem_keygen(param, seeds, device=0):
     return ek, dk
 
 
+def mlkem_encaps_shared(param, ek, m, device=0):
+    """one key for the whole batch -> ct, ss, status"""
+    EK, _, CT = KEM_SIZES[param]
+    ek, m = _u8(ek, EK), _u8(m, 32)
+    assert len(ek) == 1
+    n = len(m)
+    ct = np.empty((n, CT), np.uint8)
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_encaps_shared(param, _p(ek), _p(m), _p(ct), _p(ss), _p(st), n, device), "mlkem_encaps_shared")
+    return ct, ss, st
+
+
 # round-3 Kyber (kem/kyber/kyber{512,768,1024}): no per-item failures
 def kyber_keygen(param, seeds, device=0):
     EK, DK, _ = KEM_SIZES[param]

@@ -93,6 +93,16 @@ int circl_hip_mlkem_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_
 int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Shared-key encapsulation: all n items use the ONE encapsulation key at `ek` -- n times
+ * scheme.EncapsulateDeterministically(pk, m_i) on one parsed key, the shape of the reference's BenchmarkEncapsulate
+ * (kem/schemes/schemes_test.go:28-38), where the cached key amortises A^T and H(ek) (kyber.go:39-43).  Same
+ * outputs as circl_hip_mlkem_encaps on n copies of the key; status[i] is the key's verdict for every i. */
+int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss,
+                                  uint8_t *status, size_t n, int device);
+int circl_hip_mlkem_encaps_shared_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct,
+                                      uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_workspace,
+                                      size_t workspace_bytes, void *stream);
+
 /* ---- round-3 Kyber ------------------------------------------------------
  * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in
  * kem/schemes).  param 512 | 768 | 1024; key and ciphertext sizes are those of ML-KEM.  Differences from

@@ -40,6 +40,19 @@ def kem(param, n, pool=1 << 12):
     ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
     ms = timeit(lambda: eng.encaps(ek, m, ct, ss))
     print(f"ML-KEM-{param} encaps  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
+    L = nat.lib()
+    wsb = L.circl_hip_mlkem_workspace_size(param, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    st1 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ct_s, ss_s = torch.empty_like(ct), torch.empty_like(ss)
+
+    def shared():
+        rc = L.circl_hip_mlkem_encaps_shared_dev(param, ek[:1].data_ptr(), m.data_ptr(), ct_s.data_ptr(), ss_s.data_ptr(), st1.data_ptr(), n,
+                                                 ws.data_ptr(), wsb, stream)
+        assert rc == 0, rc
+    ms = timeit(shared)
+    print(f"ML-KEM-{param} encaps, shared key  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
     ss2 = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
     ms = timeit(lambda: eng.decaps(dk, ct, ss2))
     torch.cuda.synchronize()

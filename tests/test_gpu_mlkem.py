@@ -247,3 +247,31 @@ def test_round3_kyber_matches_oracle_incl_rejection_and_lenient_keys(param):
     want = orc.kyber_r3_decaps(param, dk, bad)
     assert (got == want).all()
     assert (got[1::2] == ss_h[1::2]).all() and not (got[::2] == ss_h[::2]).all(axis=1).any()
+
+
+# ---- shared-key encapsulation (one ek for the batch: kem/schemes/schemes_test.go:28-38 BenchmarkEncapsulate's shape) ----
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PARAMS))
+@pytest.mark.parametrize("n", [1, 7, 9, 1000, 4099])
+def test_encaps_shared_key_matches_oracle(name, n):
+    p = PARAMS[name]
+    rng = np.random.default_rng(n + p)
+    ek, dk = orc.mlkem_keygen(p, rng.integers(0, 256, (1, 64), dtype=np.uint8))
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct, ss, st = hostapi.mlkem_encaps_shared(p, ek, m)
+    ct0, ss0, st0 = orc.mlkem_encaps(p, np.tile(ek, (n, 1)), m)
+    assert (st == 0).all() and (ct == ct0).all() and (ss == ss0).all()
+    ss2, st2 = hostapi.mlkem_decaps(p, np.tile(dk, (n, 1)), ct)
+    assert (st2 == 0).all() and (ss2 == ss).all()
+
+
+@pytest.mark.gpu
+def test_encaps_shared_key_rejects_non_canonical_key():
+    rng = np.random.default_rng(3)
+    ek, _ = orc.mlkem_keygen(768, rng.integers(0, 256, (1, 64), dtype=np.uint8))
+    bad = ek.copy()
+    bad[0, 0] = 0xff
+    bad[0, 1] |= 0x0f          # first coefficient = 0xfff >= q  (cpapke.go:45-55)
+    ct, ss, st = hostapi.mlkem_encaps_shared(768, bad, rng.integers(0, 256, (50, 32), dtype=np.uint8))
+    assert (st == 1).all() and not ct.any() and not ss.any()
