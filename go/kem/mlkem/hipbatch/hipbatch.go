@@ -93,6 +93,34 @@ func EncapsulateBatch(s kem.Scheme, eks, seeds []byte, device int) (cts, sss []b
 	return
 }
 
+// EncapsulateSharedKeyBatch is n times scheme.EncapsulateDeterministically on ONE public key (the cached-key case,
+// kem/mlkem/mlkem768/kyber.go:39-43): the device derives A^T and H(ek) once for the whole batch.
+func EncapsulateSharedKeyBatch(pk kem.PublicKey, seeds []byte, device int) (cts, sss []byte, err error) {
+	s := pk.Scheme()
+	p, ok := params[s.Name()]
+	if !ok {
+		return nil, nil, kem.ErrTypeMismatch
+	}
+	if len(seeds)%s.EncapsulationSeedSize() != 0 {
+		return nil, nil, kem.ErrSeedSize
+	}
+	n := len(seeds) / s.EncapsulationSeedSize()
+	ek, err := pk.MarshalBinary()
+	if err != nil {
+		return nil, nil, err
+	}
+	cts = make([]byte, n*s.CiphertextSize())
+	sss = make([]byte, n*s.SharedKeySize())
+	st := make([]byte, n)
+	if err = status(C.circl_hip_mlkem_encaps_shared(p, ptr(ek), ptr(seeds), ptr(cts), ptr(sss), ptr(st), C.size_t(n), C.int(device)), "encaps shared"); err != nil {
+		return nil, nil, err
+	}
+	if n > 0 && st[0] != 0 {
+		return nil, nil, itemErr(st[0])
+	}
+	return
+}
+
 // DecapsulateBatch is n times scheme.UnmarshalBinaryPrivateKey + scheme.Decapsulate
 // (kyber.go:398-407, :376-386).  An invalid ciphertext is not an error (implicit rejection).
 func DecapsulateBatch(s kem.Scheme, dks, cts []byte, device int) (sss []byte, errs []error, err error) {

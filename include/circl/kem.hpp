@@ -144,6 +144,17 @@ class Scheme {
             check(circl_hip_mlkem_encaps(param_, eks, seeds, cts, sss, status, n, device));
         }
     }
+    // n encapsulations to ONE key (the cached-key case of the reference, kem/mlkem/mlkem768/kyber.go:39-43)
+    void EncapsulateSharedKeyBatch(const PublicKey &pk, const uint8_t *seeds, uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
+        if (pk.scheme != this) throw ErrTypeMismatch();
+        if (r3_) {  // no shared-key fast path for round-3 Kyber: replicate the row
+            Bytes eks((size_t)PublicKeySize() * n);
+            for (size_t i = 0; i < n; i++) std::copy(pk.packed.begin(), pk.packed.end(), eks.begin() + (size_t)PublicKeySize() * i);
+            EncapsulateBatch(eks.data(), seeds, cts, sss, status, n);
+            return;
+        }
+        check(circl_hip_mlkem_encaps_shared(param_, pk.packed.data(), seeds, cts, sss, status, n, device));
+    }
     void DecapsulateBatch(const uint8_t *dks, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
         if (r3_) {
             check(circl_hip_kyber_decaps(param_, dks, cts, sss, n, device));

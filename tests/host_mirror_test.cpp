@@ -70,6 +70,12 @@ int main() {
         for (auto x : st) REQUIRE(x == 0);
         s->DecapsulateBatch(dks.data(), cts.data(), sss2.data(), st.data(), n);
         REQUIRE(sss == sss2);
+        // shared-key batch == the same key in every row
+        std::vector<uint8_t> eks1(n * s->PublicKeySize()), cts1(cts.size()), sss1(sss.size()), cts2(cts.size()), sss3(sss.size());
+        for (size_t i = 0; i < n; i++) std::copy(pk.packed.begin(), pk.packed.end(), eks1.begin() + i * s->PublicKeySize());
+        s->EncapsulateBatch(eks1.data(), ms.data(), cts1.data(), sss1.data(), st.data(), n);
+        s->EncapsulateSharedKeyBatch(pk, ms.data(), cts2.data(), sss3.data(), st.data(), n);
+        REQUIRE(cts1 == cts2 && sss1 == sss3);
     }
     REQUIRE(kem::ByName("FrodoKEM-640-SHAKE") == nullptr);
     for (const char *name : {"ML-DSA-44", "ML-DSA-65", "ML-DSA-87"}) {
