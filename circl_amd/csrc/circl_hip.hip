@@ -372,7 +372,7 @@ template <int MODE> size_t mldsa_item_ws_bytes(size_t n) {
     return up256(n * G::MUW1) + up256(n * circl::mldsa::kBallStateBytes) + up256(n);
 }
 template <int MODE> size_t mldsa_ws_bytes(size_t n) {
-    return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES;
+    return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES + 256;  // + tr of a shared key
 }
 template <class Kern> unsigned dsa_resident_blocks(Kern kern, int lds_bytes) {
     const unsigned occ = resident_blocks(kern, lds_bytes);  // cu_count * min(occupancy, kMaxBlocksPerCU)
@@ -396,11 +396,50 @@ int mldsa_verify_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         hipLaunchKernelGGL(circl::mldsa::mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob,
-                           ctx_off, internal, muw1, ball, fail, n);
+                           ctx_off, internal, muw1, ball, fail, n, (const uint8_t *)nullptr);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
         auto kern = circl::mldsa::mldsa_verify_kernel<MODE, 0>;
+        const unsigned vb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, G::LDS_V_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_final_kernel<MODE>, dim3(hb), dim3(256), 0, st, sig, (const uint8_t *)muw1,
+                           (const uint8_t *)fail, ok, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// Shared-key verification: n signatures under ONE public key (the reference's parsed-key case, where A and tr are
+// cached in the PublicKey object, internal/dilithium.go:114-126).  tr once per launch, ExpandA once per resident
+// workgroup; 9 lane-permutations per item remain (mu, SampleInBall, c').
+template <int MODE>
+int mldsa_verify_shared_dev_impl(const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                 const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
+                                 size_t ws_bytes, hipStream_t st) {
+    using G = circl::mldsa::DG<MODE>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < mldsa_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(pk)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *muw1 = static_cast<uint8_t *>(ws);
+    uint8_t *ball = muw1 + up256(n * G::MUW1);
+    uint8_t *fail = ball + up256(n * circl::mldsa::kBallStateBytes);
+    unsigned *work = reinterpret_cast<unsigned *>(muw1 + mldsa_item_ws_bytes<MODE>(n));
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
+    uint8_t *tr = scratch + mldsa_scratch_blocks<MODE>(n) * G::SCRATCH_BYTES;  // 64 bytes behind the scratch slices
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_tr_kernel<MODE>, dim3(1), dim3(64), 0, st, pk, tr);
+        hipLaunchKernelGGL(circl::mldsa::mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off,
+                           internal, muw1, ball, fail, n, (const uint8_t *)tr);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
+        auto kern = circl::mldsa::mldsa_verify_kernel<MODE, 0, true>;
         const unsigned vb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, G::LDS_V_TOTAL));
         hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n);
     }
@@ -457,13 +496,27 @@ int mldsa_verify_dev_any(int param, const uint8_t *pk, const uint8_t *sig, const
     }
     return CIRCL_HIP_EPARAM;
 }
+int mldsa_verify_shared_dev_any(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                         const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
+                         size_t wsb, hipStream_t st) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    switch (param) {
+    case 44: return mldsa_verify_shared_dev_impl<44>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 65: return mldsa_verify_shared_dev_impl<65>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 87: return mldsa_verify_shared_dev_impl<87>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 2: return mldsa_verify_shared_dev_impl<2>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 3: return mldsa_verify_shared_dev_impl<3>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    case 5: return mldsa_verify_shared_dev_impl<5>(pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
 
 // Host-buffer ML-DSA verify on one device: fixed-size rows are chunked like ML-KEM; the message /
 // context blobs of a chunk are copied as the byte range their offsets span and addressed through
 // rebased device pointers, so the kernels keep using the caller's absolute offsets.
 int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
                           const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok,
-                          size_t n) {
+                          size_t n, bool shared = false) {
     const size_t PK = circl_hip_mldsa_pk_size(param), SIG = circl_hip_mldsa_sig_size(param);
     if (n == 0) return CIRCL_HIP_OK;
     if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
@@ -476,13 +529,14 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *
         const size_t mlo = msg_off[done], mhi = msg_off[done + cnt];
         const size_t clo = ctx_blob ? ctx_off[done] : 0, chi = ctx_blob ? ctx_off[done + cnt] : 0;
         const size_t wsb = circl_hip_mldsa_workspace_size(param, cnt);
-        const size_t need = up256(cnt * PK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
+        const size_t npk = shared ? 1 : cnt;  // a shared-key batch stages its one public key per chunk
+        const size_t need = up256(npk * PK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
                             up256(chi - clo + 16) + up256(cnt) + wsb;
         int rc = arena_reserve(a, need);
         if (rc) return rc;
         hipStream_t st = a.st[0];
         uint8_t *p = static_cast<uint8_t *>(a.base);
-        uint8_t *d_pk = p; p += up256(cnt * PK);
+        uint8_t *d_pk = p; p += up256(npk * PK);
         uint8_t *d_sig = p; p += up256(cnt * SIG + 16);
         uint8_t *d_msg = p; p += up256(mhi - mlo + 16);
         uint64_t *d_moff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
@@ -490,7 +544,7 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *
         uint64_t *d_coff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
         uint8_t *d_ok = p; p += up256(cnt);
         uint8_t *d_ws = p;
-        HIP_TRY(hipMemcpyAsync(d_pk, pk + done * PK, cnt * PK, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_pk, shared ? pk : pk + done * PK, npk * PK, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_sig, sig + done * SIG, cnt * SIG, hipMemcpyHostToDevice, st));
         if (mhi > mlo) HIP_TRY(hipMemcpyAsync(d_msg, msg_blob + mlo, mhi - mlo, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_moff, msg_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
@@ -498,8 +552,8 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, const uint8_t *
             if (chi > clo) HIP_TRY(hipMemcpyAsync(d_ctx, ctx_blob + clo, chi - clo, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(d_coff, ctx_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
         }
-        rc = mldsa_verify_dev_any(param, d_pk, d_sig, d_msg - mlo, d_moff, ctx_blob ? d_ctx - clo : nullptr,
-                                  ctx_blob ? d_coff : nullptr, internal, d_ok, cnt, d_ws, wsb, st);
+        rc = (shared ? mldsa_verify_shared_dev_any : mldsa_verify_dev_any)(param, d_pk, d_sig, d_msg - mlo, d_moff, ctx_blob ? d_ctx - clo : nullptr,
+                                                                       ctx_blob ? d_coff : nullptr, internal, d_ok, cnt, d_ws, wsb, st);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(ok + done, d_ok, cnt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -975,6 +1029,22 @@ static int mldsa_verify_host(int param, const uint8_t *pk, const uint8_t *sig, c
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return mldsa_verify_host_one(param, dev, pk + lo * PK, sig + lo * SIG, msg_blob, msg_off + lo, ctx_blob,
                                      ctx_blob ? ctx_off + lo : nullptr, internal, ok + lo, cnt);
+    });
+}
+
+int circl_hip_mldsa_verify_shared_dev(int param, const uint8_t *d_pk, const uint8_t *d_sig, const uint8_t *d_msg_blob,
+                                      const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
+                                      size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    return mldsa_verify_shared_dev_any(param, d_pk, d_sig, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, 0, d_ok, n, d_ws, ws_bytes,
+                                       static_cast<hipStream_t>(stream));
+}
+int circl_hip_mldsa_verify_shared(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                  const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n, int device) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    if (!PK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return mldsa_verify_host_one(param, dev, pk, sig + lo * SIG, msg_blob, msg_off + lo, ctx_blob, ctx_blob ? ctx_off + lo : nullptr, 0,
+                                     ok + lo, cnt, true);
     });
 }
 

@@ -140,6 +140,14 @@ __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const
     }
 }
 
+// tr of the one public key of a shared-key batch (all lanes compute the same sponge)
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_tr_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ tr_out) {
+    KeccakState s;
+    sponge17_words<DG<MODE>::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk), kDsShake);
+    if (threadIdx.x == 0) store_words<0, 8>(reinterpret_cast<uint64_t *>(tr_out), s);
+}
+
 // ---- kernel P ---------------------------------------------------------------------------------
 
 template <int MODE>
@@ -147,19 +155,23 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                          int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
-                                                         uint8_t *__restrict__ fail_ws, size_t n) {
+                                                         uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState s;
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
-    // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125)
-    sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
+    // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125); shared-key batches bring it ready-made (mldsa_tr_kernel)
     KeccakState h;
     keccak_zero(h);
+    if (tr_shared) {  // kernel-uniform
+        xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(tr_shared));
+    } else {
+        sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
 #pragma unroll
-    for (int i = 0; i < P::TR / 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+        for (int i = 0; i < P::TR / 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+    }
     const uint8_t *mp = msg_blob + msg_off[idx];
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
@@ -263,12 +275,12 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
     });
 }
 
-template <int MODE, bool NOSTORE = false>
+template <int MODE, bool NOSTORE = false, int GA = DG<MODE>::IT>
 __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *rows, const uint8_t *__restrict__ rho, size_t rho_stride,
                                                  size_t item0, size_t n, int lane) {
     using G = DG<MODE>;
     constexpr int L = G::L;
-    const bool on = lane < G::IT * G::STREAMS;
+    const bool on = lane < GA * G::STREAMS;
     const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
     const int i = p / L, j = p % L;
     size_t item = item0 + g;
@@ -389,7 +401,9 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
 // bit 3 drops the row stores of phase A, bit 4 shrinks the row loads of phase 2 to one row (L2 hits).
 // `scratch` holds gridDim.x slices of DG::SCRATCH_BYTES; `work` is the ticket counter (zeroed by the host)
 // or nullptr for one group per workgroup.
-template <int MODE, int ABLATE = 0>
+// SHARED: every item is verified under the ONE public key at `pk` (the reference's cached-key case: A and tr live in
+// the parsed PublicKey, internal/dilithium.go:114-126): ExpandA runs once per workgroup before the group loop.
+template <int MODE, int ABLATE = 0, bool SHARED = false>
 __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig, uint8_t *__restrict__ muw1_ws,
                         const uint8_t *__restrict__ ball_ws, uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ scratch,
@@ -408,14 +422,21 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     const size_t ngroups = (n + G::IT - 1) / G::IT;
     constexpr int ZH_BYTES = L * G::ZSZ + P::OMEGA + K;
     static_assert(ZH_BYTES + 8 <= G::LDS_FIFO, "staged z || hint fits in the FIFO area");
+    constexpr size_t PK_STRIDE = SHARED ? 0 : G::PK;
+    if constexpr (SHARED) {
+        expand_a_scratch<MODE, false, 1>(smem, rows, pk, 0, 0, 1, lane);  // rows 0 .. K L - 1, once
+        rows_acquire();
+    }
 
 #pragma unroll 1
   for (size_t grp = mlkem::next_group(work, lane, true, ngroups); grp < ngroups; grp = mlkem::next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * G::IT;
-    // ------------------------------ phase A ------------------------------
-    __syncthreads();  // the previous group is done with the LDS the FIFOs alias
-    if (!(ABLATE & 1)) expand_a_scratch<MODE, (ABLATE & 8) != 0>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
-    rows_acquire();
+    if constexpr (!SHARED) {
+        // ------------------------------ phase A ------------------------------
+        __syncthreads();  // the previous group is done with the LDS the FIFOs alias
+        if (!(ABLATE & 1)) expand_a_scratch<MODE, (ABLATE & 8) != 0>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
+        rows_acquire();
+    }
 
 #pragma unroll 1
     for (int g = 0; g < G::IT; g++) {
@@ -487,12 +508,12 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
         for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
             uint32_t acc[4] = {0, 0, 0, 0};
-            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : g * G::STREAMS + i * L, zhat, lane);  // a * z-hat, < 2q each
+            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : (SHARED ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // a * z-hat, < 2q each
             uint32_t t[4], w[4];
             {
                 // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,
                 // fetched as two aligned dwords (the row is 4-byte aligned), then moved to the NTT's input layout
-                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + item * G::PK + 32 + 320 * i);
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + item * PK_STRIDE + 32 + 320 * i);
                 const int b = 5 * lane, d = b >> 2;
                 const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
 #pragma unroll

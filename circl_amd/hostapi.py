@@ -168,6 +168,24 @@ def mldsa_verify(param, pk, sig, msgs, ctxs=None, device=0):
     return ok
 
 
+def mldsa_verify_shared(param, pk, sig, msgs, ctxs=None, device=0):
+    """n signatures under ONE public key -> ok (n,)"""
+    PK, SIG = DSA_SIZES[param]
+    pk, sig = _u8(pk, PK), _u8(sig, SIG)
+    assert len(pk) == 1
+    n = len(sig)
+    assert len(msgs) == n
+    mb, mo = _blob(msgs)
+    ok = np.empty(n, np.uint8)
+    if ctxs is None:
+        rc = nat.lib().circl_hip_mldsa_verify_shared(param, _p(pk), _p(sig), _p(mb), _p(mo), None, None, _p(ok), n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_mldsa_verify_shared(param, _p(pk), _p(sig), _p(mb), _p(mo), _p(cb), _p(co), _p(ok), n, device)
+    nat.check(rc, "mldsa_verify_shared")
+    return ok
+
+
 def keccak_f1600(states, rounds=24, device=0):
     a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25).copy()
     nat.check(nat.lib().circl_hip_keccak_f1600(_p(a), len(a), rounds, device), "keccak_f1600")

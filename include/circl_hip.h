@@ -155,6 +155,17 @@ int circl_hip_mldsa_verify_dev(int param, const uint8_t *d_pk, const uint8_t *d_
                                const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
                                size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Shared-key verification: all n signatures are checked under the ONE public key at `pk` -- n times
+ * scheme.Verify(pk, msg_i, sig_i, opts_i) on one parsed key, where the reference caches A and tr in the PublicKey
+ * object (sign/mldsa/mldsa65/internal/dilithium.go:114-126).  Same results as circl_hip_mldsa_verify on n copies of pk. */
+int circl_hip_mldsa_verify_shared(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob,
+                                  const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
+                                  uint8_t *ok, size_t n, int device);
+int circl_hip_mldsa_verify_shared_dev(int param, const uint8_t *d_pk, const uint8_t *d_sig,
+                                      const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                                      const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
+                                      size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- ML-DSA key generation ----------------------------------------------------------------
  * scheme.DeriveKey(seed_i), seed 32 bytes (sign/mldsa/mldsa65/dilithium.go:272-281 ->
  * internal/dilithium.go:181-267 NewKeyFromSeed); keys in MarshalBinary form.  The _dev variant

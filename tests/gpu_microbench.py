@@ -91,6 +91,13 @@ def dsa(param, n, pool=1 << 11):
     want[bad] = 0
     good = bool((ok.cpu().numpy() == np.tile(want, reps)).all())
     print(f"ML-DSA-{param} verify  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   results as expected: {good}")
+    # shared key: the pool's first key for every item (signatures of other keys fail, the work is the same)
+    def run_shared():
+        rc = L.circl_hip_mldsa_verify_shared_dev(param, d_pk.data_ptr(), d_sig.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), None, None,
+                                                 ok.data_ptr(), n, ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+    ms = timeit(run_shared)
+    print(f"ML-DSA-{param} verify, shared key  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s")
     seeds = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).cuda()
     kpk = torch.empty((n, PK), dtype=torch.uint8, device="cuda")
     ksk = torch.empty((n, SK), dtype=torch.uint8, device="cuda")

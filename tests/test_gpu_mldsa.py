@@ -268,3 +268,25 @@ def test_round3_dilithium_matches_oracle_with_corruptions(param):
     ok = hostapi.mldsa_verify(param, pk, bad, msgs)
     assert ok.tolist() == orc.mldsa_verify(param, pk, bad, msgs).tolist()
     assert ok[[i for i in range(n) if i % 4]].all() and not ok[::4].any()
+
+
+# ---- shared-key verification (one public key for the batch: the reference's parsed-key case) ----
+
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+@pytest.mark.parametrize("n", [1, 5, 333])
+def test_verify_shared_key_matches_oracle(param, n):
+    rng = np.random.default_rng(param * 1000 + n)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (1, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = None if param < 10 else [rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sig = orc.mldsa_sign(param, np.tile(sk, (n, 1)), msgs, ctxs)
+    ct = {44: 32, 65: 48, 87: 64, 3: 32}[param]
+    for i in range(0, n, 3):
+        if (i // 3) % 2 == 0:
+            sig[i, ct + 10 + i % 200] ^= 0x10     # z
+        else:
+            msgs[i] = msgs[i] + b"!"
+    ok = hostapi.mldsa_verify_shared(param, pk, sig, msgs, ctxs)
+    want = orc.mldsa_verify(param, np.tile(pk, (n, 1)), sig, msgs, ctxs)
+    assert ok.tolist() == want.tolist()
+    assert ok[[i for i in range(n) if i % 3]].all() and not ok[::3].any()
