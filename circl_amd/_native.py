@@ -14,7 +14,7 @@ SYMBOLS = [
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
     "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
     "circl_hip_mldsa_keygen", "circl_hip_mldsa_keygen_dev",
-    "circl_hip_mldsa_sign", "circl_hip_mldsa_sign_internal", "circl_hip_mldsa_sign_workspace_size", "circl_hip_mldsa_sign_dev",
+    "circl_hip_mldsa_sign", "circl_hip_mldsa_sign_shared", "circl_hip_mldsa_sign_shared_dev", "circl_hip_mldsa_sign_internal", "circl_hip_mldsa_sign_workspace_size", "circl_hip_mldsa_sign_dev",
     "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
     "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
     "circl_hip_mlkem_keygen_dev",
@@ -99,6 +99,8 @@ def lib():
         L.circl_hip_mldsa_verify_shared.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_verify_shared_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_sign.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_sign_shared.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_sign_shared_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_sign_internal.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mldsa_sign_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_keygen.argtypes = [i, vp, vp, vp, sz, i]

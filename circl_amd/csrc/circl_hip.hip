@@ -579,12 +579,14 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
 // stream once per round to read the number of items that are still unsigned.
 template <int MODE>
 int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
-                       const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, hipStream_t st) {
+                       const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, hipStream_t st,
+                       bool shared) {
     using namespace circl::mldsa;
     using B = SB<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
     uint8_t *p = static_cast<uint8_t *>(ws);
     SignState S;
+    S.shared = shared ? 1u : 0u;
     S.mr = p; p += up256(128 * n);
     S.A = reinterpret_cast<uint32_t *>(p); p += n * B::A_BYTES;
     S.sec = reinterpret_cast<uint32_t *>(p); p += n * B::SEC_BYTES;
@@ -614,13 +616,14 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                           S.mr, n);
+                           S.mr, n, shared ? 1 : 0);
     }
     const uint32_t counts0[2] = {(uint32_t)n, 0};
     HIP_TRY(hipMemcpyAsync(S.count, counts0, 8, hipMemcpyHostToDevice, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((n * K * L + 255) / 256)), dim3(256), 0, st, sk, S, n);
+        const size_t nkeys = shared ? 1 : n;
+        hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n);
     }
     // The host needs the number of unsigned items only to size the next round's grids, and the kernels bound themselves
@@ -661,7 +664,7 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
             if (spec_w > 1) HIP_TRY(hipMemsetAsync(tail_best, 0xff, 4 * (size_t)upper, st));
             hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>((size_t)upper * spec_w, tail_units)), dim3(64),
                                SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[cur],
-                               (const uint32_t *)S.attempts, (size_t)upper, spec_w, tail_best, tail_spec);
+                               (const uint32_t *)S.attempts, (size_t)upper, spec_w, tail_best, tail_spec, shared ? 1 : 0);
             if (spec_w > 1)
                 hipLaunchKernelGGL(sign_tail_commit_kernel<MODE>, dim3(upper), dim3(64), 0, st, (const uint32_t *)S.list[cur],
                                    (const uint32_t *)S.attempts, (const uint32_t *)tail_best, (const uint8_t *)tail_spec, sig, spec_w);
@@ -694,12 +697,12 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
 template <int MODE>
 int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                         const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, bool shared = false) {
     using S = circl::mldsa::SG<MODE>;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < mldsa_sign_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(rnd) || rnd == nullptr)
         return CIRCL_HIP_EWORKSPACE;
-    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st);
+    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
     uint8_t *mr = static_cast<uint8_t *>(ws);
     unsigned *work = reinterpret_cast<unsigned *>(mr + up256(128 * n));
     uint8_t *scratch = mr + up256(128 * n) + 256;
@@ -707,7 +710,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         hipLaunchKernelGGL(circl::mldsa::mldsa_sign_prep_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sk, msg_blob,
-                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n);
+                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0);
     }
     {
         auto kern = circl::mldsa::mldsa_sign_kernel<MODE>;
@@ -717,7 +720,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         const unsigned blocks = (unsigned)std::min<size_t>(n, (size_t)cu_count() * occ);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -725,15 +728,15 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
 
 int mldsa_sign_dev_any(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                        const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, size_t wsb,
-                       hipStream_t st) {
+                       hipStream_t st, bool shared = false) {
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     switch (param) {
-    case 44: return mldsa_sign_dev_impl<44>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
-    case 65: return mldsa_sign_dev_impl<65>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
-    case 87: return mldsa_sign_dev_impl<87>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
-    case 2: return mldsa_sign_dev_impl<2>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
-    case 3: return mldsa_sign_dev_impl<3>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
-    case 5: return mldsa_sign_dev_impl<5>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st);
+    case 44: return mldsa_sign_dev_impl<44>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
+    case 65: return mldsa_sign_dev_impl<65>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
+    case 87: return mldsa_sign_dev_impl<87>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
+    case 2: return mldsa_sign_dev_impl<2>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
+    case 3: return mldsa_sign_dev_impl<3>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
+    case 5: return mldsa_sign_dev_impl<5>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, wsb, st, shared);
     }
     return CIRCL_HIP_EPARAM;
 }
@@ -752,7 +755,8 @@ size_t mldsa_sign_ws_any(int param, size_t n) {
 
 // Host-buffer sign on one device (same blob handling as mldsa_verify_host_one).
 int mldsa_sign_host_one(int param, int dev, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
-                        const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n) {
+                        const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n,
+                        bool shared = false) {
     const size_t SK = circl_hip_mldsa_sk_size(param), SIG = circl_hip_mldsa_sig_size(param);
     if (n == 0) return CIRCL_HIP_OK;
     if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
@@ -765,13 +769,14 @@ int mldsa_sign_host_one(int param, int dev, const uint8_t *sk, const uint8_t *ms
         const size_t mlo = msg_off[done], mhi = msg_off[done + cnt];
         const size_t clo = ctx_blob ? ctx_off[done] : 0, chi = ctx_blob ? ctx_off[done + cnt] : 0;
         const size_t wsb = mldsa_sign_ws_any(param, cnt);
-        const size_t need = up256(cnt * SK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
+        const size_t nsk = shared ? 1 : cnt;  // a shared-key batch stages its one private key per chunk
+        const size_t need = up256(nsk * SK) + up256(cnt * SIG + 16) + up256(mhi - mlo + 16) + 2 * up256((cnt + 1) * 8) +
                             up256(chi - clo + 16) + up256(cnt * 32) + wsb;
         int rc = arena_reserve(a, need);
         if (rc) return rc;
         hipStream_t st = a.st[0];
         uint8_t *p = static_cast<uint8_t *>(a.base);
-        uint8_t *d_sk = p; p += up256(cnt * SK);
+        uint8_t *d_sk = p; p += up256(nsk * SK);
         uint8_t *d_sig = p; p += up256(cnt * SIG + 16);
         uint8_t *d_msg = p; p += up256(mhi - mlo + 16);
         uint64_t *d_moff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
@@ -779,7 +784,7 @@ int mldsa_sign_host_one(int param, int dev, const uint8_t *sk, const uint8_t *ms
         uint64_t *d_coff = reinterpret_cast<uint64_t *>(p); p += up256((cnt + 1) * 8);
         uint8_t *d_rnd = p; p += up256(cnt * 32);
         uint8_t *d_ws = p;
-        HIP_TRY(hipMemcpyAsync(d_sk, sk + done * SK, cnt * SK, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_sk, shared ? sk : sk + done * SK, nsk * SK, hipMemcpyHostToDevice, st));
         if (mhi > mlo) HIP_TRY(hipMemcpyAsync(d_msg, msg_blob + mlo, mhi - mlo, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_moff, msg_off + done, (cnt + 1) * 8, hipMemcpyHostToDevice, st));
         if (ctx_blob) {
@@ -789,7 +794,7 @@ int mldsa_sign_host_one(int param, int dev, const uint8_t *sk, const uint8_t *ms
         if (rnd) HIP_TRY(hipMemcpyAsync(d_rnd, rnd + done * 32, cnt * 32, hipMemcpyHostToDevice, st));
         else HIP_TRY(hipMemsetAsync(d_rnd, 0, cnt * 32, st));
         rc = mldsa_sign_dev_any(param, d_sk, d_msg - mlo, d_moff, ctx_blob ? d_ctx - clo : nullptr, ctx_blob ? d_coff : nullptr, d_rnd,
-                                internal, d_sig, cnt, d_ws, wsb, st);
+                                internal, d_sig, cnt, d_ws, wsb, st, shared);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(sig + done * SIG, d_sig, cnt * SIG, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1095,21 +1100,32 @@ int circl_hip_mldsa_sign_dev(int param, const uint8_t *d_sk, const uint8_t *d_ms
 }
 
 static int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
-                           const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, int device) {
+                           const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, int device, bool shared = false) {
     const size_t SK = circl_hip_mldsa_sk_size(param), SIG = circl_hip_mldsa_sig_size(param);
     if (!SK) return CIRCL_HIP_EPARAM;
     if (ctx_blob)
         for (size_t i = 0; i < n; i++)
             if (ctx_off[i + 1] - ctx_off[i] > 255) return CIRCL_HIP_EPARAM;  // sign.ErrContextTooLong
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return mldsa_sign_host_one(param, dev, sk + lo * SK, msg_blob, msg_off + lo, ctx_blob, ctx_blob ? ctx_off + lo : nullptr,
-                                   rnd ? rnd + lo * 32 : nullptr, internal, sig + lo * SIG, cnt);
+        return mldsa_sign_host_one(param, dev, shared ? sk : sk + lo * SK, msg_blob, msg_off + lo, ctx_blob, ctx_blob ? ctx_off + lo : nullptr,
+                                   rnd ? rnd + lo * 32 : nullptr, internal, sig + lo * SIG, cnt, shared);
     });
 }
 
 int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                          const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n, int device) {
     return mldsa_sign_host(param, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, 0, sig, n, device);
+}
+
+int circl_hip_mldsa_sign_shared(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                                const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n, int device) {
+    return mldsa_sign_host(param, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, 0, sig, n, device, true);
+}
+int circl_hip_mldsa_sign_shared_dev(int param, const uint8_t *d_sk, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                                    const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig,
+                                    size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    return mldsa_sign_dev_any(param, d_sk, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, d_rnd, internal, d_sig, n, d_ws, ws_bytes,
+                              static_cast<hipStream_t>(stream), true);
 }
 
 int circl_hip_mldsa_sign_internal(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *rnd,

@@ -773,13 +773,13 @@ template <int MODE>
 __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ msg_blob,
                                                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
-                                                              int internal, uint8_t *__restrict__ mr_ws, size_t n) {
+                                                              int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
-    const uint8_t *skp = sk + idx * Kg::SK;
+    const uint8_t *skp = sk + (shared_key ? 0 : idx) * Kg::SK;
     KeccakState h;
     keccak_zero(h);
     xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(skp + 64));  // tr
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                                                        uint8_t *__restrict__ sig, uint8_t *__restrict__ scratch,
                                                        unsigned *__restrict__ work, const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ attempts, size_t n, unsigned spec_w,
-                                                       uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig) {
+                                                       uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig, int shared_key) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
         const size_t t = u / spec_w;
         const unsigned spec_class = (unsigned)(u % spec_w);
         const size_t item = list ? list[t] : t;
-        const uint8_t *skp = sk + item * Kg::SK;
+        const uint8_t *skp = sk + (shared_key ? 0 : item) * Kg::SK;
         const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
         __syncthreads();
         // ---- setup 1: ExpandA(rho) into the scratch, lane = (i, j) ----

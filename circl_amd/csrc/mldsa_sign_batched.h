@@ -46,6 +46,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint8_t *done;          // n
     uint32_t *list[2];      // active lists
     uint32_t *count;        // [0], [1]: list lengths
+    uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once)
 };
 
 // ---- setup ---------------------------------------------------------------------------------------
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     uint32_t *sec = st.sec + item * (L + 2 * K) * 256;
 #pragma unroll 1
-    for (int k = 0; k < L + 2 * K; k++) {
+    for (int k = 0; k < ((st.shared && item) ? 0 : L + 2 * K); k++) {  // shared key: workgroup 0 transforms the one key
         uint32_t c[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
 #pragma unroll
         for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);
     }
-    const uint32_t *arows = st.A + item * K * L * 256;
+    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * 256;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
         uint32_t w[4] = {0, 0, 0, 0};
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
     const uint8_t *cb = st.cb + item * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
-    const uint32_t *sec = st.sec + item * (L + 2 * K) * 256;
+    const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * 256;
     uint32_t *w0 = st.w0 + item * K * 256;
     auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
         const uint4 sv = *reinterpret_cast<const uint4 *>(row + 4 * lane);

@@ -142,6 +142,24 @@ def mldsa_sign(param, sk, msgs, ctxs=None, rnd=None, internal=False, device=0):
     return sig
 
 
+def mldsa_sign_shared(param, sk, msgs, ctxs=None, rnd=None, device=0):
+    """n messages signed with ONE private key -> (n, SIG)"""
+    _, SIG = DSA_SIZES[param]
+    sk = _u8(sk, DSA_SK_SIZES[param])
+    assert len(sk) == 1
+    n = len(msgs)
+    mb, mo = _blob(msgs)
+    sig = np.empty((n, SIG), np.uint8)
+    r = None if rnd is None else _p(_u8(rnd, 32))
+    if ctxs is None:
+        rc = nat.lib().circl_hip_mldsa_sign_shared(param, _p(sk), _p(mb), _p(mo), None, None, r, _p(sig), n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_mldsa_sign_shared(param, _p(sk), _p(mb), _p(mo), _p(cb), _p(co), r, _p(sig), n, device)
+    nat.check(rc, "mldsa_sign_shared")
+    return sig
+
+
 def mldsa_verify_internal(param, pk, sig, msgs, device=0):
     PK, SIG = DSA_SIZES[param]
     pk, sig = _u8(pk, PK), _u8(sig, SIG)

@@ -111,6 +111,14 @@ class Scheme {
     }
 
     // rnd = n x 32 random bytes (hedged signing) or nullptr (deterministic)
+    // n messages signed with ONE private key (the parsed-key case: A and the NTT-domain secrets cached, internal/dilithium.go:149-179)
+    void SignSharedKeyBatch(const PrivateKey &sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                            const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, size_t n) const {
+        if (sk.scheme != this) throw ErrTypeMismatch();
+        const int rc = circl_hip_mldsa_sign_shared(param_, sk.packed.data(), msg_blob, msg_off, ctx_blob, ctx_off, rnd, sigs, n, device);
+        if (rc == CIRCL_HIP_EPARAM) throw ErrContextTooLong();
+        if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
+    }
     // n signatures under ONE public key (the parsed-key case: A and tr cached, internal/dilithium.go:114-126)
     void VerifySharedKeyBatch(const PublicKey &pk, const uint8_t *sigs, const uint8_t *msg_blob, const uint64_t *msg_off,
                               const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n) const {

@@ -192,6 +192,16 @@ int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, 
 int circl_hip_mldsa_sign_internal(int param, const uint8_t *sk, const uint8_t *msg_blob,
                                   const uint64_t *msg_off, const uint8_t *rnd, uint8_t *sig, size_t n,
                                   int device);
+/* Shared-key signing: all n messages are signed with the ONE private key at `sk` -- n times scheme.Sign(sk, msg_i, opts_i)
+ * on one parsed key, where the reference caches A and the NTT-domain secrets in the PrivateKey
+ * (sign/mldsa/mldsa65/internal/dilithium.go:149-179).  Same signatures as circl_hip_mldsa_sign on n copies of sk. */
+int circl_hip_mldsa_sign_shared(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig,
+                                size_t n, int device);
+int circl_hip_mldsa_sign_shared_dev(int param, const uint8_t *d_sk, const uint8_t *d_msg_blob,
+                                    const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off,
+                                    const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n, void *d_workspace,
+                                    size_t workspace_bytes, void *stream);
 size_t circl_hip_mldsa_sign_workspace_size(int param, size_t n);
 int circl_hip_mldsa_sign_dev(int param, const uint8_t *d_sk, const uint8_t *d_msg_blob,
                              const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off,

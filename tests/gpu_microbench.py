@@ -121,6 +121,13 @@ def dsa(param, n, pool=1 << 11):
     ms = timeit(sg, 2)
     same = bool((ssig[:pool].cpu().numpy() == sig0[:min(pool, ns)]).all()) if ns >= pool else None
     print(f"ML-DSA-{param} sign    n={ns}: {ms:8.3f} ms -> {ns / ms * 1e3:.3e}/s   equals oracle signatures: {same}")
+
+    def sg_shared():
+        rc = L.circl_hip_mldsa_sign_shared_dev(param, d_sk.data_ptr(), d_msg.data_ptr(), d_off.data_ptr(), None, None, d_rnd.data_ptr(), 0,
+                                               ssig.data_ptr(), ns, sws.data_ptr(), swsb, st)
+        assert rc == 0, rc
+    ms = timeit(sg_shared, 2)
+    print(f"ML-DSA-{param} sign, shared key  n={ns}: {ms:8.3f} ms -> {ns / ms * 1e3:.3e}/s")
     cdev.profile_enable(True)
     run(); torch.cuda.synchronize()
     cdev.profile_enable(False)

@@ -290,3 +290,18 @@ def test_verify_shared_key_matches_oracle(param, n):
     want = orc.mldsa_verify(param, np.tile(pk, (n, 1)), sig, msgs, ctxs)
     assert ok.tolist() == want.tolist()
     assert ok[[i for i in range(n) if i % 3]].all() and not ok[::3].any()
+
+
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+@pytest.mark.parametrize("n", [1, 5, 40, 700])
+def test_sign_shared_key_matches_oracle(param, n):
+    # n < 16 takes the persistent kernel, larger batches the phase-split path with its speculative tail
+    rng = np.random.default_rng(param * 77 + n)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (1, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 120)), dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = None if param < 10 else [rng.integers(0, 256, int(rng.integers(0, 20)), dtype=np.uint8).tobytes() for _ in range(n)]
+    rnd = None if param < 10 else rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sig = hostapi.mldsa_sign_shared(param, sk, msgs, ctxs, rnd)
+    want = orc.mldsa_sign(param, np.tile(sk, (n, 1)), msgs, ctxs, rnd)
+    assert (sig == want).all()
+    assert hostapi.mldsa_verify_shared(param, pk, sig, msgs, ctxs).all()
