@@ -18,7 +18,7 @@ SYMBOLS = [
     "circl_hip_mlkem_encaps", "circl_hip_mlkem_decaps", "circl_hip_mlkem_keygen",
     "circl_hip_mlkem_workspace_size", "circl_hip_mlkem_encaps_dev", "circl_hip_mlkem_decaps_dev",
     "circl_hip_mlkem_keygen_dev",
-    "circl_hip_mlkem_encaps_shared", "circl_hip_mlkem_encaps_shared_dev",
+    "circl_hip_mlkem_encaps_shared", "circl_hip_mlkem_encaps_shared_dev", "circl_hip_mlkem_decaps_shared", "circl_hip_mlkem_decaps_shared_dev",
     "circl_hip_kyber_keygen", "circl_hip_kyber_encaps", "circl_hip_kyber_decaps",
     "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_shared", "circl_hip_mldsa_verify_shared_dev", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
@@ -89,6 +89,8 @@ def lib():
         L.circl_hip_mlkem_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_encaps_shared.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
         L.circl_hip_mlkem_encaps_shared_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mlkem_decaps_shared.argtypes = [i, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_decaps_shared_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_kyber_keygen.argtypes = [i, vp, vp, vp, sz, i]
         L.circl_hip_kyber_encaps.argtypes = [i, vp, vp, vp, vp, sz, i]
         L.circl_hip_kyber_decaps.argtypes = [i, vp, vp, vp, sz, i]

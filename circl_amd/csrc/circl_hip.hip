@@ -184,6 +184,41 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
     return CIRCL_HIP_OK;
 }
 
+// Shared-key decapsulation: one dk for all n ciphertexts (the reference's parsed PrivateKey).  The key's hash check and
+// A^T happen once; per item: decrypt, G, J(z || ct) and the re-encryption's 2K+1 PRF streams (17 permutations).
+template <int K>
+int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t ws_bytes,
+                           hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    uint8_t *mprime = static_cast<uint8_t *>(ws), *r_ws = mprime + 32 * n, *kbar = mprime + 64 * n, *ssrej = mprime + 96 * n;
+    unsigned *work = reinterpret_cast<unsigned *>(mprime + up256(kKemWsPerItem * n));
+    uint8_t *key_status = reinterpret_cast<uint8_t *>(work) + 128;  // second half of the ticket-counter slot
+    uint8_t *scratch = mprime + up256(kKemWsPerItem * n) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)0, ct, mprime, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_dk_check_kernel<K>, dim3(1), dim3(64), 0, st, dk, key_status);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)0, ct, (const uint8_t *)mprime, kbar,
+                           r_ws, ssrej, status, n, (const uint8_t *)key_status);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        auto kern = circl::mlkem::mlkem_encrypt_kernel<K, circl::mlkem::REENCRYPT, 0, true, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, scratch, work, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
 // R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:156-197): no private-key check, K = KDF((ct' == ct ? K'' : z) || H(ct));
 // `status` may then be null (an n-byte slot of the workspace is used).
 template <int K, bool R3 = false>
@@ -200,7 +235,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     const unsigned hb = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, ct, mprime, n);
+        hipLaunchKernelGGL(circl::mlkem::mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)Gm::DK, ct, mprime, n);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -208,8 +243,8 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
             hipLaunchKernelGGL(circl::mlkem::kyber_r3_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (const uint8_t *)mprime, kbar, r_ws,
                                ssrej, status, n);
         else
-            hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, ct, (const uint8_t *)mprime, kbar, r_ws,
-                               ssrej, status, n);
+            hipLaunchKernelGGL(circl::mlkem::mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)Gm::DK, ct, (const uint8_t *)mprime,
+                               kbar, r_ws, ssrej, status, n, (const uint8_t *)nullptr);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -921,6 +956,34 @@ int circl_hip_mlkem_encaps_shared_dev(int param, const uint8_t *d_ek, const uint
     case 4: return encaps_shared_dev_impl<4>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
     }
     return CIRCL_HIP_EPARAM;
+}
+int circl_hip_mlkem_decaps_shared_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                      void *d_ws, size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (kem_k(param)) {
+    case 2: return decaps_shared_dev_impl<2>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 3: return decaps_shared_dev_impl<3>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    case 4: return decaps_shared_dev_impl<4>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st);
+    }
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_mlkem_decaps_shared(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        HIP_TRY(hipSetDevice(dev));
+        uint8_t *d_dk = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dk), up256(DK)));
+        int rc = hipMemcpy(d_dk, dk, DK, hipMemcpyHostToDevice) == hipSuccess ? CIRCL_HIP_OK : CIRCL_HIP_EHIP;
+        if (rc == CIRCL_HIP_OK)
+            rc = run_chunked(dev, cnt, {ct + lo * CT}, {CT}, {ss + lo * 32, status ? status + lo : nullptr}, {32, 1}, kKemWsPerItem,
+                             [&](std::vector<uint8_t *> &in, std::vector<uint8_t *> &out, size_t c, uint8_t *ws, size_t wsb, hipStream_t st) {
+                                 return circl_hip_mlkem_decaps_shared_dev(param, d_dk, in[0], out[0], out[1], c, ws, wsb, st);
+                             }, 256 + max_resident_blocks() * 64 * 512);
+        (void)hipFree(d_dk);
+        return rc;
+    });
 }
 int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
                                   int device) {

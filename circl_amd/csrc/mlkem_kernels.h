@@ -141,6 +141,18 @@ __global__ void __launch_bounds__(256) mlkem_hash_kernel(const uint8_t *__restri
     }
 }
 
+// ---- shared-key decapsulation: the private key's hash check (kyber.go:219-228), once -------------------
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_dk_check_kernel(const uint8_t *__restrict__ dk, uint8_t *__restrict__ key_status) {
+    KeccakState h;
+    sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(dk + 384 * K));
+    const uint64_t *stored = reinterpret_cast<const uint64_t *>(dk + 768 * K + 32);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
+    if (threadIdx.x == 0) *key_status = ok ? 0 : 2;
+}
+
 // ---- shared-key encapsulation: H(ek) once, then (K, r) = G(m || H(ek)) per item ------------------
 
 template <int K>
@@ -724,8 +736,8 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1, ENCAPS_LENIENT = 2 };
 // SCRATCH selects where the sampled matrix lives between phase A and phase C: the workgroup's slice of
 // a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
 // or LDS (one group per workgroup; kept for A/B measurements).
-// SHARED (ENCAPS, scratch variant only): every item uses the key at `ek` (ek_stride = 0); A^T is sampled once per
-// workgroup before the group loop and groups are GS items.
+// SHARED (ENCAPS / REENCRYPT, scratch variant only): every item uses the key at `ek` (ek_stride = 0); A^T is sampled
+// once per workgroup before the group loop and groups are GS items.
 template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true, bool SHARED = false>
 __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
@@ -737,7 +749,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
-    static_assert(!SHARED || (SCRATCH && MODE == ENCAPS && ABLATE == 0), "shared-key mode");
+    static_assert(!SHARED || (SCRATCH && (MODE == ENCAPS || MODE == REENCRYPT) && ABLATE == 0), "shared-key mode");
     int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE));
     int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
@@ -895,14 +907,14 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 
 // K-PKE.Decrypt (cpapke.go:113-130), one item per single-wave workgroup: m' -> workspace.
 template <int K>
-__global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, const uint8_t *__restrict__ ct,
+__global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
                                                           uint8_t *__restrict__ mprime_ws, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
     __shared__ __attribute__((aligned(16))) int16_t xch[256];
     const int lane = threadIdx.x;
     const size_t item = blockIdx.x;
-    const uint8_t *dkp = dk + item * Gm::DK;
+    const uint8_t *dkp = dk + item * dk_stride;  // dk_stride = 0: one private key for the whole batch
     const uint8_t *ctp = ct + item * Gm::CT;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     int acc[4] = {0, 0, 0, 0};
@@ -937,21 +949,26 @@ __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__rest
 //   (K', r') = G(m' || hpk)   with hpk = the STORED hash (kyber.go:158-162 uses sk.hpk)
 //   ss_rej   = J(z || ct) = SHAKE256(z || ct)[:32]  (kyber.go:171-174)
 template <int K>
-__global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *__restrict__ dk, const uint8_t *__restrict__ ct,
+// Shared-key batches (dk_stride = 0) bring the verdict of the key's hash check in *key_status (mlkem_dk_check_kernel).
+__global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
                                                                 const uint8_t *__restrict__ mprime_ws, uint8_t *__restrict__ kbar_ws,
                                                                 uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ssrej_ws,
-                                                                uint8_t *__restrict__ status, size_t n) {
+                                                                uint8_t *__restrict__ status, size_t n, const uint8_t *__restrict__ key_status) {
     using Gm = Geom<K>;
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < n;
     if (!live) idx = n - 1;
-    const uint8_t *dkp = dk + idx * Gm::DK;
+    const uint8_t *dkp = dk + idx * dk_stride;
     const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
     KeccakState h, g;
-    sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(dkp + 384 * K));
     bool ok = true;
+    if (key_status) {  // kernel-uniform
+        ok = *key_status == 0;
+    } else {
+        sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(dkp + 384 * K));
 #pragma unroll
-    for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
+        for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
+    }
     // G(m' || stored hpk)
     keccak_zero(g);
     xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(mprime_ws + idx * 32));

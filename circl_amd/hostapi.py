@@ -70,6 +70,18 @@ def mlkem_encaps_shared(param, ek, m, device=0):
     return ct, ss, st
 
 
+def mlkem_decaps_shared(param, dk, ct, device=0):
+    """one private key for the whole batch -> ss, status"""
+    _, DK, CT = KEM_SIZES[param]
+    dk, ct = _u8(dk, DK), _u8(ct, CT)
+    assert len(dk) == 1
+    n = len(ct)
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_decaps_shared(param, _p(dk), _p(ct), _p(ss), _p(st), n, device), "mlkem_decaps_shared")
+    return ss, st
+
+
 # round-3 Kyber (kem/kyber/kyber{512,768,1024}): no per-item failures
 def kyber_keygen(param, seeds, device=0):
     EK, DK, _ = KEM_SIZES[param]

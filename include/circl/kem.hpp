@@ -155,6 +155,11 @@ class Scheme {
         }
         check(circl_hip_mlkem_encaps_shared(param_, pk.packed.data(), seeds, cts, sss, status, n, device));
     }
+    // n ciphertexts for ONE private key (ML-KEM only)
+    void DecapsulateSharedKeyBatch(const PrivateKey &sk, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
+        if (sk.scheme != this || r3_) throw ErrTypeMismatch();
+        check(circl_hip_mlkem_decaps_shared(param_, sk.packed.data(), cts, sss, status, n, device));
+    }
     void DecapsulateBatch(const uint8_t *dks, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
         if (r3_) {
             check(circl_hip_kyber_decaps(param_, dks, cts, sss, n, device));

@@ -102,6 +102,13 @@ int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m
 int circl_hip_mlkem_encaps_shared_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct,
                                       uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_workspace,
                                       size_t workspace_bytes, void *stream);
+/* Shared-key decapsulation: n ciphertexts for the ONE private key at `dk` (n times scheme.Decapsulate(sk, ct_i) on one
+ * parsed key).  status[i] = 2 (kem.ErrPrivKey) for every i if the key fails its hash check. */
+int circl_hip_mlkem_decaps_shared(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                  size_t n, int device);
+int circl_hip_mlkem_decaps_shared_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss,
+                                      uint8_t *d_status, size_t n, void *d_workspace, size_t workspace_bytes,
+                                      void *stream);
 
 /* ---- round-3 Kyber ------------------------------------------------------
  * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in

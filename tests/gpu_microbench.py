@@ -57,6 +57,14 @@ def kem(param, n, pool=1 << 12):
     ms = timeit(lambda: eng.decaps(dk, ct, ss2))
     torch.cuda.synchronize()
     print(f"ML-KEM-{param} decaps  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   roundtrip ok: {bool((ss == ss2).all())}, status {int(eng.status.sum())}")
+    ss3 = torch.empty_like(ss2)
+
+    def dshared():
+        rc = L.circl_hip_mlkem_decaps_shared_dev(param, dk[:1].data_ptr(), ct_s.data_ptr(), ss3.data_ptr(), st1.data_ptr(), n, ws.data_ptr(), wsb, stream)
+        assert rc == 0, rc
+    ms = timeit(dshared)
+    torch.cuda.synchronize()
+    print(f"ML-KEM-{param} decaps, shared key  n={n}: {ms:8.3f} ms -> {n / ms * 1e3:.3e}/s   roundtrip ok: {bool((ss3 == ss_s).all())}")
     idx = rng.integers(0, n, 128)
     ek0, dk0 = orc.mlkem_keygen(param, seeds[idx].cpu().numpy())
     print("   keygen parity:", bool((ek0 == ek[idx].cpu().numpy()).all() and (dk0 == dk[idx].cpu().numpy()).all()))

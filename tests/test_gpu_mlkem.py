@@ -275,3 +275,22 @@ def test_encaps_shared_key_rejects_non_canonical_key():
     bad[0, 1] |= 0x0f          # first coefficient = 0xfff >= q  (cpapke.go:45-55)
     ct, ss, st = hostapi.mlkem_encaps_shared(768, bad, rng.integers(0, 256, (50, 32), dtype=np.uint8))
     assert (st == 1).all() and not ct.any() and not ss.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PARAMS))
+@pytest.mark.parametrize("n", [1, 10, 2051])
+def test_decaps_shared_key_matches_oracle(name, n):
+    p = PARAMS[name]
+    rng = np.random.default_rng(n * 3 + p)
+    ek, dk = orc.mlkem_keygen(p, rng.integers(0, 256, (1, 64), dtype=np.uint8))
+    ct, ss, _ = orc.mlkem_encaps(p, np.tile(ek, (n, 1)), rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    ct[::3, 9] ^= 2                                  # implicit rejection for every third item
+    got, st = hostapi.mlkem_decaps_shared(p, dk, ct)
+    want, st0 = orc.mlkem_decaps(p, np.tile(dk, (n, 1)), ct)
+    assert (st == 0).all() and (got == want).all()
+    assert (got[1::3] == ss[1::3]).all()
+    bad = dk.copy()
+    bad[0, -40] ^= 1                                 # stored H(ek) no longer matches: kem.ErrPrivKey for the whole batch
+    got, st = hostapi.mlkem_decaps_shared(p, bad, ct)
+    assert (st == 2).all() and not got.any()
