@@ -47,6 +47,16 @@ class MLKEMDevice:
         nat.check(rc, "mlkem_encaps_dev")
         return ct, ss, status
 
+    def encaps_shared(self, ek1, m, ct=None, ss=None, status=None):
+        """every item encapsulates to the one key ek1 (a single row)"""
+        ct = self.ct if ct is None else ct
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        rc = self.L.circl_hip_mlkem_encaps_shared_dev(self.param, _chk(ek1, self.EK), _chk(m, 32), _chk(ct, self.CT), _chk(ss, 32),
+                                                      _chk(status), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mlkem_encaps_shared_dev")
+        return ct, ss, status
+
     def decaps(self, dk, ct, ss=None, status=None):
         ss = self.ss if ss is None else ss
         status = self.status if status is None else status
