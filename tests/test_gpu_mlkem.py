@@ -294,3 +294,27 @@ def test_decaps_shared_key_matches_oracle(name, n):
     bad[0, -40] ^= 1                                 # stored H(ek) no longer matches: kem.ErrPrivKey for the whole batch
     got, st = hostapi.mlkem_decaps_shared(p, bad, ct)
     assert (st == 2).all() and not got.any()
+
+
+@pytest.mark.gpu
+def test_all_devices_sharding_gives_the_same_results():
+    # device = CIRCL_HIP_ALL_DEVICES (-1): contiguous split over every visible GPU, one host thread each, no collective
+    # (SURVEY 8e).  With one GPU it is a single shard; with more the outputs must still land in the caller's order.
+    from circl_amd import _native as nat
+    rng = np.random.default_rng(44)
+    n = 3001
+    seeds = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ek, dk = hostapi.mlkem_keygen(768, seeds, device=nat.ALL_DEVICES)
+    ek0, dk0 = orc.mlkem_keygen(768, seeds)
+    assert (ek == ek0).all() and (dk == dk0).all()
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct, ss, st = hostapi.mlkem_encaps(768, ek, m, device=nat.ALL_DEVICES)
+    ct0, ss0, _ = orc.mlkem_encaps(768, ek, m)
+    assert (st == 0).all() and (ct == ct0).all() and (ss == ss0).all()
+    ss2, st2 = hostapi.mlkem_decaps(768, dk, ct, device=nat.ALL_DEVICES)
+    assert (st2 == 0).all() and (ss2 == ss).all()
+    pk, sk = orc.mldsa_keygen(65, seeds[:200, :32])
+    msgs = [bytes([i % 256]) * (i % 50) for i in range(200)]
+    sig = hostapi.mldsa_sign(65, sk, msgs, device=nat.ALL_DEVICES)
+    assert (sig == orc.mldsa_sign(65, sk, msgs)).all()
+    assert hostapi.mldsa_verify(65, pk, sig, msgs, device=nat.ALL_DEVICES).all()
