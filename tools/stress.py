@@ -1,0 +1,53 @@
+"""Not a test: randomized soak of the batch paths against the oracle (run on the GPU box).  Looks for rare races
+(speculative signing tail, scratch-row reuse, ticket scheduling) by varying batch sizes and repeating."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from circl_amd import hostapi  # noqa: E402
+from oracle import orc  # noqa: E402
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
+it = 0
+while time.time() < t_end:
+    it += 1
+    p = int(rng.choice([512, 768, 1024]))
+    n = int(rng.choice([1, 2, 7, 63, 64, 65, 1000, 4097, 30000]))
+    seeds = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ek, dk = hostapi.mlkem_keygen(p, seeds)
+    ek0, dk0 = orc.mlkem_keygen(p, seeds)
+    assert (ek == ek0).all() and (dk == dk0).all(), ("kem keygen", p, n)
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct, ss, st = hostapi.mlkem_encaps(p, ek, m)
+    ct0, ss0, _ = orc.mlkem_encaps(p, ek, m)
+    assert (ct == ct0).all() and (ss == ss0).all() and not st.any(), ("encaps", p, n)
+    ct[:: 5, 3] ^= 1
+    ss2, st2 = hostapi.mlkem_decaps(p, dk, ct)
+    ss20, _ = orc.mlkem_decaps(p, dk, ct)
+    assert (ss2 == ss20).all(), ("decaps", p, n)
+    cts, sss, _ = hostapi.mlkem_encaps_shared(p, ek[:1], m)
+    ct1, ss1, _ = orc.mlkem_encaps(p, np.tile(ek[:1], (n, 1)), m)
+    assert (cts == ct1).all() and (sss == ss1).all(), ("encaps shared", p, n)
+    ssd, _ = hostapi.mlkem_decaps_shared(p, dk[:1], cts)
+    assert (ssd == sss).all(), ("decaps shared", p, n)
+
+    d = int(rng.choice([44, 65, 87, 2, 3, 5]))
+    n = int(rng.choice([1, 3, 15, 16, 17, 100, 513, 1025, 3000]))
+    s32 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = hostapi.mldsa_keygen(d, s32)
+    pk0, sk0 = orc.mldsa_keygen(d, s32)
+    assert (pk == pk0).all() and (sk == sk0).all(), ("dsa keygen", d, n)
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sig = hostapi.mldsa_sign(d, sk, msgs)
+    assert (sig == orc.mldsa_sign(d, sk, msgs)).all(), ("sign", d, n)
+    sig[:: 4, 40] ^= 8
+    ok = hostapi.mldsa_verify(d, pk, sig, msgs)
+    assert ok.tolist() == orc.mldsa_verify(d, pk, sig, msgs).tolist(), ("verify", d, n)
+    sg = hostapi.mldsa_sign_shared(d, sk[:1], msgs)
+    assert (sg == orc.mldsa_sign(d, np.tile(sk[:1], (n, 1)), msgs)).all(), ("sign shared", d, n)
+    assert hostapi.mldsa_verify_shared(d, pk[:1], sg, msgs).all(), ("verify shared", d, n)
+print("stress ok:", it, "iterations")
