@@ -249,7 +249,31 @@ template <int D> __device__ __forceinline__ uint32_t lds_bits(const uint32_t *p,
 // through a 16-slot LDS FIFO and leave four at a time, so that every global store is a full 16-byte
 // segment of the stream's row (row index = lane).  Branch-free acceptance: the candidate is stored at
 // slot cnt and cnt advances only if it is < q.
-template <bool TAIL, bool NOSTORE = false>
+// Polynomials that batch signing parks in HBM and re-reads in every rejection round (the matrix rows, the NTT-domain
+// secrets) are stored as 24-bit coefficients, 4 per 12 bytes in layout L4: 768 instead of 1024 bytes per polynomial
+// cuts a quarter of that path's HBM traffic (values are < 2^24: matrix coefficients < q, secrets folded).
+constexpr int kPackedRowDwords = 192;
+__device__ __forceinline__ void pack24(uint32_t (&w)[3], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    w[0] = c0 | (c1 << 24);
+    w[1] = (c1 >> 8) | (c2 << 16);
+    w[2] = (c2 >> 16) | (c3 << 8);
+}
+__device__ __forceinline__ void store_poly24(uint32_t *row, const uint32_t (&c)[4], int lane) {
+    uint32_t w[3];
+    pack24(w, c[0], c[1], c[2], c[3]);
+    uint32_t *p = row + 3 * lane;
+    p[0] = w[0]; p[1] = w[1]; p[2] = w[2];
+}
+__device__ __forceinline__ void load_poly24(uint32_t (&c)[4], const uint32_t *row, int lane) {
+    const uint32_t *p = row + 3 * lane;
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    c[0] = w0 & 0xffffffu;
+    c[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+    c[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
+    c[3] = w2 >> 8;
+}
+
+template <bool TAIL, bool NOSTORE = false, bool PACK24 = false>
 __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_t *fifo, uint32_t *row, int &cnt, int &flushed) {
     bool live = true;
     detail::static_for<0, 56>([&](auto ic) {
@@ -266,7 +290,12 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
                 if (cnt - flushed >= 4) {  // at most 7 pending here, so one flush per check suffices
                     const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 15));
                     if constexpr (NOSTORE) { if (d.x == 0x7fffffffu) row[0] = d.y; }  // profiling aid: keep the LDS read, drop the store
-                    else *reinterpret_cast<uint4 *>(row + flushed) = d;
+                    else if constexpr (PACK24) {
+                        uint32_t w[3];
+                        pack24(w, d.x, d.y, d.z, d.w);
+                        uint32_t *p = row + 3 * (flushed >> 2);
+                        p[0] = w[0]; p[1] = w[1]; p[2] = w[2];
+                    } else *reinterpret_cast<uint4 *>(row + flushed) = d;
                     flushed += 4;
                 }
                 if constexpr (TAIL) live = __any(flushed < 256);  // wave-uniform

@@ -22,8 +22,8 @@ template <int MODE> struct SB {
     using P = DP<MODE>;
     using Kg = KG<MODE>;
     static constexpr int K = P::K, L = P::L;
-    static constexpr size_t A_BYTES = (size_t)K * L * 1024;
-    static constexpr size_t SEC_BYTES = (size_t)(L + 2 * K) * 1024;
+    static constexpr size_t A_BYTES = (size_t)K * L * kPackedRowDwords * 4;          // 24-bit packed rows (pack24)
+    static constexpr size_t SEC_BYTES = (size_t)(L + 2 * K) * kPackedRowDwords * 4;
     static constexpr size_t Y_BYTES = (size_t)L * (G::ZSZ + 64);   // ZSZ payload + slack, per polynomial
     static constexpr int YROW_DW = (G::ZSZ + 64) / 4;
     static constexpr size_t W0_BYTES = (size_t)K * 1024;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__res
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(sk + item * Kg::SK));
     s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
-    uint32_t *row = st.A + (item * K * L + p) * 256;
+    uint32_t *row = st.A + (item * K * L + p) * kPackedRowDwords;
     // accepted coefficients leave through a per-lane 16-slot LDS FIFO, four at a time (16-byte stores), with the
     // branch-free acceptance of the verify kernel's ExpandA (parse23_block_fifo)
     __shared__ __attribute__((aligned(16))) uint8_t fifo_lds[256 * DG<MODE>::FIFO_STRIDE];
@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__res
 #pragma unroll 1
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(s);
-        if (on) parse23_block_fifo<false>(s, fifo, row, cnt, flushed);
+        if (on) parse23_block_fifo<false, false, true>(s, fifo, row, cnt, flushed);
     }
 #pragma unroll 1
     while (__any(flushed < 256)) {
         keccak_f1600(s);
-        parse23_block_fifo<true>(s, fifo, row, cnt, flushed);
+        parse23_block_fifo<true, false, true>(s, fifo, row, cnt, flushed);
     }
 }
 
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
     const size_t item = blockIdx.x;
     const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(sk + item * Kg::SK);
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
-    uint32_t *sec = st.sec + item * (L + 2 * K) * 256;
+    uint32_t *sec = st.sec + item * (L + 2 * K) * kPackedRowDwords;
 #pragma unroll 1
     for (int k = 0; k < ((st.shared && item) ? 0 : L + 2 * K); k++) {  // shared key: workgroup 0 transforms the one key
         uint32_t c[4];
@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
             c[r] = v < 0 ? Q + v : (uint32_t)v;
         }
         dilithium::ntt(c, z, xch, lane);
-        *reinterpret_cast<uint4 *>(sec + k * 256 + 4 * lane) =
-            make_uint4(dilithium::fold(c[0]), dilithium::fold(c[1]), dilithium::fold(c[2]), dilithium::fold(c[3]));
+        const uint32_t f[4] = {dilithium::fold(c[0]), dilithium::fold(c[1]), dilithium::fold(c[2]), dilithium::fold(c[3])};  // < 2^24
+        store_poly24(sec + k * kPackedRowDwords, f, lane);
     }
     if (lane == 0) {
         st.attempts[item] = 0;
@@ -180,17 +180,16 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
 #pragma unroll
         for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);
     }
-    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * 256;
+    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < L; j++) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * 256 + 4 * lane);
-            w[0] += dilithium::mont32(a.x, yh[j][0]);
-            w[1] += dilithium::mont32(a.y, yh[j][1]);
-            w[2] += dilithium::mont32(a.z, yh[j][2]);
-            w[3] += dilithium::mont32(a.w, yh[j][3]);
+            uint32_t a[4];
+            load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] += dilithium::mont32(a[r], yh[j][r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
@@ -251,14 +250,13 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
     const uint8_t *cb = st.cb + item * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
-    const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * 256;
+    const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * kPackedRowDwords;
     uint32_t *w0 = st.w0 + item * K * 256;
     auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
-        const uint4 sv = *reinterpret_cast<const uint4 *>(row + 4 * lane);
-        t[0] = dilithium::fold(dilithium::mont32(sv.x, chat[0]));
-        t[1] = dilithium::fold(dilithium::mont32(sv.y, chat[1]));
-        t[2] = dilithium::fold(dilithium::mont32(sv.z, chat[2]));
-        t[3] = dilithium::fold(dilithium::mont32(sv.w, chat[3]));
+        uint32_t sv[4];
+        load_poly24(sv, row, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = dilithium::fold(dilithium::mont32(sv[r], chat[r]));
         dilithium::invntt(t, z, xch, lane);
     };
     bool bad = false;
@@ -266,7 +264,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
         uint32_t t[4];
-        mul_c(t, sec + (L + i) * 256);
+        mul_c(t, sec + (L + i) * kPackedRowDwords);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int nidx = kyber::idx_l1(lane, r);
@@ -281,7 +279,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
 #pragma unroll 1
         for (int l = 0; l < L; l++) {
             uint32_t t[4];
-            mul_c(t, sec + l * 256);
+            mul_c(t, sec + l * kPackedRowDwords);
             const uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
             unsigned fld[4];
 #pragma unroll
@@ -308,7 +306,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             uint32_t t[4];
-            mul_c(t, sec + (L + K + i) * 256);
+            mul_c(t, sec + (L + K + i) * kPackedRowDwords);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
