@@ -66,7 +66,7 @@ template <int MODE> struct DG {
     static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;  // phase A; afterwards the staged z || hint bytes
     static constexpr int LDS_HINT1 = K * 32;           // one item's hint bitmap
     static constexpr int LDS_V_TOTAL = LDS_FIFO + LDS_XCH + LDS_HINT1 + LDS_MISC;
-    static constexpr int SCRATCH_BYTES = 64 * 1024;    // 64 rows of 256 dwords per workgroup
+    static constexpr int SCRATCH_BYTES = 64 * 768;     // 64 rows of 256 24-bit coefficients per workgroup
 };
 
 #ifndef CIRCL_DSA_WAVES_PER_EU
@@ -320,18 +320,18 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
     s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
     uint32_t *fifo = reinterpret_cast<uint32_t *>(lds_fifo + lane * G::FIFO_STRIDE);
-    uint32_t *row = rows + lane * 256;
+    uint32_t *row = rows + lane * kPackedRowDwords;  // 24-bit packed rows (pack24)
     int cnt = on ? 0 : 256, flushed = cnt;
     // 256 coefficients need at least 5 blocks of 56 candidates; the acceptance rate is q / 2^23 = 0.999
 #pragma unroll 1
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(s);
-        if (on) parse23_block_fifo<false, NOSTORE>(s, fifo, row, cnt, flushed);
+        if (on) parse23_block_fifo<false, NOSTORE, true>(s, fifo, row, cnt, flushed);
     }
 #pragma unroll 1
     while (__any(flushed < 256)) {  // more than 24 rejections in 280 candidates: essentially never
         keccak_f1600(s);
-        parse23_block_fifo<true, NOSTORE>(s, fifo, row, cnt, flushed);
+        parse23_block_fifo<true, NOSTORE, true>(s, fifo, row, cnt, flushed);
     }
 }
 
@@ -339,8 +339,7 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
 // Plain loads, so that the compiler may batch and hoist them; the caller runs mlkem::rows_acquire() between
 // phase A and the first load so that no L1 line left over from the previous group's rows is hit.
 __device__ __forceinline__ void load_row_l4(uint32_t (&a)[4], const uint32_t *rows, int stream, int lane) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(rows + stream * 256 + 4 * lane);
-    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    load_poly24(a, rows + stream * kPackedRowDwords, lane);
 }
 // acc += sum_j A[stream0 + j] o vhat[j]: the rows are fetched four at a time ahead of the multiplies, so
 // that their L2 latencies overlap instead of adding up.
