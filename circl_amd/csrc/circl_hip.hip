@@ -388,7 +388,7 @@ template <class PerDevice> int shard(size_t n, int device, PerDevice fn) {
 
 // ---- device-resident ML-DSA verify ------------------------------------------------------------
 
-// ML-DSA verify / keygen workspace: per-item intermediates, the ticket counter, and one 64 KB scratch slice
+// ML-DSA verify / keygen workspace: per-item intermediates, the ticket counter, and one 48 KB scratch slice
 // (the sampled matrix rows) per resident workgroup of the persistent kernel.
 int dsa_blocks_per_cu() {
     static const int v = [] {

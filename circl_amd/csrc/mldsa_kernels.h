@@ -10,7 +10,7 @@
 //                             IT = 64 / (K L) items from a ticket counter:
 //    phase A  lane = (item, i, j): ExpandA stream SHAKE128(rho || j || i), 23-bit rejection
 //             (sample.go:92-123), accepted coefficients through a 16-slot LDS FIFO into the
-//             stream's 1 KB row of the workgroup's global scratch slice (L2 / Infinity Cache).
+//             stream's 768-byte row (24-bit coefficients) of the workgroup's global scratch slice (L2 / Infinity Cache).
 //    per item, one polynomial per wavefront, everything in registers:
 //    phase 1  decode z (norm check), z-hat[j] = NTT(z[j]), strict hint decoding,
 //             c-hat = NTT(SampleInBall(c~)).
