@@ -107,6 +107,23 @@ int main() {
         sg[sg.size() / 2] ^= 4;
         REQUIRE(!s->Verify(gpk, msg, sg, &ctx));
         REQUIRE(throws<sign::ErrContextTooLong>([&] { s->Sign(gsk, msg, &longctx); }));
+        {   // shared-key batches: 20 messages under the one key pair, same bytes as the one-by-one calls
+            const size_t nb = 20;
+            std::vector<uint8_t> blob;
+            std::vector<uint64_t> off{0};
+            for (size_t i = 0; i < nb; i++) { for (size_t k = 0; k < 5 + i; k++) blob.push_back((uint8_t)(i * 17 + k)); off.push_back(blob.size()); }
+            blob.resize(blob.size() + 16);
+            std::vector<uint8_t> sigs(nb * s->SignatureSize()), ok(nb);
+            s->SignSharedKeyBatch(gsk, blob.data(), off.data(), nullptr, nullptr, nullptr, sigs.data(), nb);
+            for (size_t i = 0; i < nb; i++) {
+                sign::Bytes mi(blob.begin() + off[i], blob.begin() + off[i + 1]);
+                sign::Bytes one = s->Sign(gsk, mi);
+                REQUIRE(std::equal(one.begin(), one.end(), sigs.begin() + i * s->SignatureSize()));
+            }
+            sigs[3 * s->SignatureSize() + 100] ^= 1;
+            s->VerifySharedKeyBatch(gpk, sigs.data(), blob.data(), off.data(), nullptr, nullptr, ok.data(), nb);
+            for (size_t i = 0; i < nb; i++) REQUIRE(ok[i] == (i == 3 ? 0 : 1));
+        }
         REQUIRE(throws<std::invalid_argument>([&] { s->DeriveKey(shortsig); }));
     }
     // round-3 Dilithium2/3/5 (sign/dilithium/mode{2,3,5}/dilithium.go:213-255): no context support
