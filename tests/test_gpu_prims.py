@@ -125,3 +125,41 @@ def test_k12_id_vectors_and_oracle():
     got = hostapi.k12(msgs, 64)
     for g, m in zip(got, msgs):
         assert g.tobytes() == ok12.k12(m, b"", 64)
+
+
+# ---- error behaviour of the C ABI on a GPU box ----
+
+@pytest.mark.gpu
+def test_abi_error_codes():
+    import ctypes as C
+    import torch
+    from circl_amd import _native as nat
+    L = nat.lib()
+    n = 64
+    ek = torch.zeros((n, 1184), dtype=torch.uint8, device="cuda")
+    m = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((n, 1088), dtype=torch.uint8, device="cuda")
+    ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wsb = L.circl_hip_mlkem_workspace_size(768, n)
+    ws = torch.empty(wsb + 64, dtype=torch.uint8, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda param, ekp, wsp, wsbytes: L.circl_hip_mlkem_encaps_dev(param, ekp, m.data_ptr(), ct.data_ptr(), ss.data_ptr(), st.data_ptr(), n, wsp, wsbytes, stream)
+    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb) == nat.OK
+    assert call(769, ek.data_ptr(), ws.data_ptr(), wsb) == nat.EPARAM                 # unknown parameter set
+    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb - 1) == nat.EWORKSPACE          # workspace too small
+    assert call(768, ek.data_ptr() + 1, ws.data_ptr(), wsb) == nat.EWORKSPACE          # misaligned input
+    assert call(768, ek.data_ptr(), ws.data_ptr() + 8, wsb) == nat.EWORKSPACE          # misaligned workspace
+    assert L.circl_hip_mlkem_workspace_size(100, n) == 0 and L.circl_hip_mldsa_workspace_size(1, n) == 0
+    assert L.circl_hip_mlkem_ek_size(5) == 0 and L.circl_hip_mldsa_sig_size(66) == 0
+    # host-buffer entry points: bad device index, unknown parameter set; n = 0 is a no-op
+    a = np.zeros((1, 1184), np.uint8)
+    b = np.zeros((1, 32), np.uint8)
+    c = np.zeros((1, 1088), np.uint8)
+    s1 = np.zeros(1, np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert L.circl_hip_mlkem_encaps(768, p(a), p(b), p(c), p(b), p(s1), 1, 99) == nat.ENODEV
+    assert L.circl_hip_mlkem_encaps(7, p(a), p(b), p(c), p(b), p(s1), 1, 0) == nat.EPARAM
+    assert L.circl_hip_mlkem_encaps(768, p(a), p(b), p(c), p(b), p(s1), 0, 0) == nat.OK
+    assert L.circl_hip_xof(100, 0x1f, 24, p(a), p(np.zeros(2, np.uint64)), p(c), 32, 1, 0) == nat.EPARAM   # not a sponge rate
+    torch.cuda.synchronize()
