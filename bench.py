@@ -80,8 +80,9 @@ def cpu_baseline(ek, m, budget_s=12.0):
     orc.mlkem_encaps(PARAM, ek_np[:sample], m_np[:sample], threads=cores)
     dt = time.perf_counter() - t
     return {"value": sample / dt, "unit": "encaps/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample} items of the same batch, {dt:.1f} s, oracle/liborc.so with {cores} pthreads "
-                      "(scalar C restatement of CIRCL's generic Go; Go toolchain absent, so not CIRCL's AVX2 path)"}
+            "sample": f"first {sample} items of the same batch, {dt:.1f} s, oracle/liborc.so with {cores} pthreads = the CPUs this "
+                      f"container may use (affinity {len(os.sched_getaffinity(0))}, capped by the cgroup CPU quota); scalar C "
+                      "restatement of CIRCL's generic Go (Go toolchain absent, so not CIRCL's AVX2 path)"}
 
 
 def load_traffic():

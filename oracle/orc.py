@@ -58,7 +58,23 @@ def _u8(x, shape=None):
 
 
 def ncpu():
-    return len(os.sched_getaffinity(0))
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that sees
+    256 hardware threads may be limited to 16 CPUs' worth of time; oversubscribing it makes the threaded oracle slower)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
 
 
 # ---------------- hashes ----------------
