@@ -22,7 +22,7 @@ for f in glob.glob("gpurun_out/sq/g*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "mlkem" not in k: continue
-        k = k.split("(")[0][:60]
+        k = k.split("(")[0][:90]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 import json
 out = {}
