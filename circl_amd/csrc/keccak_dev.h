@@ -61,29 +61,18 @@ struct KeccakState {
     RC(0x00000000, 0x0000800a) RC(0x80000000, 0x8000000a) RC(0x80000000, 0x80008081)               \
     RC(0x80000000, 0x00008080) RC(0x00000000, 0x80000001) RC(0x80000000, 0x80008008)
 
-#define RC(h, l) l,
-static __device__ __constant__ const uint32_t kRcLoDev[24] = {CIRCL_RC_LIST};
-static const uint32_t kRcLoHost[24] = {CIRCL_RC_LIST};
-#undef RC
-#define RC(h, l) h,
-static __device__ __constant__ const uint32_t kRcHiDev[24] = {CIRCL_RC_LIST};
-static const uint32_t kRcHiHost[24] = {CIRCL_RC_LIST};
-#undef RC
-
-CIRCL_HD uint32_t rc_lo(int r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return kRcLoDev[r];
-#else
-    return kRcLoHost[r];
-#endif
+// (lo, hi) pairs, plus a dummy 25th entry for the prefetch of keccak_f1600's last round.  A function-local constexpr
+// array becomes a private constant addressed pc-relative: a `__device__ __constant__` table is reached through the
+// GOT, and that pointer load was re-done every round (two dependent scalar loads in front of each round constant).
+struct RcPair {
+    uint32_t lo, hi;
+};
+#define RC(h, l) {l, h},
+CIRCL_HD RcPair rc_pair(int r) {
+    constexpr uint32_t t[25][2] = {CIRCL_RC_LIST{0, 0}};
+    return RcPair{t[r][0], t[r][1]};
 }
-CIRCL_HD uint32_t rc_hi(int r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return kRcHiDev[r];
-#else
-    return kRcHiHost[r];
-#endif
-}
+#undef RC
 
 namespace detail {
 template <int I> struct IC { static constexpr int v = I; };
@@ -116,8 +105,10 @@ template <int N> CIRCL_HD void rol64(uint32_t lo, uint32_t hi, uint32_t &olo, ui
 // (keccakf.go:20-24).  The round loop is NOT unrolled: one round is ~1.5 KB of code and every
 // inlined call site stays I-cache resident.
 CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
+    RcPair rc = rc_pair(first_round);
 #pragma unroll 1
     for (int r = first_round; r < 24; r++) {
+        const RcPair rc_next = rc_pair(r + 1);  // scalar load issued a whole round ahead of its use
         uint32_t cl[5], ch[5], rl[5], rh[5], bl[25], bh[25];
 #pragma unroll
         for (int x = 0; x < 5; x++) {
@@ -143,8 +134,9 @@ CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
                 s.lo[x + y] = bitop3_chi(bl[x + y], bl[(x + 1) % 5 + y], bl[(x + 2) % 5 + y]);
                 s.hi[x + y] = bitop3_chi(bh[x + y], bh[(x + 1) % 5 + y], bh[(x + 2) % 5 + y]);
             }
-        s.lo[0] ^= rc_lo(r);
-        s.hi[0] ^= rc_hi(r);
+        s.lo[0] ^= rc.lo;
+        s.hi[0] ^= rc.hi;
+        rc = rc_next;
     }
 }
 
