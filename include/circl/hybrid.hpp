@@ -54,12 +54,12 @@ inline void DeriveKeyPairBatch(const uint8_t *seeds, uint8_t *pks, uint8_t *sks,
     for (size_t i = 0; i < n; i++) std::memcpy(&seedm[64 * i], &ex[96 * i], 64);
     detail::check(circl_hip_mlkem_keygen(768, seedm.data(), ek.data(), dk.data(), n, device), "mlkem keygen");
     detail::x_private_keys(ex.data() + 64, 96, skx.data(), n, device);
-    for (size_t i = 0; i < n; i++) {
+    xwing::detail::parallel_for(n, [&](size_t i) {
         std::memcpy(pks + PublicKeySize * i, &ek[MlkemEk * i], MlkemEk);
         detail::x25519_public(pks + PublicKeySize * i + MlkemEk, &skx[32 * i]);
         std::memcpy(sks + PrivateKeySize * i, &dk[MlkemDk * i], MlkemDk);
         std::memcpy(sks + PrivateKeySize * i + MlkemDk, &skx[32 * i], 32);
-    }
+    });
 }
 
 // status[i]: ErrPubKey if the ML-KEM half fails the encapsulation-key check or the X25519 half is a low-order point
@@ -72,7 +72,7 @@ inline void EncapsulateBatch(const uint8_t *pks, const uint8_t *eseeds, uint8_t 
     }
     detail::check(circl_hip_mlkem_encaps(768, ek.data(), m.data(), ctm.data(), ssm.data(), st.data(), n, device), "mlkem encaps");
     detail::x_private_keys(ex.data() + 32, 64, skx.data(), n, device);
-    for (size_t i = 0; i < n; i++) {
+    xwing::detail::parallel_for(n, [&](size_t i) {
         uint8_t *ct = cts + CiphertextSize * i, *ss = sss + SharedKeySize * i;
         std::memcpy(ct, &ctm[MlkemCt * i], MlkemCt);
         detail::x25519_public(ct + MlkemCt, &skx[32 * i]);
@@ -81,7 +81,7 @@ inline void EncapsulateBatch(const uint8_t *pks, const uint8_t *eseeds, uint8_t 
         const uint8_t s = (st[i] || !ok) ? ErrPubKey : Ok;
         if (s) { std::memset(ct, 0, CiphertextSize); std::memset(ss, 0, SharedKeySize); }  // the reference returns nil, nil, err
         if (status) status[i] = s;
-    }
+    });
 }
 
 // status[i]: ErrPrivKey if the ML-KEM private key fails its hash check, ErrPubKey for a low-order X25519 ciphertext
@@ -92,14 +92,14 @@ inline void DecapsulateBatch(const uint8_t *sks, const uint8_t *cts, uint8_t *ss
         std::memcpy(&ctm[MlkemCt * i], cts + CiphertextSize * i, MlkemCt);
     }
     detail::check(circl_hip_mlkem_decaps(768, dk.data(), ctm.data(), ssm.data(), st.data(), n, device), "mlkem decaps");
-    for (size_t i = 0; i < n; i++) {
+    xwing::detail::parallel_for(n, [&](size_t i) {
         uint8_t *ss = sss + SharedKeySize * i;
         std::memcpy(ss, &ssm[32 * i], 32);
         const bool ok = detail::x25519_shared_checked(ss + 32, sks + PrivateKeySize * i + MlkemDk, cts + CiphertextSize * i + MlkemCt);
         const uint8_t s = st[i] ? ErrPrivKey : (!ok ? ErrPubKey : Ok);
         if (s) std::memset(ss, 0, SharedKeySize);
         if (status) status[i] = s;
-    }
+    });
 }
 
 // single-shot forms with the reference's signatures (kem.Scheme)

@@ -7,14 +7,17 @@
 //   combiner = SHA3-256(ss_M || ss_X || ct_X || pk_X || "\.//^\")    xwing.go:53-71
 // plus batch forms.  Division of labour as SURVEY.md prescribes: the GPU does the ML-KEM-768 half and every
 // Keccak (seed expansion with SHAKE256, the SHA3-256 combiner, both as batched sponges); the CPU does
-// X25519 (OpenSSL's EVP_PKEY_X25519 -- elliptic-curve arithmetic is out of scope for the GPU path).
+// X25519 (OpenSSL's EVP_PKEY_X25519 on all host cores -- elliptic-curve arithmetic is out of scope for the GPU path).
 // Link with -lcirclhip -lcrypto.
 #pragma once
 #include <openssl/evp.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -52,6 +55,30 @@ inline void x25519_shared(uint8_t out[32], const uint8_t priv[32], const uint8_t
     EVP_PKEY_free(p);
     EVP_PKEY_free(k);
 }
+// The per-item X25519 work of a batch, spread over the host's cores (OpenSSL's EVP calls are thread-safe on distinct
+// objects).  fn(i) for i in [0, n); the first exception thrown by any worker is rethrown on the caller's thread.
+template <class F> inline void parallel_for(size_t n, F fn) {
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthreads = std::min(hw, (n + 63) / 64);  // at least 64 items (a few milliseconds of X25519) per thread
+    if (nthreads <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> err(nthreads);
+    for (size_t t = 0; t < nthreads; t++) {
+        pool.emplace_back([&, t] {
+            try {
+                for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) fn(i);
+            } catch (...) {
+                err[t] = std::current_exception();
+            }
+        });
+    }
+    for (auto &th : pool) th.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
 }  // namespace detail
 
 // expands n 32-byte seeds: SHAKE256(seed) -> seedm[64] || skx[32]  (xwing.go:119-124), on the GPU
@@ -64,11 +91,11 @@ inline void DeriveKeyPairBatch(const uint8_t *seeds, uint8_t *sks, uint8_t *pks,
     expand_seeds(seeds, ex.data(), n, device);
     for (size_t i = 0; i < n; i++) std::memcpy(&seedm[64 * i], &ex[96 * i], 64);
     detail::check(circl_hip_mlkem_keygen(768, seedm.data(), ek.data(), dk.data(), n, device), "mlkem keygen");
-    for (size_t i = 0; i < n; i++) {
+    detail::parallel_for(n, [&](size_t i) {
         std::memcpy(sks + 32 * i, seeds + 32 * i, 32);                    // the packed private key is the seed
         std::memcpy(pks + PublicKeySize * i, &ek[MlkemEk * i], MlkemEk);
         detail::x25519_public(pks + PublicKeySize * i + MlkemEk, &ex[96 * i + 64]);
-    }
+    });
 }
 
 // status[i] != 0 -> kem.ErrPubKey (the ML-KEM half failed the encapsulation-key check, xwing.go:301-311)
@@ -79,7 +106,7 @@ inline void EncapsulateBatch(const uint8_t *pks, const uint8_t *eseeds, uint8_t 
         std::memcpy(&seedm[32 * i], eseeds + 64 * i, 32);
     }
     detail::check(circl_hip_mlkem_encaps(768, ek.data(), seedm.data(), ctm.data(), ssm.data(), st.data(), n, device), "mlkem encaps");
-    for (size_t i = 0; i < n; i++) {
+    detail::parallel_for(n, [&](size_t i) {
         const uint8_t *ekx = eseeds + 64 * i + 32, *pkx = pks + PublicKeySize * i + MlkemEk;
         uint8_t *c = &comb[134 * i], *ct = cts + CiphertextSize * i;
         std::memcpy(ct, &ctm[MlkemCt * i], MlkemCt);
@@ -90,7 +117,7 @@ inline void EncapsulateBatch(const uint8_t *pks, const uint8_t *eseeds, uint8_t 
         std::memcpy(c + 96, pkx, 32);
         std::memcpy(c + 128, "\\.//^\\", 6);
         if (status) status[i] = st[i];
-    }
+    });
     detail::check(circl_hip_shake(136, 0x06, comb.data(), 134, sss, 32, n, device), "sha3-256 combiner");
 }
 
@@ -103,7 +130,7 @@ inline void DecapsulateBatch(const uint8_t *cts, const uint8_t *sks, uint8_t *ss
     }
     detail::check(circl_hip_mlkem_keygen(768, seedm.data(), ek.data(), dk.data(), n, device), "mlkem keygen");
     detail::check(circl_hip_mlkem_decaps(768, dk.data(), ctm.data(), ssm.data(), st.data(), n, device), "mlkem decaps");
-    for (size_t i = 0; i < n; i++) {
+    detail::parallel_for(n, [&](size_t i) {
         const uint8_t *skx = &ex[96 * i + 64], *ctx = cts + CiphertextSize * i + MlkemCt;
         uint8_t *c = &comb[134 * i];
         std::memcpy(c, &ssm[32 * i], 32);
@@ -111,7 +138,7 @@ inline void DecapsulateBatch(const uint8_t *cts, const uint8_t *sks, uint8_t *ss
         std::memcpy(c + 64, ctx, 32);
         detail::x25519_public(c + 96, skx);                                // sk.xpk
         std::memcpy(c + 128, "\\.//^\\", 6);
-    }
+    });
     detail::check(circl_hip_shake(136, 0x06, comb.data(), 134, sss, 32, n, device), "sha3-256 combiner");
 }
 

@@ -59,7 +59,7 @@ int main(int argc, char **argv) {
         if (!a || !b) { std::printf("FAILED size checks\n"); return 1; }
     }
     // batch with one bad item in the middle
-    const size_t n = 33;
+    const size_t n = 333;  // several host threads for the X25519 half
     std::vector<uint8_t> seeds(H::SeedSize * n), es(H::EncapsulationSeedSize * n), pks(H::PublicKeySize * n), sks(H::PrivateKeySize * n),
         cts(H::CiphertextSize * n), s1(H::SharedKeySize * n), s2(H::SharedKeySize * n), st(n), st2(n);
     for (size_t i = 0; i < seeds.size(); i++) seeds[i] = (uint8_t)(i * 11 + 3);
@@ -72,6 +72,15 @@ int main(int argc, char **argv) {
         const bool bad = i == 16;
         if (st[i] != (bad ? H::ErrPubKey : H::Ok)) { std::printf("FAILED batch status %zu\n", i); return 1; }
         if (!bad && (st2[i] != 0 || !std::equal(s1.begin() + 64 * i, s1.begin() + 64 * i + 64, s2.begin() + 64 * i))) { std::printf("FAILED batch round trip %zu\n", i); return 1; }
+    }
+    for (size_t i : {size_t(0), size_t(200), n - 1}) {  // the batch forms equal the single-shot forms item by item
+        const H::Bytes sd(seeds.begin() + H::SeedSize * i, seeds.begin() + H::SeedSize * (i + 1)), e(es.begin() + H::EncapsulationSeedSize * i, es.begin() + H::EncapsulationSeedSize * (i + 1));
+        auto [pk1, sk1] = H::DeriveKeyPair(sd);
+        auto [ct1, ss1] = H::EncapsulateDeterministically(pk1, e);
+        if (!std::equal(pk1.begin(), pk1.end(), pks.begin() + H::PublicKeySize * i) || !std::equal(sk1.begin(), sk1.end(), sks.begin() + H::PrivateKeySize * i) ||
+            !std::equal(ct1.begin(), ct1.end(), cts.begin() + H::CiphertextSize * i) || !std::equal(ss1.begin(), ss1.end(), s1.begin() + H::SharedKeySize * i)) {
+            std::printf("FAILED batch item %zu differs from single-shot\n", i); return 1;
+        }
     }
     std::printf("OK\n");
     return 0;

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _build():
     out = os.path.join(ROOT, "build", "host_mirror_test")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_mirror_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_mirror_test.cpp"),
                            "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
@@ -20,7 +20,7 @@ def _build():
 def _build_xwing():
     out = os.path.join(ROOT, "build", "xwing_test")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "xwing_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "xwing_test.cpp"),
                            "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-lcrypto", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
@@ -56,7 +56,7 @@ def test_host_mirror_runs_like_schemes_test():
 def _build_hybrid():
     out = os.path.join(ROOT, "build", "hybrid_test")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "hybrid_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "hybrid_test.cpp"),
                            "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-lcrypto", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out

@@ -48,7 +48,7 @@ int main() {
     const std::string want = "1bcd0057d861d6b866239936cadcaeee1ec0164dedc181c386e9e54fe46156fe";  // xwing_test.go:80
     if (got != want) { std::printf("FAILED transcript %s != %s\n", got.c_str(), want.c_str()); return 1; }
     // batch round trip
-    const size_t n = 64;
+    const size_t n = 300;  // enough for the host-side X25519 loop to fan out over several threads
     std::vector<uint8_t> seeds(32 * n), es(64 * n), sks(32 * n), pks(xwing::PublicKeySize * n), ss1(32 * n), ss2(32 * n), cts(xwing::CiphertextSize * n), st(n);
     for (size_t i = 0; i < seeds.size(); i++) seeds[i] = (uint8_t)(i * 11 + 3);
     for (size_t i = 0; i < es.size(); i++) es[i] = (uint8_t)(i * 7 + 1);
@@ -56,6 +56,13 @@ int main() {
     xwing::EncapsulateBatch(pks.data(), es.data(), ss1.data(), cts.data(), st.data(), n);
     xwing::DecapsulateBatch(cts.data(), sks.data(), ss2.data(), n);
     if (ss1 != ss2) { std::printf("FAILED batch round trip\n"); return 1; }
+    for (size_t i : {size_t(0), size_t(77), n - 1}) {  // the batch forms equal the single-shot forms item by item
+        const xwing::Bytes seed(seeds.begin() + 32 * i, seeds.begin() + 32 * (i + 1)), e(es.begin() + 64 * i, es.begin() + 64 * (i + 1));
+        auto [sk1, pk1] = xwing::DeriveKeyPairPacked(seed);
+        auto [s1, c1] = xwing::Encapsulate(pk1, e);
+        if (!std::equal(pk1.begin(), pk1.end(), pks.begin() + xwing::PublicKeySize * i) || !std::equal(c1.begin(), c1.end(), cts.begin() + xwing::CiphertextSize * i) ||
+            !std::equal(s1.begin(), s1.end(), ss1.begin() + 32 * i)) { std::printf("FAILED batch item %zu differs from single-shot\n", i); return 1; }
+    }
     std::printf("OK\n");
     return 0;
 }
