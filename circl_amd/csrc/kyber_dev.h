@@ -247,6 +247,14 @@ CIRCL_HD void mulhat_finish(int (&acc)[4]) {
 CIRCL_HD int cbd2_from_nibble(unsigned t) {
     return (int)((t & 1) + ((t >> 1) & 1)) - (int)(((t >> 2) & 1) + ((t >> 3) & 1));
 }
+// The eta = 2 rule on a whole PRF word: every nibble t becomes cbd2(t) + 8 (a value in 6..10; (b0+b1) + 8 - (b2+b3)
+// cannot borrow from the next nibble).  The lane-per-stream PRF pass applies it to its output words -- eight
+// coefficients per instruction, 64 streams per wave -- so that the ring phase, where a wave-instruction covers only
+// 64 coefficients of ONE polynomial, is left with a bit-field extract and a subtraction per coefficient.
+CIRCL_HD uint32_t cbd2_bias8_word(uint32_t w) {
+    const uint32_t d = (w & 0x55555555u) + ((w >> 1) & 0x55555555u);
+    return ((d & 0x33333333u) | 0x88888888u) - ((d >> 2) & 0x33333333u);
+}
 CIRCL_HD int cbd3_from_6bits(unsigned t) {
     return (int)((t & 1) + ((t >> 1) & 1) + ((t >> 2) & 1)) - (int)(((t >> 3) & 1) + ((t >> 4) & 1) + ((t >> 5) & 1));
 }

@@ -358,6 +358,15 @@ __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t
     }
 }
 
+// First 128 bytes of a PRF block to the stream's LDS slot: as biased CBD nibbles for an eta = 2 stream, raw for eta = 3.
+template <bool ETA2> __device__ __forceinline__ void store_prf_words(uint32_t *out, const KeccakState &s) {
+    detail::static_for<0, 16>([&](auto ic) {
+        constexpr int w = decltype(ic)::v;
+        out[2 * w] = ETA2 ? kyber::cbd2_bias8_word(s.lo[w]) : s.lo[w];
+        out[2 * w + 1] = ETA2 ? kyber::cbd2_bias8_word(s.hi[w]) : s.hi[w];
+    });
+}
+
 // Phases A and B of the scratch variant in one routine, so that the stragglers of phase A can ride along
 // with phase B.  After three SHAKE128 blocks 0.83 % of the matrix streams are still a few coefficients
 // short; running a fourth 64-lane permutation for one or two of them costs 12 % of phase A.  The PRF pass
@@ -453,12 +462,11 @@ __device__ __forceinline__ void sample_matrix_and_prf(uint8_t *lds_fifo, uint8_t
         }
         keccak_f1600(s);
         uint32_t *out = reinterpret_cast<uint32_t *>(lds_noise + (on ? sidx : 0) * Gm::NOISE_STRIDE);
-        if (on) {
-            detail::static_for<0, 16>([&](auto ic) {
-                constexpr int w = decltype(ic)::v;
-                out[2 * w] = s.lo[w];
-                out[2 * w + 1] = s.hi[w];
-            });
+        if constexpr (Params<K>::ETA1 == 2) {
+            if (on) store_prf_words<true>(out, s);
+        } else {
+            if (on && nonce < ETA1_COUNT) store_prf_words<false>(out, s);
+            if (on && nonce >= ETA1_COUNT) store_prf_words<true>(out, s);
         }
         if constexpr (Params<K>::ETA1 == 3) {
             // 192 bytes needed for eta1 = 3 streams: word 16 of this block, then 7 more
@@ -543,12 +551,11 @@ __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *_
         s.hi[16] = 0x80000000u;
         keccak_f1600(s);
         uint32_t *out = reinterpret_cast<uint32_t *>(lds_noise + (on ? sidx : 0) * Gm::NOISE_STRIDE);
-        if (on) {
-            detail::static_for<0, 16>([&](auto ic) {
-                constexpr int w = decltype(ic)::v;
-                out[2 * w] = s.lo[w];
-                out[2 * w + 1] = s.hi[w];
-            });
+        if constexpr (Params<K>::ETA1 == 2) {
+            if (on) store_prf_words<true>(out, s);
+        } else {
+            if (on && nonce < ETA1_COUNT) store_prf_words<false>(out, s);
+            if (on && nonce >= ETA1_COUNT) store_prf_words<true>(out, s);
         }
         if constexpr (Params<K>::ETA1 == 3) {
             // 192 bytes needed for eta1 = 3 streams: word 16 of this block, then 7 more
@@ -569,10 +576,11 @@ __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *_
 
 // ---- phase C helpers -------------------------------------------------------------------------
 
-// CBD sample of coefficient n from a PRF byte string in LDS (sample.go:31-95)
+// CBD sample of coefficient n from a PRF stream in LDS (sample.go:31-95).  eta = 2 streams were already turned into
+// biased nibbles by the PRF pass (store_prf_words / kyber::cbd2_bias8_word); eta = 3 streams are the raw bytes.
 template <int ETA> __device__ __forceinline__ int cbd_coeff(const uint8_t *buf, int n) {
     if constexpr (ETA == 2) {
-        return kyber::cbd2_from_nibble((buf[n >> 1] >> (4 * (n & 1))) & 15u);
+        return (int)((buf[n >> 1] >> (4 * (n & 1))) & 15u) - 8;
     } else {
         const int bit = 6 * n;
         const unsigned two = (unsigned)buf[bit >> 3] | ((unsigned)buf[(bit >> 3) + 1] << 8);

@@ -44,6 +44,7 @@ int hs_kyber_decompress(unsigned t, int d) {
 unsigned hs_kyber_msg_bit(int x) { return kyber::msg_bit(x); }
 int hs_kyber_cbd2(unsigned t) { return kyber::cbd2_from_nibble(t); }
 int hs_kyber_cbd3(unsigned t) { return kyber::cbd3_from_6bits(t); }
+unsigned hs_kyber_cbd2_bias8_word(unsigned w) { return kyber::cbd2_bias8_word(w); }
 // one lane's share of MulHat: a[4], b[4] are coefficients 4l..4l+3; returns the four products (Montgomery form)
 void hs_kyber_mulhat4(int *out, const int *a, const int *b, int lane) {
     int acc[4] = {0, 0, 0, 0}, x[4], y[4];

@@ -77,6 +77,15 @@ def test_compress_exact_for_all_x(hs, d):
 def test_cbd_tables(hs):
     assert [hs.hs_kyber_cbd2(t) for t in range(16)] == [bin(t & 3).count("1") - bin(t >> 2).count("1") for t in range(16)]
     assert [hs.hs_kyber_cbd3(t) for t in range(64)] == [bin(t & 7).count("1") - bin(t >> 3).count("1") for t in range(64)]
+    # the packed form used by the PRF pass: nibble k of the result is cbd2(nibble k of the word) + 8
+    hs.hs_kyber_cbd2_bias8_word.restype = C.c_uint32
+    rng = np.random.default_rng(5)
+    words = [0, 0xFFFFFFFF, 0x33333333, 0xCCCCCCCC, 0x0F0F0F0F, 0xF0F0F0F0] + [int(x) for x in rng.integers(0, 1 << 32, 2000, dtype=np.uint64)]
+    for w in words:
+        got = hs.hs_kyber_cbd2_bias8_word(w)
+        for k in range(8):
+            t = (w >> (4 * k)) & 15
+            assert ((got >> (4 * k)) & 15) - 8 == bin(t & 3).count("1") - bin(t >> 2).count("1")
 
 
 def test_ntt_network_matches_oracle(hs):
