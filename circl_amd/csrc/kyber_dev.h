@@ -1,11 +1,18 @@
 // kyber_dev.h -- the Kyber ring Z_3329[x]/(x^256+1) on gfx950, one polynomial per wavefront.
 //
 // Replaces pke/kyber/internal/common {field,ntt,poly,sample}.go and its AVX2 assembler.
-// A polynomial lives in the registers of ONE 64-lane wavefront, 4 coefficients per lane.
-// Coefficients are 32-bit registers holding small signed values; products use the full-rate
-// 24-bit multipliers (V_MUL_I32_I24 / V_MAD_I32_I24) and signed Montgomery reduction with
-// R = 2^16 exactly as the reference (field.go:4-32), so every intermediate is congruent to the
-// reference's and the packed outputs are bit-identical.
+// A polynomial lives in the registers of ONE 64-lane wavefront, 4 coefficients per lane, as NON-NEGATIVE
+// 32-bit integers.  The reference reduces with signed Montgomery arithmetic, R = 2^16 (field.go:4-32): five
+// instructions per twiddle product here (multiply, low-half multiply, sign extension, multiply-subtract, shift).
+// On gfx950 V_MUL_LO_U32 / V_MUL_HI_U32 issue at the rate of the 24-bit multipliers (profiles/r01_valu_issue_rates.txt),
+// which makes Montgomery reduction with R = 2^32 a TWO-instruction product by a constant:
+//     mulc(b, C(w)) = hi32( lo32(b * C(w)) * q )  ==  w b  (mod q),  in [0, q),      C(w) = (-w 2^32 mod q) q^-1 mod 2^32
+// (b Z with Z = -w 2^32 mod q is below 2^32 for b < 2^32 / q, so its high word is zero and the quotient word m =
+// lo32(b Z q^-1) satisfies m q = b Z + 2^32 h exactly; h = -b Z 2^-32 = w b mod q).  The same two instructions reduce any
+// 32-bit accumulator: reduce32(t) = hi32(lo32(t q^-1) q) == -t 2^-32.  Butterflies are then 5 instructions (7 before),
+// the inverse transform needs no Barrett steps at all (values stay far below the 2^32 / q bound), and its final
+// scaling leaves canonical residues.  Every value is congruent mod q to the reference's, so packed outputs are
+// bit-identical; the stray factors (-2^-32 of reduce32) are folded into the constant of the inverse transform's last step.
 //
 // Register layouts (lane l in 0..63, register r in 0..3 -> coefficient index n):
 //   L1: n = l + 64 r                              bits 7,6 of n are register-local
@@ -13,7 +20,7 @@
 //   L3: n = ((l>>2)<<4) | (r<<2) | (l&3)           bits 3,2 local
 //   L4: n = 4 l + r                                bits 1,0 local ("4 consecutive coefficients")
 // The 7 NTT layers (strides 128..2) are done two at a time on register-local pairs; between
-// them the wave re-distributes the polynomial through a 512-byte LDS scratch (3 exchanges per
+// them the wave re-distributes the polynomial through a 1 KB LDS scratch (3 exchanges per
 // transform).  L4 is the layout of MulHat (pairs (4l,4l+1) and (4l+2,4l+3) share zeta =
 // Zetas[64+l], poly.go:63-100), of the 12-bit codec and of coalesced 8-byte LDS/global access.
 #pragma once
@@ -32,27 +39,14 @@ CIRCL_HD int mul24(int a, int b) {
     return a * b;
 #endif
 }
-CIRCL_HD int mad24(int a, int b, int c) { return mul24(a, b) + c; }
-// (x mod 2^24) * C on the full-rate 24-bit multiplier, for callers that keep only low bits of the product.
-// Written as C (or with __umul24, which is C underneath) LLVM's demanded-bits analysis drops the 24-bit
-// masks -- they cannot change the low bits -- and then has to select the quarter-rate V_MUL_LO_U32.
-template <uint32_t C> CIRCL_HD uint32_t umul24_lowbits(uint32_t x) {
+CIRCL_HD uint32_t umulhi32(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "i"(C), "v"(x));
-    return r;
+    return __umulhi(a, b);
 #else
-    return (x & 0xffffffu) * C;
+    return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
 
-// field.go:4-32 montReduce: x R^-1 mod q, q^-1 = 62209 (mod 2^16).  |x| < 2^31; result is
-// x/2^16 + (-q/2, q/2).
-CIRCL_HD int mont_reduce(int x) {
-    const int m = (int)(int16_t)(uint16_t)umul24_lowbits<62209u>((uint32_t)x);
-    return (x - mul24(m, Q)) >> 16;
-}
-CIRCL_HD int mont_mul(int a, int b) { return mont_reduce(mul24(a, b)); }
 // field.go:45-64 barrettReduce for |x| < 2^15: result in [0, q]
 CIRCL_HD int barrett(int x) { return x - mul24(mul24(x, 20159) >> 26, Q); }
 // field.go:67-74 csubq
@@ -63,55 +57,86 @@ CIRCL_HD int csubq(int x) {
 // poly.go:35-39 Normalize one coefficient (|x| < 2^15) to [0, q)
 CIRCL_HD int normalize(int x) { return csubq(barrett(x)); }
 
-// ntt.go:16-28: Zetas[i] = 17^brv7(i) * 2^16 mod q, computed at compile time.
+// ---- products by constants and reductions with R = 2^32 (see the header comment) ----------------
+constexpr uint32_t qinv32() {  // q^-1 mod 2^32 by Newton iteration
+    uint32_t x = 1;
+    for (int i = 0; i < 6; i++) x = x * (2u - (uint32_t)Q * x);
+    return x;
+}
+constexpr uint32_t QINV32 = qinv32();
+static_assert((uint32_t)(QINV32 * (uint32_t)Q) == 1u, "q * qinv == 1 mod 2^32");
+constexpr uint32_t R32 = (uint32_t)((1ull << 32) % Q);  // 2^32 mod q
+constexpr uint32_t MULC_LIMIT = (uint32_t)((1ull << 32) / Q);  // operands of mulc stay below this (1 290 167)
+constexpr uint32_t modq(int64_t x) { return (uint32_t)(((x % Q) + Q) % Q); }
+constexpr uint32_t powq(uint32_t b, uint32_t e) {
+    uint32_t r = 1;
+    for (uint32_t i = 0; i < e; i++) r = r * b % Q;
+    return r;
+}
+constexpr uint32_t invq(uint32_t x) { return powq(x % Q, Q - 2); }
+// the constant C(w) of mulc for the residue w
+constexpr uint32_t mulc_const(uint32_t w) { return modq(-(int64_t)((uint64_t)(w % Q) * R32 % Q)) * QINV32; }
+// w b mod q in [0, q) for b < MULC_LIMIT
+CIRCL_HD uint32_t mulc(uint32_t b, uint32_t c) { return umulhi32(b * c, (uint32_t)Q); }
+// -t 2^-32 mod q in [0, q) for any 32-bit t
+CIRCL_HD uint32_t reduce32(uint32_t t) { return umulhi32(t * QINV32, (uint32_t)Q); }
+constexpr uint32_t NEG_R32 = modq(-(int64_t)R32);  // multiplying by it undoes the factor of reduce32
+
+// ntt.go:16-28 tabulates Zetas[i] = 17^brv7(i) 2^16; here the same powers as mulc constants, computed at compile time.
 struct ZetaTable {
-    int16_t v[128];
+    uint32_t w[128];  // 17^brv7(i) mod q
+    uint32_t c[128];  // mulc_const(w[i])
+    uint32_t cn[128]; // mulc_const(-w[i])
 };
 constexpr ZetaTable make_zetas() {
     ZetaTable t{};
     for (int i = 0; i < 128; i++) {
         int brv = 0;
         for (int b = 0; b < 7; b++) brv |= ((i >> b) & 1) << (6 - b);
-        unsigned z = 1;
-        for (int e = 0; e < brv; e++) z = z * 17 % Q;
-        t.v[i] = (int16_t)((z << 16) % Q);
+        t.w[i] = powq(17, (uint32_t)brv);
+        t.c[i] = mulc_const(t.w[i]);
+        t.cn[i] = mulc_const(modq(-(int64_t)t.w[i]));
     }
     return t;
 }
-static __device__ __constant__ const ZetaTable kZetasDev = make_zetas();
-static const ZetaTable kZetasHost = make_zetas();
-CIRCL_HD int zeta(int i) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return kZetasDev.v[i];
-#else
-    return kZetasHost.v[i];
-#endif
+CIRCL_HD uint32_t zeta_c(int i) {  // mulc constant of Zetas[i]; a function-local table is addressed pc-relative (no GOT)
+    constexpr ZetaTable t = make_zetas();
+    return t.c[i];
+}
+CIRCL_HD uint32_t zeta_cn(int i) {
+    constexpr ZetaTable t = make_zetas();
+    return t.cn[i];
+}
+CIRCL_HD uint32_t zeta_plain(int i) {
+    constexpr ZetaTable t = make_zetas();
+    return t.w[i];
 }
 
-// Per-lane twiddles, loaded once per kernel.  Forward layer t (stride 128>>t) uses
+// Per-lane twiddle constants, loaded once per kernel.  Forward layer t (stride 128>>t) uses
 // k = 2^t + (n >> (8-t)) (ntt.go:117-134); the inverse walks the same table backwards
-// (ntt.go:145-193), i.e. index 3*2^t - 1 - k.
+// (ntt.go:145-193), i.e. index 3*2^t - 1 - k.  f6n = -Zetas[64+l] is the second pair's factor in MulHat.
 struct LaneZetas {
-    int f2, f3a, f3b, f4, f5a, f5b, f6;
-    int i2, i3a, i3b, i4, i5a, i5b, i6;
+    uint32_t f2, f3a, f3b, f4, f5a, f5b, f6, f6n;
+    uint32_t i2, i3a, i3b, i4, i5a, i5b, i6;
 };
 CIRCL_HD LaneZetas load_lane_zetas(int lane) {
     LaneZetas z;
     const int h = lane >> 4, m = lane >> 2;
-    z.f2 = zeta(4 + h);
-    z.f3a = zeta(8 + 2 * h);
-    z.f3b = zeta(9 + 2 * h);
-    z.f4 = zeta(16 + m);
-    z.f5a = zeta(32 + 2 * m);
-    z.f5b = zeta(33 + 2 * m);
-    z.f6 = zeta(64 + lane);
-    z.i2 = zeta(7 - h);
-    z.i3a = zeta(15 - 2 * h);
-    z.i3b = zeta(14 - 2 * h);
-    z.i4 = zeta(31 - m);
-    z.i5a = zeta(63 - 2 * m);
-    z.i5b = zeta(62 - 2 * m);
-    z.i6 = zeta(127 - lane);
+    z.f2 = zeta_c(4 + h);
+    z.f3a = zeta_c(8 + 2 * h);
+    z.f3b = zeta_c(9 + 2 * h);
+    z.f4 = zeta_c(16 + m);
+    z.f5a = zeta_c(32 + 2 * m);
+    z.f5b = zeta_c(33 + 2 * m);
+    z.f6 = zeta_c(64 + lane);
+    z.f6n = zeta_cn(64 + lane);
+    z.i2 = zeta_c(7 - h);
+    z.i3a = zeta_c(15 - 2 * h);
+    z.i3b = zeta_c(14 - 2 * h);
+    z.i4 = zeta_c(31 - m);
+    z.i5a = zeta_c(63 - 2 * m);
+    z.i5b = zeta_c(62 - 2 * m);
+    z.i6 = zeta_c(127 - lane);
     return z;
 }
 
@@ -120,16 +145,18 @@ CIRCL_HD int idx_l2(int l, int r) { return ((l >> 4) << 6) | (r << 4) | (l & 15)
 CIRCL_HD int idx_l3(int l, int r) { return ((l >> 2) << 4) | (r << 2) | (l & 3); }
 CIRCL_HD int idx_l4(int l, int r) { return 4 * l + r; }
 
-// Cooley-Tukey / Gentleman-Sande butterflies (ntt.go:126-131, :168-176)
-CIRCL_HD void ct(int &a, int &b, int z) {
-    const int t = mont_mul(z, b);
-    b = a - t;
+// Cooley-Tukey butterfly (ntt.go:126-131) on non-negative values: both outputs grow by at most q.
+CIRCL_HD void ct(int &a, int &b, uint32_t c) {
+    const int t = (int)mulc((uint32_t)b, c);
+    b = a + Q - t;
     a = a + t;
 }
-CIRCL_HD void gs(int &a, int &b, int z) {
-    const int t = b - a;
+// Gentleman-Sande butterfly (ntt.go:168-176): a' = a + b, b' = zeta (b - a).  BOUND = a multiple of q that both
+// inputs are below; the sum doubles, the product is back in [0, q).
+template <int BOUND> CIRCL_HD void gs(int &a, int &b, uint32_t c) {
+    const int t = b + BOUND - a;
     a = a + b;
-    b = mont_mul(z, t);
+    b = (int)mulc((uint32_t)t, c);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -139,87 +166,78 @@ CIRCL_HD void gs(int &a, int &b, int z) {
 // wave-local ordering point for LDS.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
-// Re-distribute a polynomial between register layouts through `xch` (int16[256] in LDS).
-template <int FROM, int TO> __device__ __forceinline__ void relayout(int (&c)[4], int16_t *xch, int lane) {
+// Re-distribute a polynomial between register layouts through `xch` (256 elements of T in LDS: 512 bytes for
+// uint16_t, 1 KB for uint32_t -- values must fit T).
+template <int FROM, int TO, class T> __device__ __forceinline__ void relayout(int (&c)[4], void *xch_raw, int lane) {
+    T *xch = reinterpret_cast<T *>(xch_raw);
     auto idx = [&](int which, int r) {
         return which == 1 ? idx_l1(lane, r) : which == 2 ? idx_l2(lane, r) : which == 3 ? idx_l3(lane, r) : idx_l4(lane, r);
     };
     wave_sync();  // earlier readers of xch are done
 #pragma unroll
-    for (int r = 0; r < 4; r++) xch[idx(FROM, r)] = (int16_t)c[r];
+    for (int r = 0; r < 4; r++) xch[idx(FROM, r)] = (T)c[r];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = xch[idx(TO, r)];
+    for (int r = 0; r < 4; r++) c[r] = (int)xch[idx(TO, r)];
 }
 
-// Poly.NTT (ntt.go:60-135).  In: layout L1, |c| <= q.  Out: layout L4, |c| <= 8q.
-__device__ __forceinline__ void ntt(int (&c)[4], const LaneZetas &z, int16_t *xch, int lane) {
-    const int z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
+// Poly.NTT (ntt.go:60-135).  In: layout L1, 0 <= c < IN_BOUND (any bound up to 2^16 - 7q).  Out: layout L4,
+// 0 <= c < IN_BOUND + 7q, congruent to the reference's transform.
+__device__ __forceinline__ void ntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
+    const uint32_t z1 = zeta_c(1), z2 = zeta_c(2), z3 = zeta_c(3);
     ct(c[0], c[2], z1); ct(c[1], c[3], z1);
     ct(c[0], c[1], z2); ct(c[2], c[3], z3);
-    relayout<1, 2>(c, xch, lane);
+    relayout<1, 2, uint16_t>(c, xch, lane);
     ct(c[0], c[2], z.f2); ct(c[1], c[3], z.f2);
     ct(c[0], c[1], z.f3a); ct(c[2], c[3], z.f3b);
-    relayout<2, 3>(c, xch, lane);
+    relayout<2, 3, uint16_t>(c, xch, lane);
     ct(c[0], c[2], z.f4); ct(c[1], c[3], z.f4);
     ct(c[0], c[1], z.f5a); ct(c[2], c[3], z.f5b);
-    relayout<3, 4>(c, xch, lane);
+    relayout<3, 4, uint16_t>(c, xch, lane);
     ct(c[0], c[2], z.f6); ct(c[1], c[3], z.f6);
 }
 
-// Poly.InvNTT (ntt.go:145-193), including the final multiplication by 1441 = 128^-1 R^2.
-// In: layout L4, |c| <= q.  Out: layout L1, |c| < q.  The reference Barrett-reduces a lazy
-// subset of coefficients (InvNTTReductions); we reduce all four registers after every second
-// layer, which is congruent mod q and keeps every value inside int16 for the LDS exchange.
-__device__ __forceinline__ void invntt(int (&c)[4], const LaneZetas &z, int16_t *xch, int lane) {
-    gs(c[0], c[2], z.i6); gs(c[1], c[3], z.i6);
-    relayout<4, 3>(c, xch, lane);
-    gs(c[0], c[1], z.i5a); gs(c[2], c[3], z.i5b);
-    gs(c[0], c[2], z.i4); gs(c[1], c[3], z.i4);
+// Poly.InvNTT (ntt.go:145-193) times a caller-chosen residue: out = SCALE * InvNTT_true(in), where InvNTT_true
+// includes the 1/128.  (The reference's transform is the case SCALE = 2^16: its last step multiplies by 1441 =
+// 128^-1 R^2 after Montgomery products that each carried R^-1.)  In: layout L4, 0 <= c < q.  Out: layout L1, 0 <= c < q.
+// The sums double per layer (below 2^k q after k layers) and are never reduced on the way: 128 q is far below
+// MULC_LIMIT.  The first two exchanges fit 16-bit elements (< 8q), the third (< 32q) uses 32-bit ones.
+template <uint32_t SCALE> __device__ __forceinline__ void invntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
+    static_assert(128u * Q < MULC_LIMIT, "lazy sums stay inside the mulc domain");
+    gs<Q>(c[0], c[2], z.i6); gs<Q>(c[1], c[3], z.i6);
+    relayout<4, 3, uint16_t>(c, xch, lane);
+    gs<2 * Q>(c[0], c[1], z.i5a); gs<2 * Q>(c[2], c[3], z.i5b);
+    gs<4 * Q>(c[0], c[2], z.i4); gs<4 * Q>(c[1], c[3], z.i4);
+    relayout<3, 2, uint16_t>(c, xch, lane);
+    gs<8 * Q>(c[0], c[1], z.i3a); gs<8 * Q>(c[2], c[3], z.i3b);
+    gs<16 * Q>(c[0], c[2], z.i2); gs<16 * Q>(c[1], c[3], z.i2);
+    relayout<2, 1, uint32_t>(c, xch, lane);
+    const uint32_t z1 = zeta_c(1), z2 = zeta_c(2), z3 = zeta_c(3);
+    gs<32 * Q>(c[0], c[1], z3); gs<32 * Q>(c[2], c[3], z2);
+    gs<64 * Q>(c[0], c[2], z1); gs<64 * Q>(c[1], c[3], z1);
+    constexpr uint32_t fin = mulc_const((uint32_t)((uint64_t)(SCALE % Q) * invq(128) % Q));
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = barrett(c[r]);
-    relayout<3, 2>(c, xch, lane);
-    gs(c[0], c[1], z.i3a); gs(c[2], c[3], z.i3b);
-    gs(c[0], c[2], z.i2); gs(c[1], c[3], z.i2);
-#pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = barrett(c[r]);
-    relayout<2, 1>(c, xch, lane);
-    const int z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
-    gs(c[0], c[1], z3); gs(c[2], c[3], z2);
-    gs(c[0], c[2], z1); gs(c[1], c[3], z1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = mont_mul(1441, c[r]);
+    for (int r = 0; r < 4; r++) c[r] = (int)mulc((uint32_t)c[r], fin);
 }
 #endif  // device
 
-// MulHat accumulation (poly.go:63-100 + vec.go:30-37 PolyDotHat), layout L4, kept lazy:
-//   acc[0] += a0 b0 + zeta * mont(a1 b1)     acc[1] += a0 b1 + a1 b0
-//   acc[2] += a2 b2 - zeta * mont(a3 b3)     acc[3] += a2 b3 + a3 b2
-// with inputs in [0,q]: every term is < 2 q^2, so K <= 4 terms stay far below 2^31; one
-// Montgomery reduction per coefficient at the end (mulhat_finish) gives the reference's value
-// mod q (which carries the same single factor R^-1).
-CIRCL_HD void mulhat_acc(int (&acc)[4], const int (&a)[4], const int (&b)[4], int zeta64) {
-    const int t0 = mont_mul(a[1], b[1]);
-    const int t1 = mont_mul(a[3], b[3]);
-    acc[0] = mad24(a[0], b[0], mad24(t0, zeta64, acc[0]));
-    acc[1] = mad24(a[0], b[1], mad24(a[1], b[0], acc[1]));
-    acc[2] = mad24(a[2], b[2], mad24(t1, -zeta64, acc[2]));
-    acc[3] = mad24(a[2], b[3], mad24(a[3], b[2], acc[3]));
-}
-// The same accumulation on packed int16 pairs with V_DOT2_I32_I16 (two multiplies and the add per
-// instruction).  The b side is prepared once per polynomial and reused for every row of the matrix:
-//   p0 = (b0, mont(zeta b1))   q0 = (b1, b0)     p1 = (b2, mont(-zeta b3))   q1 = (b3, b2)
-// so that  acc0 += a0 b0 + a1 zeta b1 R^-1,  acc1 += a0 b1 + a1 b0  (and likewise for the second pair).
-// The a side is the pair of dwords exactly as they lie in memory (int16 coefficients 4l..4l+3).
+// MulHat accumulation (poly.go:63-100 + vec.go:30-37 PolyDotHat), layout L4, on packed int16 pairs with
+// V_DOT2_I32_I16 (two multiplies and the add per instruction), kept lazy:
+//   acc0 += a0 b0 + a1 (zeta b1)     acc1 += a0 b1 + a1 b0     acc2 += a2 b2 + a3 (-zeta b3)     acc3 += a2 b3 + a3 b2
+// The b side is prepared once per polynomial and reused for every row of the matrix:
+//   p0 = (b0, zeta b1 mod q)   q0 = (b1, b0)     p1 = (b2, -zeta b3 mod q)   q1 = (b3, b2)
+// The a side is the pair of dwords exactly as they lie in memory (int16 coefficients 4l..4l+3, in [0, q)).
+// Everything is non-negative: with b < 2^15 a term is below 2 q 2^15, so K <= 4 terms stay below 2^31; ONE
+// reduce32 per coefficient at the end (mulhat_finish) leaves -2^-32 times the true products, in [0, q).
 struct HatOperand {
     uint32_t p0, q0, p1, q1;
 };
 CIRCL_HD uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
-CIRCL_HD HatOperand hat_prepare(const int (&b)[4], int zeta64) {
+CIRCL_HD HatOperand hat_prepare(const int (&b)[4], uint32_t c_zeta, uint32_t c_neg_zeta) {
     HatOperand h;
-    h.p0 = pack16(b[0], mont_mul(b[1], zeta64));
+    h.p0 = pack16(b[0], (int)mulc((uint32_t)b[1], c_zeta));
     h.q0 = pack16(b[1], b[0]);
-    h.p1 = pack16(b[2], mont_mul(b[3], -zeta64));
+    h.p1 = pack16(b[2], (int)mulc((uint32_t)b[3], c_neg_zeta));
     h.q1 = pack16(b[3], b[2]);
     return h;
 }
@@ -239,7 +257,7 @@ CIRCL_HD void mulhat_acc_packed(int (&acc)[4], uint32_t a01, uint32_t a23, const
 }
 CIRCL_HD void mulhat_finish(int (&acc)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = mont_reduce(acc[r]);
+    for (int r = 0; r < 4; r++) acc[r] = (int)reduce32((uint32_t)acc[r]);
 }
 
 // sample.go:31-95 centred binomial: coefficient n of eta=2 is nibble n of the PRF output,
@@ -259,21 +277,17 @@ CIRCL_HD int cbd3_from_6bits(unsigned t) {
     return (int)((t & 1) + ((t >> 1) & 1) + ((t >> 2) & 1)) - (int)(((t >> 3) & 1) + ((t >> 4) & 1) + ((t >> 5) & 1));
 }
 
-// poly.go:248-332 CompressTo arithmetic for x in [0,q): round(x 2^d / q) mod 2^d with the
-// reference's multiply-shift constants (proven exact on that domain, poly.go:254-260).
+// poly.go:248-332 CompressTo arithmetic: round(x 2^d / q) mod 2^d for ANY representative 0 <= x < 4q (2q + 8 for
+// d = 11) of the coefficient -- the rounding is periodic in q modulo 2^d, so callers need not bring the sum of an
+// inverse transform's output and the noise back into [0, q).  floor(y / q) for y = x 2^d + q/2 < 2^24 as
+// (y * ceil(2^35 / q)) >> 35: both factors fit the 24-bit multiplier (V_MUL_HI_U32_U24 gives bits 32..47) and the
+// rounding error y * 2492 / (q 2^35) stays below the 1/q slack of a floor.  Same value as the reference's
+// multiply-shift constants on [0, q) (poly.go:254-260); checked for every x of the domain in tests/test_hostsim.py.
 template <int D> CIRCL_HD unsigned compress_coeff(int x) {
+    static_assert(D == 4 || D == 5 || D == 10 || D == 11, "d");
     const unsigned y = ((unsigned)x << D) + Q / 2;
-    if constexpr (D == 4 || D == 5) {
-        return (umul24_lowbits<315u>(y) >> 20) & ((1u << D) - 1);  // y < 2^17: one full-rate 24-bit multiply
-    } else {
-        // floor(y / q) for y < 2^23 as (y * ceil(2^35 / q)) >> 35: both factors fit the full-rate 24-bit
-        // multiplier (V_MUL_HI_U32_U24 gives bits 32..47); the rounding error y * 2492 / (q 2^35) < 2^-15 is
-        // below the 1/q slack of a floor.  Same value as the reference's 64-bit multiply-shift; checked for
-        // every x in tests/test_hostsim.py.
-        static_assert(D == 10 || D == 11, "du");
-        const unsigned hi = (unsigned)(((uint64_t)(y & 0xffffffu) * (uint64_t)10321340u) >> 32);
-        return (hi >> 3) & ((1u << D) - 1);
-    }
+    const unsigned hi = (unsigned)(((uint64_t)(y & 0xffffffu) * (uint64_t)10321340u) >> 32);
+    return (hi >> 3) & ((1u << D) - 1);
 }
 // poly.go:170-243 Decompress arithmetic
 template <int D> CIRCL_HD int decompress_coeff(unsigned t) { return (int)(((1u << (D - 1)) + t * Q) >> D); }

@@ -63,7 +63,7 @@ template <int K> struct Geom {
     static constexpr int HALVES = K == 2 ? 2 : 1;
     static constexpr int GH = G / HALVES;
     static constexpr int LDS_NOISE = GH * NOISE * NOISE_STRIDE;
-    static constexpr int LDS_XCH = 512;
+    static constexpr int LDS_XCH = 1024;                 // 256 x 32-bit: the widest exchange of the inverse transform
     static constexpr int LDS_TOTAL = LDS_A + LDS_NOISE + LDS_XCH;
     // "scratch" variant: the sampled matrix goes through a per-workgroup global scratch (L2 / Infinity
     // Cache resident) instead of LDS, which cuts LDS per wave from ~40 KB to ~7 KB (4 waves per SIMD).
@@ -576,15 +576,16 @@ __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *_
 
 // ---- phase C helpers -------------------------------------------------------------------------
 
-// CBD sample of coefficient n from a PRF stream in LDS (sample.go:31-95).  eta = 2 streams were already turned into
-// biased nibbles by the PRF pass (store_prf_words / kyber::cbd2_bias8_word); eta = 3 streams are the raw bytes.
+// CBD sample of coefficient n from a PRF stream in LDS (sample.go:31-95), as the non-negative representative
+// q + (-eta..eta) that the ring code of kyber_dev.h works on.  eta = 2 streams were already turned into biased nibbles
+// by the PRF pass (store_prf_words / kyber::cbd2_bias8_word); eta = 3 streams are the raw bytes.
 template <int ETA> __device__ __forceinline__ int cbd_coeff(const uint8_t *buf, int n) {
     if constexpr (ETA == 2) {
-        return (int)((buf[n >> 1] >> (4 * (n & 1))) & 15u) - 8;
+        return (int)((buf[n >> 1] >> (4 * (n & 1))) & 15u) + (Q - 8);
     } else {
         const int bit = 6 * n;
         const unsigned two = (unsigned)buf[bit >> 3] | ((unsigned)buf[(bit >> 3) + 1] << 8);
-        return kyber::cbd3_from_6bits((two >> (bit & 7)) & 63u);
+        return kyber::cbd3_from_6bits((two >> (bit & 7)) & 63u) + Q;
     }
 }
 
@@ -758,7 +759,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
     static_assert(!SHARED || (SCRATCH && (MODE == ENCAPS || MODE == REENCRYPT) && ABLATE == 0), "shared-key mode");
-    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE));
+    uint8_t *xch = lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE);
     int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
@@ -779,7 +780,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         __syncthreads();
     } else if constexpr (SCRATCH && ABLATE == 0 && Gm::HALVES == 1) {
         __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
-        sample_matrix_and_prf<K, true, Gm::NOISE, K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, ek + 384 * K, ek_stride,
+        sample_matrix_and_prf<K, true, Gm::NOISE, K>(lds_a, lds_noise, xch, rows, ek + 384 * K, ek_stride,
                                                      r_ws, 32, item0, n, lane);
         __threadfence_block();  // the rows are in L2 before anybody loads them
         __syncthreads();
@@ -828,19 +829,18 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         }
         const bool reject = MODE == ENCAPS ? __any(bad) : false;  // ENCAPS_LENIENT and REENCRYPT reduce instead
 
-        // r-hat = NTT(CBD_eta1(PRF(r, j))), Barrett-reduced (cpapke.go:142-144), layout L4
+        // r-hat = NTT(CBD_eta1(PRF(r, j))), layout L4, left lazy (< 8q + 4 < 2^15: the reference Barrett-reduces here,
+        // cpapke.go:142-144, but any representative gives the same ciphertext)
         int rh[K][4];
 #pragma unroll
         for (int j = 0; j < K; j++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) rh[j][r] = cbd_coeff<P::ETA1>(noise + j * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
             kyber::ntt(rh[j], z, xch, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) rh[j][r] = kyber::barrett(rh[j][r]);
         }
         kyber::HatOperand rop[K];
 #pragma unroll
-        for (int j = 0; j < K; j++) rop[j] = kyber::hat_prepare(rh[j], z.f6);
+        for (int j = 0; j < K; j++) rop[j] = kyber::hat_prepare(rh[j], z.f6, z.f6n);
 
         uint8_t *ctp = ct + item * Gm::CT;
         bool differs = false;
@@ -859,12 +859,12 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 kyber::mulhat_acc_packed(acc, a01, a23, rop[j]);
             }
             kyber::mulhat_finish(acc);
-            kyber::invntt(acc, z, xch, lane);
+            kyber::invntt<kyber::NEG_R32>(acc, z, xch, lane);  // undoes mulhat_finish's -2^-32: plain coefficients in [0, q)
             const uint8_t *e1 = noise + (K + i) * Gm::NOISE_STRIDE;
             unsigned cv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                cv[r] = kyber::compress_coeff<P::DU>(kyber::normalize(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r))));
+                cv[r] = kyber::compress_coeff<P::DU>(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r)));  // < 2q + 3: no reduction needed
             uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
             stage_bits_l1<P::DU>(stage, cv, lane);
             if (MODE == REENCRYPT) differs |= ref.differs(stage, lane);
@@ -879,7 +879,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll
             for (int j = 0; j < K; j++) kyber::mulhat_acc_packed(acc, kyber::pack16(th[j][0], th[j][1]), kyber::pack16(th[j][2], th[j][3]), rop[j]);
             kyber::mulhat_finish(acc);
-            kyber::invntt(acc, z, xch, lane);
+            kyber::invntt<kyber::NEG_R32>(acc, z, xch, lane);  // undoes mulhat_finish's -2^-32: plain coefficients in [0, q)
             const uint8_t *e2 = noise + 2 * K * Gm::NOISE_STRIDE;
             const uint8_t *mp = m + item * 32;
             unsigned cv[4];
@@ -887,7 +887,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             for (int r = 0; r < 4; r++) {
                 const int nidx = kyber::idx_l1(lane, r);
                 const int mbit = (mp[nidx >> 3] >> (nidx & 7)) & 1;
-                cv[r] = kyber::compress_coeff<P::DV>(kyber::normalize(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2))));
+                cv[r] = kyber::compress_coeff<P::DV>(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2)));  // < 3q
             }
             uint32_t *stage = reinterpret_cast<uint32_t *>(xch);
             stage_bits_l1<P::DV>(stage, cv, lane);
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__rest
                                                           uint8_t *__restrict__ mprime_ws, size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
-    __shared__ __attribute__((aligned(16))) int16_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     const int lane = threadIdx.x;
     const size_t item = blockIdx.x;
     const uint8_t *dkp = dk + item * dk_stride;  // dk_stride = 0: one private key for the whole batch
@@ -935,18 +935,17 @@ __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__rest
             sh[r] = kyber::csubq(sh[r]);  // PrivateKey.Unpack normalises (cpapke.go:33-36)
             u[r] = kyber::decompress_coeff<P::DU>(get_bits<P::DU>(ctp + 32 * P::DU * j, kyber::idx_l1(lane, r)));
         }
-        kyber::ntt(u, z, xch, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) u[r] = kyber::barrett(u[r]);
-        kyber::mulhat_acc(acc, sh, u, z.f6);
+        kyber::ntt(u, z, xch, lane);  // < 8q, left lazy
+        kyber::mulhat_acc_packed(acc, kyber::pack16(sh[0], sh[1]), kyber::pack16(sh[2], sh[3]), kyber::hat_prepare(u, z.f6, z.f6n));
     }
     kyber::mulhat_finish(acc);
-    kyber::invntt(acc, z, xch, lane);
+    kyber::invntt<kyber::NEG_R32>(acc, z, xch, lane);  // <s-hat, u-hat> as plain coefficients in [0, q)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int nidx = kyber::idx_l1(lane, r);
         const int v = kyber::decompress_coeff<P::DV>(get_bits<P::DV>(ctp + 32 * P::DU * K, nidx));
-        const unsigned bit = kyber::msg_bit(kyber::normalize(v - acc[r]));
+        const int d = v - acc[r];  // in (-q, q)
+        const unsigned bit = kyber::msg_bit(d + ((d >> 31) & Q));
         const unsigned long long mask = __ballot(bit != 0);  // bits of coefficients 64r .. 64r+63
         if (lane == 0) reinterpret_cast<unsigned long long *>(mprime_ws + item * 32)[r] = mask;
     }
@@ -1038,7 +1037,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;
-    int16_t *xch = reinterpret_cast<int16_t *>(lds_noise + Gm::LDS_NOISE);
+    uint8_t *xch = lds_noise + Gm::LDS_NOISE;
     int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
@@ -1049,7 +1048,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     const size_t item0 = grp * Gm::G;
     if constexpr (SCRATCH && Gm::HALVES == 1) {
         __syncthreads();
-        sample_matrix_and_prf<K, false, 2 * K, 2 * K>(lds_a, lds_noise, reinterpret_cast<uint8_t *>(xch), rows, rs_ws, 64, rs_ws + 32, 64,
+        sample_matrix_and_prf<K, false, 2 * K, 2 * K>(lds_a, lds_noise, xch, rows, rs_ws, 64, rs_ws + 32, 64,
                                                       item0, n, lane);
         __threadfence_block();
         __syncthreads();
@@ -1093,7 +1092,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         }
         kyber::HatOperand sop[K];
 #pragma unroll
-        for (int j = 0; j < K; j++) sop[j] = kyber::hat_prepare(sh[j], z.f6);
+        for (int j = 0; j < K; j++) sop[j] = kyber::hat_prepare(sh[j], z.f6, z.f6n);
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             int eh[4], acc[4] = {0, 0, 0, 0};
@@ -1110,7 +1109,8 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
             kyber::mulhat_finish(acc);
             int t[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) t[r] = kyber::normalize(kyber::mont_mul(acc[r], 1353) + eh[r]);  // ToMont, field.go:35-39
+            for (int r = 0; r < 4; r++)  // undo mulhat_finish's -2^-32 (the reference's ToMont, field.go:35-39, undoes its R^-1)
+                t[r] = kyber::normalize((int)kyber::mulc((uint32_t)acc[r], kyber::mulc_const(kyber::NEG_R32)) + eh[r]);
             pack12_l4(ekp + 384 * i, t, lane);
             pack12_l4(dkp + 384 * K + 384 * i, t, lane);
         }

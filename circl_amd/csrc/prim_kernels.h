@@ -23,25 +23,26 @@ __global__ void __launch_bounds__(256) keccak_f1600_kernel(uint64_t *states, siz
 }
 
 // One polynomial per single-wave workgroup, int16[256] in standard order, in place.
-// Outputs are normalised to [0,q).
+// Outputs are normalised to [0,q).  The inverse carries the reference's factor: Poly.InvNTT returns 2^16 times the
+// exact inverse (ntt.go:145-193; ntt_test.go:83-109 checks InvNTT(NTT(p)) = p * 2^16).
 __global__ void __launch_bounds__(64) kyber_ntt_kernel(int16_t *polys, int inverse) {
-    __shared__ __attribute__((aligned(16))) int16_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     const int lane = threadIdx.x;
     int16_t *p = polys + (size_t)blockIdx.x * 256;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     int c[4];
     if (!inverse) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) c[r] = kyber::barrett(p[kyber::idx_l1(lane, r)]);
+        for (int r = 0; r < 4; r++) c[r] = kyber::normalize(p[kyber::idx_l1(lane, r)]);
         kyber::ntt(c, z, xch, lane);
 #pragma unroll
         for (int r = 0; r < 4; r++) p[kyber::idx_l4(lane, r)] = (int16_t)kyber::normalize(c[r]);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) c[r] = kyber::barrett(p[kyber::idx_l4(lane, r)]);
-        kyber::invntt(c, z, xch, lane);
+        for (int r = 0; r < 4; r++) c[r] = kyber::normalize(p[kyber::idx_l4(lane, r)]);
+        kyber::invntt<65536u>(c, z, xch, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = (int16_t)kyber::normalize(c[r]);
+        for (int r = 0; r < 4; r++) p[kyber::idx_l1(lane, r)] = (int16_t)c[r];
     }
 }
 
@@ -50,11 +51,12 @@ __global__ void __launch_bounds__(64) kyber_mulhat_kernel(int16_t *out, const in
     const size_t off = (size_t)blockIdx.x * 256 + 4 * lane;
     int x[4], y[4], acc[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; r++) { x[r] = kyber::barrett(a[off + r]); y[r] = kyber::barrett(b[off + r]); }
-    kyber::mulhat_acc(acc, x, y, kyber::zeta(64 + lane));
-    kyber::mulhat_finish(acc);
+    for (int r = 0; r < 4; r++) { x[r] = kyber::normalize(a[off + r]); y[r] = kyber::normalize(b[off + r]); }
+    kyber::mulhat_acc_packed(acc, kyber::pack16(x[0], x[1]), kyber::pack16(x[2], x[3]), kyber::hat_prepare(y, kyber::zeta_c(64 + lane), kyber::zeta_cn(64 + lane)));
+    kyber::mulhat_finish(acc);  // -2^-32 times the products; the reference's MulHat carries 2^-16 (poly.go:63-100)
+    constexpr uint32_t fix = kyber::mulc_const(kyber::modq((int64_t)kyber::NEG_R32 * kyber::invq(65536u % kyber::Q)));
 #pragma unroll
-    for (int r = 0; r < 4; r++) out[off + r] = (int16_t)kyber::normalize(acc[r]);
+    for (int r = 0; r < 4; r++) out[off + r] = (int16_t)kyber::mulc((uint32_t)acc[r], fix);
 }
 
 // sign/internal/dilithium Poly.NTT / Poly.InvNTT, one polynomial per single-wave workgroup,

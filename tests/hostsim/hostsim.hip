@@ -21,10 +21,13 @@ void hs_keccak_f1600(uint64_t *a, int rounds) {
     for (int i = 0; i < 25; i++) a[i] = ((uint64_t)s.hi[i] << 32) | s.lo[i];
 }
 
-int hs_kyber_mont_reduce(int x) { return kyber::mont_reduce(x); }
 int hs_kyber_barrett(int x) { return kyber::barrett(x); }
 int hs_kyber_normalize(int x) { return kyber::normalize(x); }
-int hs_kyber_zeta(int i) { return kyber::zeta(i); }
+unsigned hs_kyber_zeta_plain(int i) { return kyber::zeta_plain(i); }
+// w b mod q through the two-instruction product by a constant; reduce32(t) = -t 2^-32 mod q
+unsigned hs_kyber_mulc(unsigned b, unsigned w) { return kyber::mulc(b, kyber::mulc_const(w)); }
+unsigned hs_kyber_reduce32(unsigned t) { return kyber::reduce32(t); }
+unsigned hs_kyber_mulc_limit(void) { return kyber::MULC_LIMIT; }
 unsigned hs_kyber_compress(int x, int d) {
     switch (d) {
     case 4: return kyber::compress_coeff<4>(x);
@@ -45,54 +48,56 @@ unsigned hs_kyber_msg_bit(int x) { return kyber::msg_bit(x); }
 int hs_kyber_cbd2(unsigned t) { return kyber::cbd2_from_nibble(t); }
 int hs_kyber_cbd3(unsigned t) { return kyber::cbd3_from_6bits(t); }
 unsigned hs_kyber_cbd2_bias8_word(unsigned w) { return kyber::cbd2_bias8_word(w); }
-// one lane's share of MulHat: a[4], b[4] are coefficients 4l..4l+3; returns the four products (Montgomery form)
-void hs_kyber_mulhat4(int *out, const int *a, const int *b, int lane) {
-    int acc[4] = {0, 0, 0, 0}, x[4], y[4];
-    for (int i = 0; i < 4; i++) { x[i] = a[i]; y[i] = b[i]; }
-    kyber::mulhat_acc(acc, x, y, kyber::zeta(64 + lane));
-    kyber::mulhat_finish(acc);
-    for (int i = 0; i < 4; i++) out[i] = acc[i];
-}
+// one lane's share of MulHat: a[4] in [0,q), b[4] < 2^15 are coefficients 4l..4l+3; returns reduce32 of the four lazy sums
 void hs_kyber_mulhat4_packed(int *out, const int *a, const int *b, int lane) {
     int acc[4] = {0, 0, 0, 0}, y[4];
     for (int i = 0; i < 4; i++) y[i] = b[i];
-    const kyber::HatOperand op = kyber::hat_prepare(y, kyber::zeta(64 + lane));
+    const kyber::HatOperand op = kyber::hat_prepare(y, kyber::zeta_c(64 + lane), kyber::zeta_cn(64 + lane));
     kyber::mulhat_acc_packed(acc, kyber::pack16(a[0], a[1]), kyber::pack16(a[2], a[3]), op);
     kyber::mulhat_finish(acc);
     for (int i = 0; i < 4; i++) out[i] = acc[i];
 }
-// the 4-register butterfly network of the wave-level NTT, executed lane by lane on the host:
-// exactly the layer/zeta schedule of kyber::ntt / invntt with the LDS exchanges replaced by array indexing
-void hs_kyber_ntt(int16_t *p, int inverse) {
+// the 4-register butterfly network of the wave-level NTT, executed lane by lane on the host: exactly the
+// layer / zeta schedule of kyber::ntt / invntt<scale> with the LDS exchanges replaced by array indexing
+// (including their element widths).  p holds values in [0, bound); *maxval receives the largest intermediate.
+void hs_kyber_ntt(uint32_t *p, int inverse, uint32_t scale, uint32_t *maxval) {
     int c[64][4];
+    uint32_t mx = 0;
     auto idx = [](int which, int l, int r) { return which == 1 ? kyber::idx_l1(l, r) : which == 2 ? kyber::idx_l2(l, r) : which == 3 ? kyber::idx_l3(l, r) : kyber::idx_l4(l, r); };
-    auto relayout = [&](int from, int to) {
-        int16_t x[256];
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) x[idx(from, l, r)] = (int16_t)c[l][r];
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = x[idx(to, l, r)];
+    auto track = [&]() { for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) { if (c[l][r] < 0) mx = 0xffffffffu; else if ((uint32_t)c[l][r] > mx) mx = (uint32_t)c[l][r]; } };
+    auto relayout = [&](int from, int to, bool wide) {
+        uint32_t x[256];
+        track();
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) x[idx(from, l, r)] = wide ? (uint32_t)c[l][r] : (uint32_t)(uint16_t)c[l][r];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = (int)x[idx(to, l, r)];
     };
-    const int z1 = kyber::zeta(1), z2 = kyber::zeta(2), z3 = kyber::zeta(3);
+    const uint32_t z1 = kyber::zeta_c(1), z2 = kyber::zeta_c(2), z3 = kyber::zeta_c(3);
     if (!inverse) {
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = p[idx(1, l, r)];
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = (int)p[idx(1, l, r)];
         for (int l = 0; l < 64; l++) { int *v = c[l]; kyber::ct(v[0], v[2], z1); kyber::ct(v[1], v[3], z1); kyber::ct(v[0], v[1], z2); kyber::ct(v[2], v[3], z3); }
-        relayout(1, 2);
+        relayout(1, 2, false);
         for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f2); kyber::ct(v[1], v[3], z.f2); kyber::ct(v[0], v[1], z.f3a); kyber::ct(v[2], v[3], z.f3b); }
-        relayout(2, 3);
+        relayout(2, 3, false);
         for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f4); kyber::ct(v[1], v[3], z.f4); kyber::ct(v[0], v[1], z.f5a); kyber::ct(v[2], v[3], z.f5b); }
-        relayout(3, 4);
+        relayout(3, 4, false);
         for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::ct(v[0], v[2], z.f6); kyber::ct(v[1], v[3], z.f6); }
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(4, l, r)] = (int16_t)c[l][r];
+        track();
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(4, l, r)] = (uint32_t)c[l][r];
     } else {
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = p[idx(4, l, r)];
-        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[2], z.i6); kyber::gs(v[1], v[3], z.i6); }
-        relayout(4, 3);
-        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[1], z.i5a); kyber::gs(v[2], v[3], z.i5b); kyber::gs(v[0], v[2], z.i4); kyber::gs(v[1], v[3], z.i4); for (int r = 0; r < 4; r++) v[r] = kyber::barrett(v[r]); }
-        relayout(3, 2);
-        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs(v[0], v[1], z.i3a); kyber::gs(v[2], v[3], z.i3b); kyber::gs(v[0], v[2], z.i2); kyber::gs(v[1], v[3], z.i2); for (int r = 0; r < 4; r++) v[r] = kyber::barrett(v[r]); }
-        relayout(2, 1);
-        for (int l = 0; l < 64; l++) { int *v = c[l]; kyber::gs(v[0], v[1], z3); kyber::gs(v[2], v[3], z2); kyber::gs(v[0], v[2], z1); kyber::gs(v[1], v[3], z1); for (int r = 0; r < 4; r++) v[r] = kyber::mont_mul(1441, v[r]); }
-        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(1, l, r)] = (int16_t)c[l][r];
+        constexpr int Q = kyber::Q;
+        const uint32_t fin = kyber::mulc_const((uint32_t)((uint64_t)(scale % Q) * kyber::invq(128) % Q));
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) c[l][r] = (int)p[idx(4, l, r)];
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs<Q>(v[0], v[2], z.i6); kyber::gs<Q>(v[1], v[3], z.i6); }
+        relayout(4, 3, false);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs<2 * Q>(v[0], v[1], z.i5a); kyber::gs<2 * Q>(v[2], v[3], z.i5b); kyber::gs<4 * Q>(v[0], v[2], z.i4); kyber::gs<4 * Q>(v[1], v[3], z.i4); }
+        relayout(3, 2, false);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; auto z = kyber::load_lane_zetas(l); kyber::gs<8 * Q>(v[0], v[1], z.i3a); kyber::gs<8 * Q>(v[2], v[3], z.i3b); kyber::gs<16 * Q>(v[0], v[2], z.i2); kyber::gs<16 * Q>(v[1], v[3], z.i2); }
+        relayout(2, 1, true);
+        for (int l = 0; l < 64; l++) { int *v = c[l]; kyber::gs<32 * Q>(v[0], v[1], z3); kyber::gs<32 * Q>(v[2], v[3], z2); kyber::gs<64 * Q>(v[0], v[2], z1); kyber::gs<64 * Q>(v[1], v[3], z1); }
+        track();
+        for (int l = 0; l < 64; l++) for (int r = 0; r < 4; r++) p[idx(1, l, r)] = kyber::mulc((uint32_t)c[l][r], fin);
     }
+    *maxval = mx;
 }
 
 uint32_t hs_dil_mont32(uint32_t a, uint32_t b) { return dilithium::mont32(a, b); }

@@ -49,25 +49,37 @@ def test_keccak_host_instantiation(hs):
 
 
 def test_kyber_field_and_zetas(hs):
-    # field_test.go: montReduce / barrettReduce over their whole documented ranges (sampled), zetas table
-    z = orc.kyber_zetas()
-    assert [hs.hs_kyber_zeta(i) for i in range(128)] == z.tolist()
-    rng = np.random.default_rng(1)
-    for x in np.concatenate([rng.integers(-(1 << 30), 1 << 30, 20000), np.arange(-70000, 70000, 7)]):
-        r = hs.hs_kyber_mont_reduce(int(x))
-        assert (r * (1 << 16) - int(x)) % Q == 0 and abs(r) <= abs(int(x)) // 65536 + Q // 2 + 1
+    # field_test.go: barrettReduce over its whole documented range; the zetas table; and the two-instruction
+    # products / reductions with R = 2^32 that replace montReduce on the device (kyber_dev.h)
+    z = orc.kyber_zetas()          # the reference's table: zeta^brv * 2^16
+    assert [hs.hs_kyber_zeta_plain(i) * 65536 % Q for i in range(128)] == [int(v) % Q for v in z]
     for x in range(-32768, 32768):
         r = hs.hs_kyber_barrett(x)
         assert 0 <= r <= Q and (r - x) % Q == 0
         n = hs.hs_kyber_normalize(x)
         assert n == x % Q
+    hs.hs_kyber_mulc.restype = hs.hs_kyber_reduce32.restype = hs.hs_kyber_mulc_limit.restype = C.c_uint32
+    hs.hs_kyber_mulc.argtypes = [C.c_uint32, C.c_uint32]
+    hs.hs_kyber_reduce32.argtypes = [C.c_uint32]
+    lim = hs.hs_kyber_mulc_limit()
+    assert lim == (1 << 32) // Q
+    rng = np.random.default_rng(1)
+    edge = [0, 1, 2, Q - 1, Q, Q + 1, 8 * Q + 3, 128 * Q - 1, lim - 1]
+    for w in range(Q):              # every residue as the constant, edge operands
+        for b in edge:
+            assert hs.hs_kyber_mulc(b, w) == w * b % Q
+    for b, w in zip(rng.integers(0, lim, 200000), rng.integers(0, Q, 200000)):
+        assert hs.hs_kyber_mulc(int(b), int(w)) == int(w) * int(b) % Q
+    inv32 = pow(1 << 32, -1, Q)
+    for t in [0, 1, Q, (1 << 31) - 1, 1 << 31, (1 << 32) - 1] + [int(v) for v in rng.integers(0, 1 << 32, 200000, dtype=np.uint64)]:
+        assert hs.hs_kyber_reduce32(t) == (-t * inv32) % Q
 
 
 @pytest.mark.parametrize("d", [4, 5, 10, 11])
 def test_compress_exact_for_all_x(hs, d):
-    # poly_test.go:351-378
-    for x in range(Q):
-        want = ((x << d) + Q // 2) // Q % (1 << d)
+    # poly_test.go:351-378, on the extended domain the kernels use: any representative below 4q (2q + 8 for d = 11)
+    for x in range(4 * Q if d != 11 else 2 * Q + 8):
+        want = (((x % Q) << d) + Q // 2) // Q % (1 << d)
         assert hs.hs_kyber_compress(x, d) == want
     for t in range(1 << d):
         assert hs.hs_kyber_decompress(t, d) == (t * Q + (1 << (d - 1))) >> d
@@ -89,32 +101,49 @@ def test_cbd_tables(hs):
 
 
 def test_ntt_network_matches_oracle(hs):
-    # ntt_test.go:49-81 with the device's layer / layout / zeta schedule executed on the host
+    # ntt_test.go:49-109 with the device's layer / layout / twiddle schedule executed on the host, including the
+    # element widths of the LDS exchanges and the no-reduction bounds of the lazy arithmetic
     rng = np.random.default_rng(2)
-    for _ in range(30):
-        p = rng.integers(-Q + 1, Q, 256).astype(np.int16)
-        a = p.copy()
-        hs.hs_kyber_ntt(a.ctypes.data_as(C.c_void_p), 0)
-        assert (a == orc.kyber_ntt(p)).all()          # forward: identical without normalisation
-        p = rng.integers(0, Q, 256).astype(np.int16)
-        b = p.copy()
-        hs.hs_kyber_ntt(b.ctypes.data_as(C.c_void_p), 1)
-        assert (orc.kyber_normalize(b) == orc.kyber_normalize(orc.kyber_invntt(p))).all()
+    mx = C.c_uint32()
+    inv16 = pow(1 << 16, -1, Q)
+    neg_r32 = (-(1 << 32)) % Q
+
+    def run(p, inverse, scale):
+        a = np.ascontiguousarray(p, dtype=np.uint32)
+        hs.hs_kyber_ntt(a.ctypes.data_as(C.c_void_p), inverse, scale, C.byref(mx))
+        return a.astype(np.int64)
+
+    fwd_inputs = [rng.integers(0, Q + 4, 256) for _ in range(30)] + [np.full(256, Q + 3), np.zeros(256, np.int64), np.arange(256) % 2 * (Q + 3)]
+    for p in fwd_inputs:
+        got = run(p, 0, 0)
+        want = orc.kyber_normalize(orc.kyber_ntt(orc.kyber_normalize(p.astype(np.int16))))
+        assert (got % Q == want).all()
+        assert got.max() < Q + 4 + 7 * Q and mx.value < (1 << 15)     # int16 operands of V_DOT2, 16-bit exchanges
+    inv_inputs = [rng.integers(0, Q, 256) for _ in range(30)] + [np.full(256, Q - 1), np.arange(256) % 2 * (Q - 1), (np.arange(256) // 2) % 2 * (Q - 1)]
+    for p in inv_inputs:
+        ref = orc.kyber_normalize(orc.kyber_invntt(p.astype(np.int16))).astype(np.int64)   # 2^16 times the exact inverse
+        got = run(p, 1, 65536)
+        assert (got == ref).all() and mx.value < 128 * Q                # canonical output, lazy sums inside the mulc domain
+        got = run(p, 1, neg_r32)
+        assert (got == ref * inv16 * neg_r32 % Q).all()
+    # round trip (ntt_test.go:83-109): InvNTT(NTT(p)) = p * 2^16
+    p = rng.integers(0, Q, 256)
+    assert (run(orc.kyber_normalize(run(p, 0, 0).astype(np.int16)), 1, 65536) == p * 65536 % Q).all()
 
 
 def test_mulhat_lane_share(hs):
+    # poly_test.go:92-133: the V_DOT2 formulation of the kernels, b lazy (< 2^15), result = -2^-32 times the products
     rng = np.random.default_rng(3)
-    a = rng.integers(0, Q + 1, 256).astype(np.int16)
-    b = rng.integers(0, Q + 1, 256).astype(np.int16)
-    want = orc.kyber_normalize(orc.kyber_mulhat(a, b))
-    out = (C.c_int * 4)()
-    for lane in range(64):
-        ai = (C.c_int * 4)(*[int(v) for v in a[4 * lane:4 * lane + 4]])
-        bi = (C.c_int * 4)(*[int(v) for v in b[4 * lane:4 * lane + 4]])
-        hs.hs_kyber_mulhat4(out, ai, bi, lane)
-        assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
-        hs.hs_kyber_mulhat4_packed(out, ai, bi, lane)   # V_DOT2 formulation used by the kernels
-        assert [v % Q for v in out] == want[4 * lane:4 * lane + 4].tolist()
+    a = rng.integers(0, Q, 256).astype(np.int16)
+    for b in (rng.integers(0, Q, 256), rng.integers(0, 8 * Q + 4, 256), np.full(256, 8 * Q + 3)):
+        plain = orc.kyber_normalize(orc.kyber_mulhat(a, orc.kyber_normalize(b.astype(np.int16)))).astype(np.int64) * 65536 % Q
+        want = (-plain * pow(1 << 32, -1, Q)) % Q
+        out = (C.c_int * 4)()
+        for lane in range(64):
+            ai = (C.c_int * 4)(*[int(v) for v in a[4 * lane:4 * lane + 4]])
+            bi = (C.c_int * 4)(*[int(v) for v in b[4 * lane:4 * lane + 4]])
+            hs.hs_kyber_mulhat4_packed(out, ai, bi, lane)   # V_DOT2 formulation used by the kernels
+            assert list(out) == want[4 * lane:4 * lane + 4].tolist()
 
 
 def test_dilithium_mont32_and_zetas(hs):

@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(64) ntt_loop(int16_t *out, int iters) {
     for (int i = 0; i < iters; i++) {
         kyber::ntt(c, z, xch, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) c[r] = kyber::barrett(c[r]);
-        kyber::invntt(c, z, xch, lane);
+        for (int r = 0; r < 4; r++) c[r] = kyber::normalize(c[r]);
+        kyber::invntt<1u>(c, z, xch, lane);
     }
     if (c[0] == 12345) out[0] = (int16_t)c[1];
 }
