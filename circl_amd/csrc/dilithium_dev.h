@@ -78,6 +78,15 @@ CIRCL_HD uint32_t mont32(uint32_t a, uint32_t b) {
     const uint32_t m = lo * QINV32;
     return hi - umulhi32(m, Q) + Q;
 }
+// The same reduction of a 64-bit value t < 2^32 q (a lazily accumulated sum of products): t 2^-32 mod q in (0, 2q).
+// A dot product of L terms is then L V_MAD_U64_U32 and ONE reduction instead of L mont32.
+CIRCL_HD uint32_t mont64(uint64_t t) {
+    uint32_t lo = (uint32_t)t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(lo));  // as in mont32
+#endif
+    return (uint32_t)(t >> 32) - umulhi32(lo * QINV32, Q) + Q;
+}
 // field.go:5-13 ReduceLe2Q generalised: x < 2^32 -> < 2^24 (and < 2q when x < 2^28)
 CIRCL_HD uint32_t fold(uint32_t x) { return (x & 0x7fffff) + umul24(x >> 23, 8191u); }
 // field.go:27-31 le2qModQ: x < 2q -> [0,q)
@@ -186,6 +195,11 @@ __device__ __forceinline__ void ntt(uint32_t (&c)[4], const LaneZetas &z, uint32
 // Exact inverse transform INCLUDING the factor 1/256 (the reference's InvNTT returns R/256 times
 // this, ntt.go:212-216, compensated by its R^-1-carrying MulHat).  In: layout L4, c < 2q.
 // Out: layout L1, c < 2q.  No reduction between the layers: values double and stay below 512 q.
+// FINAL is the last step's multiplier in mont32 form: INV256_R (default) for the exact inverse, INV256_RR when the input
+// carries a factor 2^-32 (it came out of mont64 / mont32 on unscaled operands) that should disappear on the way.
+constexpr uint32_t INV256_R = (uint32_t)((uint64_t)cpow(256, Q - 2) * R32 % Q);
+constexpr uint32_t INV256_RR = (uint32_t)((uint64_t)INV256_R * R32 % Q);
+template <uint32_t FINAL = INV256_R>
 __device__ __forceinline__ void invntt(uint32_t (&c)[4], const LaneZetas &z, uint32_t *xch, int lane) {
     gs<2>(c[0], c[1], z.i7a); gs<2>(c[2], c[3], z.i7b);
     gs<4>(c[0], c[2], z.i6); gs<4>(c[1], c[3], z.i6);
@@ -200,9 +214,8 @@ __device__ __forceinline__ void invntt(uint32_t (&c)[4], const LaneZetas &z, uin
     gs<128>(c[0], c[1], z3); gs<128>(c[2], c[3], z2);
     gs<256>(c[0], c[2], z1); gs<256>(c[1], c[3], z1);
     // times 256^-1:  mont32(x, 2^32 / 256) = x / 256   (x < 512 q)
-    constexpr uint32_t inv256R = (uint32_t)((uint64_t)cpow(256, Q - 2) * R32 % Q);
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = mont32(c[r], inv256R);
+    for (int r = 0; r < 4; r++) c[r] = mont32(c[r], FINAL);
 }
 #endif
 

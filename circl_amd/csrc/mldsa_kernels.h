@@ -341,10 +341,13 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
 __device__ __forceinline__ void load_row_l4(uint32_t (&a)[4], const uint32_t *rows, int stream, int lane) {
     load_poly24(a, rows + stream * kPackedRowDwords, lane);
 }
-// acc += sum_j A[stream0 + j] o vhat[j]: the rows are fetched four at a time ahead of the multiplies, so
-// that their L2 latencies overlap instead of adding up.
-template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&acc)[4], const uint32_t *rows, int stream0, const uint32_t (&vhat)[L][4],
+// out = 2^-32 sum_j A[stream0 + j] o vhat[j] mod q, in (0, 2q): the products accumulate un-reduced in 64 bits
+// (V_MAD_U64_U32; a < 2^23, vhat < 2^28, L <= 7 terms: below 2^32 q) and are Montgomery-reduced once per coefficient.
+// vhat is the plain transform (no 2^32 pre-scaling); callers drop the 2^-32 in their inverse transform (INV256_RR).
+// The rows are fetched four at a time ahead of the multiplies, so that their L2 latencies overlap instead of adding up.
+template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&out)[4], const uint32_t *rows, int stream0, const uint32_t (&vhat)[L][4],
                                                          int lane) {
+    uint64_t acc[4] = {0, 0, 0, 0};
     detail::static_for<0, (L + 3) / 4>([&](auto ic) {
         constexpr int j0 = 4 * decltype(ic)::v, CNT = L - j0 < 4 ? L - j0 : 4;
         uint32_t a[CNT][4];
@@ -353,16 +356,19 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&acc)[4], co
 #pragma unroll
         for (int j = 0; j < CNT; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] += dilithium::mont32(a[j][r], vhat[j0 + j][r]);
+            for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[j][r] * vhat[j0 + j][r];
     });
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[r] = dilithium::mont64(acc[r]);
 }
-// SampleInBall (sample.go:299-339) followed by the NTT: c-hat * 2^32 in layout L4.
+// SampleInBall (sample.go:299-339) followed by the NTT: c-hat in layout L4, times 2^32 if SCALED (so that
+// mont32(x, c-hat) is the plain product) or plain (the product then carries 2^-32, like mac_rows' output).
 // `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
 // 8 sign bytes, then bytes b <= i pick the positions.  Lane p keeps bytes p, p+64 and p+128 of the
 // current 136-byte block in registers; one step is three compares + ballots, scalar bit tricks and
 // one v_readlane -- no memory traffic.  `blk` (>= 136 B of LDS) is only used if a second block is
 // needed (rare).
-template <int MODE>
+template <int MODE, bool SCALED = true>
 __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const uint8_t *st, uint8_t *blk, uint32_t *xch,
                                                    const dilithium::LaneZetas &z, int lane) {
     using P = DP<MODE>;
@@ -420,7 +426,7 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
     for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
     dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-    for (int r = 0; r < 4; r++) chat[r] = dilithium::mont32(c[r], dilithium::R32SQ);
+    for (int r = 0; r < 4; r++) chat[r] = SCALED ? dilithium::mont32(c[r], dilithium::R32SQ) : c[r];
 }
 
 // ---- kernel V -----------------------------------------------------------------------------------
@@ -475,7 +481,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
         bool bad = false;
         if (!(ABLATE & 2)) {
             const uint8_t *sg = sig + item * G::SIG;
-            sample_in_ball_hat<MODE>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // first: z-hat is not live yet
+            sample_in_ball_hat<MODE, false>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // first: z-hat is not live yet
             __syncthreads();
             if (lane < K * 8) hintbits[lane] = 0;
             stage_unaligned(stg, sg + P::CT, ZH_BYTES, lane);
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                 }
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) zhat[j][r] = dilithium::mont32(c[r], dilithium::R32SQ);  // z-hat * 2^32
+                for (int r = 0; r < 4; r++) zhat[j][r] = c[r];  // plain z-hat, < 17q
             }
             // hints: strict decoding (pack.go:113-141)
             {
@@ -536,7 +542,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
         for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
             uint32_t acc[4] = {0, 0, 0, 0};
-            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : (SHARED ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // a * z-hat, < 2q each
+            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : (SHARED ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
             uint32_t t[4], w[4];
             {
                 // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,
@@ -551,10 +557,10 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             dilithium::ntt(t, z, xch, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t ct1 = dilithium::mont32(t[r], chat[r]);  // c-hat * t1-hat, < 3q
-                w[r] = dilithium::fold(acc[r] + 4 * Q - ct1);
+                const uint32_t ct1 = dilithium::mont32(t[r], chat[r]);  // 2^-32 c-hat * t1-hat, < 2q
+                w[r] = dilithium::fold(acc[r] + 2 * Q - ct1);           // < 4q, folded below 2q for the inverse transform
             }
-            dilithium::invntt(w, z, xch, lane);
+            dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);  // both terms carried 2^-32
             unsigned w1v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -714,7 +720,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             if (k < L) {
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) shat[k < L ? k : 0][r] = dilithium::mont32(c[r], dilithium::R32SQ);
+                for (int r = 0; r < 4; r++) shat[k < L ? k : 0][r] = c[r];  // plain s1-hat
             }
         }
 
@@ -722,10 +728,8 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             uint32_t w[4] = {0, 0, 0, 0};
-            mac_rows<L>(w, rows, g * G::STREAMS + i * L, shat, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
-            dilithium::invntt(w, z, xch, lane);
+            mac_rows<L>(w, rows, g * G::STREAMS + i * L, shat, lane);  // 2^-32 A s1-hat, < 2q
+            dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
             const int8_t *s2 = sec + (g * NS + L + i) * Kg::S_STRIDE;
             unsigned t1[4], t0[4];
 #pragma unroll
@@ -966,25 +970,24 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                     x += (uint32_t)((int32_t)x >> 31) & Q;
                     yh[l][r] = x;
                 }
-                dilithium::ntt(yh[l], z, xch, lane);
-#pragma unroll
-                for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);  // y-hat * 2^32
+                dilithium::ntt(yh[l], z, xch, lane);  // plain y-hat, < 17q
             }
             // ---- w = InvNTT(A y-hat), Decompose, w1 packing (dilithium.go:385-398) ----
 #pragma unroll 1
             for (int i = 0; i < K; i++) {
-                uint32_t w[4] = {0, 0, 0, 0};
+                uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient (see mac_rows)
 #pragma unroll
                 for (int j = 0; j < L; j++) {
                     const uint4 a = *reinterpret_cast<const uint4 *>(arows + (i * L + j) * S::A_ROW + 4 * lane);
-                    w[0] += dilithium::mont32(a.x, yh[j][0]);
-                    w[1] += dilithium::mont32(a.y, yh[j][1]);
-                    w[2] += dilithium::mont32(a.z, yh[j][2]);
-                    w[3] += dilithium::mont32(a.w, yh[j][3]);
+                    acc[0] += (uint64_t)a.x * yh[j][0];
+                    acc[1] += (uint64_t)a.y * yh[j][1];
+                    acc[2] += (uint64_t)a.z * yh[j][2];
+                    acc[3] += (uint64_t)a.w * yh[j][3];
                 }
+                uint32_t w[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
-                dilithium::invntt(w, z, xch, lane);
+                for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
+                dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
                 unsigned w1v[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {

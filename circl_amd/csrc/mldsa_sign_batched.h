@@ -176,24 +176,23 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
             x += (uint32_t)((int32_t)x >> 31) & Q;
             yh[l][r] = x;
         }
-        dilithium::ntt(yh[l], z, xch, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) yh[l][r] = dilithium::mont32(yh[l][r], dilithium::R32SQ);
+        dilithium::ntt(yh[l], z, xch, lane);  // plain y-hat, < 17q
     }
     const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
-        uint32_t w[4] = {0, 0, 0, 0};
+        uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient (see mac_rows)
 #pragma unroll
         for (int j = 0; j < L; j++) {
             uint32_t a[4];
             load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) w[r] += dilithium::mont32(a[r], yh[j][r]);
+            for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * yh[j][r];
         }
+        uint32_t w[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) w[r] = dilithium::fold(w[r]);
-        dilithium::invntt(w, z, xch, lane);
+        for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
+        dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
         unsigned w1v[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {

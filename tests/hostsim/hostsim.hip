@@ -101,6 +101,7 @@ void hs_kyber_ntt(uint32_t *p, int inverse, uint32_t scale, uint32_t *maxval) {
 }
 
 uint32_t hs_dil_mont32(uint32_t a, uint32_t b) { return dilithium::mont32(a, b); }
+uint32_t hs_dil_mont64(uint64_t t) { return dilithium::mont64(t); }
 uint32_t hs_dil_fold(uint32_t x) { return dilithium::fold(x); }
 uint32_t hs_dil_normalize(uint32_t x) { return dilithium::normalize(x); }
 uint32_t hs_dil_zeta(int i) { return dilithium::zeta(i); }

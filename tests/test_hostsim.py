@@ -167,6 +167,21 @@ def test_dilithium_mont32_and_zetas(hs):
         assert hs.hs_dil_normalize(int(x)) == int(x) % DQ
 
 
+def test_dilithium_mont64_lazy_dot_product(hs):
+    # the single reduction of a 64-bit lazily accumulated dot product (mac_rows): t 2^-32 mod q in (0, 2q) for t < 2^32 q
+    hs.hs_dil_mont64.restype = C.c_uint32
+    hs.hs_dil_mont64.argtypes = [C.c_uint64]
+    inv32 = pow(1 << 32, -1, DQ)
+    rng = np.random.default_rng(12)
+    ts = [0, 1, DQ, (1 << 32) - 1, 1 << 32, (DQ << 32) - 1, 7 * (DQ - 1) * (17 * DQ)]
+    ts += [int(a) * int(b) for a, b in zip(rng.integers(0, DQ, 3000), rng.integers(0, 17 * DQ, 3000))]
+    ts += [int(v) for v in rng.integers(0, DQ << 32, 3000, dtype=np.uint64)]
+    for t in ts:
+        assert t < (DQ << 32)
+        r = hs.hs_dil_mont64(t)
+        assert 0 < r < 2 * DQ and r % DQ == t * inv32 % DQ
+
+
 @pytest.mark.parametrize("g88", [0, 1])
 def test_decompose_use_hint_laws(hs, g88):
     # sign/mldsa/mldsa65/internal/rounding_test.go:14-67
