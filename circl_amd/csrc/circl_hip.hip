@@ -489,7 +489,6 @@ int mldsa_verify_shared_dev_impl(const uint8_t *pk, const uint8_t *sig, const ui
 
 template <int MODE>
 int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
-    using G = circl::mldsa::DG<MODE>;
     using Kg = circl::mldsa::KG<MODE>;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < mldsa_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(seed32) || !aligned16(pk) || !aligned16(sk))
@@ -609,6 +608,29 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
     const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 3 + up256(n) + 256 + up256(4 * tail_units) + tail_units * S::SPEC_STRIDE;
     return n < kSignBatchedMin ? persistent : persistent + batched;  // the batched path finishes its tail persistently
 }
+// Page-locked read-back slots for the per-round counts: a small pool, so that concurrent signing calls never share a slot.
+struct PinnedCounts {
+    std::mutex mu;
+    std::vector<uint32_t *> free_slots[64];
+    uint32_t *acquire(int dev) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_slots[dev].empty()) {
+                uint32_t *p = free_slots[dev].back();
+                free_slots[dev].pop_back();
+                return p;
+            }
+        }
+        uint32_t *p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&p), 256, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return p;
+    }
+    void release(int dev, uint32_t *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_slots[dev].push_back(p);
+    }
+};
+PinnedCounts g_pinned_counts;
 
 // Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h).  Synchronises the
 // stream once per round to read the number of items that are still unsigned.
@@ -665,12 +687,16 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     // with the device-side count, so it runs one round ahead: round r is launched with the count read back after round
     // r - 2 (an over-estimate, the list only shrinks) while round r - 1 still executes, and the read-back of round r - 1
     // has arrived by the time round r + 1 is enqueued.  Only the hand-over to the tail kernel needs the exact count.
-    static uint32_t *pinned[64] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return CIRCL_HIP_ENODEV;
-    if (!pinned[dev]) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned[dev]), 256, hipHostMallocDefault));
-    volatile uint32_t *h_count = pinned[dev];  // [0], [1]: counts after even / odd rounds
+    struct SlotGuard {
+        int dev;
+        uint32_t *p;
+        ~SlotGuard() { if (p) g_pinned_counts.release(dev, p); }
+    } slot{dev, g_pinned_counts.acquire(dev)};
+    if (!slot.p) { g_err = "hipHostMalloc failed"; return CIRCL_HIP_EHIP; }
+    volatile uint32_t *h_count = slot.p;  // [0], [1]: counts after even / odd rounds
     hipEvent_t ev[2];
     HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
@@ -724,7 +750,7 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         // (with pending == 1, i.e. right after an exact count, `upper` stays the bound for one more round)
         else exact = false;
     }
-    HIP_TRY(hipStreamSynchronize(st));  // the pinned slots and events are reused by the next call
+    HIP_TRY(hipStreamSynchronize(st));  // the pinned slot and the events go back to their pools
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
