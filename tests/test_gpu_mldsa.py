@@ -305,3 +305,53 @@ def test_sign_shared_key_matches_oracle(param, n):
     want = orc.mldsa_sign(param, np.tile(sk, (n, 1)), msgs, ctxs, rnd)
     assert (sig == want).all()
     assert hostapi.mldsa_verify_shared(param, pk, sig, msgs, ctxs).all()
+
+
+@pytest.mark.gpu
+def test_concurrent_device_sign_calls_do_not_share_state():
+    # The C ABI is re-entrant (SURVEY 8b "Threading"): three host threads sign different batches at the same time on one
+    # device through the device-pointer entry point, each on its own stream and workspace.  The per-round count read-backs
+    # of the batched signer must not be shared between the calls.
+    import ctypes as C
+    import threading
+    import torch
+    from circl_amd import _native as nat
+    L = nat.lib()
+    param = 65
+    PK, SK, SIG = orc.DSA_SIZES[param]
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t, n in enumerate((700, 450, 900)):
+        pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+        msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+        jobs.append({"n": n, "sk": sk, "msgs": msgs, "want": orc.mldsa_sign(param, sk, msgs)})
+    for j in jobs:
+        n = j["n"]
+        j["d_sk"] = torch.from_numpy(j["sk"]).cuda()
+        j["d_msg"] = torch.from_numpy(np.frombuffer(b"".join(j["msgs"]) + bytes(16), dtype=np.uint8).copy()).cuda()
+        j["d_off"] = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+        j["d_rnd"] = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+        j["sig"] = torch.empty((n, SIG), dtype=torch.uint8, device="cuda")
+        wsb = L.circl_hip_mldsa_sign_workspace_size(param, n)
+        j["ws"], j["wsb"] = torch.empty(wsb, dtype=torch.uint8, device="cuda"), wsb
+        j["stream"] = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def run(j):
+        torch.cuda.set_device(0)
+        for _ in range(3):
+            j["rc"] = L.circl_hip_mldsa_sign_dev(param, j["d_sk"].data_ptr(), j["d_msg"].data_ptr(), j["d_off"].data_ptr(), None, None,
+                                                 j["d_rnd"].data_ptr(), 0, j["sig"].data_ptr(), j["n"], j["ws"].data_ptr(), j["wsb"],
+                                                 C.c_void_p(j["stream"].cuda_stream))
+            if j["rc"] != 0:
+                return
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert j["rc"] == 0
+        assert (j["sig"].cpu().numpy() == j["want"]).all()
