@@ -132,6 +132,12 @@ int main() {
     RUNS(6, 16, "scratch A only");
     RUNS(3, 16, "scratch C only");
     RUNS(5, 16, "scratch B only");
+    // would a split into a sampling kernel (A + B) and a ring kernel (C) pay?  Each compiled alone needs fewer VGPRs
+    RUNS(4, 16, "scratch A + B only");
+    RUNS(4, 20, "scratch A + B only");
+    RUNS(4, 24, "scratch A + B only");
+    RUNS(3, 20, "scratch C only");
+    RUNS(3, 24, "scratch C only");
     {
         float ms = time_ms([](void *v) { E *e = (E *)v;
             hipLaunchKernelGGL(mlkem::mlkem_hash_kernel<K>, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, 0, e->ek, e->m, e->ss, (uint8_t *)e->r, e->n); }, &e);
