@@ -66,6 +66,17 @@ def make_inputs(batch, rank, dev):
     return ek, m
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(ek, m, budget_s=12.0):
     """Oracle ('port': scalar C restatement, NOT the reference's AVX2 path) on the host cores."""
     from oracle import orc
@@ -80,6 +91,7 @@ def cpu_baseline(ek, m, budget_s=12.0):
     orc.mlkem_encaps(PARAM, ek_np[:sample], m_np[:sample], threads=cores)
     dt = time.perf_counter() - t
     return {"value": sample / dt, "unit": "encaps/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model(),
             "sample": f"first {sample} items of the same batch, {dt:.1f} s, oracle/liborc.so with {cores} pthreads = the CPUs this "
                       f"container may use (affinity {len(os.sched_getaffinity(0))}, capped by the cgroup CPU quota); scalar C "
                       "restatement of CIRCL's generic Go (Go toolchain absent, so not CIRCL's AVX2 path)"}
