@@ -1035,6 +1035,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                     bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
                     w0[i * 256 + nidx] = v;
                 }
+                if (__any(bad)) break;  // one polynomial out of range decides the attempt
             }
             if (__any(bad)) continue;
             // ---- z = y + c s1 (dilithium.go:420-429), packed as it will appear in the signature ----
@@ -1057,6 +1058,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                 }
                 mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
                 for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+                if (__any(bad)) break;
             }
             if (__any(bad)) continue;
             // ---- c t0, hints (dilithium.go:431-450) ----

@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
             bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
             w0[i * 256 + nidx] = v;
         }
+        if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
     }
     bool reject = __any(bad);
     // z = y + c s1
@@ -293,6 +294,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
             }
             mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
             for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+            if (__any(bad)) break;
         }
         reject = __any(bad);
     }
