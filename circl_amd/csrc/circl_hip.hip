@@ -605,7 +605,7 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
     using B = circl::mldsa::SB<MODE>;
     const size_t persistent = up256(128 * n) + 256 + (size_t)cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
     const size_t tail_units = (size_t)cu_count() * kSignBlocksPerCU;  // speculative tail: best[] and one parked signature per unit
-    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 3 + up256(n) + 256 + up256(4 * tail_units) + tail_units * S::SPEC_STRIDE;
+    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 4 + 256 + up256(4 * tail_units) + tail_units * S::SPEC_STRIDE;
     return n < kSignBatchedMin ? persistent : persistent + batched;  // the batched path finishes its tail persistently
 }
 // Page-locked read-back slots for the per-round counts: a small pool, so that concurrent signing calls never share a slot.
@@ -656,7 +656,7 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     S.attempts = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.list[0] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.list[1] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
-    S.done = p; p += up256(n);
+    S.best = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
     S.count = reinterpret_cast<uint32_t *>(p); p += 256;
     unsigned *tail_work = reinterpret_cast<unsigned *>(p);          // persistent-kernel ticket counter
     uint8_t *tail_scratch = p + 256;
@@ -669,6 +669,15 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         return (uint32_t)(x >= 1 && x <= 1024 ? x : 2);  // measured optimum (tools/sign_tail_sweep.sh): 2 leftover items per CU
     }();
     const uint32_t tail_threshold = (uint32_t)cu_count() * tail_mult;
+    // Speculative rounds: once at most spec_target entries are left, a round costs its five dependent launches whatever
+    // the count, so every item gets k = spec_target / items (<= 8) consecutive attempts per round.
+    static const uint32_t spec_per_cu = [] {  // tuning aid: CIRCL_HIP_SIGN_SPEC = list entries per CU below which rounds speculate (0 = never)
+        const char *e = getenv("CIRCL_HIP_SIGN_SPEC");
+        const int x = e ? atoi(e) : -1;
+        return (uint32_t)(x >= 0 && x <= 4096 ? x : 128);  // plateau 96 .. 256 at 2^16 items; 0 costs 15 % (ML-DSA-65)
+    }();
+    const uint32_t spec_target = (uint32_t)std::min<size_t>((size_t)cu_count() * spec_per_cu, n);
+    if (n >= (size_t(1) << circl::mldsa::kEntryShift)) return CIRCL_HIP_EPARAM;
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -683,10 +692,10 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n);
     }
-    // The host needs the number of unsigned items only to size the next round's grids, and the kernels bound themselves
-    // with the device-side count, so it runs one round ahead: round r is launched with the count read back after round
-    // r - 2 (an over-estimate, the list only shrinks) while round r - 1 still executes, and the read-back of round r - 1
-    // has arrived by the time round r + 1 is enqueued.  Only the hand-over to the tail kernel needs the exact count.
+    // The host needs the number of list entries only to size the next round's grids, and the kernels bound themselves
+    // with the device-side count.  While the rounds are throughput-bound it runs one round ahead: round r is launched with
+    // the count read back after round r - 2 (an over-estimate, the list only shrinks) while round r - 1 still executes.
+    // In the latency-bound regime (and for the hand-over to the tail kernel) it waits for the exact count every round.
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return CIRCL_HIP_ENODEV;
@@ -702,53 +711,75 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     struct EvGuard { hipEvent_t *e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } guard{ev};
     int cur = 0;
-    uint32_t upper = (uint32_t)n;   // bound on the current list's length
+    uint32_t upper = (uint32_t)n;   // bound on the current list's length (entries)
+    unsigned k_cur = 1;             // entries per item in the current list
     bool exact = true;              // upper is the exact length
     int pending = 0;                // read-backs in flight: rounds (round - pending) .. (round - 1)
     for (int round = 0; upper > 0; round++) {
         if (round > 4096) { g_err = "mldsa sign: rejection loop did not terminate"; return CIRCL_HIP_EHIP; }
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        if (upper <= tail_threshold + tail_threshold / 2 && !exact) {  // close to the hand-over: get the exact count
+        const bool late = upper / k_cur <= std::max(spec_target, tail_threshold + tail_threshold / 2);
+        if (late && !exact) {  // latency-bound rounds, or close to the hand-over: work with the exact count
             HIP_TRY(hipStreamSynchronize(st));
             upper = h_count[(round - 1) & 1];
             exact = true;
             pending = 0;
             if (upper == 0) break;
         }
-        if (upper <= tail_threshold) {
-            // few items left: rounds would be launch-bound, so every leftover item gets its own wavefront(s), which
-            // run that item's remaining rejection iterations to the end (continuing its nonce sequence).
-            // The tail's duration is the unluckiest item's ~30 sequential attempts, with most of the chip idle: when the
-            // resident slots allow, 2, 4 or 8 wavefronts share an item and try its attempts in parallel (first success wins).
-            const unsigned spec_w = (size_t)upper * 8 <= tail_units ? 8u : (size_t)upper * 4 <= tail_units ? 4u : (size_t)upper * 2 <= tail_units ? 2u : 1u;
+        const uint32_t items = (upper + k_cur - 1) / k_cur;  // exact when `exact`
+        if (exact && items <= tail_threshold) {
+            // few items left: every leftover item gets its own wavefront(s), which run that item's remaining rejection
+            // iterations to the end (continuing its nonce sequence).  The tail's duration is the unluckiest item's ~30
+            // sequential attempts, with most of the chip idle: when the resident slots allow, 2, 4 or 8 wavefronts share
+            // an item and try its attempts in parallel (first success wins).
+            if (k_cur > 1) {  // the tail wants one entry per item: keep the first of each
+                HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
+                hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur, 0u, 1u);
+                cur ^= 1;
+            }
+            const unsigned spec_w = (size_t)items * 8 <= tail_units ? 8u : (size_t)items * 4 <= tail_units ? 4u : (size_t)items * 2 <= tail_units ? 2u : 1u;
             HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
-            if (spec_w > 1) HIP_TRY(hipMemsetAsync(tail_best, 0xff, 4 * (size_t)upper, st));
-            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>((size_t)upper * spec_w, tail_units)), dim3(64),
+            if (spec_w > 1) HIP_TRY(hipMemsetAsync(tail_best, 0xff, 4 * (size_t)items, st));
+            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>((size_t)items * spec_w, tail_units)), dim3(64),
                                SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[cur],
-                               (const uint32_t *)S.attempts, (size_t)upper, spec_w, tail_best, tail_spec, shared ? 1 : 0);
+                               (const uint32_t *)S.attempts, (size_t)items, spec_w, tail_best, tail_spec, shared ? 1 : 0);
             if (spec_w > 1)
-                hipLaunchKernelGGL(sign_tail_commit_kernel<MODE>, dim3(upper), dim3(64), 0, st, (const uint32_t *)S.list[cur],
+                hipLaunchKernelGGL(sign_tail_commit_kernel<MODE>, dim3(items), dim3(64), 0, st, (const uint32_t *)S.list[cur],
                                    (const uint32_t *)S.attempts, (const uint32_t *)tail_best, (const uint8_t *)tail_spec, sig, spec_w);
             break;
         }
+        // attempts per item in the NEXT list: the survivors of this round are at most `items`
+        unsigned k_next = 1;
+        if (exact && spec_target > 0 && items <= spec_target)
+            k_next = (unsigned)std::min<uint32_t>(circl::mldsa::kMaxSpec, std::max<uint32_t>(1u, spec_target / items));
         hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3((unsigned)(((size_t)upper * L + 255) / 256)), dim3(256), 0, st, S, cur);
         hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur);
         hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig);
+        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig, k_cur);
+        if (k_cur > 1) hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig);
         HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
-        hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur, k_cur, k_next);
         cur ^= 1;
         HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(&h_count[round & 1]), S.count + cur, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(ev[round & 1], st));
         pending++;
-        if (pending == 2) {  // the count after round - 1 has long arrived: it bounds the list of round + 1
-            HIP_TRY(hipEventSynchronize(ev[(round - 1) & 1]));
-            upper = h_count[(round - 1) & 1];
-            exact = false;
-            pending = 1;
+        if (k_cur == 1 && k_next == 1) {
+            if (pending == 2) {  // the count after round - 1 has long arrived: it bounds the list of round + 1
+                HIP_TRY(hipEventSynchronize(ev[(round - 1) & 1]));
+                upper = h_count[(round - 1) & 1];
+                exact = false;
+                pending = 1;
+            } else {
+                exact = false;  // (right after an exact count, `upper` stays the bound for one more round)
+            }
+        } else {
+            // the entry count changes with k: no stale bound is valid for the new list, so wait for this round's count
+            HIP_TRY(hipStreamSynchronize(st));
+            upper = h_count[round & 1];
+            exact = true;
+            pending = 0;
         }
-        // (with pending == 1, i.e. right after an exact count, `upper` stays the bound for one more round)
-        else exact = false;
+        k_cur = k_next;
     }
     HIP_TRY(hipStreamSynchronize(st));  // the pinned slot and the events go back to their pools
     HIP_TRY(hipGetLastError());

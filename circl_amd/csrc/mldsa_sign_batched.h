@@ -5,12 +5,19 @@
 // rounds over the list of still-unsigned items.  Per-item state lives in the workspace:
 //   A rows (K L KB), s1-hat / s2-hat / t0-hat ((L+2K) KB), y bytes, w0, w1, mu || w1, c~ + ball sponge.
 // One round = five launches over the active list:
-//   mask   lane = (active item, l)      ExpandMask streams, 64 useful lanes per wave
-//   w      wave = active item           y-hat, w = InvNTT(A y-hat), Decompose, w1 packing
-//   chal   lane = active item           c~ = H(mu || w1), first SampleInBall block
-//   finish wave = active item           c s2 / z / c t0 / hints, accept or bump the attempt counter
-//   compact                             next active list
-// The host reads the active count back every few rounds and stops when it is zero.
+//   mask   lane = (entry, l)            ExpandMask streams, 64 useful lanes per wave
+//   w      wave = entry                 y-hat, w = InvNTT(A y-hat), Decompose, w1 packing
+//   chal   lane = entry                 c~ = H(mu || w1), first SampleInBall block
+//   finish wave = entry                 c s2 / z / c t0 / hints; a success lowers best[item]
+//   compact                             next active list, attempt counters
+// An ENTRY of the active list is (item, off): attempt number attempts[item] + off of that item.  Early rounds have one
+// entry per item.  Once so few items are left that a round is latency-bound (five dependent launches whatever the
+// count), the list carries k <= 8 consecutive attempts per item, tried in the same round: the signature is the one of
+// the LOWEST successful attempt (atomicMin on best[item]; a commit launch copies it out), exactly the attempt the
+// sequential loop of the reference would have stopped at, and the number of rounds shrinks.  The per-attempt buffers
+// (y, w0, w1, mu || w1, c~) are indexed by the entry's position in the list, which never exceeds n.
+// The host reads the entry count back (one round behind while the rounds are throughput-bound, every round once they
+// are latency-bound) and stops when it is zero.
 #pragma once
 #include "mldsa_kernels.h"
 
@@ -42,12 +49,17 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint8_t *w1;            // n x K x 256
     uint8_t *muw1;          // n x MUW1_BYTES
     uint8_t *cb;            // n x 320
-    uint32_t *attempts;     // n
-    uint8_t *done;          // n
-    uint32_t *list[2];      // active lists
+    uint32_t *attempts;     // n: attempts already spent on the item
+    uint32_t *best;         // n: lowest successful `off` of the current round, kNoSuccess while unsigned
+    uint32_t *list[2];      // active lists of entries: item | off << 28
     uint32_t *count;        // [0], [1]: list lengths
     uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once)
 };
+
+constexpr uint32_t kNoSuccess = 0xffffffffu;
+constexpr int kEntryShift = 28;
+constexpr uint32_t kEntryItemMask = (1u << kEntryShift) - 1;
+constexpr unsigned kMaxSpec = 8;
 
 // ---- setup ---------------------------------------------------------------------------------------
 
@@ -113,10 +125,9 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
     }
     if (lane == 0) {
         st.attempts[item] = 0;
-        st.done[item] = 0;
-        st.list[0][item] = (uint32_t)item;
+        st.best[item] = kNoSuccess;
+        st.list[0][item] = (uint32_t)item;  // off = 0
     }
-    if (lane < 16) reinterpret_cast<uint32_t *>(st.muw1 + item * SB<MODE>::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
 }
 
 // ---- one round -------------------------------------------------------------------------------------
@@ -131,14 +142,17 @@ __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if ((size_t)(blockIdx.x * 256) >= (size_t)cnt * L) return;  // whole block idle
     const bool on = sidx < (size_t)cnt * L;
-    const size_t item = st.list[cur][on ? sidx / L : 0];
+    const size_t slot = on ? sidx / L : 0;
+    const uint32_t e = st.list[cur][slot];
+    const size_t item = e & kEntryItemMask;
+    const uint32_t off = e >> kEntryShift;
     const int l = on ? (int)(sidx % L) : 0;
     KeccakState s;
     keccak_zero(s);
     xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
-    s.lo[8] = ((st.attempts[item] * L + l) & 0xffff) | (kDsShake << 16);
+    s.lo[8] = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
     s.hi[16] = 0x80000000u;
-    uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+    uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
 #pragma unroll 1
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(s);
@@ -164,12 +178,15 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     if (blockIdx.x >= st.count[cur]) return;
     const int lane = threadIdx.x;
-    const size_t item = st.list[cur][blockIdx.x];
+    const size_t slot = blockIdx.x;
+    const size_t item = st.list[cur][slot] & kEntryItemMask;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    if (lane < 16)  // mu in front of the w1 bytes that follow
+        reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
     uint32_t yh[L][4];
 #pragma unroll
     for (int l = 0; l < L; l++) {
-        const uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+        const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
@@ -199,12 +216,12 @@ __global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
             const int nidx = kyber::idx_l1(lane, r);
             uint32_t a0, a1;
             dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
-            st.w0[(item * K + i) * 256 + nidx] = a0;
-            st.w1[(item * K + i) * 256 + nidx] = (uint8_t)a1;
+            st.w0[(slot * K + i) * 256 + nidx] = a0;
+            st.w1[(slot * K + i) * 256 + nidx] = (uint8_t)a1;
             w1v[r] = a1;
         }
         mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
-        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + item * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
+        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
     }
 }
 
@@ -216,10 +233,9 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
     using B = SB<MODE>;
     const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= st.count[cur]) return;
-    const size_t item = st.list[cur][a];
     KeccakState s;
-    sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + item * B::MUW1_BYTES), kDsShake);
-    uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + item * B::CB_BYTES);
+    sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
+    uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
     store_words<0, P::CT / 8>(cb, s);
     KeccakState bs;
     keccak_zero(bs);
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
 
 // wave = active item: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88)
 template <int MODE>
-__global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+__global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig, unsigned k) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
@@ -243,14 +259,18 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
     __shared__ __attribute__((aligned(16))) uint8_t blk[144];
     if (blockIdx.x >= st.count[cur]) return;
+    static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
     const int lane = threadIdx.x;
-    const size_t item = st.list[cur][blockIdx.x];
+    const size_t slot = blockIdx.x;
+    const uint32_t e = st.list[cur][slot];
+    const size_t item = e & kEntryItemMask;
+    const uint32_t off = e >> kEntryShift;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
-    const uint8_t *cb = st.cb + item * B::CB_BYTES;
+    const uint8_t *cb = st.cb + slot * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
     const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * kPackedRowDwords;
-    uint32_t *w0 = st.w0 + item * K * 256;
+    uint32_t *w0 = st.w0 + slot * K * 256;
     auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
         uint32_t sv[4];
         load_poly24(sv, row, lane);
@@ -280,7 +300,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
         for (int l = 0; l < L; l++) {
             uint32_t t[4];
             mul_c(t, sec + l * kPackedRowDwords);
-            const uint32_t *yrow = st.y + (item * L + l) * B::YROW_DW;
+            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
             unsigned fld[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -314,7 +334,7 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
                 const uint32_t ct0 = dilithium::csubq(t[r]);
                 bad |= dilithium::exceeds(ct0, P::GAMMA2);
                 const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
-                const uint32_t r1 = st.w1[(item * K + i) * 256 + nidx];
+                const uint32_t r1 = st.w1[(slot * K + i) * 256 + nidx];
                 const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
                 const unsigned long long mask = __ballot(hbit);
                 if (hbit) {
@@ -327,24 +347,48 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
         }
         reject = __any(bad) || pop > (unsigned)P::OMEGA;
     }
-    if (reject) {
-        if (lane == 0) st.attempts[item] += 1;
-        return;
-    }
-    __syncthreads();
-    uint8_t *sg = sig + item * G::SIG;
+    if (reject) return;  // sign_compact_kernel charges the round's attempts to the item
+    __syncthreads();     // every lane is done with w0
+    // with one attempt per item the signature goes straight out; with several, this one is parked in the slot's w0
+    // area and sign_commit_kernel copies the lowest successful attempt's
+    uint8_t *sg = k == 1 ? sig + item * G::SIG : reinterpret_cast<uint8_t *>(w0);
     for (int b = lane; b < P::CT; b += 64) sg[b] = cb[b];
     for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
     for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
-    if (lane == 0) st.done[item] = 1;
+    if (lane == 0) atomicMin(&st.best[item], off);
 }
 
-// next active list = the items of the current one that are still unsigned
-__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur) {
+// wave = entry, rounds with several attempts per item only: the lowest successful attempt's parked signature -> sig
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+    using G = DG<MODE>;
+    constexpr int K = DP<MODE>::K;
+    const size_t slot = blockIdx.x;
+    if (slot >= st.count[cur]) return;
+    const uint32_t e = st.list[cur][slot];
+    const size_t item = e & kEntryItemMask;
+    if (st.best[item] != (e >> kEntryShift)) return;
+    const uint32_t *src = st.w0 + slot * K * 256;
+    uint8_t *dst = sig + item * G::SIG;   // SIG is not a multiple of 4 for every parameter set: dwords, then the tail bytes
+    for (int d = threadIdx.x; d < G::SIG / 4; d += 64) {
+        const uint32_t w = src[d];
+        dst[4 * d] = (uint8_t)w; dst[4 * d + 1] = (uint8_t)(w >> 8); dst[4 * d + 2] = (uint8_t)(w >> 16); dst[4 * d + 3] = (uint8_t)(w >> 24);
+    }
+    for (int b = (G::SIG / 4) * 4 + threadIdx.x; b < G::SIG; b += 64) dst[b] = reinterpret_cast<const uint8_t *>(src)[b];
+}
+
+// next active list: every item of the current one (k entries each) that is still unsigned has spent k attempts and gets
+// k_next entries
+__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, unsigned k, unsigned k_next) {
     const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= st.count[cur]) return;
-    const uint32_t item = st.list[cur][a];
-    if (!st.done[item]) st.list[cur ^ 1][atomicAdd(&st.count[cur ^ 1], 1u)] = item;
+    const uint32_t e = st.list[cur][a];
+    if ((e >> kEntryShift) != 0) return;  // the item's first entry speaks for it
+    const uint32_t item = e & kEntryItemMask;
+    if (st.best[item] != kNoSuccess) return;
+    st.attempts[item] += k;
+    const uint32_t base = atomicAdd(&st.count[cur ^ 1], k_next);
+    for (unsigned j = 0; j < k_next; j++) st.list[cur ^ 1][base + j] = item | (j << kEntryShift);
 }
 
 }  // namespace mldsa

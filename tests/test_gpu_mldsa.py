@@ -355,3 +355,23 @@ def test_concurrent_device_sign_calls_do_not_share_state():
     for j in jobs:
         assert j["rc"] == 0
         assert (j["sig"].cpu().numpy() == j["want"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("param,shared", [(65, False), (44, False), (87, True)])
+def test_sign_speculative_rounds_match_oracle(param, shared):
+    # 3000 items: above the hand-over to the persistent tail (2 items per CU) and below the speculation target, so the
+    # batched rounds run with k = 1, 2, 3, ... attempts per item and the commit picks the lowest successful one --
+    # the signature must still be the one of the reference's sequential rejection loop.
+    rng = np.random.default_rng(1234 + param)
+    n = 3000
+    nk = 1 if shared else n
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (nk, 32), dtype=np.uint8))
+    msgs = [rng.integers(0, 256, 1 + (i % 90), dtype=np.uint8).tobytes() for i in range(n)]
+    if shared:
+        want = orc.mldsa_sign(param, np.repeat(sk, n, axis=0), msgs)
+        got = hostapi.mldsa_sign_shared(param, sk[0], msgs)
+    else:
+        want = orc.mldsa_sign(param, sk, msgs)
+        got = hostapi.mldsa_sign(param, sk, msgs)
+    assert (got == want).all()
