@@ -36,7 +36,7 @@ while time.time() < t_end:
     assert (ssd == sss).all(), ("decaps shared", p, n)
 
     d = int(rng.choice([44, 65, 87, 2, 3, 5]))
-    n = int(rng.choice([1, 3, 15, 16, 17, 100, 513, 1025, 3000]))
+    n = int(rng.choice([1, 3, 15, 16, 17, 100, 513, 1025, 3000, 9000]))
     s32 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     pk, sk = hostapi.mldsa_keygen(d, s32)
     pk0, sk0 = orc.mldsa_keygen(d, s32)
