@@ -3,9 +3,16 @@ ROCM ?= /opt/rocm
 HIPCC ?= $(ROCM)/bin/hipcc
 ARCH ?= gfx950
 
+UNITS = host_runtime api_mlkem api_mldsa api_prims
+OBJS = $(UNITS:%=build/%.o)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable
+
 lib: circl_amd/libcirclhip.so
-circl_amd/libcirclhip.so: circl_amd/csrc/circl_hip.hip $(wildcard circl_amd/csrc/*.h) include/circl_hip.h
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -shared -fPIC -Wall -Wno-unused-function -Wno-unused-variable -o $@ -x hip $<
+build/%.o: circl_amd/csrc/%.hip $(wildcard circl_amd/csrc/*.h) include/circl_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+circl_amd/libcirclhip.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
 
 oracle:
 	$(MAKE) -C oracle

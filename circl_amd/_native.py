@@ -10,7 +10,10 @@ LIB_PATH = os.path.join(_HERE, "libcirclhip.so")
 
 # every symbol include/circl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "circl_hip_init", "circl_hip_device_count", "circl_hip_last_error", "circl_hip_version",
+    "circl_hip_init", "circl_hip_device_count", "circl_hip_last_error", "circl_hip_version", "circl_hip_device_info",
+    "circl_hip_mlkem_encaps_keyed", "circl_hip_mlkem_decaps_keyed", "circl_hip_mlkem_keyed_workspace_size",
+    "circl_hip_mlkem_encaps_keyed_dev", "circl_hip_mlkem_decaps_keyed_dev",
+    "circl_hip_mldsa_verify_keyed", "circl_hip_mldsa_keyed_workspace_size", "circl_hip_mldsa_verify_keyed_dev",
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
     "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
     "circl_hip_mldsa_keygen", "circl_hip_mldsa_keygen_dev",
@@ -75,6 +78,9 @@ def lib():
         for s in ("circl_hip_mlkem_workspace_size", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_sign_workspace_size"):
             getattr(L, s).restype = C.c_size_t
             getattr(L, s).argtypes = [C.c_int, C.c_size_t]
+        for s in ("circl_hip_mlkem_keyed_workspace_size", "circl_hip_mldsa_keyed_workspace_size"):
+            getattr(L, s).restype = C.c_size_t
+            getattr(L, s).argtypes = [C.c_int, C.c_size_t, C.c_size_t]
         L.circl_hip_last_error.restype = C.c_char_p
         L.circl_hip_version.restype = C.c_char_p
         L.circl_hip_alloc_host.restype = C.c_void_p
@@ -91,6 +97,13 @@ def lib():
         L.circl_hip_mlkem_encaps_shared_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_decaps_shared.argtypes = [i, vp, vp, vp, vp, sz, i]
         L.circl_hip_mlkem_decaps_shared_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_device_info.argtypes = [i, vp, vp]
+        L.circl_hip_mlkem_encaps_keyed.argtypes = [i, vp, sz, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_decaps_keyed.argtypes = [i, vp, sz, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mlkem_encaps_keyed_dev.argtypes = [i, vp, sz, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mlkem_decaps_keyed_dev.argtypes = [i, vp, sz, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mldsa_verify_keyed.argtypes = [i, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_mldsa_verify_keyed_dev.argtypes = [i, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_kyber_keygen.argtypes = [i, vp, vp, vp, sz, i]
         L.circl_hip_kyber_encaps.argtypes = [i, vp, vp, vp, vp, sz, i]
         L.circl_hip_kyber_decaps.argtypes = [i, vp, vp, vp, sz, i]

@@ -1,0 +1,537 @@
+// api_mlkem.hip -- ML-KEM (FIPS 203) and round-3 Kyber entry points of the C ABI (include/circl_hip.h).
+//
+// There is deliberately no CPU path in this file: every compute entry point launches the HIP kernels of
+// mlkem_kernels.h or fails with CIRCL_HIP_ENODEV.
+#include "host_common.h"
+#include "mlkem_kernels.h"
+
+using namespace circl::host;
+
+namespace {
+
+// ML-KEM workspace: 129 B per item + one 32 KB scratch slice per resident workgroup
+constexpr size_t kKemWsPerItem = 129;  // four 32-byte slots + one status byte (round-3 decapsulation has no caller-side status)
+size_t kem_scratch_bytes() { return 256 + max_resident_blocks() * 64 * 512; }
+size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
+
+int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
+
+// key-table cache behind the per-item workspace: A^T rows (whole groups of G entries), H(ek) and a status byte per entry
+template <int K> size_t kem_table_bytes(size_t nkeys) {
+    using Gm = circl::mlkem::Geom<K>;
+    const size_t padded = (nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    return up256(padded * K * K * 512) + up256(nkeys * 32) + up256(nkeys);
+}
+size_t kem_table_bytes_any(int param, size_t nkeys) {
+    switch (kem_k(param)) {
+    case 2: return kem_table_bytes<2>(nkeys);
+    case 3: return kem_table_bytes<3>(nkeys);
+    case 4: return kem_table_bytes<4>(nkeys);
+    }
+    return 0;
+}
+
+struct KemWs {  // the carving of a ML-KEM workspace every launch sequence below uses
+    uint8_t *slot0, *slot1, *slot2, *slot3, *status_slot;
+    unsigned *work;
+    uint8_t *scratch;
+    KemWs(void *ws, size_t n) {
+        slot0 = static_cast<uint8_t *>(ws);
+        slot1 = slot0 + 32 * n;
+        slot2 = slot0 + 64 * n;
+        slot3 = slot0 + 96 * n;
+        status_slot = slot0 + 128 * n;
+        work = reinterpret_cast<unsigned *>(slot0 + up256(kKemWsPerItem * n));
+        scratch = slot0 + up256(kKemWsPerItem * n) + 256;
+    }
+};
+
+// ---- device-resident ML-KEM ---------------------------------------------------------------
+
+// R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:105-154): m = H(seed), lenient key decoding, K = KDF(K' || H(ct)).
+template <int K, bool R3 = false>
+int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                    void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+        return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *r_ws = w.slot0, *m_ws = w.slot1;
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        if (R3) hipLaunchKernelGGL(kyber_r3_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, m_ws, n);
+        else hipLaunchKernelGGL(mlkem_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, n);
+    }
+    {
+        auto kern = mlkem_encrypt_kernel<K, R3 ? ENCAPS_LENIENT : ENCAPS, 0, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, R3 ? (const uint8_t *)m_ws : m, (const uint8_t *)r_ws,
+                           ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr);
+    }
+    if (R3) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(kyber_r3_finish_kernel<K>, dim3(hb), dim3(256), 0, st, (const uint8_t *)ct, ss, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// Shared-key encapsulation: one ek for all n items (the reference's BenchmarkEncapsulate shape; SURVEY 8d "secondary
+// input").  H(ek) and A^T are computed once (per launch / per resident workgroup), leaving 8 permutations per item.
+template <int K>
+int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws,
+                           size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+        return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *r_ws = w.slot0, *h_ws = w.slot1;
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_hek_kernel<K>, dim3(1), dim3(64), 0, st, ek, h_ws);
+        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)h_ws, m, ss,
+                           r_ws, n, (const uint32_t *)nullptr);
+    }
+    {
+        auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_SHARED>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)0, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// Key-table encapsulation: item i encapsulates to entry key_idx[i] of ek_table (nkeys rows).  Per TABLE ENTRY: H(ek) and
+// A^T (the reference's parsed-key cache, kyber.go:39-43 / cpapke.go:19-25); per ITEM: G, the 2K+1 PRF streams and the ring
+// phase (8 permutations for ML-KEM-768).  The workspace is kem_ws_bytes(n) followed by kem_table_bytes<K>(nkeys).
+template <int K>
+int encaps_keyed_dev_impl(const uint8_t *ek_table, size_t nkeys, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss,
+                          uint8_t *status, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (nkeys == 0) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < kem_ws_bytes(n) + kem_table_bytes<K>(nkeys) || !aligned16(ws) || !aligned16(ek_table) || !aligned16(m) || !aligned16(ct) ||
+        !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
+        return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *r_ws = w.slot0;
+    const size_t padded = (nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_ws_bytes(n));
+    uint8_t *key_h = reinterpret_cast<uint8_t *>(key_rows) + up256(padded * K * K * 512);
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYTABLE, st);
+        hipLaunchKernelGGL(mlkem_hek_table_kernel<K>, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, ek_table, (size_t)Gm::EK, (size_t)0,
+                           key_h, (uint8_t *)nullptr, 0, nkeys);
+        hipLaunchKernelGGL(mlkem_expand_keys_kernel<K>, dim3((unsigned)(padded / Gm::G)), dim3(64), Gm::LDS_FIFO, st, ek_table, (size_t)Gm::EK,
+                           (size_t)(384 * K), key_rows, nkeys);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)key_h, m, ss, r_ws, n, key_idx);
+    }
+    {
+        auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek_table, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, key_idx, (const int16_t *)key_rows);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// Shared-key decapsulation: one dk for all n ciphertexts (the reference's parsed PrivateKey).  The key's hash check and
+// A^T happen once; per item: decrypt, G, J(z || ct) and the re-encryption's 2K+1 PRF streams (17 permutations).
+template <int K>
+int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t ws_bytes,
+                           hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
+    uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)0, ct, mprime, n, (const uint32_t *)nullptr);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_dk_check_kernel<K>, dim3(1), dim3(64), 0, st, dk, key_status);
+        hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)0, ct, (const uint8_t *)mprime, kbar,
+                           r_ws, ssrej, status, n, (const uint8_t *)key_status, (const uint32_t *)nullptr);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_SHARED>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
+                           (const uint32_t *)nullptr, (const int16_t *)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// Key-table decapsulation: item i is decapsulated with entry key_idx[i] of dk_table.  Per table entry: the private key's
+// hash check (kyber.go:219-228) and A^T; per item the 17 permutations of the shared-key path.
+template <int K>
+int decaps_keyed_dev_impl(const uint8_t *dk_table, size_t nkeys, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status,
+                          size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (nkeys == 0) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < kem_ws_bytes(n) + kem_table_bytes<K>(nkeys) || !aligned16(ws) || !aligned16(dk_table) || !aligned16(ct) || !aligned16(ss) ||
+        (reinterpret_cast<uintptr_t>(key_idx) & 3))
+        return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
+    const size_t padded = (nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_ws_bytes(n));
+    uint8_t *key_h = reinterpret_cast<uint8_t *>(key_rows) + up256(padded * K * K * 512);
+    uint8_t *key_status = key_h + up256(nkeys * 32);
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYTABLE, st);
+        hipLaunchKernelGGL(mlkem_hek_table_kernel<K>, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, dk_table, (size_t)Gm::DK,
+                           (size_t)(384 * K), key_h, key_status, 1, nkeys);
+        hipLaunchKernelGGL(mlkem_expand_keys_kernel<K>, dim3((unsigned)(padded / Gm::G)), dim3(64), Gm::LDS_FIFO, st, dk_table, (size_t)Gm::DK,
+                           (size_t)(768 * K), key_rows, nkeys);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk_table, (size_t)Gm::DK, ct, mprime, n, key_idx);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk_table, (size_t)Gm::DK, ct, (const uint8_t *)mprime, kbar,
+                           r_ws, ssrej, status, n, (const uint8_t *)key_status, key_idx);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk_table + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
+                           (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch,
+                           w.work, n, key_idx, (const int16_t *)key_rows);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+// R3 = round-3 Kyber (kem/kyber/kyber768/kyber.go:156-197): no private-key check, K = KDF((ct' == ct ? K'' : z) || H(ct));
+// `status` may then be null (an n-byte slot of the workspace is used).
+template <int K, bool R3 = false>
+int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t ws_bytes,
+                    hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
+    if (R3) status = w.status_slot;
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)Gm::DK, ct, mprime, n, (const uint32_t *)nullptr);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        if (R3)
+            hipLaunchKernelGGL(kyber_r3_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (const uint8_t *)mprime, kbar, r_ws,
+                               ssrej, status, n);
+        else
+            hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)Gm::DK, ct, (const uint8_t *)mprime,
+                               kbar, r_ws, ssrej, status, n, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true>;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
+                           (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej,
+                           w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)nullptr);
+    }
+    if (R3) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(kyber_r3_finish_kernel<K>, dim3(hb), dim3(256), 0, st, ct, ss, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+template <int K, bool R3 = false>
+int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *rs = w.slot0;
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL((mlkem_keygen_seed_kernel<K, R3>), dim3(hb), dim3(256), 0, st, seed64, rs, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
+        auto kern = mlkem_keygen_kernel<K, true>;
+        const unsigned kb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, (const uint8_t *)rs, ek, dk, w.scratch, w.work, n);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_FINISH, st);
+        hipLaunchKernelGGL(mlkem_keygen_finish_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, (const uint8_t *)ek, dk, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
+PipeOpts kem_opts(bool secret) {
+    PipeOpts o;
+    o.chunk_items = host_chunk_items(size_t(1) << 15);
+    o.wipe_device = secret;
+    return o;
+}
+std::function<size_t(size_t)> kem_ws_fn() {
+    return [](size_t cnt) { return kem_ws_bytes(cnt); };
+}
+
+// host-side check of a key-index vector (the device path trusts its caller: an out-of-range index would read past the table)
+int check_key_idx(const uint32_t *key_idx, size_t n, size_t nkeys) {
+    if (nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
+    for (size_t i = 0; i < n; i++)
+        if (key_idx[i] >= nkeys) return CIRCL_HIP_EPARAM;
+    return CIRCL_HIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+size_t circl_hip_mlkem_ek_size(int param) { const int k = kem_k(param); return k ? 384 * k + 32 : 0; }
+size_t circl_hip_mlkem_dk_size(int param) { const int k = kem_k(param); return k ? 768 * k + 96 : 0; }
+size_t circl_hip_mlkem_ct_size(int param) {
+    switch (param) {
+    case 512: return 768;
+    case 768: return 1088;
+    case 1024: return 1568;
+    }
+    return 0;
+}
+
+size_t circl_hip_mlkem_workspace_size(int param, size_t n) { return kem_k(param) ? kem_ws_bytes(n) : 0; }
+size_t circl_hip_mlkem_keyed_workspace_size(int param, size_t n, size_t nkeys) {
+    return kem_k(param) ? kem_ws_bytes(n) + kem_table_bytes_any(param, nkeys) : 0;
+}
+
+#define KEM_DISPATCH(call2, call3, call4)                  \
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;              \
+    hipStream_t st = static_cast<hipStream_t>(stream);     \
+    switch (kem_k(param)) {                                \
+    case 2: return call2;                                  \
+    case 3: return call3;                                  \
+    case 4: return call4;                                  \
+    }                                                      \
+    return CIRCL_HIP_EPARAM
+
+int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
+                               uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(encaps_dev_impl<2>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_dev_impl<3>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_dev_impl<4>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                               void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(decaps_dev_impl<2>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_dev_impl<3>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_dev_impl<4>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk, size_t n, void *d_ws,
+                               size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(keygen_dev_impl<2>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st),
+                 keygen_dev_impl<3>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st),
+                 keygen_dev_impl<4>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_encaps_shared_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status,
+                                      size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(encaps_shared_dev_impl<2>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_shared_dev_impl<3>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_shared_dev_impl<4>(d_ek, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_decaps_shared_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                      void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(decaps_shared_dev_impl<2>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_shared_dev_impl<3>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_shared_dev_impl<4>(d_dk, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_encaps_keyed_dev(int param, const uint8_t *d_ek_table, size_t nkeys, const uint32_t *d_key_idx, const uint8_t *d_m,
+                                     uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(encaps_keyed_dev_impl<2>(d_ek_table, nkeys, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_keyed_dev_impl<3>(d_ek_table, nkeys, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_keyed_dev_impl<4>(d_ek_table, nkeys, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_t nkeys, const uint32_t *d_key_idx, const uint8_t *d_ct,
+                                     uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    KEM_DISPATCH(decaps_keyed_dev_impl<2>(d_dk_table, nkeys, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_keyed_dev_impl<3>(d_dk_table, nkeys, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_keyed_dev_impl<4>(d_dk_table, nkeys, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+
+// ---- host buffers ---------------------------------------------------------------------------------
+
+int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                           size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {m + lo * 32, 32, true}}, {},
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false),
+                            [&](Chunk &c) { return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+
+int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
+                            kem_ws_fn(), kem_opts(true),
+                            [&](Chunk &c) { return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+
+int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(true),
+                            [&](Chunk &c) { return circl_hip_mlkem_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+
+int circl_hip_mlkem_decaps_shared(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{dk, DK, true, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
+                            kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
+                                return circl_hip_mlkem_decaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                                  int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{ek, EK, false, true}, {m + lo * 32, 32, true}}, {},
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
+                                return circl_hip_mlkem_encaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+
+// Key tables through host buffers: the table travels with every chunk (it is small next to a chunk of items: nkeys rows
+// against 2^15 items), so each chunk is self-contained and chunks overlap like those of the other entry points.
+int circl_hip_mlkem_encaps_keyed(int param, const uint8_t *ek_table, size_t nkeys, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct,
+                                 uint8_t *ss, uint8_t *status, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (int rc = check_key_idx(key_idx, n, nkeys)) return rc;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{ek_table, EK * nkeys, false, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {m + lo * 32, 32, true}}, {},
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(false), [&](Chunk &c) {
+                                return circl_hip_mlkem_encaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
+                                                                        c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkeys, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss,
+                                 uint8_t *status, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (int rc = check_key_idx(key_idx, n, nkeys)) return rc;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{dk_table, DK * nkeys, true, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {ct + lo * CT, CT}}, {},
+                            {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(true), [&](Chunk &c) {
+                                return circl_hip_mlkem_decaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
+                                                                        c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+
+// ---- round-3 Kyber (kem/kyber/kyber{512,768,1024}), SURVEY 8f row f3 ------------------------------------
+
+int circl_hip_kyber_keygen_dev(int param, const uint8_t *d_seed64, uint8_t *d_ek, uint8_t *d_dk, size_t n, void *d_ws, size_t ws_bytes,
+                               void *stream) {
+    KEM_DISPATCH((keygen_dev_impl<2, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st)),
+                 (keygen_dev_impl<3, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st)),
+                 (keygen_dev_impl<4, true>(d_seed64, d_ek, d_dk, n, d_ws, ws_bytes, st)));
+}
+int circl_hip_kyber_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_seed32, uint8_t *d_ct, uint8_t *d_ss, size_t n, void *d_ws,
+                               size_t ws_bytes, void *stream) {
+    KEM_DISPATCH((encaps_dev_impl<2, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)),
+                 (encaps_dev_impl<3, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)),
+                 (encaps_dev_impl<4, true>(d_ek, d_seed32, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)));
+}
+int circl_hip_kyber_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_ct, uint8_t *d_ss, size_t n, void *d_ws, size_t ws_bytes,
+                               void *stream) {
+    KEM_DISPATCH((decaps_dev_impl<2, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)),
+                 (decaps_dev_impl<3, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)),
+                 (decaps_dev_impl<4, true>(d_dk, d_ct, d_ss, nullptr, n, d_ws, ws_bytes, st)));
+}
+int circl_hip_kyber_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(true),
+                            [&](Chunk &c) { return circl_hip_kyber_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+int circl_hip_kyber_encaps(int param, const uint8_t *ek, const uint8_t *seed32, uint8_t *ct, uint8_t *ss, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {seed32 + lo * 32, 32, true}}, {}, {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}}, kem_ws_fn(),
+                            kem_opts(false),
+                            [&](Chunk &c) { return circl_hip_kyber_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+int circl_hip_kyber_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, size_t n, int device) {
+    const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!DK) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}}, kem_ws_fn(), kem_opts(true),
+                            [&](Chunk &c) { return circl_hip_kyber_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// host_common.h -- host-side plumbing shared by the translation units of libcirclhip.so.
+//
+//   per-device state     CU count, NUMA node, occupancy cache keyed on (device, kernel), all race-free
+//   kernel profiling     HIP-event brackets on the launch stream (circl_hip_profile_*)
+//   host-buffer pipeline a per-device pool of staging slots (page-locked host staging + device staging + stream),
+//                        filled and drained by a small per-device thread pool pinned to the GPU's NUMA node, so that a
+//                        caller with ordinary pageable memory (a Go []byte) reaches the PCIe-bound rate; concurrent
+//                        callers take different slots and overlap
+//   shard()              contiguous split of a batch over the visible devices, one host thread each, no collective
+//
+// There is deliberately no CPU compute path anywhere in this library: the thread pool only moves bytes.
+#pragma once
+#include "../../include/circl_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace circl {
+namespace host {
+
+extern thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char b_[256];                                                                          \
+            snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            ::circl::host::g_err = b_;                                                             \
+            return e_ == hipErrorOutOfMemory ? CIRCL_HIP_ENOMEM : CIRCL_HIP_EHIP;                   \
+        }                                                                                          \
+    } while (0)
+
+inline size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- devices ----------------------------------------------------------------------------------
+int ndev();                      // visible HIP devices (0 if none), fixed at first call
+struct DeviceInfo {
+    int cus = 256;               // compute units
+    int numa = -1;               // NUMA node of the PCIe function, -1 unknown
+    std::vector<int> cpus;       // CPUs of that node this process may run on (empty: no pinning)
+};
+const DeviceInfo &dev_info(int dev);
+int current_device();            // hipGetDevice, 0 on failure
+inline int cu_count() { return dev_info(current_device()).cus; }  // of the CURRENT device (launch geometry)
+int max_cu_count();              // over all visible devices (workspace sizing: valid whichever device runs the call)
+int usable_cpus();               // affinity mask capped by the cgroup CPU quota
+
+// ---- persistent-launch geometry for the scratch-based kernels -----------------------------------
+#ifndef CIRCL_MAX_BLOCKS_PER_CU
+#define CIRCL_MAX_BLOCKS_PER_CU 16  // 4 single-wave workgroups per SIMD
+#endif
+constexpr int kMaxBlocksPerCU = CIRCL_MAX_BLOCKS_PER_CU;
+// upper bound on resident single-wave workgroups on any device: sizes the scratch part of a workspace
+inline size_t max_resident_blocks() { return (size_t)max_cu_count() * kMaxBlocksPerCU; }
+unsigned resident_blocks_cached(int dev, const void *key, const std::function<int()> &query);
+// resident single-wave workgroups of `kern` on the current device (occupancy query cached per (device, kernel))
+template <class Kern> unsigned resident_blocks(Kern kern, int lds_bytes) {
+    const int dev = current_device();
+    return resident_blocks_cached(dev, reinterpret_cast<const void *>(kern), [&]() -> int {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, (size_t)lds_bytes) != hipSuccess || occ < 1) occ = 4;
+        return occ;
+    });
+}
+
+// ---- kernel-level profiling ---------------------------------------------------------------
+bool prof_on();
+void prof_push(int kernel, hipEvent_t a, hipEvent_t b);
+// RAII bracket around one or more kernel launches on `st`
+struct ProfScope {
+    int kernel = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    ProfScope(int k, hipStream_t s) : st(s) {
+        if (!prof_on()) return;
+        if (hipEventCreate(&a) != hipSuccess) return;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        kernel = k;
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (kernel < 0) return;
+        (void)hipEventRecord(b, st);
+        prof_push(kernel, a, b);
+    }
+};
+
+// ---- host thread pool (byte movers) ---------------------------------------------------------
+// run(n, fn): fn(0) .. fn(n-1) spread over the device's worker threads and the calling thread; returns when all are done.
+void pool_run(int dev, size_t n, const std::function<void(size_t)> &fn);
+struct CopyJob { void *dst; const void *src; size_t bytes; };  // src == nullptr: zero-fill dst
+void parallel_copy(int dev, const std::vector<CopyJob> &jobs);
+
+// ---- staging slots ----------------------------------------------------------------------------
+struct Slot {
+    int dev = -1;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t *d = nullptr;     size_t d_cap = 0;      // device staging: inputs, outputs, workspace of one chunk
+    uint8_t *hin = nullptr;   size_t hin_cap = 0;    // page-locked staging, host -> device
+    uint8_t *hout = nullptr;  size_t hout_cap = 0;   // page-locked staging, device -> host
+    int ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes);
+};
+Slot *slot_acquire(int dev);     // blocks while every slot of the device is in use; nullptr + g_err on failure
+void slot_release(Slot *s);
+bool is_pinned_host(const void *p);  // page-locked (hipHostMalloc / hipHostRegister) memory: DMA-able as is
+
+// ---- the pipeline -------------------------------------------------------------------------------
+struct HIn {                 // fixed-size rows: item i is row i
+    const uint8_t *p;
+    size_t row;
+    bool secret = false;     // wipe the staging copy afterwards
+    bool per_call = false;   // ONE row for the whole call (a shared key): re-staged with every chunk
+};
+struct HBlob {               // ragged rows: item i is blob[off[i] .. off[i+1]); blob == nullptr: absent (kernels get nullptr)
+    const uint8_t *blob;
+    const uint64_t *off;
+};
+struct HOut {
+    uint8_t *p;              // nullptr: the device buffer exists but nothing is copied back
+    size_t row;
+    bool secret = false;
+};
+struct Chunk {               // what `launch` gets: device pointers of one chunk
+    std::vector<uint8_t *> in;            // one per HIn
+    std::vector<const uint8_t *> blob;    // one per HBlob, REBASED so that the caller's absolute offsets index it (nullptr if absent)
+    std::vector<const uint64_t *> off;    // one per HBlob: the chunk's cnt + 1 offsets (nullptr if absent)
+    std::vector<uint8_t *> out;           // one per HOut
+    uint8_t *ws;
+    size_t ws_bytes;
+    size_t cnt;
+    hipStream_t st;
+};
+struct PipeOpts {
+    size_t chunk_items = size_t(1) << 15;
+    int depth = 3;            // chunks in flight per call
+    bool wipe_device = false; // zero the device staging of every chunk once its results are out
+};
+// Runs items [0, n) on device `dev`: per chunk  stage-in (host threads) -> H2D -> launch -> D2H -> stage-out (host threads),
+// with `depth` chunks in flight on separate streams.  ws_bytes(cnt) = workspace the launch needs for cnt items.
+int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
+                 const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch);
+size_t host_chunk_items(size_t dflt);  // CIRCL_HIP_HOST_CHUNK overrides the default chunk size (tuning aid)
+
+// Contiguous split of [0,n) over the visible devices, one host thread each (pinned to the device's NUMA node), no collective.
+int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn);
+
+}  // namespace host
+}  // namespace circl

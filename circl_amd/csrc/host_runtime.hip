@@ -1,0 +1,651 @@
+// host_runtime.hip -- device table, profiling, byte-mover thread pools, staging slots and the host-buffer pipeline
+// (declared in host_common.h).  No compute happens on the CPU here: the threads only copy bytes between the caller's
+// memory and page-locked staging buffers.
+#include "host_common.h"
+
+#include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
+
+#include <cctype>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+namespace circl {
+namespace host {
+
+thread_local std::string g_err;
+
+// ---- devices ----------------------------------------------------------------------------------
+namespace {
+
+struct DeviceTable {
+    int n = 0;
+    std::vector<DeviceInfo> info;
+    int max_cus = 256;
+};
+DeviceTable *g_devs = nullptr;
+std::once_flag g_devs_once;
+
+std::vector<int> parse_cpulist(const std::string &s) {  // "0-15,128-143"
+    std::vector<int> out;
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        if (tok.empty()) continue;
+        const size_t dash = tok.find('-');
+        const int lo = atoi(tok.c_str()), hi = dash == std::string::npos ? lo : atoi(tok.c_str() + dash + 1);
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) out.push_back(c);
+    }
+    return out;
+}
+
+void init_devices() {
+    auto *t = new DeviceTable;  // never freed: worker threads may outlive static destruction
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    t->n = n;
+    t->info.resize(n > 0 ? n : 0);
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    const bool have_aff = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
+    int mx = 0;
+    for (int d = 0; d < n; d++) {
+        DeviceInfo &di = t->info[d];
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && cus > 0) di.cus = cus;
+        mx = std::max(mx, di.cus);
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof bdf, d) == hipSuccess) {
+            for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+            std::ifstream f(std::string("/sys/bus/pci/devices/") + bdf + "/numa_node");
+            int node = -1;
+            if (f >> node && node >= 0) {
+                di.numa = node;
+                std::ifstream g("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+                std::string list;
+                if (std::getline(g, list))
+                    for (int c : parse_cpulist(list))
+                        if (!have_aff || CPU_ISSET(c, &allowed)) di.cpus.push_back(c);
+            }
+        }
+    }
+    if (mx > 0) t->max_cus = mx;
+    g_devs = t;
+}
+const DeviceTable &devs() {
+    std::call_once(g_devs_once, init_devices);
+    return *g_devs;
+}
+
+void pin_to(const std::vector<int> &cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
+int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo || v > hi ? dflt : v;
+}
+
+}  // namespace
+
+int ndev() { return devs().n; }
+const DeviceInfo &dev_info(int dev) {
+    static const DeviceInfo fallback;
+    const DeviceTable &t = devs();
+    return dev >= 0 && dev < t.n ? t.info[dev] : fallback;
+}
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
+int max_cu_count() { return devs().max_cus; }
+
+int usable_cpus() {
+    static const int v = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        std::ifstream f("/sys/fs/cgroup/cpu.max");  // cgroup v2: "<quota> <period>" or "max <period>"
+        std::string q;
+        long period = 0;
+        if (f >> q >> period) {
+            if (q != "max" && period > 0) n = std::min<long>(n, std::max<long>(1, (atol(q.c_str()) + period - 1) / period));
+        } else {
+            std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            long quota = -1;
+            if ((fq >> quota) && (fp >> period) && quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        return n;
+    }();
+    return v;
+}
+
+// ---- occupancy cache, keyed on (device, kernel) --------------------------------------------------
+unsigned resident_blocks_cached(int dev, const void *key, const std::function<int()> &query) {
+    struct Entry { int dev; const void *key; unsigned blocks; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : cache)
+            if (e.dev == dev && e.key == key) return e.blocks;
+    }
+    int occ = query();  // outside the lock: the runtime call may be slow
+    if (occ > kMaxBlocksPerCU) occ = kMaxBlocksPerCU;
+    const unsigned v = (unsigned)(dev_info(dev).cus * occ);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : cache)
+        if (e.dev == dev && e.key == key) return e.blocks;
+    cache.push_back({dev, key, v});
+    return v;
+}
+
+// ---- kernel-level profiling ---------------------------------------------------------------
+namespace {
+struct ProfRec { int kernel; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::atomic<bool> g_prof_on{false};
+std::vector<ProfRec> g_prof_pending;
+double g_prof_ms[CIRCL_HIP_KERNEL_COUNT];
+uint64_t g_prof_n[CIRCL_HIP_KERNEL_COUNT];
+}  // namespace
+bool prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
+void prof_push(int kernel, hipEvent_t a, hipEvent_t b) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({kernel, a, b});
+}
+
+// ---- byte-mover thread pools ------------------------------------------------------------------
+namespace {
+
+struct Batch {
+    size_t n = 0;
+    const std::function<void(size_t)> *fn = nullptr;
+    std::atomic<size_t> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Batch>> q;
+    int nthreads = 0;
+};
+std::mutex g_pools_mu;
+std::vector<Pool *> g_pools;  // one per device, created lazily, never destroyed
+
+void worker_main(Pool *p, std::vector<int> cpus) {
+    pin_to(cpus);
+    for (;;) {
+        std::shared_ptr<Batch> b;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return !p->q.empty(); });
+            b = p->q.front();
+        }
+        const size_t i = b->next.fetch_add(1);
+        if (i >= b->n) {  // exhausted: retire it so that the next batch becomes visible
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (!p->q.empty() && p->q.front() == b) p->q.pop_front();
+            continue;
+        }
+        (*b->fn)(i);
+        if (b->done.fetch_add(1) + 1 == b->n) {
+            std::lock_guard<std::mutex> lk(b->mu);
+            b->cv.notify_all();
+        }
+    }
+}
+
+Pool *pool_of(int dev) {
+    const int nd = std::max(ndev(), 1);
+    if (dev < 0 || dev >= nd) dev = 0;
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    if (g_pools.empty()) g_pools.assign(nd, nullptr);
+    if (!g_pools[dev]) {
+        Pool *p = new Pool;
+        // the calling thread works too, so a pool of T threads gives T + 1 movers; the CPUs are shared by all devices
+        const int dflt = std::min(16, std::max(1, usable_cpus() / nd));
+        p->nthreads = env_int("CIRCL_HIP_HOST_THREADS", dflt, 0, 256);
+        const std::vector<int> cpus = dev_info(dev).cpus;
+        for (int t = 0; t < p->nthreads; t++) std::thread(worker_main, p, cpus).detach();
+        g_pools[dev] = p;
+    }
+    return g_pools[dev];
+}
+
+// Streaming copy: non-temporal stores keep the destination out of the caches (no read-for-ownership traffic, and the
+// DMA engine / the caller reads it from memory anyway).  dst / src arbitrary alignment.
+__attribute__((target("avx2"))) void copy_stream_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+    const size_t head = std::min(n, (size_t)((32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31));
+    if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+void copy_bytes(void *dst, const void *src, size_t n) {
+    static const bool nt = env_int("CIRCL_HIP_HOST_NT", 1, 0, 1) != 0 && __builtin_cpu_supports("avx2");
+    if (nt && n >= 4096) copy_stream_avx2(static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src), n);
+    else memcpy(dst, src, n);
+}
+
+}  // namespace
+
+void pool_run(int dev, size_t n, const std::function<void(size_t)> &fn) {
+    if (n == 0) return;
+    Pool *p = pool_of(dev);
+    if (n == 1 || p->nthreads == 0) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    auto b = std::make_shared<Batch>();
+    b->n = n;
+    b->fn = &fn;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->q.push_back(b);
+    }
+    p->cv.notify_all();
+    for (;;) {  // the caller is a mover too
+        const size_t i = b->next.fetch_add(1);
+        if (i >= n) break;
+        fn(i);
+        b->done.fetch_add(1);
+    }
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv.wait(lk, [&] { return b->done.load() >= n; });
+    }
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (auto it = p->q.begin(); it != p->q.end(); ++it)
+        if (*it == b) { p->q.erase(it); break; }
+}
+
+void parallel_copy(int dev, const std::vector<CopyJob> &jobs) {
+    constexpr size_t PIECE = size_t(1) << 20;
+    size_t total = 0;
+    for (auto &j : jobs) total += j.bytes;
+    if (total == 0) return;
+    auto one = [](const CopyJob &j, size_t lo, size_t len) {
+        if (j.src) copy_bytes(static_cast<uint8_t *>(j.dst) + lo, static_cast<const uint8_t *>(j.src) + lo, len);
+        else memset(static_cast<uint8_t *>(j.dst) + lo, 0, len);
+    };
+    if (total <= (size_t(1) << 18)) {  // not worth waking anybody
+        for (auto &j : jobs)
+            if (j.bytes) one(j, 0, j.bytes);
+        return;
+    }
+    struct Piece { const CopyJob *j; size_t lo, len; };
+    std::vector<Piece> pieces;
+    pieces.reserve(total / PIECE + jobs.size());
+    for (auto &j : jobs)
+        for (size_t lo = 0; lo < j.bytes; lo += PIECE) pieces.push_back({&j, lo, std::min(PIECE, j.bytes - lo)});
+    pool_run(dev, pieces.size(), [&](size_t i) { one(*pieces[i].j, pieces[i].lo, pieces[i].len); });
+}
+
+// ---- staging slots ----------------------------------------------------------------------------
+namespace {
+struct SlotPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot *> free_slots;
+    int created = 0;
+};
+std::mutex g_slot_pools_mu;
+std::vector<SlotPool *> g_slot_pools;
+SlotPool *slot_pool_of(int dev) {
+    std::lock_guard<std::mutex> lk(g_slot_pools_mu);
+    if (g_slot_pools.empty()) g_slot_pools.assign(std::max(ndev(), 1), nullptr);
+    if (!g_slot_pools[dev]) g_slot_pools[dev] = new SlotPool;
+    return g_slot_pools[dev];
+}
+int max_slots() {
+    static const int v = env_int("CIRCL_HIP_HOST_SLOTS", 8, 1, 64);
+    return v;
+}
+}  // namespace
+
+int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
+    if (d_bytes > d_cap) {
+        if (d) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d)); }
+        d = nullptr; d_cap = 0;
+        const size_t want = up256(d_bytes + d_bytes / 8);  // a little head-room: ragged chunks differ in size
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), want));
+        d_cap = want;
+    }
+    if (hin_bytes > hin_cap) {
+        if (hin) HIP_TRY(hipHostFree(hin));
+        hin = nullptr; hin_cap = 0;
+        const size_t want = up256(hin_bytes + hin_bytes / 8);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hin), want, hipHostMallocDefault));  // default placement: the device's NUMA node
+        hin_cap = want;
+    }
+    if (hout_bytes > hout_cap) {
+        if (hout) HIP_TRY(hipHostFree(hout));
+        hout = nullptr; hout_cap = 0;
+        const size_t want = up256(hout_bytes + hout_bytes / 8);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hout), want, hipHostMallocDefault));
+        hout_cap = want;
+    }
+    return CIRCL_HIP_OK;
+}
+
+Slot *slot_acquire(int dev) {
+    SlotPool *p = slot_pool_of(dev);
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        for (;;) {
+            if (!p->free_slots.empty()) {
+                Slot *s = p->free_slots.back();
+                p->free_slots.pop_back();
+                return s;
+            }
+            if (p->created < max_slots()) { p->created++; break; }
+            p->cv.wait(lk);
+        }
+    }
+    Slot *s = new Slot;
+    s->dev = dev;
+    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess) {
+        g_err = "slot_acquire: stream / event creation failed";
+        (void)hipGetLastError();
+        if (s->st) (void)hipStreamDestroy(s->st);
+        delete s;
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->created--;
+        p->cv.notify_one();
+        return nullptr;
+    }
+    return s;
+}
+void slot_release(Slot *s) {
+    if (!s) return;
+    SlotPool *p = slot_pool_of(s->dev);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->free_slots.push_back(s);
+    }
+    p->cv.notify_one();
+}
+
+bool is_pinned_host(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+size_t host_chunk_items(size_t dflt) {
+    static const int lg = env_int("CIRCL_HIP_HOST_CHUNK", 0, 8, 24);  // log2 of the chunk size, 0 = per-operation default
+    return lg ? size_t(1) << lg : dflt;
+}
+
+// ---- the pipeline -------------------------------------------------------------------------------
+namespace {
+struct Seg { size_t dofs = 0, hofs = 0, bytes = 0; bool staged = false; };  // device offset, staging offset, payload bytes
+struct InFlight {
+    Slot *slot = nullptr;
+    size_t lo = 0, cnt = 0;
+    std::vector<Seg> out;      // per HOut
+    std::vector<Seg> secret_in;  // staged secret inputs to wipe
+};
+}  // namespace
+
+int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
+                 const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch) {
+    if (n == 0) return CIRCL_HIP_OK;
+    if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    const size_t chunk = std::max<size_t>(1, std::min(n, opts.chunk_items));
+    const size_t depth = (size_t)std::max(1, opts.depth);
+    std::vector<char> in_pinned(ins.size()), out_pinned(outs.size()), blob_pinned(blobs.size());
+    for (size_t k = 0; k < ins.size(); k++) in_pinned[k] = is_pinned_host(ins[k].p);
+    for (size_t k = 0; k < outs.size(); k++) out_pinned[k] = outs[k].p && is_pinned_host(outs[k].p);
+    for (size_t k = 0; k < blobs.size(); k++) blob_pinned[k] = blobs[k].blob && is_pinned_host(blobs[k].blob);
+
+    std::deque<InFlight> inflight;
+    // error paths must not recycle a slot (or return to the caller) with copies or kernels still in flight
+    struct Drain {
+        std::deque<InFlight> &q;
+        ~Drain() {
+            for (auto &f : q) {
+                (void)hipStreamSynchronize(f.slot->st);
+                slot_release(f.slot);
+            }
+            (void)hipGetLastError();
+        }
+    } drain{inflight};
+
+    auto retire = [&](InFlight &f) -> int {
+        HIP_TRY(hipEventSynchronize(f.slot->done));
+        std::vector<CopyJob> jobs;
+        for (size_t k = 0; k < outs.size(); k++)
+            if (outs[k].p && f.out[k].staged) jobs.push_back({outs[k].p + f.lo * outs[k].row, f.slot->hout + f.out[k].hofs, f.out[k].bytes});
+        parallel_copy(dev, jobs);
+        jobs.clear();
+        for (size_t k = 0; k < outs.size(); k++)
+            if (outs[k].secret && f.out[k].staged) jobs.push_back({f.slot->hout + f.out[k].hofs, nullptr, f.out[k].bytes});
+        for (auto &s : f.secret_in) jobs.push_back({f.slot->hin + s.hofs, nullptr, s.bytes});
+        parallel_copy(dev, jobs);
+        return CIRCL_HIP_OK;
+    };
+
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t cnt = std::min(chunk, n - lo);
+        if (inflight.size() >= depth) {
+            const int rc = retire(inflight.front());
+            if (rc) return rc;
+            slot_release(inflight.front().slot);
+            inflight.pop_front();
+        }
+        // ---- layout of this chunk ----
+        size_t dofs = 0, hin_ofs = 0, hout_ofs = 0;
+        auto take_d = [&](size_t bytes) { const size_t o = dofs; dofs += up256(bytes + 16); return o; };  // + slack: kernels may read whole dwords
+        auto take_hin = [&](size_t bytes) { const size_t o = hin_ofs; hin_ofs += (bytes + 63) & ~size_t(63); return o; };
+        auto take_hout = [&](size_t bytes) { const size_t o = hout_ofs; hout_ofs += (bytes + 63) & ~size_t(63); return o; };
+        std::vector<Seg> sin(ins.size()), sblob(blobs.size()), soff(blobs.size());
+        InFlight f;
+        f.lo = lo; f.cnt = cnt;
+        f.out.resize(outs.size());
+        for (size_t k = 0; k < ins.size(); k++) {
+            Seg &s = sin[k];
+            s.bytes = ins[k].row * (ins[k].per_call ? 1 : cnt);
+            s.dofs = take_d(s.bytes);
+            s.staged = !in_pinned[k];
+            if (s.staged) s.hofs = take_hin(s.bytes);
+        }
+        for (size_t k = 0; k < blobs.size(); k++) {
+            if (!blobs[k].blob) continue;
+            sblob[k].bytes = (size_t)(blobs[k].off[lo + cnt] - blobs[k].off[lo]);
+            sblob[k].dofs = take_d(sblob[k].bytes);
+            sblob[k].staged = !blob_pinned[k];
+            if (sblob[k].staged) sblob[k].hofs = take_hin(sblob[k].bytes);
+            soff[k].bytes = (cnt + 1) * 8;
+            soff[k].dofs = take_d(soff[k].bytes);
+            soff[k].staged = true;
+            soff[k].hofs = take_hin(soff[k].bytes);
+        }
+        for (size_t k = 0; k < outs.size(); k++) {
+            Seg &s = f.out[k];
+            s.bytes = outs[k].row * cnt;
+            s.dofs = take_d(s.bytes);
+            s.staged = outs[k].p && !out_pinned[k];
+            if (s.staged) s.hofs = take_hout(s.bytes);
+        }
+        const size_t wsb = ws_bytes(cnt);
+        const size_t ws_ofs = dofs;
+        dofs += up256(wsb);
+
+        Slot *slot = slot_acquire(dev);
+        if (!slot) return CIRCL_HIP_EHIP;
+        f.slot = slot;
+        inflight.push_back(f);  // from here on the Drain guard owns the slot
+        InFlight &cur = inflight.back();
+        int rc = slot->ensure(dofs, hin_ofs, hout_ofs);
+        if (rc) return rc;
+
+        // ---- stage in ----
+        std::vector<CopyJob> jobs;
+        for (size_t k = 0; k < ins.size(); k++)
+            if (sin[k].staged && sin[k].bytes) {
+                jobs.push_back({slot->hin + sin[k].hofs, ins[k].p + (ins[k].per_call ? 0 : lo * ins[k].row), sin[k].bytes});
+                if (ins[k].secret) cur.secret_in.push_back(sin[k]);
+            }
+        for (size_t k = 0; k < blobs.size(); k++) {
+            if (!blobs[k].blob) continue;
+            if (sblob[k].staged && sblob[k].bytes) jobs.push_back({slot->hin + sblob[k].hofs, blobs[k].blob + blobs[k].off[lo], sblob[k].bytes});
+            jobs.push_back({slot->hin + soff[k].hofs, blobs[k].off + lo, soff[k].bytes});
+        }
+        parallel_copy(dev, jobs);
+
+        // ---- enqueue: H2D, kernels, D2H ----
+        hipStream_t st = slot->st;
+        Chunk c;
+        c.cnt = cnt; c.st = st;
+        c.ws = slot->d + ws_ofs; c.ws_bytes = up256(wsb);
+        for (size_t k = 0; k < ins.size(); k++) {
+            uint8_t *dp = slot->d + sin[k].dofs;
+            c.in.push_back(dp);
+            if (!sin[k].bytes) continue;
+            const void *src = sin[k].staged ? (const void *)(slot->hin + sin[k].hofs) : (const void *)(ins[k].p + (ins[k].per_call ? 0 : lo * ins[k].row));
+            HIP_TRY(hipMemcpyAsync(dp, src, sin[k].bytes, hipMemcpyHostToDevice, st));
+        }
+        for (size_t k = 0; k < blobs.size(); k++) {
+            if (!blobs[k].blob) { c.blob.push_back(nullptr); c.off.push_back(nullptr); continue; }
+            uint8_t *dp = slot->d + sblob[k].dofs;
+            if (sblob[k].bytes) {
+                const void *src = sblob[k].staged ? (const void *)(slot->hin + sblob[k].hofs) : (const void *)(blobs[k].blob + blobs[k].off[lo]);
+                HIP_TRY(hipMemcpyAsync(dp, src, sblob[k].bytes, hipMemcpyHostToDevice, st));
+            }
+            HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, st));
+            c.blob.push_back(dp - blobs[k].off[lo]);  // the kernels index it with the caller's absolute offsets
+            c.off.push_back(reinterpret_cast<const uint64_t *>(slot->d + soff[k].dofs));
+        }
+        for (size_t k = 0; k < outs.size(); k++) c.out.push_back(slot->d + cur.out[k].dofs);
+        rc = launch(c);
+        if (rc) return rc;
+        for (size_t k = 0; k < outs.size(); k++) {
+            if (!outs[k].p || !cur.out[k].bytes) continue;
+            void *dst = cur.out[k].staged ? (void *)(slot->hout + cur.out[k].hofs) : (void *)(outs[k].p + lo * outs[k].row);
+            HIP_TRY(hipMemcpyAsync(dst, slot->d + cur.out[k].dofs, cur.out[k].bytes, hipMemcpyDeviceToHost, st));
+        }
+        if (opts.wipe_device) HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, st));  // keys, seeds and intermediates do not outlive the chunk
+        HIP_TRY(hipEventRecord(slot->done, st));
+    }
+    while (!inflight.empty()) {
+        const int rc = retire(inflight.front());
+        if (rc) return rc;
+        slot_release(inflight.front().slot);
+        inflight.pop_front();
+    }
+    return CIRCL_HIP_OK;
+}
+
+// ---- shard ----------------------------------------------------------------------------------------
+int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn) {
+    const int nd = ndev();
+    if (nd <= 0) return CIRCL_HIP_ENODEV;
+    if (device >= 0) return device < nd ? fn(device, size_t(0), n) : CIRCL_HIP_ENODEV;
+    if (device != CIRCL_HIP_ALL_DEVICES) return CIRCL_HIP_EPARAM;
+    if (nd == 1) return fn(0, size_t(0), n);
+    std::vector<int> rcs(nd, 0);
+    std::vector<std::string> errs(nd);
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; d++) {
+        const size_t lo = n * d / nd, hi = n * (d + 1) / nd;
+        th.emplace_back([&, d, lo, hi] {
+            pin_to(dev_info(d).cpus);  // this thread drives device d: stay on its NUMA node
+            rcs[d] = hi > lo ? fn(d, lo, hi - lo) : CIRCL_HIP_OK;
+            errs[d] = g_err;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < nd; d++)
+        if (rcs[d]) {
+            g_err = errs[d];
+            return rcs[d];
+        }
+    return CIRCL_HIP_OK;
+}
+
+}  // namespace host
+}  // namespace circl
+
+// ---- library management, profiling and pinned-memory helpers of the C ABI ----------------------------
+using namespace circl::host;
+
+extern "C" {
+
+int circl_hip_init(void) {
+    const int n = ndev();
+    return n > 0 ? n : CIRCL_HIP_ENODEV;
+}
+int circl_hip_device_count(void) { return std::max(ndev(), 0); }
+const char *circl_hip_last_error(void) { return g_err.c_str(); }
+const char *circl_hip_version(void) { return "circl-hip 0.2 (gfx950)"; }
+
+int circl_hip_device_info(int device, int *cus, int *numa_node) {
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
+    const DeviceInfo &di = dev_info(device);
+    if (cus) *cus = di.cus;
+    if (numa_node) *numa_node = di.numa;
+    return CIRCL_HIP_OK;
+}
+
+int circl_hip_profile_enable(int on) {
+    g_prof_on.store(on != 0);
+    return CIRCL_HIP_OK;
+}
+int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
+    if (kernel < 0 || kernel >= CIRCL_HIP_KERNEL_COUNT) return CIRCL_HIP_EPARAM;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_prof_ms[r.kernel] += ms;
+            g_prof_n[r.kernel] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof_pending.clear();
+    if (total_ms) *total_ms = g_prof_ms[kernel];
+    if (launches) *launches = g_prof_n[kernel];
+    g_prof_ms[kernel] = 0;
+    g_prof_n[kernel] = 0;
+    return CIRCL_HIP_OK;
+}
+
+void *circl_hip_alloc_host(size_t bytes) {
+    void *p = nullptr;
+    if (ndev() <= 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void circl_hip_free_host(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

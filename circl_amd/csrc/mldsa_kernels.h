@@ -148,6 +148,17 @@ __global__ void __launch_bounds__(64) mldsa_tr_kernel(const uint8_t *__restrict_
     if (threadIdx.x == 0) store_words<0, 8>(reinterpret_cast<uint64_t *>(tr_out), s);
 }
 
+// Key tables (grouped keys): tr of every table entry, lane = entry -> tr_out[j] (64-byte slots).  The reference keeps tr
+// and A in the parsed PublicKey (internal/dilithium.go:114-126), i.e. once per key however many signatures it checks.
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_tr_table_kernel(const uint8_t *__restrict__ pk_table, uint8_t *__restrict__ tr_out, size_t nkeys) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nkeys) return;
+    KeccakState s;
+    sponge17_words<DG<MODE>::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk_table + j * DG<MODE>::PK), kDsShake);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(tr_out + j * 64), s);
+}
+
 // ---- kernel P ---------------------------------------------------------------------------------
 
 template <int MODE>
@@ -155,18 +166,21 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                          int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
-                                                         uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared) {
+                                                         uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared,
+                                                         const uint32_t *__restrict__ key_idx) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState s;
+    const bool ctx_unsupported = !P::NIST && !internal && ctx_blob && ctx_off[idx + 1] != ctx_off[idx];  // round 3 has no contexts
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
-    // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125); shared-key batches bring it ready-made (mldsa_tr_kernel)
+    // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125); shared-key batches bring it ready-made (mldsa_tr_kernel), key-table
+    // batches one 64-byte slot per table entry (mldsa_tr_table_kernel), selected by key_idx
     KeccakState h;
     keccak_zero(h);
     if (tr_shared) {  // kernel-uniform
-        xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(tr_shared));
+        xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
     } else {
         sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
 #pragma unroll
@@ -193,7 +207,9 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
     s.hi[16] ^= 0x80000000u;
     keccak_f1600(s);
     store_words<0, 25>(reinterpret_cast<uint64_t *>(ball_ws + idx * kBallStateBytes), s);
-    fail_ws[idx] = (!internal && clen > 255) ? 1 : 0;  // mldsa65/dilithium.go:116-118
+    // mldsa65/dilithium.go:116-118: a context longer than 255 bytes never verifies; round-3 Dilithium has no contexts at
+    // all (sign.ErrContextNotSupported, sign/dilithium/mode3/dilithium.go:54-75), so a non-empty one never verifies either
+    fail_ws[idx] = ((!internal && clen > 255) || ctx_unsupported) ? 1 : 0;
 }
 
 // ---- verify kernel helpers ----------------------------------------------------------------------
@@ -435,13 +451,16 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
 // bit 3 drops the row stores of phase A, bit 4 shrinks the row loads of phase 2 to one row (L2 hits).
 // `scratch` holds gridDim.x slices of DG::SCRATCH_BYTES; `work` is the ticket counter (zeroed by the host)
 // or nullptr for one group per workgroup.
-// SHARED: every item is verified under the ONE public key at `pk` (the reference's cached-key case: A and tr live in
-// the parsed PublicKey, internal/dilithium.go:114-126): ExpandA runs once per workgroup before the group loop.
-template <int MODE, int ABLATE = 0, bool SHARED = false>
+// KM = mlkem::KM_SHARED: every item is verified under the ONE public key at `pk` (the reference's cached-key case: A and tr
+// live in the parsed PublicKey, internal/dilithium.go:114-126): ExpandA runs once per workgroup before the group loop.
+// KM = mlkem::KM_KEYED: item t is verified under entry key_idx[t] of the key table at `pk`; the matrices of all entries
+// were expanded beforehand into key_rows (mldsa_expand_keys_kernel: K L packed rows per entry) and are read-only here.
+template <int MODE, int ABLATE = 0, int KM = mlkem::KM_ITEM>
 __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig, uint8_t *__restrict__ muw1_ws,
                         const uint8_t *__restrict__ ball_ws, uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ scratch,
-                        unsigned *__restrict__ work, size_t n) {
+                        unsigned *__restrict__ work, size_t n, const uint32_t *__restrict__ key_idx, const uint32_t *__restrict__ key_rows) {
+    constexpr bool SHARED = KM == mlkem::KM_SHARED, KEYED = KM == mlkem::KM_KEYED;
     using G = DG<MODE>;
     using P = DP<MODE>;
     constexpr int K = P::K, L = P::L;
@@ -457,6 +476,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     constexpr int ZH_BYTES = L * G::ZSZ + P::OMEGA + K;
     static_assert(ZH_BYTES + 8 <= G::LDS_FIFO, "staged z || hint fits in the FIFO area");
     constexpr size_t PK_STRIDE = SHARED ? 0 : G::PK;
+    if constexpr (KEYED) rows = nullptr;
     if constexpr (SHARED) {
         expand_a_scratch<MODE, false, 1>(smem, rows, pk, 0, 0, 1, lane);  // rows 0 .. K L - 1, once
         rows_acquire();
@@ -465,7 +485,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
   for (size_t grp = mlkem::next_group(work, lane, true, ngroups); grp < ngroups; grp = mlkem::next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * G::IT;
-    if constexpr (!SHARED) {
+    if constexpr (!SHARED && !KEYED) {
         // ------------------------------ phase A ------------------------------
         __syncthreads();  // the previous group is done with the LDS the FIFOs alias
         if (!(ABLATE & 1)) expand_a_scratch<MODE, (ABLATE & 8) != 0>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
@@ -476,6 +496,8 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     for (int g = 0; g < G::IT; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
+        const size_t kq = KEYED ? (size_t)key_idx[item] : item;  // wave-uniform
+        const uint32_t *irows = KEYED ? key_rows + kq * (size_t)(G::STREAMS * kPackedRowDwords) : rows;
         // ------------------------------ phase 1 ------------------------------
         uint32_t zhat[L][4], chat[4] = {0, 0, 0, 0};
         bool bad = false;
@@ -542,12 +564,12 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
 #pragma unroll 1
         for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
             uint32_t acc[4] = {0, 0, 0, 0};
-            mac_rows<L>(acc, rows, (ABLATE & 16) ? 0 : (SHARED ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
+            mac_rows<L>(acc, irows, (ABLATE & 16) ? 0 : ((SHARED || KEYED) ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
             uint32_t t[4], w[4];
             {
                 // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,
                 // fetched as two aligned dwords (the row is 4-byte aligned), then moved to the NTT's input layout
-                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + item * PK_STRIDE + 32 + 320 * i);
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + kq * PK_STRIDE + 32 + 320 * i);
                 const int b = 5 * lane, d = b >> 2;
                 const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
 #pragma unroll
@@ -574,6 +596,17 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
         if (lane == 0 && failed) fail_ws[item] = 1;
     }
   }
+}
+
+// Key tables: ExpandA of every table entry, once.  Single-wave workgroups, IT entries each; entry e gets rows
+// e K L .. e K L + K L - 1 of the cache (24-bit packed).  The cache holds a whole number of groups.
+template <int MODE>
+__global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
+    mldsa_expand_keys_kernel(const uint8_t *__restrict__ pk_table, uint32_t *__restrict__ key_rows, size_t nkeys) {
+    using G = DG<MODE>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const size_t e0 = (size_t)blockIdx.x * G::IT;
+    expand_a_scratch<MODE>(smem, key_rows + e0 * (size_t)(G::STREAMS * kPackedRowDwords), pk_table, (size_t)G::PK, e0, nkeys, threadIdx.x);
 }
 
 // ---- kernel F -----------------------------------------------------------------------------------
@@ -805,11 +838,19 @@ template <int MODE>
 __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__restrict__ sk, const uint8_t *__restrict__ msg_blob,
                                                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
-                                                              int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key) {
+                                                              int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key,
+                                                              uint8_t *__restrict__ dead_ws) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    {
+        // sign.ErrContextTooLong (mldsa65/dilithium.go:63-65) / sign.ErrContextNotSupported (round 3): the host-buffer entry
+        // points refuse such a batch up front; device-resident callers get an all-zero signature for the item
+        // (mldsa_sign_zero_dead_kernel) instead of one over a truncated length byte or a silently dropped context
+        const size_t cl = (ctx_blob && !internal) ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+        dead_ws[idx] = (cl > 255 || (!P::NIST && cl > 0)) ? 1 : 0;
+    }
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
     const uint8_t *skp = sk + (shared_key ? 0 : idx) * Kg::SK;
     KeccakState h;
@@ -832,6 +873,15 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
     s.hi[16] ^= 0x80000000u;
     keccak_f1600(s);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), s);  // rho''
+}
+
+// lane = item: items whose context the scheme refuses (see mldsa_sign_prep_kernel) leave with an all-zero signature
+template <int MODE>
+__global__ void __launch_bounds__(256) mldsa_sign_zero_dead_kernel(uint8_t *__restrict__ sig, const uint8_t *__restrict__ dead_ws, size_t n) {
+    const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= n || !dead_ws[item]) return;
+    uint8_t *dst = sig + item * DG<MODE>::SIG;
+    for (int b = 0; b < DG<MODE>::SIG; b++) dst[b] = 0;
 }
 
 // D-bit field n of a little-endian bit stream of aligned dwords in global memory

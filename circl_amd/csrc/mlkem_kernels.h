@@ -161,14 +161,42 @@ __global__ void __launch_bounds__(64) mlkem_hek_kernel(const uint8_t *__restrict
     sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek));
     if (threadIdx.x == 0) store_words<0, 4>(reinterpret_cast<uint64_t *>(h_ws), h);
 }
-__global__ void __launch_bounds__(256) mlkem_g_shared_kernel(const uint8_t *__restrict__ h_ws, const uint8_t *__restrict__ m,
-                                                             uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws, size_t n) {
+
+// ---- key tables (grouped keys): what the reference caches in a parsed key object, once per table entry ----------
+// The reference keeps A^T and H(ek) in the parsed PublicKey / PrivateKey (kem/mlkem/mlkem768/kyber.go:39-43, :247-263;
+// pke/kyber/kyber768/internal/cpapke.go:19-25), so a batch over a handful of distinct keys pays matrix expansion once
+// per key.  lane = table entry: H(ek) of the key at keys + j * stride + ek_off -> h_out[j]; for private keys
+// (stored != 0) the hash is also compared with the one stored behind the embedded ek -> key_status[j] = 0 | 2.
+template <int K>
+__global__ void __launch_bounds__(256) mlkem_hek_table_kernel(const uint8_t *__restrict__ keys, size_t stride, size_t ek_off,
+                                                              uint8_t *__restrict__ h_out, uint8_t *__restrict__ key_status, int stored,
+                                                              size_t nkeys) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < nkeys;
+    if (!live) j = nkeys - 1;
+    const uint8_t *ekp = keys + j * stride + ek_off;
+    KeccakState h;
+    sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(ekp));
+    if (!live) return;
+    store_words<0, 4>(reinterpret_cast<uint64_t *>(h_out + j * 32), h);
+    if (stored) {
+        const uint64_t *st = reinterpret_cast<const uint64_t *>(ekp + Geom<K>::EK);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == st[i];
+        key_status[j] = ok ? 0 : 2;
+    }
+}
+// key_idx != nullptr (key-table batches): item idx uses the hash of table entry key_idx[idx].
+static __global__ void __launch_bounds__(256) mlkem_g_shared_kernel(const uint8_t *__restrict__ h_ws, const uint8_t *__restrict__ m,
+                                                             uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws, size_t n,
+                                                             const uint32_t *__restrict__ key_idx) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState g;
     keccak_zero(g);
     xor_words<0, 4>(g, reinterpret_cast<const uint64_t *>(m + idx * 32));
-    xor_words<4, 4>(g, reinterpret_cast<const uint64_t *>(h_ws));
+    xor_words<4, 4>(g, reinterpret_cast<const uint64_t *>(h_ws + (key_idx ? (size_t)key_idx[idx] * 32 : 0)));
     g.lo[8] = kDsSha3;
     g.hi[8] = 0x80000000u;
     keccak_f1600(g);
@@ -517,6 +545,14 @@ struct AFromScratch {
         a01 = (uint32_t)w; a23 = (uint32_t)(w >> 32);
     }
 };
+// Rows of a key table's expanded matrices: written by an earlier launch, read-only here, so ordinary cached loads.
+struct AFromCache {
+    const int16_t *rows;
+    __device__ __forceinline__ void load(uint32_t &a01, uint32_t &a23, int stream, int lane) const {
+        const uint2 w = *reinterpret_cast<const uint2 *>(rows + stream * 256 + 4 * lane);
+        a01 = w.x; a23 = w.y;
+    }
+};
 // Ends a sampling phase whose rows are read back with plain loads: the wave's row stores have left the CU (L1 is
 // write-through; the release orders them), every lane has arrived, and the agent-scope acquire
 // invalidates the CU's L1 (buffer_inv sc1).
@@ -745,27 +781,36 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1, ENCAPS_LENIENT = 2 };
 // SCRATCH selects where the sampled matrix lives between phase A and phase C: the workgroup's slice of
 // a global scratch (persistent launch: gridDim.x resident workgroups loop over the groups of G items)
 // or LDS (one group per workgroup; kept for A/B measurements).
-// SHARED (ENCAPS / REENCRYPT, scratch variant only): every item uses the key at `ek` (ek_stride = 0); A^T is sampled
-// once per workgroup before the group loop and groups are GS items.
-template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true, bool SHARED = false>
+// KM (ENCAPS / REENCRYPT, scratch variant only) = where the key material of an item comes from:
+//   KM_ITEM    every item has its own key row (ek_stride = row bytes); A^T is sampled per group of G items.
+//   KM_SHARED  every item uses the key at `ek` (ek_stride = 0); A^T is sampled once per workgroup before the group loop
+//              and groups are GS items.
+//   KM_KEYED   item t uses entry key_idx[t] of a key table at `ek` (row stride ek_stride); A^T of every table entry was
+//              expanded beforehand into key_rows (mlkem_expand_keys_kernel: K^2 rows of 256 int16 per entry) and is read
+//              with plain cached loads; groups are GS items.  This is the reference's parsed-key cache
+//              (kem/mlkem/mlkem768/kyber.go:39-43) for a batch over a handful of distinct keys.
+enum KeyMode { KM_ITEM = 0, KM_SHARED = 1, KM_KEYED = 2 };
+template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true, int KM = KM_ITEM>
 __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                           uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
-                                                          const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n) {
+                                                          const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n,
+                                                          const uint32_t *__restrict__ key_idx, const int16_t *__restrict__ key_rows) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
-    static_assert(!SHARED || (SCRATCH && (MODE == ENCAPS || MODE == REENCRYPT) && ABLATE == 0), "shared-key mode");
+    constexpr bool SHARED = KM != KM_ITEM;                      // one PRF pass per group of GS items, no per-group sampling
+    static_assert(!SHARED || (SCRATCH && (MODE == ENCAPS || MODE == REENCRYPT) && ABLATE == 0), "shared-key / key-table mode");
     uint8_t *xch = lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE);
-    int16_t *rows = reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
+    int16_t *rows = KM == KM_KEYED ? nullptr : reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     constexpr int GI = SHARED ? Gm::GS : Gm::G;  // items per group
     const size_t ngroups = (n + GI - 1) / GI;
-    if constexpr (SHARED) {
+    if constexpr (KM == KM_SHARED) {
         sample_matrix_scratch<K, true, 1>(lds_a, rows, ek + 384 * K, 0, 0, 1, lane);  // rows 0 .. K^2 - 1, once
         __threadfence_block();
         __syncthreads();
@@ -812,7 +857,9 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 __syncthreads();
             }
         }
-        const uint8_t *ekp = ek + item * ek_stride;
+        const size_t kq = KM == KM_KEYED ? (size_t)key_idx[item] : item;  // wave-uniform
+        const uint8_t *ekp = ek + kq * ek_stride;
+        const int16_t *krows = KM == KM_KEYED ? key_rows + kq * (size_t)(K * K * 256) : nullptr;
         const uint8_t *noise = lds_noise + (SHARED ? g : g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
 
         // t-hat (12-bit codec) in layout L4; ENCAPS applies UnpackMLKEM's range check
@@ -854,7 +901,8 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 uint32_t a01, a23;
-                if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, SHARED ? i * K + j : (g * K + i) * K + j, lane);
+                if constexpr (KM == KM_KEYED) AFromCache{krows}.load(a01, a23, i * K + j, lane);
+                else if constexpr (SCRATCH) AFromScratch{rows}.load(a01, a23, SHARED ? i * K + j : (g * K + i) * K + j, lane);
                 else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, (g * K + i) * K + j, lane);
                 kyber::mulhat_acc_packed(acc, a01, a23, rop[j]);
             }
@@ -911,18 +959,33 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
   }
 }
 
+// ---- key tables: A^T of every table entry, once ---------------------------------------------------
+// Single-wave workgroups, G table entries each: lane = (entry, i, j) runs the entry's SHAKE128 stream exactly as phase A
+// of the encrypt kernel does, but the rows go to the table's cache (entry e: rows e K^2 .. e K^2 + K^2 - 1 of 256 int16)
+// instead of a per-workgroup scratch.  The cache is allocated for a whole number of groups (the lanes of a partial last
+// group repeat the last entry into the padding).  rho of entry e is at keys + e * stride + rho_off.
+template <int K>
+__global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_expand_keys_kernel(const uint8_t *__restrict__ keys, size_t stride, size_t rho_off,
+                                                                                      int16_t *__restrict__ key_rows, size_t nkeys) {
+    using Gm = Geom<K>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const size_t e0 = (size_t)blockIdx.x * Gm::G;
+    sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), keys + rho_off, stride, e0, nkeys, threadIdx.x);
+}
+
 // ---- decapsulation ---------------------------------------------------------------------------
 
 // K-PKE.Decrypt (cpapke.go:113-130), one item per single-wave workgroup: m' -> workspace.
 template <int K>
 __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
-                                                          uint8_t *__restrict__ mprime_ws, size_t n) {
+                                                          uint8_t *__restrict__ mprime_ws, size_t n, const uint32_t *__restrict__ key_idx) {
     using Gm = Geom<K>;
     using P = Params<K>;
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     const int lane = threadIdx.x;
     const size_t item = blockIdx.x;
-    const uint8_t *dkp = dk + item * dk_stride;  // dk_stride = 0: one private key for the whole batch
+    // dk_stride = 0: one private key for the whole batch; key_idx: item t uses entry key_idx[t] of a key table
+    const uint8_t *dkp = dk + (key_idx ? (size_t)key_idx[item] : item) * dk_stride;
     const uint8_t *ctp = ct + item * Gm::CT;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     int acc[4] = {0, 0, 0, 0};
@@ -960,17 +1023,19 @@ template <int K>
 __global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
                                                                 const uint8_t *__restrict__ mprime_ws, uint8_t *__restrict__ kbar_ws,
                                                                 uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ssrej_ws,
-                                                                uint8_t *__restrict__ status, size_t n, const uint8_t *__restrict__ key_status) {
+                                                                uint8_t *__restrict__ status, size_t n, const uint8_t *__restrict__ key_status,
+                                                                const uint32_t *__restrict__ key_idx) {
     using Gm = Geom<K>;
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < n;
     if (!live) idx = n - 1;
-    const uint8_t *dkp = dk + idx * dk_stride;
+    const size_t kq = key_idx ? (size_t)key_idx[idx] : idx;  // key-table batches (key_status then holds one verdict per table entry)
+    const uint8_t *dkp = dk + kq * dk_stride;
     const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
     KeccakState h, g;
     bool ok = true;
     if (key_status) {  // kernel-uniform
-        ok = *key_status == 0;
+        ok = key_status[key_idx ? kq : 0] == 0;
     } else {
         sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(dkp + 384 * K));
 #pragma unroll

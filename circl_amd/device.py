@@ -10,8 +10,10 @@ import torch
 from . import _native as nat
 
 KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
+DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 4627),  # pk, sk, sig
+             2: (1312, 2528, 2420), 3: (1952, 4000, 3293), 5: (2592, 4864, 4595)}
 KERNELS = {"mlkem_hash": 0, "mlkem_encrypt": 1, "mlkem_decrypt": 2, "mlkem_keygen": 3, "mlkem_finish": 4,
-           "mldsa_hash": 5, "mldsa_verify": 6}
+           "mldsa_hash": 5, "mldsa_verify": 6, "mldsa_keygen": 7, "mldsa_sign": 8, "mlkem_keytable": 9, "mldsa_keytable": 10}
 
 
 def _stream():
@@ -74,6 +76,111 @@ class MLKEMDevice:
                                                self.ws.data_ptr(), self.wsb, _stream())
         nat.check(rc, "mlkem_keygen_dev")
         return ek, dk
+
+
+    def encaps_keyed(self, ek_table, key_idx, m, ct=None, ss=None, status=None):
+        """item i encapsulates to row key_idx[i] (int32 / uint32 tensor) of ek_table"""
+        ct = self.ct if ct is None else ct
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        nkeys = ek_table.shape[0]
+        wsb = self.L.circl_hip_mlkem_keyed_workspace_size(self.param, self.n, nkeys)
+        if getattr(self, "_kws", None) is None or self._kws.numel() < wsb:
+            self._kws = torch.empty(wsb, dtype=torch.uint8, device=ek_table.device)
+        assert key_idx.is_cuda and key_idx.dtype in (torch.int32, torch.uint32) and key_idx.is_contiguous() and key_idx.numel() == self.n
+        rc = self.L.circl_hip_mlkem_encaps_keyed_dev(self.param, _chk(ek_table, self.EK), nkeys, key_idx.data_ptr(), _chk(m, 32), _chk(ct, self.CT),
+                                                     _chk(ss, 32), _chk(status), self.n, self._kws.data_ptr(), wsb, _stream())
+        nat.check(rc, "mlkem_encaps_keyed_dev")
+        return ct, ss, status
+
+    def decaps_keyed(self, dk_table, key_idx, ct, ss=None, status=None):
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        nkeys = dk_table.shape[0]
+        wsb = self.L.circl_hip_mlkem_keyed_workspace_size(self.param, self.n, nkeys)
+        if getattr(self, "_kws", None) is None or self._kws.numel() < wsb:
+            self._kws = torch.empty(wsb, dtype=torch.uint8, device=dk_table.device)
+        assert key_idx.is_cuda and key_idx.dtype in (torch.int32, torch.uint32) and key_idx.is_contiguous() and key_idx.numel() == self.n
+        rc = self.L.circl_hip_mlkem_decaps_keyed_dev(self.param, _chk(dk_table, self.DK), nkeys, key_idx.data_ptr(), _chk(ct, self.CT), _chk(ss, 32),
+                                                     _chk(status), self.n, self._kws.data_ptr(), wsb, _stream())
+        nat.check(rc, "mlkem_decaps_keyed_dev")
+        return ss, status
+
+    def decaps_shared(self, dk1, ct, ss=None, status=None):
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        rc = self.L.circl_hip_mlkem_decaps_shared_dev(self.param, _chk(dk1, self.DK), _chk(ct, self.CT), _chk(ss, 32), _chk(status), self.n,
+                                                      self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mlkem_decaps_shared_dev")
+        return ss, status
+
+
+class MLDSADevice:
+    """Device-resident ML-DSA batch of n items with fixed-length messages (msg_len bytes each) and no contexts:
+    the shape of BASELINE.json's ML-DSA configs.  Holds the workspaces and the offset array."""
+
+    def __init__(self, param, n, device="cuda", msg_len=32, nkeys=0, sign=False):
+        self.param, self.n, self.msg_len = param, n, msg_len
+        self.PK, self.SK, self.SIG = DSA_SIZES[param]
+        self.L = nat.lib()
+        self.wsb = max(self.L.circl_hip_mldsa_workspace_size(param, n),
+                       self.L.circl_hip_mldsa_keyed_workspace_size(param, n, nkeys) if nkeys else 0)
+        self.ws = torch.empty(max(self.wsb, 256), dtype=torch.uint8, device=device)
+        self.off = torch.arange(0, msg_len * (n + 1), msg_len, dtype=torch.int64, device=device)
+        self.ok = torch.empty(n, dtype=torch.uint8, device=device)
+        self.sws = None
+        if sign:
+            self.swsb = self.L.circl_hip_mldsa_sign_workspace_size(param, n)
+            self.sws = torch.empty(self.swsb, dtype=torch.uint8, device=device)
+            self.rnd0 = torch.zeros((n, 32), dtype=torch.uint8, device=device)
+
+    def _msg(self, msg):
+        assert msg.is_cuda and msg.dtype == torch.uint8 and msg.is_contiguous() and msg.numel() >= self.n * self.msg_len + 4, \
+            "messages: contiguous uint8 CUDA tensor with >= 4 bytes of slack behind the last one"
+        return msg.data_ptr()
+
+    def keygen(self, seeds, pk=None, sk=None):
+        pk = torch.empty((self.n, self.PK), dtype=torch.uint8, device=seeds.device) if pk is None else pk
+        sk = torch.empty((self.n, self.SK), dtype=torch.uint8, device=seeds.device) if sk is None else sk
+        rc = self.L.circl_hip_mldsa_keygen_dev(self.param, _chk(seeds, 32), _chk(pk, self.PK), _chk(sk, self.SK), self.n, self.ws.data_ptr(), self.wsb,
+                                               _stream())
+        nat.check(rc, "mldsa_keygen_dev")
+        return pk, sk
+
+    def sign(self, sk, msg, sig=None, rnd=None, shared=False):
+        """deterministic unless rnd (n, 32) is given; HOST-BLOCKING (include/circl_hip.h)"""
+        assert self.sws is not None, "construct with sign=True"
+        sig = torch.empty(self.n * self.SIG + 16, dtype=torch.uint8, device=sk.device)[:self.n * self.SIG].view(self.n, self.SIG) if sig is None else sig
+        rnd = self.rnd0 if rnd is None else rnd
+        fn = self.L.circl_hip_mldsa_sign_shared_dev if shared else self.L.circl_hip_mldsa_sign_dev
+        rc = fn(self.param, _chk(sk, self.SK), self._msg(msg), self.off.data_ptr(), None, None, _chk(rnd, 32), 0, _chk(sig, self.SIG), self.n,
+                self.sws.data_ptr(), self.swsb, _stream())
+        nat.check(rc, "mldsa_sign_dev")
+        return sig
+
+    def verify(self, pk, sig, msg, ok=None):
+        ok = self.ok if ok is None else ok
+        rc = self.L.circl_hip_mldsa_verify_dev(self.param, _chk(pk, self.PK), _chk(sig, self.SIG), self._msg(msg), self.off.data_ptr(), None, None,
+                                               _chk(ok), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mldsa_verify_dev")
+        return ok
+
+    def verify_shared(self, pk1, sig, msg, ok=None):
+        ok = self.ok if ok is None else ok
+        rc = self.L.circl_hip_mldsa_verify_shared_dev(self.param, _chk(pk1, self.PK), _chk(sig, self.SIG), self._msg(msg), self.off.data_ptr(), None, None,
+                                                      _chk(ok), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mldsa_verify_shared_dev")
+        return ok
+
+    def verify_keyed(self, pk_table, key_idx, sig, msg, ok=None):
+        ok = self.ok if ok is None else ok
+        nkeys = pk_table.shape[0]
+        assert self.L.circl_hip_mldsa_keyed_workspace_size(self.param, self.n, nkeys) <= self.wsb, "construct with nkeys="
+        assert key_idx.is_cuda and key_idx.dtype in (torch.int32, torch.uint32) and key_idx.is_contiguous() and key_idx.numel() == self.n
+        rc = self.L.circl_hip_mldsa_verify_keyed_dev(self.param, _chk(pk_table, self.PK), nkeys, key_idx.data_ptr(), _chk(sig, self.SIG), self._msg(msg),
+                                                     self.off.data_ptr(), None, None, _chk(ok), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mldsa_verify_keyed_dev")
+        return ok
 
 
 def profile_enable(on=True):

@@ -82,6 +82,39 @@ def mlkem_decaps_shared(param, dk, ct, device=0):
     return ss, st
 
 
+def _idx(key_idx, n):
+    a = np.ascontiguousarray(key_idx, dtype=np.uint32).reshape(-1)
+    assert len(a) == n
+    return a
+
+
+def mlkem_encaps_keyed(param, ek_table, key_idx, m, device=0):
+    """item i encapsulates to row key_idx[i] of ek_table -> ct, ss, status"""
+    EK, _, CT = KEM_SIZES[param]
+    ek_table, m = _u8(ek_table, EK), _u8(m, 32)
+    n = len(m)
+    idx = _idx(key_idx, n)
+    ct = np.empty((n, CT), np.uint8)
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_encaps_keyed(param, _p(ek_table), len(ek_table), _p(idx), _p(m), _p(ct), _p(ss), _p(st), n, device),
+              "mlkem_encaps_keyed")
+    return ct, ss, st
+
+
+def mlkem_decaps_keyed(param, dk_table, key_idx, ct, device=0):
+    """item i is decapsulated with row key_idx[i] of dk_table -> ss, status"""
+    _, DK, CT = KEM_SIZES[param]
+    dk_table, ct = _u8(dk_table, DK), _u8(ct, CT)
+    n = len(ct)
+    idx = _idx(key_idx, n)
+    ss = np.empty((n, 32), np.uint8)
+    st = np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_decaps_keyed(param, _p(dk_table), len(dk_table), _p(idx), _p(ct), _p(ss), _p(st), n, device),
+              "mlkem_decaps_keyed")
+    return ss, st
+
+
 # round-3 Kyber (kem/kyber/kyber{512,768,1024}): no per-item failures
 def kyber_keygen(param, seeds, device=0):
     EK, DK, _ = KEM_SIZES[param]
@@ -213,6 +246,24 @@ def mldsa_verify_shared(param, pk, sig, msgs, ctxs=None, device=0):
         cb, co = _blob(ctxs)
         rc = nat.lib().circl_hip_mldsa_verify_shared(param, _p(pk), _p(sig), _p(mb), _p(mo), _p(cb), _p(co), _p(ok), n, device)
     nat.check(rc, "mldsa_verify_shared")
+    return ok
+
+
+def mldsa_verify_keyed(param, pk_table, key_idx, sig, msgs, ctxs=None, device=0):
+    """signature i is checked under row key_idx[i] of pk_table -> ok (n,)"""
+    PK, SIG = DSA_SIZES[param]
+    pk_table, sig = _u8(pk_table, PK), _u8(sig, SIG)
+    n = len(sig)
+    assert len(msgs) == n
+    idx = _idx(key_idx, n)
+    mb, mo = _blob(msgs)
+    ok = np.empty(n, np.uint8)
+    if ctxs is None:
+        rc = nat.lib().circl_hip_mldsa_verify_keyed(param, _p(pk_table), len(pk_table), _p(idx), _p(sig), _p(mb), _p(mo), None, None, _p(ok), n, device)
+    else:
+        cb, co = _blob(ctxs)
+        rc = nat.lib().circl_hip_mldsa_verify_keyed(param, _p(pk_table), len(pk_table), _p(idx), _p(sig), _p(mb), _p(mo), _p(cb), _p(co), _p(ok), n, device)
+    nat.check(rc, "mldsa_verify_keyed")
     return ok
 
 

@@ -54,6 +54,15 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, x):
+        """per-rank values as a list indexed by rank (on every rank)"""
+        if self.dist is None:
+            return [float(x)]
+        t = self._tensor(x)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()

@@ -19,6 +19,18 @@
  *   - the *_dev variants take DEVICE pointers and a hipStream_t (as void*), enqueue the
  *     kernels and return without synchronising: this is what bench.py times with inputs
  *     already resident in HBM.  All device pointers must be 16-byte aligned.
+ *     The device the pointers live on must be the calling thread's CURRENT device (hipSetDevice); workspace sizes are
+ *     valid for every visible device.  Rows that are not a multiple of 4 bytes (ML-DSA signatures, contexts and
+ *     messages) are read as whole aligned dwords: device arrays must have at least 4 bytes of addressable slack
+ *     behind their last row (the host-buffer entry points provide it themselves).
+ *   - host-buffer entry points accept ANY alignment and ordinary pageable memory (a Go []byte sub-slice): every
+ *     device owns a pool of staging slots (page-locked host staging + device staging + a stream each) that a small
+ *     per-device thread pool, pinned to the GPU's NUMA node, fills and drains, so H2D, kernels and D2H of
+ *     successive chunks overlap and a pageable caller reaches the PCIe-bound rate.  Page-locked caller buffers
+ *     (circl_hip_alloc_host / hipHostRegister) are DMA-ed directly.  Entry points are re-entrant: concurrent
+ *     callers take different slots.  Staging copies of secret inputs / outputs (seeds, private keys, m, shared
+ *     secrets) are wiped before a slot is recycled.  Tuning aids: CIRCL_HIP_HOST_THREADS, CIRCL_HIP_HOST_CHUNK
+ *     (log2 items per chunk), CIRCL_HIP_HOST_SLOTS.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point
  *     returns CIRCL_HIP_ENODEV.
  */
@@ -50,6 +62,8 @@ int circl_hip_init(void);               /* idempotent; returns the number of dev
 int circl_hip_device_count(void);
 const char *circl_hip_last_error(void); /* thread-local message for the last CIRCL_HIP_EHIP */
 const char *circl_hip_version(void);
+/* compute units and NUMA node (-1 unknown) of one device; either pointer may be NULL */
+int circl_hip_device_info(int device, int *cus, int *numa_node);
 
 /* ---- sizes (kem.Scheme.PublicKeySize etc., kem/kem.go:33-82; sign/sign.go:48-94) -------- */
 size_t circl_hip_mlkem_ek_size(int param); /* 512|768|1024 -> 800|1184|1568, 0 if unknown */
@@ -110,6 +124,27 @@ int circl_hip_mlkem_decaps_shared_dev(int param, const uint8_t *d_dk, const uint
                                       uint8_t *d_status, size_t n, void *d_workspace, size_t workspace_bytes,
                                       void *stream);
 
+/* ---- ML-KEM key tables (grouped keys) -----------------------------------------------------------
+ * A batch over a handful of distinct keys: item i uses row key_idx[i] of a table of nkeys keys.  This is the
+ * reference's parsed-key object applied to a batch: kem.Scheme.UnmarshalBinaryPublicKey expands A^T and H(ek) once
+ * per KEY (kem/mlkem/mlkem768/kyber.go:39-43, :247-263; pke/kyber/kyber768/internal/cpapke.go:19-25) and every later
+ * EncapsulateDeterministically / Decapsulate on that object reuses them.  Here: matrix expansion, H(ek) and the
+ * private key's hash check once per TABLE ENTRY, then the shared-key work per item.  Results are identical to
+ * circl_hip_mlkem_encaps / _decaps on the gathered rows ek_table[key_idx[i]] / dk_table[key_idx[i]]; status[i] is the
+ * verdict of item i's key.  Host entry points return CIRCL_HIP_EPARAM for an index >= nkeys; the _dev variants
+ * trust d_key_idx (4-byte aligned) and need circl_hip_mlkem_keyed_workspace_size(param, n, nkeys) bytes. */
+int circl_hip_mlkem_encaps_keyed(int param, const uint8_t *ek_table, size_t nkeys, const uint32_t *key_idx,
+                                 const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device);
+int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkeys, const uint32_t *key_idx,
+                                 const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device);
+size_t circl_hip_mlkem_keyed_workspace_size(int param, size_t n, size_t nkeys);
+int circl_hip_mlkem_encaps_keyed_dev(int param, const uint8_t *d_ek_table, size_t nkeys, const uint32_t *d_key_idx,
+                                     const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                     void *d_workspace, size_t workspace_bytes, void *stream);
+int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_t nkeys, const uint32_t *d_key_idx,
+                                     const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                     void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- round-3 Kyber ------------------------------------------------------
  * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in
  * kem/schemes).  param 512 | 768 | 1024; key and ciphertext sizes are those of ML-KEM.  Differences from
@@ -140,7 +175,9 @@ int circl_hip_kyber_decaps_dev(int param, const uint8_t *d_dk, const uint8_t *d_
  * lattice, 32-byte tr and c~ (sign/dilithium/mode3/internal/params.go:5-18), key seed hashed without the K, L domain
  * bytes (internal/dilithium.go:191-193), mu = CRH(tr || msg) without a context prefix (mode3/dilithium.go:54-75) and
  * deterministic signing (no rnd, internal/dilithium.go:360-362).  For these modes contexts must be empty / NULL
- * (the reference panics with sign.ErrContextNotSupported) and rnd is ignored.
+ * (the reference fails with sign.ErrContextNotSupported) and rnd is ignored: the host-buffer entry points return
+ * CIRCL_HIP_EPARAM when any context of the batch is non-empty; the device-resident ones (which cannot inspect the
+ * offsets without synchronising) give ok[i] = 0 / an all-zero signature for such an item.
  *
  * ---- ML-DSA verify ----------------------------------------------------------------------
  * scheme.UnmarshalBinaryPublicKey(pk_i) + scheme.Verify(pk_i, msg_i, sig_i, &SignatureOpts{Context: ctx_i})
@@ -173,6 +210,20 @@ int circl_hip_mldsa_verify_shared_dev(int param, const uint8_t *d_pk, const uint
                                       const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok,
                                       size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Key-table verification: signature i is checked under row key_idx[i] of a table of nkeys public keys -- a verifier that
+ * sees a few CA keys across a large batch.  tr and ExpandA (what PublicKey.Unpack caches per key,
+ * sign/mldsa/mldsa65/internal/dilithium.go:114-126; benchmark note internal/dilithium_test.go:37-39) run once per TABLE
+ * ENTRY.  Same results as circl_hip_mldsa_verify on the gathered rows.  The _dev variant needs
+ * circl_hip_mldsa_keyed_workspace_size(param, n, nkeys) bytes and trusts d_key_idx. */
+int circl_hip_mldsa_verify_keyed(int param, const uint8_t *pk_table, size_t nkeys, const uint32_t *key_idx,
+                                 const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                 const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n, int device);
+size_t circl_hip_mldsa_keyed_workspace_size(int param, size_t n, size_t nkeys);
+int circl_hip_mldsa_verify_keyed_dev(int param, const uint8_t *d_pk_table, size_t nkeys, const uint32_t *d_key_idx,
+                                     const uint8_t *d_sig, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                                     const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n,
+                                     void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- ML-DSA key generation ----------------------------------------------------------------
  * scheme.DeriveKey(seed_i), seed 32 bytes (sign/mldsa/mldsa65/dilithium.go:272-281 ->
  * internal/dilithium.go:181-267 NewKeyFromSeed); keys in MarshalBinary form.  The _dev variant
@@ -190,9 +241,12 @@ int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk
  * than 255 bytes makes the host-buffer call return CIRCL_HIP_EPARAM (sign.ErrContextTooLong).
  * circl_hip_mldsa_sign_internal is ML-DSA.Sign_internal (unsafeSignInternal, dilithium.go:90-99).
  * The _dev variant needs circl_hip_mldsa_sign_workspace_size(param, n) bytes (about 60 KB per item for
- * ML-DSA-65: expanded matrix and NTT-domain secrets per item); d_rnd must not be NULL.  Unlike the other
- * _dev calls it SYNCHRONISES the stream: the rejection loop runs as rounds over the unsigned items and
- * the host reads their count after each round. */
+ * ML-DSA-65: expanded matrix and NTT-domain secrets per item); d_rnd must not be NULL.  An item whose context is
+ * longer than 255 bytes gets an ALL-ZERO signature from the _dev variants (never one over a truncated length).
+ * The workspace holds key-equivalent intermediates while the call runs; its secret regions are zeroed before the
+ * call's work completes.  Unlike the other _dev calls the batched signer is HOST-BLOCKING: it synchronises `stream`
+ * (the rejection loop runs as rounds over the unsigned items and the host reads their count) and cannot be captured
+ * into a graph. */
 int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
                          const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig,
                          size_t n, int device);
@@ -260,7 +314,9 @@ int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_
 #define CIRCL_HIP_KERNEL_MLDSA_VERIFY 6
 #define CIRCL_HIP_KERNEL_MLDSA_KEYGEN 7
 #define CIRCL_HIP_KERNEL_MLDSA_SIGN 8
-#define CIRCL_HIP_KERNEL_COUNT 10
+#define CIRCL_HIP_KERNEL_MLKEM_KEYTABLE 9  /* key tables: H(ek) + A^T per table entry */
+#define CIRCL_HIP_KERNEL_MLDSA_KEYTABLE 10 /* key tables: tr + ExpandA per table entry */
+#define CIRCL_HIP_KERNEL_COUNT 12
 int circl_hip_profile_enable(int on);
 int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
 

@@ -14,11 +14,16 @@ typedef struct job {
     uint8_t *o1, *o2, *st;
 } job;
 
-enum { J_KEM_KEYGEN, J_KEM_ENCAPS, J_KEM_DECAPS, J_DSA_KEYGEN, J_DSA_SIGN, J_DSA_VERIFY };
+enum { J_KEM_KEYGEN, J_KEM_ENCAPS, J_KEM_DECAPS, J_DSA_KEYGEN, J_DSA_SIGN, J_DSA_VERIFY, J_KEM_ENCAPS_SHARED };
 
 static void *run(void *arg) {
     job *j = (job *)arg;
     int p = j->param;
+    if (j->kind == J_KEM_ENCAPS_SHARED) { /* one parsed key per thread, its slice of the messages */
+        size_t ct = orc_mlkem_ct_size(p);
+        orc_mlkem_encaps_cached(p, j->a, j->b + 32 * j->lo, j->o1 + ct * j->lo, j->o2 + 32 * j->lo, j->hi - j->lo);
+        return 0;
+    }
     if (j->kind <= J_KEM_DECAPS) {
         size_t ek = orc_mlkem_ek_size(p), dk = orc_mlkem_dk_size(p), ct = orc_mlkem_ct_size(p);
         for (size_t i = j->lo; i < j->hi; i++) {
@@ -83,6 +88,11 @@ int orc_mlkem_encaps_batch(int param, const uint8_t *ek, const uint8_t *m, uint8
                            uint8_t *status, size_t n, int threads) {
     if (!orc_mlkem_ek_size(param)) return -1;
     job j = {.kind = J_KEM_ENCAPS, .param = param, .a = ek, .b = m, .o1 = ct, .o2 = ss, .st = status};
+    return fan(&j, n, threads);
+}
+int orc_mlkem_encaps_shared_batch(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, size_t n, int threads) {
+    if (!orc_mlkem_ek_size(param)) return -1;
+    job j = {.kind = J_KEM_ENCAPS_SHARED, .param = param, .a = ek, .b = m, .o1 = ct, .o2 = ss};
     return fan(&j, n, threads);
 }
 int orc_mlkem_decaps_batch(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss,

@@ -327,14 +327,25 @@ static void kpke_keygen(uint8_t *ek, uint8_t *sk_packed, const uint8_t *seed, si
 }
 
 /* cpapke.go:137-181 EncryptTo */
+static void kpke_encrypt_parsed(uint8_t *ct, const pvec *th, const pmat *AT, const uint8_t pt[32],
+                                const uint8_t seed[32], const kparams *P);
 static void kpke_encrypt(uint8_t *ct, const uint8_t *ekbuf, const uint8_t pt[32],
                          const uint8_t seed[32], const kparams *P) {
     int K = P->k;
     static __thread pmat AT;
-    pvec th, rh, e1, u;
-    poly e2, v, m;
+    pvec th;
     pk_unpack_th(&th, ekbuf, K);
     mat_derive(&AT, ekbuf + 384 * K, 1, K);
+    kpke_encrypt_parsed(ct, &th, &AT, pt, seed, P);
+}
+/* EncryptTo on a parsed key: cpapke.go:19-25 PublicKey{rho, th, aT} caches th and A^T; :137-181 is the work left per message */
+static void kpke_encrypt_parsed(uint8_t *ct, const pvec *thp, const pmat *ATp, const uint8_t pt[32],
+                                const uint8_t seed[32], const kparams *P) {
+    int K = P->k;
+    pvec rh, e1, u;
+    poly e2, v, m;
+#define th (*thp)
+#define AT (*ATp)
     for (int i = 0; i < K; i++) {
         poly_noise(&rh.v[i], seed, (uint8_t)i, P->eta1);
         poly_ntt(&rh.v[i]);
@@ -360,6 +371,8 @@ static void kpke_encrypt(uint8_t *ct, const uint8_t *ekbuf, const uint8_t pt[32]
     }
     poly_normalize(&v);
     poly_compress(ct + 32 * P->du * K, &v, P->dv);
+#undef th
+#undef AT
 }
 
 /* cpapke.go:113-130 DecryptTo (sh = Unpack + Normalize, cpapke.go:33-36) */
@@ -425,6 +438,34 @@ int orc_mlkem_encaps(int param, const uint8_t *ek, const uint8_t m[32], uint8_t 
     orc_sha3_512(kr, g_in, 64);
     kpke_encrypt(ct, ek, m, kr + 32, &P);
     memcpy(ss, kr, 32);
+    return 0;
+}
+
+/* n encapsulations to ONE parsed key: kyber.go:247-263 Unpack once (th, A^T, H(ek): kyber.go:39-43), then
+ * kyber.go:103-137 EncapsulateTo per message -- the shape of the reference's BenchmarkEncapsulate
+ * (kem/schemes/schemes_test.go:28-38).  Returns 0 or ORC_ERR_PUBKEY (then nothing is written). */
+int orc_mlkem_encaps_cached(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, size_t n) {
+    kparams P;
+    if (kyber_params(param, &P)) return -1;
+    if (!zetas_ready) zetas_init();
+    int K = P.k;
+    size_t ctsz = (size_t)(32 * (P.du * K + P.dv));
+    static __thread pmat AT;
+    pvec th;
+    uint8_t buf2[384 * 4], hpk[32];
+    pk_unpack_th(&th, ek, K);
+    for (int i = 0; i < K; i++) poly_pack(buf2 + 384 * i, &th.v[i]);
+    if (memcmp(buf2, ek, (size_t)(384 * K)) != 0) return ORC_ERR_PUBKEY;
+    mat_derive(&AT, ek + 384 * K, 1, K);
+    orc_sha3_256(hpk, ek, (size_t)(384 * K + 32));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t g_in[64], kr[64];
+        memcpy(g_in, m + 32 * i, 32);
+        memcpy(g_in + 32, hpk, 32);
+        orc_sha3_512(kr, g_in, 64);
+        kpke_encrypt_parsed(ct + ctsz * i, &th, &AT, m + 32 * i, kr + 32, &P);
+        memcpy(ss + 32 * i, kr, 32);
+    }
     return 0;
 }
 

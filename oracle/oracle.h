@@ -29,6 +29,8 @@ size_t orc_mlkem_ct_size(int param);
 int orc_mlkem_keygen(int param, const uint8_t seed[64], uint8_t *ek, uint8_t *dk);
 int orc_mlkem_encaps(int param, const uint8_t *ek, const uint8_t m[32], uint8_t *ct, uint8_t ss[32]);
 int orc_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint8_t ss[32]);
+int orc_mlkem_encaps_cached(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, size_t n);
+int orc_mlkem_encaps_shared_batch(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, size_t n, int threads);
 
 /* batch forms, `threads` pthreads over contiguous slices; status[n] per item.
  * On a per-item error the item's outputs are zero-filled. */

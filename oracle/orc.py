@@ -143,6 +143,20 @@ def mlkem_encaps(param, ek, m, threads=None):
     return ct, ss, st
 
 
+def mlkem_encaps_shared(param, ek, m, threads=None):
+    """n encapsulations to ONE parsed key (the reference's BenchmarkEncapsulate shape) -> ct (n,CT), ss (n,32)"""
+    EK, _, CT = KEM_SIZES[param]
+    ek = _u8(ek).reshape(-1, EK)
+    assert len(ek) == 1
+    m = _u8(m).reshape(-1, 32)
+    n = len(m)
+    ct = np.zeros((n, CT), np.uint8)
+    ss = np.zeros((n, 32), np.uint8)
+    r = lib().orc_mlkem_encaps_shared_batch(param, _p(ek), _p(m), _p(ct), _p(ss), C.c_size_t(n), threads or ncpu())
+    assert r == 0
+    return ct, ss
+
+
 def mlkem_decaps(param, dk, ct, threads=None):
     _, DK, CT = KEM_SIZES[param]
     dk = _u8(dk).reshape(-1, DK)

@@ -30,7 +30,7 @@ for k, d in agg.items():
     print(k)
     for c, v in sorted(d.items()):
         v = sorted(v); print(f"   {c:28s} median {v[len(v)//2]:.4e}  n={len(v)}")
-    if "mlkem_encrypt_kernel<3" in k and "true, true>" not in k:  # the distinct-key kernel (not bench.py's shared-key steps)
+    if "mlkem_encrypt_kernel<3, 0, 0, true, 0>" in k:  # the distinct-key kernel (not bench.py's shared-key steps)
         med = lambda c: sorted(d[c])[len(d[c]) // 2]
         out = {"mlkem768_encrypt_valu_insts_per_launch_2p20": med("SQ_INSTS_VALU"), "salu": med("SQ_INSTS_SALU"), "lds": med("SQ_INSTS_LDS"),
                "grbm_gui_active_per_xcd": med("GRBM_GUI_ACTIVE") / 8, "wave_quad_cycles": med("SQ_WAVE_CYCLES"),

@@ -73,11 +73,11 @@ def pmc(raw, tag):
         hbm = (2 * f_avg + w_avg) * 1024
         out_lines.append(f"{short(k):72s} {max(len(fz), len(wz)):8d} {f_avg:22.1f} {w_avg:22.1f} {hbm:30.3e}")
         # <K = 3, MODE = ENCAPS, ABLATE = 0, SCRATCH = true, SHARED = false>: the distinct-key kernel of the headline metric
-        if "mlkem_encrypt_kernel<3, 0, 0, true, false>" in k or ("mlkem_encrypt_kernel<3" in k and "true, true>" not in k and ", 0, 0," in k):
+        if "mlkem_encrypt_kernel<3, 0, 0, true, 0>" in k or "mlkem_encrypt_kernel<3, 0, 0, true, false>" in k:  # (the bool spelling: round-1 builds)
             traffic["mlkem768_encrypt_bytes_per_launch_2p20"] = hbm
             traffic["mlkem768_encrypt_fetch_kb_reported"] = f_avg
             traffic["mlkem768_encrypt_write_kb_reported"] = w_avg
-        if "mlkem_encrypt_kernel<3, 0, 0, true, true>" in k:  # bench.py's secondary shared-key steps
+        if "mlkem_encrypt_kernel<3, 0, 0, true, 1>" in k or "mlkem_encrypt_kernel<3, 0, 0, true, true>" in k:  # bench.py's secondary shared-key steps
             traffic["mlkem768_encrypt_shared_key_bytes_per_launch_2p20"] = hbm
         if "mlkem_hash_kernel<3" in k or "mlkem_hash_kernelILi3" in k:
             traffic["mlkem768_hash_bytes_per_launch_2p20"] = hbm

@@ -101,7 +101,7 @@ int main() {
     {                                                                                                                           \
         float ms = time_ms([](void *v) { E *e = (E *)v;                                                                         \
             hipLaunchKernelGGL((mlkem::mlkem_encrypt_kernel<K, mlkem::ENCAPS, MASK, false>), dim3(e->eb), dim3(64), Gm::LDS_TOTAL, 0, e->ek, \
-                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, (unsigned *)nullptr, e->n); }, &e); \
+                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, (unsigned *)nullptr, e->n, (const uint32_t *)nullptr, (const int16_t *)nullptr); }, &e); \
         printf("  %-28s %.3f ms\n", NAME, ms);                                                                                  \
     }
 #define RUNS(MASK, BPC, NAME)                                                                                                   \
@@ -110,7 +110,7 @@ int main() {
         float ms = time_ms([](void *v) { E *e = (E *)v;                                                                         \
             hipMemsetAsync(e->work, 0, 4, 0);                                                                                   \
             hipLaunchKernelGGL((mlkem::mlkem_encrypt_kernel<K, mlkem::ENCAPS, MASK, true>), dim3(e->eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, 0, e->ek, \
-                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, e->work, e->n); }, &e); \
+                               (size_t)Gm::EK, e->m, e->r, e->ct, e->ss, e->st, (const uint8_t *)nullptr, (const uint8_t *)nullptr, e->scratch, e->work, e->n, (const uint32_t *)nullptr, (const int16_t *)nullptr); }, &e); \
         printf("  %-28s %.3f ms  (%d blocks/CU)\n", NAME, ms, BPC);                                                              \
         e.eb = eb;                                                                                                              \
     }

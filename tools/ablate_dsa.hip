@@ -20,7 +20,7 @@ template <int MODE, int MASK> float run(const uint8_t *pk, const uint8_t *sig, u
     auto launch = [&] {
         CK(hipMemsetAsync(g_work, 0, 256, 0));
         hipLaunchKernelGGL((mldsa::mldsa_verify_kernel<MODE, MASK>), dim3(256 * g_bpc), dim3(64), G::LDS_V_TOTAL, 0, pk, sig, muw1,
-                           (const uint8_t *)ball, fail, g_scratch, g_work, n);
+                           (const uint8_t *)ball, fail, g_scratch, g_work, n, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     };
     launch();
     CK(hipDeviceSynchronize());
