@@ -2,7 +2,7 @@
 //
 //   per-device state     CU count, NUMA node, occupancy cache keyed on (device, kernel), all race-free
 //   kernel profiling     HIP-event brackets on the launch stream (circl_hip_profile_*)
-//   host-buffer pipeline a per-device pool of staging slots (page-locked host staging + device staging + stream),
+//   host-buffer pipeline a per-device pool of staging slots (page-locked host staging + device staging + events),
 //                        filled and drained by a small per-device thread pool pinned to the GPU's NUMA node, so that a
 //                        caller with ordinary pageable memory (a Go []byte) reaches the PCIe-bound rate; concurrent
 //                        callers take different slots and overlap
@@ -107,14 +107,15 @@ void parallel_copy(int dev, const std::vector<CopyJob> &jobs);
 // ---- staging slots ----------------------------------------------------------------------------
 struct Slot {
     int dev = -1;
-    hipStream_t st = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr, ev_in = nullptr, ev_k = nullptr;  // outputs are home / inputs have arrived / kernels are done
     uint8_t *d = nullptr;     size_t d_cap = 0;      // device staging: inputs, outputs, workspace of one chunk
     uint8_t *hin = nullptr;   size_t hin_cap = 0;    // page-locked staging, host -> device
     uint8_t *hout = nullptr;  size_t hout_cap = 0;   // page-locked staging, device -> host
     int ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes);
 };
-Slot *slot_acquire(int dev);     // blocks while every slot of the device is in use; nullptr + g_err on failure
+// block = true: waits while every slot of the device is in use; false: returns nullptr at once in that case.
+// nullptr with a non-empty g_err = creating a slot failed.
+Slot *slot_acquire(int dev, bool block = true);
 void slot_release(Slot *s);
 bool is_pinned_host(const void *p);  // page-locked (hipHostMalloc / hipHostRegister) memory: DMA-able as is
 
@@ -146,7 +147,7 @@ struct Chunk {               // what `launch` gets: device pointers of one chunk
 };
 struct PipeOpts {
     size_t chunk_items = size_t(1) << 15;
-    int depth = 3;            // chunks in flight per call
+    int depth = 6;            // chunks in flight per call (staging slots held)
     bool wipe_device = false; // zero the device staging of every chunk once its results are out
 };
 // Runs items [0, n) on device `dev`: per chunk  stage-in (host threads) -> H2D -> launch -> D2H -> stage-out (host threads),

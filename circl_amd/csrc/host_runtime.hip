@@ -311,6 +311,16 @@ struct SlotPool {
     std::condition_variable cv;
     std::vector<Slot *> free_slots;
     int created = 0;
+    // One stream per DIRECTION per device, shared by all slots and callers: a stream that alternates H2D and D2H copies
+    // gets 60-68 GB/s for both directions together on this platform, a dedicated H2D stream next to a dedicated D2H
+    // stream 81-95 GB/s (tools/pcie_probe.hip) -- the SDMA engines are bound per queue.
+    // The kernels of all chunks of a call go to ONE compute stream (taken round-robin from two per device, so that two
+    // concurrent callers do not share one): a chunk's kernels fill the GPU anyway, and the runtime multiplexes streams
+    // onto a handful of hardware queues -- with a stream per slot, compute streams ended up behind the copy streams'
+    // barrier packets and the PCIe rate depended erratically on the pipeline depth (tools/host_path.py sweeps).
+    std::once_flag copy_once;
+    hipStream_t h2d = nullptr, d2h = nullptr, compute[2] = {nullptr, nullptr};
+    std::atomic<unsigned> next_compute{0};
 };
 std::mutex g_slot_pools_mu;
 std::vector<SlotPool *> g_slot_pools;
@@ -320,15 +330,29 @@ SlotPool *slot_pool_of(int dev) {
     if (!g_slot_pools[dev]) g_slot_pools[dev] = new SlotPool;
     return g_slot_pools[dev];
 }
+int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *compute) {
+    SlotPool *p = slot_pool_of(dev);
+    std::call_once(p->copy_once, [&] {
+        if (hipStreamCreateWithFlags(&p->h2d, hipStreamNonBlocking) != hipSuccess) p->h2d = nullptr;
+        if (hipStreamCreateWithFlags(&p->d2h, hipStreamNonBlocking) != hipSuccess) p->d2h = nullptr;
+        for (auto &c : p->compute)
+            if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) c = nullptr;
+    });
+    if (!p->h2d || !p->d2h || !p->compute[0] || !p->compute[1]) { g_err = "stream creation failed"; (void)hipGetLastError(); return CIRCL_HIP_EHIP; }
+    *h2d = p->h2d;
+    *d2h = p->d2h;
+    *compute = p->compute[p->next_compute.fetch_add(1) & 1];
+    return CIRCL_HIP_OK;
+}
 int max_slots() {
-    static const int v = env_int("CIRCL_HIP_HOST_SLOTS", 8, 1, 64);
+    static const int v = env_int("CIRCL_HIP_HOST_SLOTS", 12, 1, 64);
     return v;
 }
 }  // namespace
 
 int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
     if (d_bytes > d_cap) {
-        if (d) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d)); }
+        if (d) HIP_TRY(hipFree(d));  // (a slot is idle whenever it is resized: its last chunk was retired)
         d = nullptr; d_cap = 0;
         const size_t want = up256(d_bytes + d_bytes / 8);  // a little head-room: ragged chunks differ in size
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), want));
@@ -351,7 +375,7 @@ int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
     return CIRCL_HIP_OK;
 }
 
-Slot *slot_acquire(int dev) {
+Slot *slot_acquire(int dev, bool block) {
     SlotPool *p = slot_pool_of(dev);
     {
         std::unique_lock<std::mutex> lk(p->mu);
@@ -362,16 +386,19 @@ Slot *slot_acquire(int dev) {
                 return s;
             }
             if (p->created < max_slots()) { p->created++; break; }
+            if (!block) return nullptr;
             p->cv.wait(lk);
         }
     }
     Slot *s = new Slot;
     s->dev = dev;
-    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess) {
-        g_err = "slot_acquire: stream / event creation failed";
+    if (hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming) != hipSuccess) {
+        g_err = "slot_acquire: event creation failed";
         (void)hipGetLastError();
-        if (s->st) (void)hipStreamDestroy(s->st);
+        for (hipEvent_t e : {s->done, s->ev_in, s->ev_k})
+            if (e) (void)hipEventDestroy(e);
         delete s;
         std::lock_guard<std::mutex> lk(p->mu);
         p->created--;
@@ -420,47 +447,59 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
     HIP_TRY(hipSetDevice(dev));
     const size_t chunk = std::max<size_t>(1, std::min(n, opts.chunk_items));
-    const size_t depth = (size_t)std::max(1, opts.depth);
+    static const int depth_env = env_int("CIRCL_HIP_HOST_DEPTH", 0, 1, 32);  // tuning aid: chunks in flight per call
+    const size_t depth = (size_t)std::max(1, (depth_env && opts.depth > 1) ? depth_env : opts.depth);
     std::vector<char> in_pinned(ins.size()), out_pinned(outs.size()), blob_pinned(blobs.size());
     for (size_t k = 0; k < ins.size(); k++) in_pinned[k] = is_pinned_host(ins[k].p);
     for (size_t k = 0; k < outs.size(); k++) out_pinned[k] = outs[k].p && is_pinned_host(outs[k].p);
     for (size_t k = 0; k < blobs.size(); k++) blob_pinned[k] = blobs[k].blob && is_pinned_host(blobs[k].blob);
 
+    hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
+    if (int rc = pipeline_streams(dev, &h2d, &d2h, &st)) return rc;
     std::deque<InFlight> inflight;
     // error paths must not recycle a slot (or return to the caller) with copies or kernels still in flight
     struct Drain {
         std::deque<InFlight> &q;
+        hipStream_t h2d, d2h, st;
         ~Drain() {
-            for (auto &f : q) {
-                (void)hipStreamSynchronize(f.slot->st);
-                slot_release(f.slot);
-            }
+            if (q.empty()) return;
+            (void)hipStreamSynchronize(h2d);
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(d2h);
+            for (auto &f : q) slot_release(f.slot);
             (void)hipGetLastError();
         }
-    } drain{inflight};
+    } drain{inflight, h2d, d2h, st};
 
-    auto retire = [&](InFlight &f) -> int {
-        HIP_TRY(hipEventSynchronize(f.slot->done));
-        std::vector<CopyJob> jobs;
+    // stage-out of a finished chunk = copy jobs (staging -> caller memory), then wipe jobs (secret staging areas)
+    auto out_jobs = [&](InFlight &f, std::vector<CopyJob> &jobs) {
         for (size_t k = 0; k < outs.size(); k++)
             if (outs[k].p && f.out[k].staged) jobs.push_back({outs[k].p + f.lo * outs[k].row, f.slot->hout + f.out[k].hofs, f.out[k].bytes});
-        parallel_copy(dev, jobs);
-        jobs.clear();
+    };
+    auto wipe_jobs = [&](InFlight &f, std::vector<CopyJob> &jobs) {
         for (size_t k = 0; k < outs.size(); k++)
             if (outs[k].secret && f.out[k].staged) jobs.push_back({f.slot->hout + f.out[k].hofs, nullptr, f.out[k].bytes});
         for (auto &s : f.secret_in) jobs.push_back({f.slot->hin + s.hofs, nullptr, s.bytes});
+    };
+    auto retire = [&](InFlight &f) -> int {
+        HIP_TRY(hipEventSynchronize(f.slot->done));
+        std::vector<CopyJob> jobs;
+        out_jobs(f, jobs);
+        parallel_copy(dev, jobs);
+        jobs.clear();
+        wipe_jobs(f, jobs);
         parallel_copy(dev, jobs);
         return CIRCL_HIP_OK;
     };
+    // Before chunk c is enqueued, the inputs of chunk c - AHEAD must have arrived: at most AHEAD chunks' worth of copies is
+    // ever queued on the H2D stream, however many slots the call holds.  Measured (tools/host_path.py, 2^20 ML-KEM-768
+    // encapsulations): without the bound the rate falls with every extra chunk in flight (4.0e7/s at depth 3, 2.6e7 at 4,
+    // 2.0e7 at 6, page-locked caller buffers); with AHEAD = 1 it is 4.0e7/s (48.6 + 44.8 GB/s, the bidirectional PCIe
+    // ceiling of this box) at any depth.  0 = no bound (tuning aid).
+    static const int ahead = env_int("CIRCL_HIP_HOST_AHEAD", 1, 0, 32);
 
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = std::min(chunk, n - lo);
-        if (inflight.size() >= depth) {
-            const int rc = retire(inflight.front());
-            if (rc) return rc;
-            slot_release(inflight.front().slot);
-            inflight.pop_front();
-        }
         // ---- layout of this chunk ----
         size_t dofs = 0, hin_ofs = 0, hout_ofs = 0;
         auto take_d = [&](size_t bytes) { const size_t o = dofs; dofs += up256(bytes + 16); return o; };  // + slack: kernels may read whole dwords
@@ -499,15 +538,28 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         const size_t ws_ofs = dofs;
         dofs += up256(wsb);
 
-        Slot *slot = slot_acquire(dev);
-        if (!slot) return CIRCL_HIP_EHIP;
+        // A call never WAITS for a slot while it holds one (several concurrent callers doing that on a small pool would
+        // deadlock): if the pool is exhausted it first drains its own oldest chunk; only a call that holds nothing blocks.
+        Slot *slot = nullptr;
+        for (;;) {
+            g_err.clear();
+            slot = slot_acquire(dev, inflight.empty());
+            if (slot) break;
+            if (inflight.empty()) return CIRCL_HIP_EHIP;  // creation failed (g_err says why)
+            if (!g_err.empty()) return CIRCL_HIP_EHIP;
+            const int rc = retire(inflight.front());
+            if (rc) return rc;
+            slot_release(inflight.front().slot);
+            inflight.pop_front();
+        }
         f.slot = slot;
         inflight.push_back(f);  // from here on the Drain guard owns the slot
         InFlight &cur = inflight.back();
         int rc = slot->ensure(dofs, hin_ofs, hout_ofs);
         if (rc) return rc;
 
-        // ---- stage in ----
+        // ---- stage in -- together with the stage-out of the oldest chunk when the call holds `depth` slots: one batch for
+        // the byte movers instead of two half-empty ones ----
         std::vector<CopyJob> jobs;
         for (size_t k = 0; k < ins.size(); k++)
             if (sin[k].staged && sin[k].bytes) {
@@ -519,10 +571,22 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             if (sblob[k].staged && sblob[k].bytes) jobs.push_back({slot->hin + sblob[k].hofs, blobs[k].blob + blobs[k].off[lo], sblob[k].bytes});
             jobs.push_back({slot->hin + soff[k].hofs, blobs[k].off + lo, soff[k].bytes});
         }
+        const bool retire_front = inflight.size() > depth;  // (the new chunk is already in the deque)
+        if (retire_front) {
+            HIP_TRY(hipEventSynchronize(inflight.front().slot->done));
+            out_jobs(inflight.front(), jobs);
+        }
         parallel_copy(dev, jobs);
+        if (retire_front) {
+            jobs.clear();
+            wipe_jobs(inflight.front(), jobs);
+            parallel_copy(dev, jobs);
+            slot_release(inflight.front().slot);
+            inflight.pop_front();
+        }
+        if (ahead > 0 && inflight.size() > (size_t)ahead) HIP_TRY(hipEventSynchronize(inflight[inflight.size() - 1 - ahead].slot->ev_in));
 
-        // ---- enqueue: H2D, kernels, D2H ----
-        hipStream_t st = slot->st;
+        // ---- enqueue: H2D on the device's H2D stream, kernels on the call's compute stream, D2H on the device's D2H stream ----
         Chunk c;
         c.cnt = cnt; c.st = st;
         c.ws = slot->d + ws_ofs; c.ws_bytes = up256(wsb);
@@ -531,29 +595,33 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             c.in.push_back(dp);
             if (!sin[k].bytes) continue;
             const void *src = sin[k].staged ? (const void *)(slot->hin + sin[k].hofs) : (const void *)(ins[k].p + (ins[k].per_call ? 0 : lo * ins[k].row));
-            HIP_TRY(hipMemcpyAsync(dp, src, sin[k].bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dp, src, sin[k].bytes, hipMemcpyHostToDevice, h2d));
         }
         for (size_t k = 0; k < blobs.size(); k++) {
             if (!blobs[k].blob) { c.blob.push_back(nullptr); c.off.push_back(nullptr); continue; }
             uint8_t *dp = slot->d + sblob[k].dofs;
             if (sblob[k].bytes) {
                 const void *src = sblob[k].staged ? (const void *)(slot->hin + sblob[k].hofs) : (const void *)(blobs[k].blob + blobs[k].off[lo]);
-                HIP_TRY(hipMemcpyAsync(dp, src, sblob[k].bytes, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(dp, src, sblob[k].bytes, hipMemcpyHostToDevice, h2d));
             }
-            HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, h2d));
             c.blob.push_back(dp - blobs[k].off[lo]);  // the kernels index it with the caller's absolute offsets
             c.off.push_back(reinterpret_cast<const uint64_t *>(slot->d + soff[k].dofs));
         }
         for (size_t k = 0; k < outs.size(); k++) c.out.push_back(slot->d + cur.out[k].dofs);
+        HIP_TRY(hipEventRecord(slot->ev_in, h2d));
+        HIP_TRY(hipStreamWaitEvent(st, slot->ev_in, 0));
         rc = launch(c);
         if (rc) return rc;
+        HIP_TRY(hipEventRecord(slot->ev_k, st));
+        HIP_TRY(hipStreamWaitEvent(d2h, slot->ev_k, 0));
         for (size_t k = 0; k < outs.size(); k++) {
             if (!outs[k].p || !cur.out[k].bytes) continue;
             void *dst = cur.out[k].staged ? (void *)(slot->hout + cur.out[k].hofs) : (void *)(outs[k].p + lo * outs[k].row);
-            HIP_TRY(hipMemcpyAsync(dst, slot->d + cur.out[k].dofs, cur.out[k].bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(dst, slot->d + cur.out[k].dofs, cur.out[k].bytes, hipMemcpyDeviceToHost, d2h));
         }
-        if (opts.wipe_device) HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, st));  // keys, seeds and intermediates do not outlive the chunk
-        HIP_TRY(hipEventRecord(slot->done, st));
+        if (opts.wipe_device) HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, d2h));  // keys, seeds and intermediates do not outlive the chunk
+        HIP_TRY(hipEventRecord(slot->done, d2h));
     }
     while (!inflight.empty()) {
         const int rc = retire(inflight.front());

@@ -218,7 +218,7 @@ def test_host_api_three_concurrent_callers():
     assert res["ver"].all()
 
 
-def _run_py(code, env_extra=None, timeout=600):
+def _run_py(code, env_extra=None, timeout=240):
     env = dict(os.environ)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
@@ -378,7 +378,7 @@ print("proc ok")
 """ % ROOT
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
     ps = [subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
-    outs = [p.communicate(timeout=600) for p in ps]
+    outs = [p.communicate(timeout=240) for p in ps]
     assert all(p.returncode == 0 for p in ps), outs
     assert all("proc ok" in o[0] for o in outs)
 
