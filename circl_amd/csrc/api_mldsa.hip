@@ -217,207 +217,134 @@ constexpr int kSignBlocksPerCU = 8;
 
 constexpr size_t kSignBatchedMin = 16;  // below this the single persistent kernel has less launch overhead
 
-template <int MODE> size_t mldsa_sign_ws_core(size_t n) {
+// The carving of a signing workspace (one definition for the size query and for the launches).
+template <int MODE> struct SignLayout {
     using S = circl::mldsa::SG<MODE>;
     using B = circl::mldsa::SB<MODE>;
-    const size_t persistent = up256(128 * n) + 256 + (size_t)max_cu_count() * kSignBlocksPerCU * S::SCRATCH_BYTES;
-    const size_t tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;  // speculative tail: best[] and one parked signature per unit
-    const size_t batched = up256(n * B::PER_ITEM) + 256 + up256(4 * n) * 4 + 256 + up256(4 * tail_units) + tail_units * S::SPEC_STRIDE;
-    return n < kSignBatchedMin ? persistent : persistent + batched;  // the batched path finishes its tail persistently
-}
-// ... followed by one byte per item: the "context refused" flags of mldsa_sign_prep_kernel
-template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) { return mldsa_sign_ws_core<MODE>(n) + up256(n); }
-
-// Page-locked read-back slots for the per-round counts: a small pool, so that concurrent signing calls never share a slot.
-struct PinnedCounts {
-    std::mutex mu;
-    std::vector<std::pair<int, uint32_t *>> free_slots;  // (device, slot)
-    uint32_t *acquire(int dev) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (size_t i = 0; i < free_slots.size(); i++)
-                if (free_slots[i].first == dev) {
-                    uint32_t *p = free_slots[i].second;
-                    free_slots.erase(free_slots.begin() + i);
-                    return p;
-                }
+    size_t n, E, tail_units;
+    size_t o_mr, o_work, o_scratch;                 // persistent kernel (also the tail of the batched path)
+    size_t o_A, o_sec, o_y, o_w0, o_w1, o_muw1, o_cb, o_attempts, o_best, o_list0, o_list1, o_ctl, o_secret_end;  // batched path
+    size_t o_dead, total;
+    explicit SignLayout(size_t n_) : n(n_) {
+        E = std::max(n, circl::mldsa::kMinEntryCapacity);
+        tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
+        o_mr = take(128 * n);
+        o_work = take(256);
+        o_scratch = take(tail_units * S::SCRATCH_BYTES);
+        if (n >= kSignBatchedMin) {
+            o_A = take(n * B::A_BYTES);
+            o_sec = take(n * B::SEC_BYTES);
+            o_y = take(E * B::Y_BYTES);
+            o_w0 = take(E * B::W0_BYTES);
+            o_w1 = take(E * B::W1_BYTES);
+            o_muw1 = take(E * B::MUW1_BYTES);
+            o_cb = take(E * B::CB_BYTES);
+            o_secret_end = o;
+            o_attempts = take(4 * n);
+            o_best = take(4 * n);
+            o_list0 = take(4 * E);
+            o_list1 = take(4 * E);
+            o_ctl = take(256);
+        } else {
+            o_A = o_sec = o_y = o_w0 = o_w1 = o_muw1 = o_cb = o_secret_end = o_attempts = o_best = o_list0 = o_list1 = o_ctl = o;
         }
-        uint32_t *p = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void **>(&p), 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return p;
-    }
-    void release(int dev, uint32_t *p) {
-        std::lock_guard<std::mutex> lk(mu);
-        free_slots.emplace_back(dev, p);
+        o_dead = take(n);  // one byte per item: the "context refused" flags of mldsa_sign_prep_kernel
+        total = o;
     }
 };
-PinnedCounts g_pinned_counts;
+template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) { return SignLayout<MODE>(n).total; }
 
-// Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h).  Synchronises the
-// stream once per round to read the number of items that are still unsigned.
+// Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h), driven by the device: the host
+// enqueues a fixed schedule of rounds plus the persistent tail and reads nothing back, so the call is asynchronous.
 template <int MODE>
 int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                        const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, hipStream_t st,
-                       bool shared, uint8_t *dead) {
+                       bool shared) {
     using namespace circl::mldsa;
-    using B = SB<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
+    const SignLayout<MODE> lay(n);
+    if (lay.E >= (size_t(1) << kEntryShift)) return CIRCL_HIP_EPARAM;
     const int cus = cu_count();
-    uint8_t *p = static_cast<uint8_t *>(ws);
+    uint8_t *base = static_cast<uint8_t *>(ws);
     SignState S;
     S.shared = shared ? 1u : 0u;
-    S.mr = p; p += up256(128 * n);
-    S.A = reinterpret_cast<uint32_t *>(p); p += n * B::A_BYTES;
-    S.sec = reinterpret_cast<uint32_t *>(p); p += n * B::SEC_BYTES;
-    S.y = reinterpret_cast<uint32_t *>(p); p += n * B::Y_BYTES;
-    S.w0 = reinterpret_cast<uint32_t *>(p); p += n * B::W0_BYTES;
-    S.w1 = p; p += n * B::W1_BYTES;
-    S.muw1 = p; p += n * B::MUW1_BYTES;
-    S.cb = p; p += n * B::CB_BYTES;
-    p = static_cast<uint8_t *>(ws) + up256(n * B::PER_ITEM) + 256;  // (mr was rounded up separately)
-    S.attempts = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
-    S.list[0] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
-    S.list[1] = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
-    S.best = reinterpret_cast<uint32_t *>(p); p += up256(4 * n);
-    S.count = reinterpret_cast<uint32_t *>(p); p += 256;
-    unsigned *tail_work = reinterpret_cast<unsigned *>(p);          // persistent-kernel ticket counter
-    uint8_t *tail_scratch = p + 256;
-    const size_t tail_units = (size_t)cus * kSignBlocksPerCU;
-    const size_t tail_units_ws = (size_t)max_cu_count() * kSignBlocksPerCU;  // what the workspace was sized for
-    uint32_t *tail_best = reinterpret_cast<uint32_t *>(tail_scratch + tail_units_ws * SG<MODE>::SCRATCH_BYTES);
-    uint8_t *tail_spec = reinterpret_cast<uint8_t *>(tail_best) + up256(4 * tail_units_ws);
-    static const uint32_t tail_mult = [] {  // tuning aid: CIRCL_HIP_SIGN_TAIL = leftover items per CU handed to the persistent kernel
-        const char *e = getenv("CIRCL_HIP_SIGN_TAIL");
-        const int x = e ? atoi(e) : 0;
-        return (uint32_t)(x >= 1 && x <= 1024 ? x : 2);  // measured optimum (tools/sign_tail_sweep.sh): 2 leftover items per CU
-    }();
-    const uint32_t tail_threshold = (uint32_t)cus * tail_mult;
-    // Speculative rounds: once at most spec_target entries are left, a round costs its five dependent launches whatever
-    // the count, so every item gets k = spec_target / items (<= 8) consecutive attempts per round.
+    S.mr = base + lay.o_mr;
+    S.A = reinterpret_cast<uint32_t *>(base + lay.o_A);
+    S.sec = reinterpret_cast<uint32_t *>(base + lay.o_sec);
+    S.y = reinterpret_cast<uint32_t *>(base + lay.o_y);
+    S.w0 = reinterpret_cast<uint32_t *>(base + lay.o_w0);
+    S.w1 = base + lay.o_w1;
+    S.muw1 = base + lay.o_muw1;
+    S.cb = base + lay.o_cb;
+    S.attempts = reinterpret_cast<uint32_t *>(base + lay.o_attempts);
+    S.best = reinterpret_cast<uint32_t *>(base + lay.o_best);
+    S.list[0] = reinterpret_cast<uint32_t *>(base + lay.o_list0);
+    S.list[1] = reinterpret_cast<uint32_t *>(base + lay.o_list1);
+    S.count = reinterpret_cast<uint32_t *>(base + lay.o_ctl);
+    S.kk = S.count + 2;
+    S.capacity = (uint32_t)lay.E;
+    uint8_t *dead = base + lay.o_dead;
+    unsigned *tail_work = reinterpret_cast<unsigned *>(base + lay.o_work);
+    uint8_t *tail_scratch = base + lay.o_scratch;
+    // Speculative rounds: once at most spec_target entries would result, every surviving item gets
+    // k = spec_target / items (<= 64) consecutive attempts per round (a round costs its five dependent launches whatever
+    // the count).
     static const uint32_t spec_per_cu = [] {  // tuning aid: CIRCL_HIP_SIGN_SPEC = list entries per CU below which rounds speculate (0 = never)
         const char *e = getenv("CIRCL_HIP_SIGN_SPEC");
         const int x = e ? atoi(e) : -1;
-        return (uint32_t)(x >= 0 && x <= 4096 ? x : 128);  // plateau 96 .. 256 at 2^16 items; 0 costs 15 % (ML-DSA-65)
+        return (uint32_t)(x >= 0 && x <= 4096 ? x : 128);  // plateau 96 .. 256 at 2^16 items
     }();
-    const uint32_t spec_target = (uint32_t)std::min<size_t>((size_t)cus * spec_per_cu, n);
-    if (n >= (size_t(1) << circl::mldsa::kEntryShift)) return CIRCL_HIP_EPARAM;
+    S.spec_target = (uint32_t)std::min<size_t>((size_t)cus * spec_per_cu, lay.E);
+    const unsigned k0 = sign_next_k(n, S.spec_target);
+    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
                            S.mr, n, shared ? 1 : 0, dead);
     }
-    const uint32_t counts0[2] = {(uint32_t)n, 0};
-    HIP_TRY(hipMemcpyAsync(S.count, counts0, 8, hipMemcpyHostToDevice, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         const size_t nkeys = shared ? 1 : n;
         hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
-        hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n);
+        hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n, k0);
     }
-    // The host needs the number of list entries only to size the next round's grids, and the kernels bound themselves
-    // with the device-side count.  While the rounds are throughput-bound it runs one round ahead: round r is launched with
-    // the count read back after round r - 2 (an over-estimate, the list only shrinks) while round r - 1 still executes.
-    // In the latency-bound regime (and for the hand-over to the tail kernel) it waits for the exact count every round.
-    const int dev = current_device();
-    // error paths must not hand the pinned slot or the events back while copies into the slot (or the kernels) are still
-    // in flight on the stream: a concurrent signer could pick the recycled slot up and read a stale count
-    struct Guard {
-        int dev;
-        hipStream_t st;
-        uint32_t *slot = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        ~Guard() {
-            (void)hipStreamSynchronize(st);
-            for (auto e : ev)
-                if (e) (void)hipEventDestroy(e);
-            if (slot) g_pinned_counts.release(dev, slot);
-        }
-    } guard{dev, st};
-    guard.slot = g_pinned_counts.acquire(dev);
-    if (!guard.slot) { g_err = "hipHostMalloc failed"; return CIRCL_HIP_EHIP; }
-    volatile uint32_t *h_count = guard.slot;  // [0], [1]: counts after even / odd rounds
-    HIP_TRY(hipEventCreateWithFlags(&guard.ev[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&guard.ev[1], hipEventDisableTiming));
-    hipEvent_t *ev = guard.ev;
-    int cur = 0;
-    uint32_t upper = (uint32_t)n;   // bound on the current list's length (entries)
-    unsigned k_cur = 1;             // entries per item in the current list
-    bool exact = true;              // upper is the exact length
-    int pending = 0;                // read-backs in flight: rounds (round - pending) .. (round - 1)
-    for (int round = 0; upper > 0; round++) {
-        if (round > 4096) { g_err = "mldsa sign: rejection loop did not terminate"; return CIRCL_HIP_EHIP; }
+    // grids: the kernels loop over the device-side count, so any grid is correct; these fill the chip when the lists
+    // are long and keep the launches of the late (and the empty) rounds small
+    const size_t wave_cap = (size_t)cus * 16, lane_cap = (size_t)cus * 10;
+    size_t upper = n * k0;  // entries of round 0; afterwards the capacity bounds every list
+    for (int round = 0; round < rounds; round++) {
+        const int cur = round & 1;
+        const unsigned gw = (unsigned)std::max<size_t>(1, std::min(upper, wave_cap));
+        const unsigned gm = (unsigned)std::max<size_t>(1, std::min((upper * L + 255) / 256, lane_cap));
+        const unsigned gc = (unsigned)std::max<size_t>(1, std::min((upper + 255) / 256, lane_cap));
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        const bool late = upper / k_cur <= std::max(spec_target, tail_threshold + tail_threshold / 2);
-        if (late && !exact) {  // latency-bound rounds, or close to the hand-over: work with the exact count
-            HIP_TRY(hipStreamSynchronize(st));
-            upper = h_count[(round - 1) & 1];
-            exact = true;
-            pending = 0;
-            if (upper == 0) break;
-        }
-        const uint32_t items = (upper + k_cur - 1) / k_cur;  // exact when `exact`
-        if (exact && items <= tail_threshold) {
-            // few items left: every leftover item gets its own wavefront(s), which run that item's remaining rejection
-            // iterations to the end (continuing its nonce sequence).  The tail's duration is the unluckiest item's ~30
-            // sequential attempts, with most of the chip idle: when the resident slots allow, 2, 4 or 8 wavefronts share
-            // an item and try its attempts in parallel (first success wins).
-            if (k_cur > 1) {  // the tail wants one entry per item: keep the first of each
-                HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
-                hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur, 0u, 1u);
-                cur ^= 1;
-            }
-            const unsigned spec_w = (size_t)items * 8 <= tail_units ? 8u : (size_t)items * 4 <= tail_units ? 4u : (size_t)items * 2 <= tail_units ? 2u : 1u;
-            HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
-            if (spec_w > 1) HIP_TRY(hipMemsetAsync(tail_best, 0xff, 4 * (size_t)items, st));
-            hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>((size_t)items * spec_w, tail_units)), dim3(64),
-                               SG<MODE>::LDS_TOTAL, st, sk, (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[cur],
-                               (const uint32_t *)S.attempts, (size_t)items, spec_w, tail_best, tail_spec, shared ? 1 : 0);
-            if (spec_w > 1)
-                hipLaunchKernelGGL(sign_tail_commit_kernel<MODE>, dim3(items), dim3(64), 0, st, (const uint32_t *)S.list[cur],
-                                   (const uint32_t *)S.attempts, (const uint32_t *)tail_best, (const uint8_t *)tail_spec, sig, spec_w);
-            break;
-        }
-        // attempts per item in the NEXT list: the survivors of this round are at most `items`
-        unsigned k_next = 1;
-        if (exact && spec_target > 0 && items <= spec_target)
-            k_next = (unsigned)std::min<uint32_t>(circl::mldsa::kMaxSpec, std::max<uint32_t>(1u, spec_target / items));
-        hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3((unsigned)(((size_t)upper * L + 255) / 256)), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig, k_cur);
-        if (k_cur > 1) hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(upper), dim3(64), 0, st, S, cur, sig);
-        HIP_TRY(hipMemsetAsync(S.count + (cur ^ 1), 0, 4, st));
-        hipLaunchKernelGGL(sign_compact_kernel, dim3((upper + 255) / 256), dim3(256), 0, st, S, cur, k_cur, k_next);
-        cur ^= 1;
-        HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(&h_count[round & 1]), S.count + cur, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(ev[round & 1], st));
-        pending++;
-        if (k_cur == 1 && k_next == 1) {
-            if (pending == 2) {  // the count after round - 1 has long arrived: it bounds the list of round + 1
-                HIP_TRY(hipEventSynchronize(ev[(round - 1) & 1]));
-                upper = h_count[(round - 1) & 1];
-                exact = false;
-                pending = 1;
-            } else {
-                exact = false;  // (right after an exact count, `upper` stays the bound for one more round)
-            }
-        } else {
-            // the entry count changes with k: no stale bound is valid for the new list, so wait for this round's count
-            HIP_TRY(hipStreamSynchronize(st));
-            upper = h_count[round & 1];
-            exact = true;
-            pending = 0;
-        }
-        k_cur = k_next;
+        hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3(gm), dim3(256), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(gc), dim3(256), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
+        hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
+        hipLaunchKernelGGL(sign_compact_kernel, dim3(gc), dim3(256), 0, st, S, cur, round == rounds - 1 ? 1 : 0);
+        upper = std::min(upper, std::max<size_t>(n, S.spec_target));  // survivors x k_next never exceeds this
     }
-    hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
+    {
+        // whatever the schedule left unsigned (probability below 2^-40 by construction): one wavefront per item runs that
+        // item's remaining rejection iterations to the end
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
+        HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
+        const int fin = rounds & 1;
+        hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>(lay.tail_units, 512)), dim3(64), SG<MODE>::LDS_TOTAL, st, sk,
+                           (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[fin], (const uint32_t *)S.attempts, (size_t)0, 1u,
+                           (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin));
+        hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
+    }
     // The workspace held rho'', the NTT-domain secrets, the accepted attempts' y next to c~ (z - y = c s1) and parked
-    // signatures: nothing key-equivalent stays behind in the caller's workspace.
+    // signatures: nothing key-equivalent stays behind in the caller's workspace (the matrix rows are public).
     HIP_TRY(hipMemsetAsync(S.mr, 0, up256(128 * n), st));
-    HIP_TRY(hipMemsetAsync(S.sec, 0, (size_t)((S.cb + n * B::CB_BYTES) - reinterpret_cast<uint8_t *>(S.sec)), st));  // (the matrix rows are public)
-    HIP_TRY(hipMemsetAsync(tail_scratch, 0, tail_units_ws * SG<MODE>::SCRATCH_BYTES + up256(4 * tail_units_ws) + tail_units_ws * SG<MODE>::SPEC_STRIDE, st));
-    HIP_TRY(hipStreamSynchronize(st));  // the pinned slot and the events go back to their pools
+    HIP_TRY(hipMemsetAsync(tail_scratch, 0, lay.tail_units * SG<MODE>::SCRATCH_BYTES, st));
+    HIP_TRY(hipMemsetAsync(S.sec, 0, lay.o_secret_end - lay.o_sec, st));
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -431,11 +358,11 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < mldsa_sign_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(rnd) || rnd == nullptr)
         return CIRCL_HIP_EWORKSPACE;
-    uint8_t *dead = static_cast<uint8_t *>(ws) + mldsa_sign_ws_core<MODE>(n);
-    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared, dead);
-    uint8_t *mr = static_cast<uint8_t *>(ws);
-    unsigned *work = reinterpret_cast<unsigned *>(mr + up256(128 * n));
-    uint8_t *scratch = mr + up256(128 * n) + 256;
+    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
+    const SignLayout<MODE> lay(n);
+    uint8_t *base = static_cast<uint8_t *>(ws);
+    uint8_t *mr = base + lay.o_mr, *dead = base + lay.o_dead, *scratch = base + lay.o_scratch;
+    unsigned *work = reinterpret_cast<unsigned *>(base + lay.o_work);
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -449,10 +376,12 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         const unsigned blocks = (unsigned)std::min<size_t>(n, resident);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0,
+                           (const uint32_t *)nullptr);
         hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }
-    HIP_TRY(hipMemsetAsync(ws, 0, mldsa_sign_ws_core<MODE>(n), st));  // rho'', NTT-domain secrets (see mldsa_sign_batched)
+    HIP_TRY(hipMemsetAsync(mr, 0, up256(128 * n), st));  // rho'' and the NTT-domain secrets do not stay behind
+    HIP_TRY(hipMemsetAsync(scratch, 0, std::min<size_t>(n, lay.tail_units) * S::SCRATCH_BYTES, st));
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -480,7 +409,7 @@ int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const
     if (!SK) return CIRCL_HIP_EPARAM;
     if (n == 0) return CIRCL_HIP_OK;
     if (!internal && check_contexts(param, ctx_blob, ctx_off, n) != CTX_OK) return CIRCL_HIP_EPARAM;  // sign.ErrContextTooLong / ErrContextNotSupported
-    const PipeOpts opts = dsa_opts(size_t(1) << 14, true, /*depth=*/1);  // the batched signer synchronises its stream: nothing to overlap
+    const PipeOpts opts = dsa_opts(size_t(1) << 13, true, /*depth=*/3);  // (each chunk's workspace is ~60 KB per item)
     std::vector<uint8_t> zeros;
     if (!rnd) zeros.assign(32 * std::min(n, opts.chunk_items), 0);  // deterministic signing: 32 zero bytes per item
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {

@@ -94,49 +94,57 @@ template <int NWORDS> __device__ __forceinline__ void sponge17_words(KeccakState
 // internal = the ACVP interface without the prefix).  On entry words 0..TRW-1 of h hold tr (TRW = 8, or 4 for
 // round-3 Dilithium) and the rest is zero; on exit words 0..7 hold mu.  One sponge per lane, message lengths
 // may differ per lane.
+// The bytes of M' come from three places (prefix, context, message) at arbitrary alignment, so every absorbed word is
+// gathered byte by byte.  Doing that inside the statically unrolled xor of the 17 rate words kept ~100 gathered bytes
+// live next to the sponge state (204 VGPRs, 2 waves per SIMD; 328 + 156 spilled for round 3): the words of a block are
+// therefore gathered in a rolled loop into the lane's row of an LDS staging area (kStageStride dwords apart: an odd
+// stride, so the 64 rows of a wave hit distinct banks) and xor-ed into the state from there.
+constexpr int kStageStride = 35;
 template <int TRW>
 __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const uint8_t *mp, size_t mlen, const uint8_t *cp,
-                                                           size_t clen, int internal) {
+                                                           size_t clen, int internal, uint32_t *stage) {
     const size_t pre = internal ? 0 : 2;
     const size_t total = pre + (internal ? 0 : clen) + mlen;  // length of M'
-    auto mbyte = [&](size_t k) -> uint64_t {
+    auto mbyte = [&](size_t k) -> uint32_t {
         if (k > total) return 0;
         if (k == total) return kDsShake;
         if (!internal) {
             if (k == 0) return 0;
-            if (k == 1) return (uint64_t)(clen & 0xff);
+            if (k == 1) return (uint32_t)(clen & 0xff);
             if (k < 2 + clen) return cp[k - 2];
             return mp[k - 2 - clen];
         }
         return mp[k];
     };
-    // first block: words 0..TRW-1 hold tr, words TRW..16 the first FIRST bytes of M'
-    constexpr size_t FIRST = 136 - 8 * TRW;
-    size_t pos = 0;  // M' bytes consumed
-    bool done = false;
-    {
-        detail::static_for<TRW, 17>([&](auto ic) {
-            constexpr int w = decltype(ic)::v;
-            uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v |= mbyte(8 * (size_t)(w - TRW) + b) << (8 * b);
-            h.lo[w] ^= (uint32_t)v;
-            h.hi[w] ^= (uint32_t)(v >> 32);
-        });
-        if (total < FIRST) { done = true; h.hi[16] ^= 0x80000000u; }
-        keccak_f1600(h);
-        pos = FIRST;
-    }
-    while (!done) {
+    size_t pos = 0;   // M' bytes consumed
+    int w0 = TRW;     // the first block's words 0..TRW-1 hold tr
+    for (;;) {
+#pragma unroll 1
+        for (int w = w0; w < 17; w++) {
+            const size_t base = pos + 8 * (size_t)(w - w0);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                lo |= mbyte(base + b) << (8 * b);
+                hi |= mbyte(base + 4 + b) << (8 * b);
+            }
+            stage[2 * w] = lo;
+            stage[2 * w + 1] = hi;
+        }
         detail::static_for<0, 17>([&](auto ic) {
             constexpr int w = decltype(ic)::v;
-            uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v |= mbyte(pos + 8 * (size_t)w + b) << (8 * b);
-            h.lo[w] ^= (uint32_t)v;
-            h.hi[w] ^= (uint32_t)(v >> 32);
+            if (w >= w0) {
+                h.lo[w] ^= stage[2 * w];
+                h.hi[w] ^= stage[2 * w + 1];
+            }
         });
-        if (total < pos + 136) { done = true; h.hi[16] ^= 0x80000000u; }
+        const size_t span = 8 * (size_t)(17 - w0);
+        const bool last = total < pos + span;
+        if (last) h.hi[16] ^= 0x80000000u;
         keccak_f1600(h);
-        pos += 136;
+        if (last) break;
+        pos += span;
+        w0 = 0;
     }
 }
 
@@ -170,28 +178,30 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint32_t *__restrict__ key_idx) {
     using G = DG<MODE>;
     using P = DP<MODE>;
+    __shared__ uint32_t stage_lds[256 * kStageStride];
+    uint32_t *stage = stage_lds + threadIdx.x * kStageStride;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState s;
     const bool ctx_unsupported = !P::NIST && !internal && ctx_blob && ctx_off[idx + 1] != ctx_off[idx];  // round 3 has no contexts
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
     // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125); shared-key batches bring it ready-made (mldsa_tr_kernel), key-table
-    // batches one 64-byte slot per table entry (mldsa_tr_table_kernel), selected by key_idx
-    KeccakState h;
-    keccak_zero(h);
+    // batches one 64-byte slot per table entry (mldsa_tr_table_kernel), selected by key_idx.  ONE sponge state is live at
+    // a time (tr, then mu, then the SampleInBall sponge reuse `s`): two states side by side cost 204 VGPRs = 2 waves per SIMD.
     if (tr_shared) {  // kernel-uniform
-        xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
+        keccak_zero(s);
+        xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
     } else {
         sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
 #pragma unroll
-        for (int i = 0; i < P::TR / 8; i++) { h.lo[i] = s.lo[i]; h.hi[i] = s.hi[i]; }
+        for (int i = P::TR / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }
     }
     const uint8_t *mp = msg_blob + msg_off[idx];
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal);
-    store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), h);  // mu
+    absorb_message_and_squeeze<P::TR / 8>(s, mp, mlen, cp, clen, internal, stage);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), s);  // mu
     // SampleInBall's sponge: SHAKE256(c~), first block (sample.go:299-306); the whole state is
     // parked so that the verify kernel can squeeze further blocks in the (rare) case it must.
     const uint8_t *sg = sig + idx * G::SIG;
@@ -842,6 +852,8 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               uint8_t *__restrict__ dead_ws) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
+    __shared__ uint32_t stage_lds[256 * kStageStride];
+    uint32_t *stage = stage_lds + threadIdx.x * kStageStride;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     {
@@ -860,19 +872,22 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal);
+    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal, stage);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128), h);  // mu
-    KeccakState s;
-    keccak_zero(s);
-    xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(skp + 32));          // key
+    // rho'' = H(key || rnd || mu): built in the same state (mu moves up from words 0..7), one sponge live at a time
     constexpr int MU0 = P::NIST ? 8 : 4;                                       // round 3: rho'' = CRH(key || mu), no rnd (dilithium.go:357-364)
-    if constexpr (P::NIST) xor_words<4, 4>(s, reinterpret_cast<const uint64_t *>(rnd + idx * 32));  // rnd (zero = deterministic)
 #pragma unroll
-    for (int i = 0; i < 8; i++) { s.lo[MU0 + i] = h.lo[i]; s.hi[MU0 + i] = h.hi[i]; }
-    s.lo[MU0 + 8] ^= kDsShake;
-    s.hi[16] ^= 0x80000000u;
-    keccak_f1600(s);
-    store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), s);  // rho''
+    for (int i = 7; i >= 0; i--) { h.lo[MU0 + i] = h.lo[i]; h.hi[MU0 + i] = h.hi[i]; }
+#pragma unroll
+    for (int i = 0; i < MU0; i++) { h.lo[i] = 0; h.hi[i] = 0; }
+#pragma unroll
+    for (int i = MU0 + 8; i < 25; i++) { h.lo[i] = 0; h.hi[i] = 0; }
+    xor_words<0, 4>(h, reinterpret_cast<const uint64_t *>(skp + 32));          // key
+    if constexpr (P::NIST) xor_words<4, 4>(h, reinterpret_cast<const uint64_t *>(rnd + idx * 32));  // rnd (zero = deterministic)
+    h.lo[MU0 + 8] ^= kDsShake;
+    h.hi[16] ^= 0x80000000u;
+    keccak_f1600(h);
+    store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), h);  // rho''
 }
 
 // lane = item: items whose context the scheme refuses (see mldsa_sign_prep_kernel) leave with an all-zero signature
@@ -896,7 +911,8 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                                                        uint8_t *__restrict__ sig, uint8_t *__restrict__ scratch,
                                                        unsigned *__restrict__ work, const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ attempts, size_t n, unsigned spec_w,
-                                                       uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig, int shared_key) {
+                                                       uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig, int shared_key,
+                                                       const uint32_t *__restrict__ count_ptr) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
@@ -917,17 +933,18 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
 
     // `list` (optional) names the n items to sign and `attempts` how many rejection rounds each of them
-    // has already been through (the tail of mldsa_sign_batched); otherwise items are 0..n-1 from scratch.
+    // has already been through (the tail of mldsa_sign_batched, n = *count_ptr); otherwise items are 0..n-1 from scratch.
     // spec_w > 1 (tail only): spec_w wavefronts share an item and try its attempts a0 + w, a0 + w + spec_w, ...
     // in parallel.  The signature of the reference is the one of the FIRST successful attempt, so every success
     // lowers best[t] (atomicMin), a wave gives up once its next attempt lies beyond best[t], successful waves park
     // their signature in slot (t, w) of spec_sig, and sign_tail_commit_kernel copies the winner's slot out.
+    if (count_ptr) n = *count_ptr;  // the tail of the device-driven batched signer: the list's length lives on the device
     const size_t units = n * spec_w;
 #pragma unroll 1
     for (size_t u = mlkem::next_group(work, lane, true, units); u < units; u = mlkem::next_group(work, lane, false, units)) {
         const size_t t = u / spec_w;
         const unsigned spec_class = (unsigned)(u % spec_w);
-        const size_t item = list ? list[t] : t;
+        const size_t item = list ? (list[t] & 0x03ffffffu) : t;  // (entries carry an attempt offset above bit 26; the tail's are 0)
         const uint8_t *skp = sk + (shared_key ? 0 : item) * Kg::SK;
         const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
         __syncthreads();
@@ -1154,21 +1171,6 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
         for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
         for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
     }
-}
-
-// Speculative tail of batch signing: workgroup t copies the signature of item list[t]'s first successful attempt
-// (best[t], found by class (best[t] - attempts[item]) mod spec_w) from its parking slot to the output row.
-template <int MODE>
-__global__ void __launch_bounds__(64) sign_tail_commit_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ attempts,
-                                                             const uint32_t *__restrict__ best, const uint8_t *__restrict__ spec_sig,
-                                                             uint8_t *__restrict__ sig, unsigned spec_w) {
-    using G = DG<MODE>;
-    const size_t t = blockIdx.x;
-    const size_t item = list[t];
-    const unsigned cls = (best[t] - attempts[item]) % spec_w;
-    const uint8_t *src = spec_sig + (t * spec_w + cls) * SG<MODE>::SPEC_STRIDE;
-    uint8_t *dst = sig + item * G::SIG;
-    for (int b = threadIdx.x; b < G::SIG; b += 64) dst[b] = src[b];
 }
 
 }  // namespace mldsa

@@ -9,15 +9,22 @@
 //   w      wave = entry                 y-hat, w = InvNTT(A y-hat), Decompose, w1 packing
 //   chal   lane = entry                 c~ = H(mu || w1), first SampleInBall block
 //   finish wave = entry                 c s2 / z / c t0 / hints; a success lowers best[item]
-//   compact                             next active list, attempt counters
+//   commit wave = entry                 (k > 1 only) the lowest successful attempt's signature -> sig
+//   compact lane = entry                survivors -> next list
 // An ENTRY of the active list is (item, off): attempt number attempts[item] + off of that item.  Early rounds have one
 // entry per item.  Once so few items are left that a round is latency-bound (five dependent launches whatever the
-// count), the list carries k <= 8 consecutive attempts per item, tried in the same round: the signature is the one of
-// the LOWEST successful attempt (atomicMin on best[item]; a commit launch copies it out), exactly the attempt the
+// count), the list carries k <= 64 consecutive attempts per item, tried in the same round: the signature is the one of
+// the LOWEST successful attempt (atomicMin on best[item]; the commit launch copies it out), exactly the attempt the
 // sequential loop of the reference would have stopped at, and the number of rounds shrinks.  The per-attempt buffers
-// (y, w0, w1, mu || w1, c~) are indexed by the entry's position in the list, which never exceeds n.
-// The host reads the entry count back (one round behind while the rounds are throughput-bound, every round once they
-// are latency-bound) and stops when it is zero.
+// (y, w0, w1, mu || w1, c~) are indexed by the entry's position in the list, which never exceeds the entry capacity.
+//
+// THE DEVICE DRIVES THE LOOP.  The list lengths and the attempts-per-item factor k live in device memory (SignState::count,
+// ::kk, double-buffered by round parity); every kernel is a grid-stride / persistent loop bounded by the device-side
+// count, and the commit kernel derives the next round's k from the count it sees.  The host therefore enqueues a FIXED
+// schedule of rounds (sized so that the probability of an item surviving it is below 2^-40, sign_round_schedule) and
+// never reads anything back: circl_hip_mldsa_sign_dev is asynchronous like every other _dev entry point.  Rounds that
+// find their list empty cost five near-empty launches.  Whatever is still unsigned after the schedule (practically never)
+// is finished by the persistent kernel of mldsa_kernels.h, which takes the final list and its device-side length.
 #pragma once
 #include "mldsa_kernels.h"
 
@@ -37,7 +44,8 @@ template <int MODE> struct SB {
     static constexpr size_t W1_BYTES = (size_t)K * 256;
     static constexpr size_t MUW1_BYTES = ((G::MUW1 + 63) / 64) * 64;
     static constexpr size_t CB_BYTES = 320;                          // c~ (<= 64 B), 56 B pad, ball state (200 B)
-    static constexpr size_t PER_ITEM = A_BYTES + SEC_BYTES + Y_BYTES + W0_BYTES + W1_BYTES + MUW1_BYTES + CB_BYTES + 128 /* mu, rho'' */;
+    static constexpr size_t PER_ITEM = A_BYTES + SEC_BYTES + 128 /* mu, rho'' */;                   // per item (key material)
+    static constexpr size_t PER_ENTRY = Y_BYTES + W0_BYTES + W1_BYTES + MUW1_BYTES + CB_BYTES;      // per list entry (one attempt)
 };
 
 struct SignState {          // device pointers into the workspace, passed by value to the kernels
@@ -51,15 +59,27 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint8_t *cb;            // n x 320
     uint32_t *attempts;     // n: attempts already spent on the item
     uint32_t *best;         // n: lowest successful `off` of the current round, kNoSuccess while unsigned
-    uint32_t *list[2];      // active lists of entries: item | off << 28
-    uint32_t *count;        // [0], [1]: list lengths
+    uint32_t *list[2];      // active lists of entries: item | off << kEntryShift; round r reads list[r & 1]
+    uint32_t *count;        // [0], [1]: list lengths (round r reads count[r & 1], its commit kernel fills count[(r + 1) & 1])
+    uint32_t *kk;           // [0], [1]: entries per item of the list with the same parity
     uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once)
+    uint32_t spec_target;   // rounds speculate (k > 1) once at most this many entries would result
+    uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
 };
 
 constexpr uint32_t kNoSuccess = 0xffffffffu;
-constexpr int kEntryShift = 28;
+constexpr int kEntryShift = 26;
 constexpr uint32_t kEntryItemMask = (1u << kEntryShift) - 1;
-constexpr unsigned kMaxSpec = 8;
+constexpr unsigned kMaxSpec = 64;  // 6 bits of `off`
+constexpr size_t kMinEntryCapacity = 2048;  // small batches may still try many attempts per item and round
+
+// attempts per item of the NEXT list when `items` items may survive into it (the same rule on the host, which sizes the
+// schedule, and on the device, which applies it to the real counts)
+__host__ __device__ inline unsigned sign_next_k(unsigned long long items, unsigned spec_target) {
+    if (items == 0 || items > spec_target) return 1u;
+    const unsigned long long k = spec_target / items;
+    return (unsigned)(k < 1 ? 1 : k > kMaxSpec ? kMaxSpec : k);
+}
 
 // ---- setup ---------------------------------------------------------------------------------------
 
@@ -96,9 +116,10 @@ __global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__res
     }
 }
 
-// wave = item: NTT of s1, s2, t0 (dilithium.go:149-179) into the workspace; initial active list
+// wave = item: NTT of s1, s2, t0 (dilithium.go:149-179) into the workspace; initial active list with k0 entries per
+// item (k0 > 1: a small batch speculates from its first round on) and the loop's control words
 template <int MODE>
-__global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restrict__ sk, SignState st, size_t n) {
+__global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restrict__ sk, SignState st, size_t n, unsigned k0) {
     using P = DP<MODE>;
     using Kg = KG<MODE>;
     constexpr int K = P::K, L = P::L;
@@ -126,146 +147,158 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
     if (lane == 0) {
         st.attempts[item] = 0;
         st.best[item] = kNoSuccess;
-        st.list[0][item] = (uint32_t)item;  // off = 0
+    }
+    if ((unsigned)lane < k0) st.list[0][item * k0 + lane] = (uint32_t)item | ((uint32_t)lane << kEntryShift);
+    if (item == 0 && lane == 0) {
+        st.count[0] = (uint32_t)(n * k0);
+        st.count[1] = 0;
+        st.kk[0] = k0;
+        st.kk[1] = 1;
     }
 }
 
 // ---- one round -------------------------------------------------------------------------------------
+// Every kernel of a round takes the round's parity `cur` and bounds itself with the device-side list length
+// st.count[cur]; grids are fixed-size (the host does not know the count), work is distributed by grid-stride loops.
 
-// lane = (active item, l): y = ExpandMask(rho'', L * attempts + l)  (sample.go:178-196)
+// lane = (entry, l): y = ExpandMask(rho'', L * attempts + l)  (sample.go:178-196).  Also clears the next list's length.
 template <int MODE>
 __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     using G = DG<MODE>;
     using B = SB<MODE>;
     constexpr int L = DP<MODE>::L;
-    const unsigned cnt = st.count[cur];
-    const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if ((size_t)(blockIdx.x * 256) >= (size_t)cnt * L) return;  // whole block idle
-    const bool on = sidx < (size_t)cnt * L;
-    const size_t slot = on ? sidx / L : 0;
-    const uint32_t e = st.list[cur][slot];
-    const size_t item = e & kEntryItemMask;
-    const uint32_t off = e >> kEntryShift;
-    const int l = on ? (int)(sidx % L) : 0;
-    KeccakState s;
-    keccak_zero(s);
-    xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
-    s.lo[8] = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
-    s.hi[16] = 0x80000000u;
-    uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+    const size_t total = (size_t)st.count[cur] * L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // filled by this round's commit kernel, several launches later
 #pragma unroll 1
-    for (int blk = 0; blk < 5; blk++) {
-        keccak_f1600(s);
-        if (on) {
-            detail::static_for<0, 17>([&](auto ic) {
-                constexpr int w = decltype(ic)::v;
-                if (34 * blk + 2 * w < G::ZSZ / 4) {  // only the ZSZ payload bytes are kept
-                    yrow[34 * blk + 2 * w] = s.lo[w];
-                    yrow[34 * blk + 2 * w + 1] = s.hi[w];
-                }
-            });
+    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {  // block-uniform
+        const size_t sidx = base + threadIdx.x;
+        const bool on = sidx < total;
+        const size_t slot = on ? sidx / L : 0;
+        const uint32_t e = st.list[cur][slot];
+        const size_t item = e & kEntryItemMask;
+        const uint32_t off = e >> kEntryShift;
+        const int l = on ? (int)(sidx % L) : 0;
+        KeccakState s;
+        keccak_zero(s);
+        xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
+        s.lo[8] = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
+        s.hi[16] = 0x80000000u;
+        uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+#pragma unroll 1
+        for (int blk = 0; blk < 5; blk++) {
+            keccak_f1600(s);
+            if (on) {
+                detail::static_for<0, 17>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;
+                    if (34 * blk + 2 * w < G::ZSZ / 4) {  // only the ZSZ payload bytes are kept
+                        yrow[34 * blk + 2 * w] = s.lo[w];
+                        yrow[34 * blk + 2 * w + 1] = s.hi[w];
+                    }
+                });
+            }
         }
     }
 }
 
-// wave = active item: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398)
+// wave = entry: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398)
 template <int MODE>
-__global__ void __launch_bounds__(64) sign_w_kernel(SignState st, int cur) {
+__global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
-    if (blockIdx.x >= st.count[cur]) return;
     const int lane = threadIdx.x;
-    const size_t slot = blockIdx.x;
-    const size_t item = st.list[cur][slot] & kEntryItemMask;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
-    if (lane < 16)  // mu in front of the w1 bytes that follow
-        reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
-    uint32_t yh[L][4];
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
-            x += (uint32_t)((int32_t)x >> 31) & Q;
-            yh[l][r] = x;
-        }
-        dilithium::ntt(yh[l], z, xch, lane);  // plain y-hat, < 17q
-    }
-    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+    const size_t count = st.count[cur];
 #pragma unroll 1
-    for (int i = 0; i < K; i++) {
-        uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient (see mac_rows)
+    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        const size_t item = st.list[cur][slot] & kEntryItemMask;
+        if (lane < 16)  // mu in front of the w1 bytes that follow
+            reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
+        uint32_t yh[L][4];
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-            uint32_t a[4];
-            load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
+        for (int l = 0; l < L; l++) {
+            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * yh[j][r];
+            for (int r = 0; r < 4; r++) {
+                uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+                x += (uint32_t)((int32_t)x >> 31) & Q;
+                yh[l][r] = x;
+            }
+            dilithium::ntt(yh[l], z, xch, lane);  // plain y-hat, < 17q
         }
-        uint32_t w[4];
+        const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient (see mac_rows)
 #pragma unroll
-        for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
-        dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
-        unsigned w1v[4];
+            for (int j = 0; j < L; j++) {
+                uint32_t a[4];
+                load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int nidx = kyber::idx_l1(lane, r);
-            uint32_t a0, a1;
-            dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
-            st.w0[(slot * K + i) * 256 + nidx] = a0;
-            st.w1[(slot * K + i) * 256 + nidx] = (uint8_t)a1;
-            w1v[r] = a1;
+                for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * yh[j][r];
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
+            dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
+            unsigned w1v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                uint32_t a0, a1;
+                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
+                st.w0[(slot * K + i) * 256 + nidx] = a0;
+                st.w1[(slot * K + i) * 256 + nidx] = (uint8_t)a1;
+                w1v[r] = a1;
+            }
+            mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
+            mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
         }
-        mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
-        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
+        __syncthreads();  // xch is reused by the next entry
     }
 }
 
-// lane = active item: c~ = SHAKE256(mu || w1)[:CT] and the first SampleInBall block (dilithium.go:400-405)
+// lane = entry: c~ = SHAKE256(mu || w1)[:CT] and the first SampleInBall block (dilithium.go:400-405)
 template <int MODE>
 __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int cur) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
-    const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (a >= st.count[cur]) return;
-    KeccakState s;
-    sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
-    uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
-    store_words<0, P::CT / 8>(cb, s);
-    KeccakState bs;
-    keccak_zero(bs);
+    const size_t count = st.count[cur];
+#pragma unroll 1
+    for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {
+        const size_t a = base + threadIdx.x;
+        if (a >= count) continue;
+        KeccakState s;
+        sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
+        uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
+        store_words<0, P::CT / 8>(cb, s);
 #pragma unroll
-    for (int i = 0; i < P::CT / 8; i++) { bs.lo[i] = s.lo[i]; bs.hi[i] = s.hi[i]; }
-    bs.lo[P::CT / 8] ^= kDsShake;
-    bs.hi[16] ^= 0x80000000u;
-    keccak_f1600(bs);
-    store_words<0, 25>(cb + 15, bs);  // ball state at byte 120
+        for (int i = P::CT / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }  // the SampleInBall sponge absorbs c~: same state
+        s.lo[P::CT / 8] ^= kDsShake;
+        s.hi[16] ^= 0x80000000u;
+        keccak_f1600(s);
+        store_words<0, 25>(cb + 15, s);  // ball state at byte 120
+    }
 }
 
-// wave = active item: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88)
+// wave = entry: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88).
+// One entry's work is a function of its own (not inlined into the grid-stride loop of the kernel): inlined, the loop's
+// register allocation grew from 102 to 164 VGPRs (26-30 spilled under the 128-register cap of 4 waves per SIMD).
 template <int MODE>
-__global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig, unsigned k) {
+__device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
+                                               uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
-    __shared__ __attribute__((aligned(16))) uint8_t zpk[L * G::ZSZ];
-    __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
-    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
-    if (blockIdx.x >= st.count[cur]) return;
-    static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
     const int lane = threadIdx.x;
-    const size_t slot = blockIdx.x;
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const uint32_t e = st.list[cur][slot];
     const size_t item = e & kEntryItemMask;
     const uint32_t off = e >> kEntryShift;
-    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const uint8_t *cb = st.cb + slot * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
@@ -293,102 +326,157 @@ __global__ void __launch_bounds__(64) sign_finish_kernel(SignState st, int cur, 
         }
         if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
     }
-    bool reject = __any(bad);
+    if (__any(bad)) return;  // the compact kernel charges the round's attempts to the item
     // z = y + c s1
-    if (!reject) {
 #pragma unroll 1
-        for (int l = 0; l < L; l++) {
-            uint32_t t[4];
-            mul_c(t, sec + l * kPackedRowDwords);
-            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
-            unsigned fld[4];
+    for (int l = 0; l < L; l++) {
+        uint32_t t[4];
+        mul_c(t, sec + l * kPackedRowDwords);
+        const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+        unsigned fld[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint32_t y = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
-                y += (uint32_t)((int32_t)y >> 31) & Q;
-                const uint32_t zz = dilithium::normalize(t[r] + y);
-                bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
-                uint32_t f = G::GAMMA1 - zz;
-                f += (uint32_t)((int32_t)f >> 31) & Q;
-                fld[r] = f;
-            }
-            mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
-            for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
-            if (__any(bad)) break;
+        for (int r = 0; r < 4; r++) {
+            uint32_t y = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+            y += (uint32_t)((int32_t)y >> 31) & Q;
+            const uint32_t zz = dilithium::normalize(t[r] + y);
+            bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
+            uint32_t f = G::GAMMA1 - zz;
+            f += (uint32_t)((int32_t)f >> 31) & Q;
+            fld[r] = f;
         }
-        reject = __any(bad);
+        mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
+        for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+        if (__any(bad)) break;
     }
+    if (__any(bad)) return;
     // c t0, hints
     unsigned pop = 0;
-    if (!reject) {
-        __syncthreads();
-        for (int i = lane; i < 24; i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
-        __syncthreads();
+    __syncthreads();
+    for (int i = lane; i < 24; i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
+    __syncthreads();
 #pragma unroll 1
-        for (int i = 0; i < K; i++) {
-            uint32_t t[4];
-            mul_c(t, sec + (L + K + i) * kPackedRowDwords);
+    for (int i = 0; i < K; i++) {
+        uint32_t t[4];
+        mul_c(t, sec + (L + K + i) * kPackedRowDwords);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int nidx = kyber::idx_l1(lane, r);
-                const uint32_t ct0 = dilithium::csubq(t[r]);
-                bad |= dilithium::exceeds(ct0, P::GAMMA2);
-                const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
-                const uint32_t r1 = st.w1[(slot * K + i) * 256 + nidx];
-                const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
-                const unsigned long long mask = __ballot(hbit);
-                if (hbit) {
-                    const unsigned slot = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
-                    if (slot < (unsigned)P::OMEGA) hbytes[slot] = (uint8_t)nidx;
-                }
-                pop += (unsigned)__popcll(mask);
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            const uint32_t ct0 = dilithium::csubq(t[r]);
+            bad |= dilithium::exceeds(ct0, P::GAMMA2);
+            const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
+            const uint32_t r1 = st.w1[(slot * K + i) * 256 + nidx];
+            const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+            const unsigned long long mask = __ballot(hbit);
+            if (hbit) {
+                const unsigned hs = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
+                if (hs < (unsigned)P::OMEGA) hbytes[hs] = (uint8_t)nidx;
             }
-            if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
+            pop += (unsigned)__popcll(mask);
         }
-        reject = __any(bad) || pop > (unsigned)P::OMEGA;
+        if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
     }
-    if (reject) return;  // sign_compact_kernel charges the round's attempts to the item
-    __syncthreads();     // every lane is done with w0
+    if (__any(bad) || pop > (unsigned)P::OMEGA) return;
+    __syncthreads();       // every lane is done with w0
     // with one attempt per item the signature goes straight out; with several, this one is parked in the slot's w0
-    // area and sign_commit_kernel copies the lowest successful attempt's
+    // area and the commit kernel copies the lowest successful attempt's
     uint8_t *sg = k == 1 ? sig + item * G::SIG : reinterpret_cast<uint8_t *>(w0);
     for (int b = lane; b < P::CT; b += 64) sg[b] = cb[b];
     for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
     for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
     if (lane == 0) atomicMin(&st.best[item], off);
 }
+template <int MODE>
+__global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+    using G = DG<MODE>;
+    constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t zpk[L * G::ZSZ];
+    __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
+    const size_t count = st.count[cur];
+    const unsigned k = st.kk[cur];
+#pragma unroll 1
+    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        __syncthreads();  // the previous entry is done with the LDS buffers
+        sign_finish_entry<MODE>(st, cur, sig, slot, k, xch, zpk, hbytes, blk);
+    }
+}
 
-// wave = entry, rounds with several attempts per item only: the lowest successful attempt's parked signature -> sig
+// wave = entry, rounds with several attempts per item only (k == 1: every block leaves at once): the lowest successful
+// attempt's parked signature -> sig
 template <int MODE>
 __global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
     using G = DG<MODE>;
     constexpr int K = DP<MODE>::K;
-    const size_t slot = blockIdx.x;
-    if (slot >= st.count[cur]) return;
-    const uint32_t e = st.list[cur][slot];
-    const size_t item = e & kEntryItemMask;
-    if (st.best[item] != (e >> kEntryShift)) return;
-    const uint32_t *src = st.w0 + slot * K * 256;
-    uint8_t *dst = sig + item * G::SIG;   // SIG is not a multiple of 4 for every parameter set: dwords, then the tail bytes
-    for (int d = threadIdx.x; d < G::SIG / 4; d += 64) {
-        const uint32_t w = src[d];
-        dst[4 * d] = (uint8_t)w; dst[4 * d + 1] = (uint8_t)(w >> 8); dst[4 * d + 2] = (uint8_t)(w >> 16); dst[4 * d + 3] = (uint8_t)(w >> 24);
+    if (st.kk[cur] == 1) return;
+    const size_t count = st.count[cur];
+#pragma unroll 1
+    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        const uint32_t e = st.list[cur][slot];
+        const uint32_t item = e & kEntryItemMask;
+        if (st.best[item] != (e >> kEntryShift)) continue;
+        const uint32_t *src = st.w0 + slot * K * 256;
+        uint8_t *dst = sig + (size_t)item * G::SIG;   // SIG is not a multiple of 4 for every parameter set: dwords, then the tail bytes
+        for (int d = threadIdx.x; d < G::SIG / 4; d += 64) {
+            const uint32_t w = src[d];
+            dst[4 * d] = (uint8_t)w; dst[4 * d + 1] = (uint8_t)(w >> 8); dst[4 * d + 2] = (uint8_t)(w >> 16); dst[4 * d + 3] = (uint8_t)(w >> 24);
+        }
+        for (int b = (G::SIG / 4) * 4 + threadIdx.x; b < G::SIG; b += 64) dst[b] = reinterpret_cast<const uint8_t *>(src)[b];
     }
-    for (int b = (G::SIG / 4) * 4 + threadIdx.x; b < G::SIG; b += 64) dst[b] = reinterpret_cast<const uint8_t *>(src)[b];
 }
 
-// next active list: every item of the current one (k entries each) that is still unsigned has spent k attempts and gets
-// k_next entries
-__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, unsigned k, unsigned k_next) {
-    const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (a >= st.count[cur]) return;
-    const uint32_t e = st.list[cur][a];
-    if ((e >> kEntryShift) != 0) return;  // the item's first entry speaks for it
-    const uint32_t item = e & kEntryItemMask;
-    if (st.best[item] != kNoSuccess) return;
-    st.attempts[item] += k;
-    const uint32_t base = atomicAdd(&st.count[cur ^ 1], k_next);
-    for (unsigned j = 0; j < k_next; j++) st.list[cur ^ 1][base + j] = item | (j << kEntryShift);
+// lane = entry: the next active list.  Every item of the current one that is still unsigned has spent k attempts and gets
+// k_next entries; k_next follows from the current list's item count (an upper bound on the survivors), the same for every
+// lane.  One atomic per wavefront reserves the survivors' entries.  `last`: the list is for the persistent tail kernel, which
+// wants one entry per item.
+__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, int last) {
+    const size_t count = st.count[cur];
+    const unsigned k = st.kk[cur];
+    const unsigned k_next = last ? 1u : sign_next_k((count + k - 1) / k, st.spec_target);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.kk[cur ^ 1] = k_next;
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {
+        const size_t a = base + threadIdx.x;
+        uint32_t item = 0;
+        bool survivor = false;
+        if (a < count) {
+            const uint32_t e = st.list[cur][a];
+            item = e & kEntryItemMask;
+            survivor = (e >> kEntryShift) == 0 && st.best[item] == kNoSuccess;  // the item's first entry speaks for it
+        }
+        const unsigned long long m = __ballot(survivor);
+        if (m == 0) continue;  // wave-uniform
+        uint32_t wbase = 0;
+        if (lane == (int)(__ffsll((long long)m) - 1)) wbase = atomicAdd(&st.count[cur ^ 1], (uint32_t)__popcll(m) * k_next);
+        wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, __ffsll((long long)m) - 1);
+        if (survivor) {
+            st.attempts[item] += k;
+            const uint32_t at = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1)) * k_next;
+            for (unsigned j = 0; j < k_next; j++) st.list[cur ^ 1][at + j] = item | (j << kEntryShift);
+        }
+    }
+}
+
+// The fixed schedule: how many rounds the host enqueues for n items.  The survivors of a round are at most the items
+// that entered it; with success probability p per attempt an item survives k attempts with (1 - p)^k.  The schedule follows
+// the EXPECTED survivor count (with a pessimistic p and a safety margin on the count that drives k) until it is below
+// 2^-40; the persistent tail kernel behind the schedule makes the result independent of that estimate.
+template <int MODE> inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target) {
+    // expected attempts per signature 4.25 / 5.1 / 3.85 (FIPS 204 table 1): success probability per attempt, times 0.85
+    const double p = 0.85 * (DP<MODE>::K == 4 ? 0.235 : DP<MODE>::K == 6 ? 0.196 : 0.26);
+    double items = (double)n;
+    unsigned k = k0;
+    int rounds = 0;
+    while (items > 9.1e-13 && rounds < 400) {
+        const double survive = __builtin_pow(1.0 - p, (double)k);
+        // the device derives the next k from the items that ENTERED this round
+        k = sign_next_k((unsigned long long)(items * 1.25 + 8.0), spec_target);
+        items *= survive;
+        rounds++;
+    }
+    return rounds;
 }
 
 }  // namespace mldsa

@@ -807,7 +807,6 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     uint8_t *xch = lds_noise + (SHARED ? Gm::LDS_NOISE_SHARED : Gm::LDS_NOISE);
     int16_t *rows = KM == KM_KEYED ? nullptr : reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
-    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     constexpr int GI = SHARED ? Gm::GS : Gm::G;  // items per group
     const size_t ngroups = (n + GI - 1) / GI;
     if constexpr (KM == KM_SHARED) {
@@ -846,6 +845,11 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         }
     }
 
+    // The 15 per-lane twiddle constants are only needed by the ring phase: they are (re)loaded here, behind an opaque copy
+    // of the lane index, so that they are not live (or spilled) across the sampling phases' 100-register Keccak rounds.
+    int lane_ring = lane;
+    asm volatile("" : "+v"(lane_ring));
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane_ring);
 #pragma unroll 1
     for (int g = 0; g < ((ABLATE & 4) ? 0 : GI); g++) {
         const size_t item = item0 + g;

@@ -148,7 +148,7 @@ class MLDSADevice:
         return pk, sk
 
     def sign(self, sk, msg, sig=None, rnd=None, shared=False):
-        """deterministic unless rnd (n, 32) is given; HOST-BLOCKING (include/circl_hip.h)"""
+        """deterministic unless rnd (n, 32) is given; asynchronous on the current stream"""
         assert self.sws is not None, "construct with sign=True"
         sig = torch.empty(self.n * self.SIG + 16, dtype=torch.uint8, device=sk.device)[:self.n * self.SIG].view(self.n, self.SIG) if sig is None else sig
         rnd = self.rnd0 if rnd is None else rnd

@@ -244,9 +244,10 @@ int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk
  * ML-DSA-65: expanded matrix and NTT-domain secrets per item); d_rnd must not be NULL.  An item whose context is
  * longer than 255 bytes gets an ALL-ZERO signature from the _dev variants (never one over a truncated length).
  * The workspace holds key-equivalent intermediates while the call runs; its secret regions are zeroed before the
- * call's work completes.  Unlike the other _dev calls the batched signer is HOST-BLOCKING: it synchronises `stream`
- * (the rejection loop runs as rounds over the unsigned items and the host reads their count) and cannot be captured
- * into a graph. */
+ * call's work completes.  Like every other _dev call the signer is ASYNCHRONOUS: the rejection loop runs as rounds
+ * over the list of unsigned items whose length lives in device memory; the host enqueues a fixed schedule of rounds
+ * (sized so that the chance of an item surviving it is below 2^-40) followed by a persistent kernel that finishes
+ * whatever is left, and never reads anything back, so nothing synchronises `stream`. */
 int circl_hip_mldsa_sign(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off,
                          const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig,
                          size_t n, int device);
