@@ -298,7 +298,9 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     }();
     S.spec_target = (uint32_t)std::min<size_t>((size_t)cus * spec_per_cu, lay.E);
     const unsigned k0 = sign_next_k(n, S.spec_target);
-    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target);
+    constexpr int kMaxRounds = 400;
+    size_t entries_upper[kMaxRounds];
+    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, entries_upper, kMaxRounds);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -311,13 +313,14 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n, k0);
     }
-    // grids: the kernels loop over the device-side count, so any grid is correct; these fill the chip when the lists
-    // are long and keep the launches of the late (and the empty) rounds small
-    const size_t wave_cap = (size_t)cus * 16, lane_cap = (size_t)cus * 10;
-    size_t upper = n * k0;  // entries of round 0; afterwards the capacity bounds every list
+    // grids: the kernels loop over the device-side count, so any grid is correct; the schedule's upper estimate of a
+    // round's entries gives (nearly) one workgroup per entry while the lists are long, and small launches for the late and
+    // the empty rounds
+    const size_t lane_cap = (size_t)cus * 10;
     for (int round = 0; round < rounds; round++) {
         const int cur = round & 1;
-        const unsigned gw = (unsigned)std::max<size_t>(1, std::min(upper, wave_cap));
+        const size_t upper = std::min(round == 0 ? n * k0 : entries_upper[round], lay.E);
+        const unsigned gw = (unsigned)std::max<size_t>(1, upper);
         const unsigned gm = (unsigned)std::max<size_t>(1, std::min((upper * L + 255) / 256, lane_cap));
         const unsigned gc = (unsigned)std::max<size_t>(1, std::min((upper + 255) / 256, lane_cap));
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
@@ -327,7 +330,6 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
         hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
         hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
         hipLaunchKernelGGL(sign_compact_kernel, dim3(gc), dim3(256), 0, st, S, cur, round == rounds - 1 ? 1 : 0);
-        upper = std::min(upper, std::max<size_t>(n, S.spec_target));  // survivors x k_next never exceeds this
     }
     {
         // whatever the schedule left unsigned (probability below 2^-40 by construction): one wavefront per item runs that

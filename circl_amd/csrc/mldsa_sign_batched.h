@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     using B = SB<MODE>;
     constexpr int L = DP<MODE>::L;
     const size_t total = (size_t)st.count[cur] * L;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // filled by this round's commit kernel, several launches later
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // filled by this round's compact kernel, several launches later
 #pragma unroll 1
     for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {  // block-uniform
         const size_t sidx = base + threadIdx.x;
@@ -312,6 +312,10 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
         dilithium::invntt(t, z, xch, lane);
     };
     bool bad = false;
+    // The three norm tests decide together and their order is free; the reference's (r0, z, hints: dilithium.go:409-450) is also
+    // the cheap one: for ML-DSA-65 the r0 test rejects 68 % of the attempts (1536 coefficients against gamma2 - beta), the z
+    // test 38 % (1280 against gamma1 - beta), so r0 first costs ~6.4 inverse transforms per attempt, z first ~7.8 (measured:
+    // 14.7 vs 16.3 ms of finish kernels per 2^18 signatures).
     // w0 - c s2
 #pragma unroll 1
     for (int i = 0; i < K; i++) {
@@ -326,14 +330,14 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
         }
         if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
     }
-    if (__any(bad)) return;  // the compact kernel charges the round's attempts to the item
+    if (__any(bad)) return;
     // z = y + c s1
-#pragma unroll 1
+    unsigned zfld[L][4];
+#pragma unroll
     for (int l = 0; l < L; l++) {
         uint32_t t[4];
         mul_c(t, sec + l * kPackedRowDwords);
         const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
-        unsigned fld[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             uint32_t y = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
@@ -342,13 +346,17 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
             bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
             uint32_t f = G::GAMMA1 - zz;
             f += (uint32_t)((int32_t)f >> 31) & Q;
-            fld[r] = f;
+            zfld[l][r] = f;
         }
-        mlkem::stage_bits_l1<G::ZBITS>(xch, fld, lane);
-        for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
         if (__any(bad)) break;
     }
     if (__any(bad)) return;
+    // z passed: bit-pack it as it will appear in the signature (pack.go:202-254) -- only now: most attempts never get here
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        mlkem::stage_bits_l1<G::ZBITS>(xch, zfld[l], lane);
+        for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+    }
     // c t0, hints
     unsigned pop = 0;
     __syncthreads();
@@ -396,6 +404,8 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
     static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
     const size_t count = st.count[cur];
     const unsigned k = st.kk[cur];
+    // (static split: handing entries out through an atomic ticket -- per entry or in chunks of 8 -- balances the uneven
+    // attempts but measured slower, 17.5 and 14.6 ms against 12.3 ms per 2^16 ML-DSA-65 signatures)
 #pragma unroll 1
     for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
         __syncthreads();  // the previous entry is done with the LDS buffers
@@ -463,13 +473,17 @@ __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur
 // that entered it; with success probability p per attempt an item survives k attempts with (1 - p)^k.  The schedule follows
 // the EXPECTED survivor count (with a pessimistic p and a safety margin on the count that drives k) until it is below
 // 2^-40; the persistent tail kernel behind the schedule makes the result independent of that estimate.
-template <int MODE> inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target) {
+template <int MODE> inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target, size_t *entries_upper, int max_rounds) {
     // expected attempts per signature 4.25 / 5.1 / 3.85 (FIPS 204 table 1): success probability per attempt, times 0.85
     const double p = 0.85 * (DP<MODE>::K == 4 ? 0.235 : DP<MODE>::K == 6 ? 0.196 : 0.26);
     double items = (double)n;
     unsigned k = k0;
     int rounds = 0;
-    while (items > 9.1e-13 && rounds < 400) {
+    while (items > 9.1e-13 && rounds < max_rounds) {
+        // an upper estimate of the round's entries sizes its grids (one workgroup per entry: the hardware then balances the
+        // unevenly long attempts; workgroups beyond the real count leave at once, and the kernels' grid-stride loops keep a
+        // too-small estimate correct)
+        entries_upper[rounds] = (size_t)(items * k * 1.03) + 64;
         const double survive = __builtin_pow(1.0 - p, (double)k);
         // the device derives the next k from the items that ENTERED this round
         k = sign_next_k((unsigned long long)(items * 1.25 + 8.0), spec_target);

@@ -173,3 +173,67 @@ func DeriveKeyPairBatch(s kem.Scheme, seeds []byte, device int) (eks, dks []byte
 	}
 	return
 }
+
+func ptr32(b []uint32) *C.uint32_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint32_t)(unsafe.Pointer(&b[0]))
+}
+
+// EncapsulateKeyedBatch: a table of nkeys public keys (row-major MarshalBinary forms) and one index per item.  The
+// device expands A^T and H(ek) once per TABLE ENTRY -- what UnmarshalBinaryPublicKey caches in the key object
+// (kem/mlkem/mlkem768/kyber.go:39-43, :247-263) -- and then does the per-message work of EncapsulateDeterministically.
+func EncapsulateKeyedBatch(s kem.Scheme, ekTable []byte, idx []uint32, seeds []byte, device int) (cts, sss []byte, errs []error, err error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		return nil, nil, nil, kem.ErrTypeMismatch
+	}
+	if len(ekTable) == 0 || len(ekTable)%s.PublicKeySize() != 0 {
+		return nil, nil, nil, kem.ErrPubKeySize
+	}
+	n := len(idx)
+	if len(seeds) != n*s.EncapsulationSeedSize() {
+		return nil, nil, nil, kem.ErrSeedSize
+	}
+	nkeys := len(ekTable) / s.PublicKeySize()
+	cts = make([]byte, n*s.CiphertextSize())
+	sss = make([]byte, n*s.SharedKeySize())
+	st := make([]byte, n)
+	if err = status(C.circl_hip_mlkem_encaps_keyed(p, ptr(ekTable), C.size_t(nkeys), ptr32(idx), ptr(seeds), ptr(cts), ptr(sss), ptr(st),
+		C.size_t(n), C.int(device)), "encaps keyed"); err != nil {
+		return nil, nil, nil, err
+	}
+	errs = make([]error, n)
+	for i, c := range st {
+		errs[i] = itemErr(c)
+	}
+	return
+}
+
+// DecapsulateKeyedBatch: a table of private keys and one index per ciphertext (a server with a handful of static keys).
+func DecapsulateKeyedBatch(s kem.Scheme, dkTable []byte, idx []uint32, cts []byte, device int) (sss []byte, errs []error, err error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		return nil, nil, kem.ErrTypeMismatch
+	}
+	if len(dkTable) == 0 || len(dkTable)%s.PrivateKeySize() != 0 {
+		return nil, nil, kem.ErrPrivKeySize
+	}
+	n := len(idx)
+	if len(cts) != n*s.CiphertextSize() {
+		return nil, nil, kem.ErrCiphertextSize
+	}
+	nkeys := len(dkTable) / s.PrivateKeySize()
+	sss = make([]byte, n*s.SharedKeySize())
+	st := make([]byte, n)
+	if err = status(C.circl_hip_mlkem_decaps_keyed(p, ptr(dkTable), C.size_t(nkeys), ptr32(idx), ptr(cts), ptr(sss), ptr(st), C.size_t(n),
+		C.int(device)), "decaps keyed"); err != nil {
+		return nil, nil, err
+	}
+	errs = make([]error, n)
+	for i, c := range st {
+		errs[i] = itemErr(c)
+	}
+	return
+}

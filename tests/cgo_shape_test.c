@@ -1,0 +1,108 @@
+/* tests/cgo_shape_test.c -- drives the C ABI exactly the way cgo's generated stubs for go/.../hipbatch do, so that the only
+ * part of the Go bridge this repository cannot test (there is no Go toolchain in the image) is Go syntax:
+ *   - every buffer is a byte-aligned SUB-SLICE of a larger allocation (Go slices carry no alignment promise),
+ *   - zero-length batches pass NULL pointers (ptr() in hipbatch.go returns nil for an empty slice),
+ *   - status == NULL where the bridge has no use for it,
+ *   - blobs carry one spare byte and n + 1 uint64 offsets built by appending (VerifyBatch / SignBatch),
+ *   - key tables + uint32 index vectors (EncapsulateKeyedBatch, VerifyKeyedBatch),
+ *   - the same call from several threads at once (goroutines on different OS threads).
+ * Results are checked against the ABI's own other paths (keygen -> encaps -> decaps round trips; sign -> verify; keyed
+ * == per-item); bit-exactness against the oracle is the job of the Python tests.  Prints OK.
+ *   gcc -O1 -pthread -Iinclude tests/cgo_shape_test.c -Lcircl_amd -lcirclhip -Wl,-rpath,$PWD/circl_amd -Wl,-rpath,/opt/rocm/lib */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "circl_hip.h"
+
+#define CHECK(c)                                                                                    \
+    do {                                                                                            \
+        if (!(c)) { fprintf(stderr, "%s:%d: check failed: %s (%s)\n", __FILE__, __LINE__, #c, circl_hip_last_error()); exit(1); } \
+    } while (0)
+
+/* a "Go slice": n bytes starting `skew` bytes into a fresh allocation */
+static uint8_t *slice(size_t n, size_t skew) {
+    uint8_t *base = malloc(n + 64);
+    CHECK(base);
+    memset(base, 0, n + 64);
+    return base + skew; /* (never freed: test process) */
+}
+static void fill(uint8_t *p, size_t n, unsigned seed) {
+    for (size_t i = 0; i < n; i++) p[i] = (uint8_t)((i * 2654435761u + seed * 40503u) >> 11);
+}
+
+static void kem_round_trip(int param, size_t n, int device) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    uint8_t *seed = slice(64 * n, 1), *m = slice(32 * n, 3), *ek = slice(EK * n, 5), *dk = slice(DK * n, 7), *ct = slice(CT * n, 9);
+    uint8_t *ss = slice(32 * n, 11), *ss2 = slice(32 * n, 13), *st = slice(n, 15);
+    fill(seed, 64 * n, (unsigned)param);
+    fill(m, 32 * n, (unsigned)param + 1);
+    CHECK(circl_hip_mlkem_keygen(param, seed, ek, dk, n, device) == 0);
+    CHECK(circl_hip_mlkem_encaps(param, ek, m, ct, ss, st, n, device) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(st[i] == 0);
+    CHECK(circl_hip_mlkem_decaps(param, dk, ct, ss2, NULL /* the bridge may not want the status */, n, device) == 0);
+    CHECK(memcmp(ss, ss2, 32 * n) == 0);
+    /* key table: the first 5 keys, index i mod 5 */
+    const size_t nk = n < 5 ? n : 5;
+    uint32_t *idx = (uint32_t *)slice(4 * n + 8, 4); /* a []uint32 is 4-byte aligned in Go */
+    uint8_t *ekg = slice(EK * n, 1), *ct2 = slice(CT * n, 3), *ss3 = slice(32 * n, 5), *ct3 = slice(CT * n, 7), *ss4 = slice(32 * n, 9);
+    for (size_t i = 0; i < n; i++) { idx[i] = (uint32_t)(i % nk); memcpy(ekg + EK * i, ek + EK * idx[i], EK); }
+    CHECK(circl_hip_mlkem_encaps_keyed(param, ek, nk, idx, m, ct2, ss3, st, n, device) == 0);
+    CHECK(circl_hip_mlkem_encaps(param, ekg, m, ct3, ss4, st, n, device) == 0);
+    CHECK(memcmp(ct2, ct3, CT * n) == 0 && memcmp(ss3, ss4, 32 * n) == 0);
+    CHECK(circl_hip_mlkem_decaps_keyed(param, dk, nk, idx, ct2, ss2, st, n, device) == 0);
+    CHECK(memcmp(ss2, ss3, 32 * n) == 0);
+    uint32_t bad_idx[1] = {(uint32_t)nk};
+    CHECK(circl_hip_mlkem_encaps_keyed(param, ek, nk, bad_idx, m, ct2, ss3, st, 1, device) == CIRCL_HIP_EPARAM);
+}
+
+static void dsa_round_trip(int param, size_t n, int device) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SK = circl_hip_mldsa_sk_size(param), SIG = circl_hip_mldsa_sig_size(param);
+    uint8_t *seed = slice(32 * n, 1), *pk = slice(PK * n, 3), *sk = slice(SK * n, 5), *sig = slice(SIG * n, 7), *ok = slice(n, 9);
+    fill(seed, 32 * n, (unsigned)param);
+    CHECK(circl_hip_mldsa_keygen(param, seed, pk, sk, n, device) == 0);
+    /* blobs as VerifyBatch builds them: appended rows, one spare byte, n + 1 offsets */
+    uint64_t *moff = (uint64_t *)slice(8 * (n + 1), 8), *coff = (uint64_t *)slice(8 * (n + 1), 8);
+    size_t mt = 0, ctot = 0;
+    for (size_t i = 0; i < n; i++) { moff[i] = mt; coff[i] = ctot; mt += 1 + i % 70; ctot += i % 9; }
+    moff[n] = mt; coff[n] = ctot;
+    uint8_t *mblob = slice(mt + 1, 3), *cblob = slice(ctot + 1, 5);
+    fill(mblob, mt, 77);
+    fill(cblob, ctot, 78);
+    CHECK(circl_hip_mldsa_sign(param, sk, mblob, moff, cblob, coff, NULL /* deterministic */, sig, n, device) == 0);
+    CHECK(circl_hip_mldsa_verify(param, pk, sig, mblob, moff, cblob, coff, ok, n, device) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
+    sig[SIG * (n / 2) + 40] ^= 1;
+    uint32_t *idx = (uint32_t *)slice(4 * n + 8, 4);
+    for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i; /* the table is the whole key array here */
+    CHECK(circl_hip_mldsa_verify_keyed(param, pk, n, idx, sig, mblob, moff, cblob, coff, ok, n, device) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(ok[i] == (i == n / 2 ? 0 : 1));
+}
+
+static void *thread_main(void *arg) {
+    kem_round_trip(768, 3000 + 100 * (size_t)(intptr_t)arg, 0);
+    return NULL;
+}
+
+int main(void) {
+    CHECK(circl_hip_init() > 0);
+    /* zero-length batches: nil slices become NULL pointers */
+    CHECK(circl_hip_mlkem_encaps(768, NULL, NULL, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_mlkem_decaps(768, NULL, NULL, NULL, NULL, 0, CIRCL_HIP_ALL_DEVICES) == 0);
+    CHECK(circl_hip_mlkem_keygen(1024, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_mldsa_verify(65, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_mldsa_sign(65, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_mlkem_encaps(999, NULL, NULL, NULL, NULL, NULL, 0, 0) == CIRCL_HIP_EPARAM);
+    kem_round_trip(512, 1, 0);      /* a batch of one */
+    kem_round_trip(768, 4099, CIRCL_HIP_ALL_DEVICES);
+    kem_round_trip(1024, 777, 0);
+    dsa_round_trip(44, 1, 0);
+    dsa_round_trip(65, 333, CIRCL_HIP_ALL_DEVICES);
+    dsa_round_trip(87, 100, 0);
+    pthread_t th[3];
+    for (intptr_t i = 0; i < 3; i++) CHECK(pthread_create(&th[i], NULL, thread_main, (void *)i) == 0);
+    for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);
+    printf("OK\n");
+    return 0;
+}

@@ -123,3 +123,27 @@ def test_hybrid_x25519mlkem768_against_oracle():
         assert int(st[0]) == 0
         assert t["ct"] == bytes(ct[0]) + X.public(esk)
         assert t["ss"] == bytes(ss[0]) + X.x25519(esk, t["pk"][1184:])
+
+
+def _build_cgo_shape():
+    out = os.path.join(ROOT, "build", "cgo_shape_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cgo_shape_test.c"),
+                           "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
+def test_cgo_shape_harness_compiles():
+    from circl_amd import build as cbuild
+    cbuild.build()
+    _build_cgo_shape()
+
+
+@pytest.mark.gpu
+def test_cgo_shaped_calls():
+    # the C ABI called the way cgo's stubs for go/*/hipbatch call it: byte-aligned sub-slices, NULL for empty slices,
+    # status == NULL, appended blobs, key tables, three OS threads at once
+    exe = _build_cgo_shape()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
