@@ -391,6 +391,8 @@ def main():
         print("bench.py needs a GPU (circl_amd has no CPU path)", file=sys.stderr)
         sys.exit(2)
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CIRCL_BENCH_SHARE_GPU"):  # test aid: several ranks on one device (then with CIRCL_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from circl_amd import parallel

@@ -21,14 +21,16 @@ class Ranks:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self.dist = None
+        self.backend = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("CIRCL_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            self.backend = backend
 
     def barrier(self):
         if self.dist is not None:
@@ -37,7 +39,7 @@ class Ranks:
             torch.cuda.synchronize()
 
     def _tensor(self, x):
-        dev = self.device if (self.device is not None and torch.cuda.is_available()) else "cpu"
+        dev = self.device if (self.device is not None and torch.cuda.is_available() and self.backend != "gloo") else "cpu"
         return torch.tensor([float(x)], dtype=torch.float64, device=dev)
 
     def max(self, x):

@@ -81,6 +81,35 @@ def pmc(raw, tag):
             traffic["mlkem768_encrypt_shared_key_bytes_per_launch_2p20"] = hbm
         if "mlkem_hash_kernel<3" in k or "mlkem_hash_kernelILi3" in k:
             traffic["mlkem768_hash_bytes_per_launch_2p20"] = hbm
+    # which build the figures belong to: bench.py reports them only for the very same libcirclhip.so
+    try:
+        import hashlib
+        h = hashlib.sha256()
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "circl_amd", "libcirclhip.so"), "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(blk)
+        traffic["lib_sha256"] = h.hexdigest()
+    except OSError:
+        pass
+    # SQ counters of the same kernel (sq*/ passes)
+    valu = {}
+    sq = defaultdict(list)
+    for f in find(os.path.join(raw, "sq1"), "*counter_collection.csv") + find(os.path.join(raw, "sq2"), "*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r["Kernel_Name"]
+                if "mlkem_encrypt_kernel<3, 0, 0, true, 0>" in k or "mlkem_encrypt_kernel<3, 0, 0, true, false>" in k:
+                    sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    med = lambda c: sorted(sq[c])[len(sq[c]) // 2] if sq.get(c) else None
+    if sq:
+        valu = {"mlkem768_encrypt_valu_insts_per_launch_2p20": med("SQ_INSTS_VALU"), "salu": med("SQ_INSTS_SALU"), "lds": med("SQ_INSTS_LDS"),
+                "vmem_rd": med("SQ_INSTS_VMEM_RD"), "vmem_wr": med("SQ_INSTS_VMEM_WR"), "waves": med("SQ_WAVES"),
+                "grbm_gui_active_per_xcd": (med("GRBM_GUI_ACTIVE") or 0) / 8, "wave_quad_cycles": med("SQ_WAVE_CYCLES"),
+                "busy_cycles": med("SQ_BUSY_CYCLES"), "active_inst_valu": med("SQ_ACTIVE_INST_VALU"), "lib_sha256": traffic.get("lib_sha256"),
+                "method": "rocprofv3 --pmc SQ_* (own passes, kernel-trace only), median over the launches of bench.py --pmc-child; "
+                          "GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES counts in units of 4 cycles"}
+        json.dump(valu, open(os.path.join(raw, "valu.json"), "w"), indent=1)
+        out_lines.append("SQ counters of mlkem_encrypt_kernel<3, ENCAPS> per launch of 2^20: " + json.dumps({k: v for k, v in valu.items() if k not in ("method", "lib_sha256")}))
     traffic["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only); "
                          "median over the timed launches; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of a wide "
                          "coalesced stream, MI355X_MICROARCH.md HBM section); write bytes = WRITE_SIZE x 1024 (uncalibrated)")

@@ -38,8 +38,8 @@ def test_mlkem768_roundtrip_2p20_device_resident():
     torch.cuda.synchronize()
     assert int((ss3 == ss).all(dim=1).sum()) == 0
     ct[:, 17] ^= 0x20
-    # bit-exact oracle parity on a uniform sample of 2^12 items, all three operations
-    idx = torch.from_numpy(np.random.default_rng(1).choice(n, 1 << 12, replace=False)).cuda()
+    # bit-exact oracle parity on a uniform sample of 2^16 items, all three operations
+    idx = torch.from_numpy(np.random.default_rng(1).choice(n, 1 << 16, replace=False)).cuda()
     ek0, dk0 = orc.mlkem_keygen(768, seeds[idx].cpu().numpy())
     assert (ek0 == ek[idx].cpu().numpy()).all() and (dk0 == dk[idx].cpu().numpy()).all()
     ct0, ss0, _ = orc.mlkem_encaps(768, ek0, m[idx].cpu().numpy())
@@ -181,3 +181,68 @@ def test_mixed_mlkem1024_and_mldsa87_concurrently():
     ti = torch.from_numpy(idx).cuda()
     ct0, ss0, _ = orc.mlkem_encaps(1024, ek[ti].cpu().numpy(), m[ti].cpu().numpy())
     assert (ct0 == ct[ti].cpu().numpy()).all() and (ss0 == ss[ti].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("param", [65])
+def test_mldsa_verify_2p18_distinct_keys(param):
+    # configs[3] as SURVEY 8(d) words it: DISTINCT pk_i from seeded keygen, signatures from the deterministic signer, >= 1 %
+    # corrupted (bit flip in z, in c~, non-canonical hint).  Keys and signatures are made on the GPU (both parity-pinned:
+    # ACVP keyGen / sigGen, KAT hashes) and re-checked here: the oracle verifies a 2^14 sample of them and signs a 2^10 one.
+    import torch
+    from circl_amd import device as cdev
+    from oracle import orc
+    n = 1 << 18
+    g = torch.Generator(device="cuda").manual_seed(param)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    msg = torch.randint(0, 256, (n * 32 + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    eng = cdev.MLDSADevice(param, n, "cuda", msg_len=32, sign=True)
+    pk, sk = eng.keygen(seeds)
+    sig = eng.sign(sk, msg)
+    torch.cuda.synchronize()
+    assert int((pk[1:] == pk[:-1]).all(dim=1).sum()) == 0  # keys are distinct
+    good = sig.clone()
+    bad = torch.arange(0, n, 64, device="cuda")
+    kinds = torch.arange(bad.numel(), device="cuda") % 3
+    ct = {44: 32, 65: 48, 87: 64}[param]
+    sig[bad[kinds == 0], ct + 200] ^= 0x10
+    sig[bad[kinds == 1], 5] ^= 0x80
+    sig[bad[kinds == 2], eng.SIG - 1] = 0xFF
+    ok = eng.verify(pk, sig, msg)
+    torch.cuda.synchronize()
+    want = torch.ones(n, dtype=torch.uint8, device="cuda")
+    want[bad] = 0
+    assert bool((ok == want).all())
+    idx = np.sort(np.random.default_rng(3).choice(n, 1 << 14, replace=False))
+    ti = torch.from_numpy(idx).cuda()
+    msgs = [bytes(r) for r in msg[:n * 32].view(n, 32)[ti].cpu().numpy()]
+    assert (orc.mldsa_verify(param, pk[ti].cpu().numpy(), sig[ti].cpu().numpy(), msgs) == ok[ti].cpu().numpy()).all()
+    si = ti[:1 << 10]
+    assert (orc.mldsa_sign(param, sk[si].cpu().numpy(), msgs[:1 << 10]) == good[si].cpu().numpy()).all()
+    pk0, sk0 = orc.mldsa_keygen(param, seeds[si].cpu().numpy())
+    assert (pk0 == pk[si].cpu().numpy()).all() and (sk0 == sk[si].cpu().numpy()).all()
+
+
+def test_sign_dev_is_asynchronous():
+    # the signer returns before its work is done (no hidden stream synchronisation): the enqueue takes a fraction of the
+    # time to completion, and work queued behind it on the same stream sees the finished signatures
+    import time
+    import torch
+    from circl_amd import device as cdev
+    n = 1 << 16
+    g = torch.Generator(device="cuda").manual_seed(9)
+    eng = cdev.MLDSADevice(65, n, "cuda", msg_len=32, sign=True)
+    pk, sk = eng.keygen(torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g))
+    msg = torch.randint(0, 256, (n * 32 + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    sig = eng.sign(sk, msg)
+    torch.cuda.synchronize()
+    sig.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.sign(sk, msg, sig)
+    ok = eng.verify(pk, sig, msg)       # same stream, no synchronisation in between
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert bool(ok.all())
+    print(f"sign+verify 2^16: enqueued in {t_enq * 1e3:.2f} ms, complete after {t_all * 1e3:.2f} ms")
+    assert t_enq < 0.8 * t_all

@@ -402,3 +402,28 @@ def test_bench_py_small_run_emits_every_config():
     assert cfg["host_abi"]["pageable"]["all_ct_equal_device_resident_run"] and cfg["host_abi"]["pinned"]["all_ct_equal_device_resident_run"]
     assert cfg["keyed"]["equals_per_item_api_on_gathered_keys"]
     assert out["roofline"]["frac"] > 0
+
+
+def test_bench_py_two_ranks_control_flow():
+    # bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU) cannot run on a 1-GPU box with
+    # RCCL; with the process group on gloo and both ranks sharing the one device, everything else of the N > 1 path runs:
+    # per-rank batches, barriers, max-over-ranks timing, whole-job aggregation, per-rank gathers, rank 0's JSON line
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(1 << 13)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["parity"]["ranks_failing"] == 0
+    assert len(out["per_rank"]["encaps_per_s"]) == 2
+    cfg = out["configs"]
+    assert len(cfg["config4"]["per_rank_per_s"]) == 2 and cfg["config4"]["parity"]["ranks_failing"] == 0
+    assert len(cfg["config5"]["per_rank_per_s"]) == 2 and cfg["config5"]["parity"]["ranks_failing"] == 0
+    assert cfg["decaps"]["parity"]["ranks_failing"] == 0 and len(cfg["host_abi"]["per_rank_pageable_per_s"]) == 2
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # the whole-job value is the sum of the ranks' items over the slowest rank's time
+    assert out["value"] <= sum(out["per_rank"]["encaps_per_s"]) * 1.001
