@@ -508,6 +508,37 @@ int circl_hip_mldsa_verify_keyed(int param, const uint8_t *pk_table, size_t nkey
     });
 }
 
+// PolyDeriveUniformBall (sign/mldsa/mldsa65/internal/sample.go:299-339) of n challenge seeds: a unit-level primitive for
+// the parity tests, like circl_hip_kyber_ntt.  sequential != 0 takes the reference-order scan that is otherwise only the
+// fallback of the block-parallel form.
+int circl_hip_mldsa_sample_in_ball(int param, const uint8_t *ctilde, uint32_t *polys, size_t n, int sequential, int device) {
+    using namespace circl::mldsa;
+    const size_t CT = param == 44 ? 32 : param == 65 ? 48 : param == 87 ? 64 : (param == 2 || param == 3 || param == 5) ? 32 : 0;
+    if (!CT) return CIRCL_HIP_EPARAM;
+    uint8_t *po = reinterpret_cast<uint8_t *>(polys);
+    PipeOpts o;
+    o.chunk_items = host_chunk_items(size_t(1) << 14);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{ctilde + lo * CT, CT}}, {}, {{po + lo * 1024, 1024}}, [](size_t) { return size_t(0); }, o, [&](Chunk &c) {
+#define CALL(M) hipLaunchKernelGGL(mldsa_sample_in_ball_kernel<M>, dim3((unsigned)c.cnt), dim3(64), 0, c.st, (const uint8_t *)c.in[0], \
+                                   reinterpret_cast<uint32_t *>(c.out[0]), sequential)
+            int rc = CIRCL_HIP_OK;
+            switch (param) {
+            case 44: CALL(44); break;
+            case 65: CALL(65); break;
+            case 87: CALL(87); break;
+            case 2: CALL(2); break;
+            case 3: CALL(3); break;
+            case 5: CALL(5); break;
+            default: rc = CIRCL_HIP_EPARAM;
+            }
+#undef CALL
+            HIP_TRY(hipGetLastError());
+            return rc;
+        });
+    });
+}
+
 int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes,
                                void *stream) {
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;

@@ -140,6 +140,43 @@ CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// Keccak-f[1600] on ONE state by one wavefront, for rare serial paths inside register-tight kernels (the second SHAKE256
+// block of SampleInBall): lanes 0..24 own one 64-bit lane each, theta / pi / chi exchange through LDS.  It needs a dozen
+// registers instead of the ~120 of the lane-per-state form, at ~60 instructions and four barriers per round.
+// `ws` = 55 x 8 bytes of LDS: a[25] (the state, in and out), c[5], b[25].  Single-wave workgroups only.
+__device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
+    uint64_t *a = ws, *c = ws + 25, *b = ws + 30;
+    const bool on = lane < 25;
+    const int i = on ? lane : 0, x = i % 5, y = i / 5;
+    constexpr int rho_t[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    const int rho = rho_t[i], dst = y + 5 * ((2 * x + 3 * y) % 5);
+    __syncthreads();
+    uint64_t v = a[i];
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        if (lane < 5) c[lane] = a[lane] ^ a[lane + 5] ^ a[lane + 10] ^ a[lane + 15] ^ a[lane + 20];
+        __syncthreads();
+        if (on) {
+            const uint64_t c1 = c[(x + 1) % 5];
+            v ^= c[(x + 4) % 5] ^ ((c1 << 1) | (c1 >> 63));
+            if (rho) v = (v << rho) | (v >> (64 - rho));
+            b[dst] = v;
+        }
+        __syncthreads();
+        if (on) {
+            v = b[i] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+            if (lane == 0) {
+                const RcPair rc = rc_pair(r);
+                v ^= ((uint64_t)rc.hi << 32) | rc.lo;
+            }
+            a[i] = v;
+        }
+        __syncthreads();
+    }
+}
+#endif
+
 CIRCL_HD void keccak_zero(KeccakState &s) {
 #pragma unroll
     for (int i = 0; i < 25; i++) s.lo[i] = s.hi[i] = 0;

@@ -387,27 +387,24 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&out)[4], co
 #pragma unroll
     for (int r = 0; r < 4; r++) out[r] = dilithium::mont64(acc[r]);
 }
-// SampleInBall (sample.go:299-339) followed by the NTT: c-hat in layout L4, times 2^32 if SCALED (so that
-// mont32(x, c-hat) is the plain product) or plain (the product then carries 2^-32, like mac_rows' output).
-// `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
-// 8 sign bytes, then bytes b <= i pick the positions.  Lane p keeps bytes p, p+64 and p+128 of the
-// current 136-byte block in registers; one step is three compares + ballots, scalar bit tricks and
-// one v_readlane -- no memory traffic.  `blk` (>= 136 B of LDS) is only used if a second block is
-// needed (rare).
-template <int MODE, bool SCALED = true>
-__device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const uint8_t *st, uint8_t *blk, uint32_t *xch,
-                                                   const dilithium::LaneZetas &z, int lane) {
+// The positions j_t of SampleInBall the way the reference finds them (sample.go:299-339): step t = 0 .. tau-1 reads bytes
+// until one is <= i_t = 256 - tau + t.  Returns j_t in lane t.  One step is three compares + ballots, scalar bit tricks and
+// one v_readlane; a further SHAKE256 block is squeezed (keccak_f1600_coop: the wave works on the one state through LDS)
+// when the current one runs out.  This sequential form is the fallback of sample_in_ball: the first block practically
+// always holds tau acceptable bytes.  `kws` = 440 B of LDS for the sponge, `blk` >= 136 B for the squeezed block.
+template <int MODE>
+__device__ __noinline__ uint32_t sample_in_ball_positions_sequential(const uint8_t *st, uint8_t *blk, uint64_t *kws, int lane) {
     using P = DP<MODE>;
-    const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
     uint32_t b0 = st[lane], b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
     int off = 8;      // next unread byte of the block
     uint32_t jt = 0;  // lane t keeps j_t
-    KeccakState bs;
     bool have_state = false;
+#pragma unroll 1
     for (int t = 0; t < P::TAU; t++) {
         const uint32_t i = 256 - P::TAU + t;
         int found = -1;
         uint32_t jv = 0;
+#pragma unroll 1
         while (found < 0) {
             unsigned long long m0 = __ballot(b0 <= i), m1 = __ballot(b1 <= i), m2 = __ballot(b2 <= i);
             if (off >= 128) { m0 = 0; m1 = 0; m2 &= ~0ull << (off - 128); }
@@ -417,15 +414,14 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
             else if (m1) { const int p = __ffsll((long long)m1) - 1; found = 64 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b1, p); }
             else if (m2) { const int p = __ffsll((long long)m2) - 1; found = 128 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b2, p); }
             else {
-                // block exhausted (rare): squeeze the next one; every lane runs the same permutation
+                // block exhausted (rare): squeeze the next one
+                __syncthreads();
                 if (!have_state) {
-                    keccak_zero(bs);
-                    xor_words<0, 25>(bs, reinterpret_cast<const uint64_t *>(st));
+                    if (lane < 25) kws[lane] = reinterpret_cast<const uint64_t *>(st)[lane];
                     have_state = true;
                 }
-                keccak_f1600(bs);
-                __syncthreads();
-                if (lane == 0) store_words<0, 17>(reinterpret_cast<uint64_t *>(blk), bs);
+                keccak_f1600_coop(kws, lane);
+                if (lane < 17) reinterpret_cast<uint64_t *>(blk)[lane] = kws[lane];
                 __syncthreads();
                 b0 = blk[lane]; b1 = blk[64 + lane]; b2 = lane < 8 ? (uint32_t)blk[128 + lane] : 0xfffu;
                 off = 0;
@@ -433,6 +429,56 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
         }
         if (lane == t) jt = jv;
         off = found + 1;
+    }
+    return jt;
+}
+
+// SampleInBall (sample.go:299-339) followed by the NTT: c-hat in layout L4, times 2^32 if SCALED (so that
+// mont32(x, c-hat) is the plain product) or plain (the product then carries 2^-32, like mac_rows' output).
+// `st` = the 200-byte SHAKE256(c~) sponge state after its first permutation (global or LDS):
+// 8 sign bytes, then bytes b <= i pick the positions.  `blk` (>= 136 B of LDS) is scratch.
+//
+// Which bytes the reference's sequential scan accepts is found for the whole block at once: byte p (p >= 8) is taken at
+// step t_p = (number of bytes taken before p) iff b_p <= 256 - tau + t_p.  Starting from the bytes <= 256 - tau (taken at
+// any step) and re-evaluating every byte against its current rank converges from below to exactly that set in a few
+// ballot + popcount passes (a byte's rank only depends on earlier bytes, so the smallest position where the fixed point
+// and the sequential scan could differ cannot exist); the t-th taken byte is j_t.  ~60 wave-instructions instead of
+// tau dependent steps of ~15.  Fewer than tau taken bytes in the block (essentially never): the sequential fallback.
+// FORCE_SEQUENTIAL (a parity-test aid of circl_hip_mldsa_sample_in_ball) always takes the fallback.
+template <int MODE, bool SCALED = true, bool FORCE_SEQUENTIAL = false, bool WANT_HAT = true>
+__device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const uint8_t *st, uint8_t *blk, uint32_t *xch,
+                                                   const dilithium::LaneZetas &z, int lane) {
+    using P = DP<MODE>;
+    const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
+    uint32_t jt = 0;  // lane t keeps j_t
+    if constexpr (FORCE_SEQUENTIAL) {
+        jt = sample_in_ball_positions_sequential<MODE>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);
+    } else {
+        constexpr uint32_t T0 = 256 - P::TAU;
+        // positions lane (valid from 8 on), 64 + lane, 128 + lane (valid below 136): 0xfff never passes a test
+        const uint32_t b0 = lane >= 8 ? (uint32_t)st[lane] : 0xfffu, b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
+        const unsigned long long below = (1ull << lane) - 1;
+        unsigned long long m0 = __ballot(b0 <= T0), m1 = __ballot(b1 <= T0), m2 = __ballot(b2 <= T0);
+        uint32_t r0, r1, r2;
+        for (;;) {  // wave-uniform
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1);
+            r0 = (uint32_t)__popcll(m0 & below);
+            r1 = c0 + (uint32_t)__popcll(m1 & below);
+            r2 = c0 + c1 + (uint32_t)__popcll(m2 & below);
+            const unsigned long long n0 = __ballot(b0 <= T0 + r0), n1 = __ballot(b1 <= T0 + r1), n2 = __ballot(b2 <= T0 + r2);
+            if (n0 == m0 && n1 == m1 && n2 == m2) break;
+            m0 = n0; m1 = n1; m2 = n2;
+        }
+        if (__popcll(m0) + __popcll(m1) + __popcll(m2) >= P::TAU) {
+            __syncthreads();  // earlier users of blk are done
+            if (((m0 >> lane) & 1) && r0 < (uint32_t)P::TAU) blk[r0] = (uint8_t)b0;
+            if (((m1 >> lane) & 1) && r1 < (uint32_t)P::TAU) blk[r1] = (uint8_t)b1;
+            if (((m2 >> lane) & 1) && r2 < (uint32_t)P::TAU) blk[r2] = (uint8_t)b2;
+            __syncthreads();
+            jt = lane < P::TAU ? (uint32_t)blk[lane] : 0u;
+        } else {
+            jt = sample_in_ball_positions_sequential<MODE>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);  // (xch is free until the polynomial is built)
+        }
     }
     // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a later
     // step t2 with j_t2 == (its current position) moves it to i_t2
@@ -450,9 +496,46 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
     uint32_t c[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
+    if constexpr (!WANT_HAT) {  // the polynomial itself, layout L1 (circl_hip_mldsa_sample_in_ball)
+#pragma unroll
+        for (int r = 0; r < 4; r++) chat[r] = c[r];
+        return;
+    }
     dilithium::ntt(c, z, xch, lane);
 #pragma unroll
     for (int r = 0; r < 4; r++) chat[r] = SCALED ? dilithium::mont32(c[r], dilithium::R32SQ) : c[r];
+}
+
+// ---- primitive: PolyDeriveUniformBall (sample.go:299-339) of n challenge seeds, one polynomial per wavefront ----
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_sample_in_ball_kernel(const uint8_t *__restrict__ ctilde, uint32_t *__restrict__ polys, int sequential) {
+    using P = DP<MODE>;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t st[200];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    const int lane = threadIdx.x;
+    const uint8_t *seed = ctilde + (size_t)blockIdx.x * P::CT;
+    // SHAKE256(c~), first block, every lane the same sponge (a primitive for parity tests, not a hot path)
+    KeccakState s;
+    keccak_zero(s);
+    detail::static_for<0, P::CT / 8>([&](auto ic) {
+        constexpr int w = decltype(ic)::v;
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)seed[8 * w + b] << (8 * b);
+        s.lo[w] = (uint32_t)v;
+        s.hi[w] = (uint32_t)(v >> 32);
+    });
+    s.lo[P::CT / 8] ^= kDsShake;
+    s.hi[16] ^= 0x80000000u;
+    keccak_f1600(s);
+    if (lane == 0) store_words<0, 25>(reinterpret_cast<uint64_t *>(st), s);
+    __syncthreads();
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    uint32_t c[4];
+    if (sequential) sample_in_ball_hat<MODE, true, true, false>(c, st, blk, xch, z, lane);
+    else sample_in_ball_hat<MODE, true, false, false>(c, st, blk, xch, z, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) polys[(size_t)blockIdx.x * 256 + kyber::idx_l1(lane, r)] = c[r];
 }
 
 // ---- kernel V -----------------------------------------------------------------------------------

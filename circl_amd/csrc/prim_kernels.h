@@ -22,6 +22,17 @@ __global__ void __launch_bounds__(256) keccak_f1600_kernel(uint64_t *states, siz
     for (int w = 0; w < 25; w++) p[w] = ((uint64_t)s.hi[w] << 32) | s.lo[w];
 }
 
+// The wave-cooperative form of the permutation (keccak_f1600_coop: one state per wavefront, lanes 0..24 own a lane each),
+// which the ML-DSA kernels use on a rare serial path: one state per single-wave workgroup.
+__global__ void __launch_bounds__(64) keccak_f1600_coop_kernel(uint64_t *states) {
+    __shared__ uint64_t ws[55];
+    const int lane = threadIdx.x;
+    uint64_t *p = states + (size_t)blockIdx.x * 25;
+    if (lane < 25) ws[lane] = p[lane];
+    keccak_f1600_coop(ws, lane);
+    if (lane < 25) p[lane] = ws[lane];
+}
+
 // One polynomial per single-wave workgroup, int16[256] in standard order, in place.
 // Outputs are normalised to [0,q).  The inverse carries the reference's factor: Poly.InvNTT returns 2^16 times the
 // exact inverse (ntt.go:145-193; ntt_test.go:83-109 checks InvNTT(NTT(p)) = p * 2^16).

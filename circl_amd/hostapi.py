@@ -273,6 +273,21 @@ def keccak_f1600(states, rounds=24, device=0):
     return a
 
 
+def keccak_f1600_coop(states, device=0):
+    a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25).copy()
+    nat.check(nat.lib().circl_hip_keccak_f1600_coop(_p(a), len(a), device), "keccak_f1600_coop")
+    return a
+
+
+def mldsa_sample_in_ball(param, ctilde, sequential=False, device=0):
+    """c~ rows -> (n, 256) uint32 challenge polynomials (PolyDeriveUniformBall)"""
+    ct = {44: 32, 65: 48, 87: 64, 2: 32, 3: 32, 5: 32}[param]
+    c = _u8(ctilde, ct)
+    out = np.empty((len(c), 256), np.uint32)
+    nat.check(nat.lib().circl_hip_mldsa_sample_in_ball(param, _p(c), _p(out), len(c), int(sequential), device), "mldsa_sample_in_ball")
+    return out
+
+
 def kyber_ntt(polys, inverse=False, device=0):
     a = np.ascontiguousarray(polys, dtype=np.int16).reshape(-1, 256).copy()
     nat.check(nat.lib().circl_hip_kyber_ntt(_p(a), len(a), int(inverse), device), "kyber_ntt")

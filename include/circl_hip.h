@@ -285,6 +285,14 @@ int circl_hip_mldsa_sign_dev(int param, const uint8_t *d_sk, const uint8_t *d_ms
  *                          (internal/sha3 State.Write/Read).
  */
 int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device);
+/* the same 24-round permutation through the wave-cooperative form (one state per wavefront, lanes exchange through LDS)
+ * that the ML-DSA kernels use on a rare serial path; exported so that the parity tests can pin it */
+int circl_hip_keccak_f1600_coop(uint64_t *states, size_t n, int device);
+/* sign/mldsa/mldsa65/internal/sample.go:299-339 PolyDeriveUniformBall: n challenge seeds c~ (32 / 48 / 64 bytes for
+ * ML-DSA-44 / 65 / 87, 32 for the round-3 modes) -> n polynomials uint32[256] with tau coefficients in {1, q-1}.
+ * sequential != 0 runs the reference-order byte scan (otherwise the fallback of the block-parallel form). */
+int circl_hip_mldsa_sample_in_ball(int param, const uint8_t *ctilde, uint32_t *polys, size_t n, int sequential,
+                                   int device);
 int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device);
 int circl_hip_kyber_mulhat(int16_t *out, const int16_t *a, const int16_t *b, size_t n, int device);
 int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device);

@@ -577,4 +577,10 @@ void orc_dilithium_ntt(uint32_t p[256]) { if (!dz_ready) dz_init(); dpoly_ntt((d
 void orc_dilithium_invntt(uint32_t p[256]) { if (!dz_ready) dz_init(); dpoly_invntt((dpoly *)p); }
 void orc_dilithium_normalize(uint32_t p[256]) { dpoly_normalize((dpoly *)p); }
 void orc_dilithium_uniform(uint32_t p[256], const uint8_t seed[32], uint16_t nonce) { dpoly_uniform((dpoly *)p, seed, nonce); }
+int orc_dilithium_ball(int param, uint32_t p[256], const uint8_t *ctilde) {
+    dparams P;
+    if (dil_params(param, &P)) return -1;
+    dpoly_ball((dpoly *)p, ctilde, &P);
+    return 0;
+}
 const uint32_t *orc_dilithium_zetas(void) { if (!dz_ready) dz_init(); return DZETAS; }

@@ -82,6 +82,7 @@ void orc_dilithium_ntt(uint32_t p[256]);
 void orc_dilithium_invntt(uint32_t p[256]);
 void orc_dilithium_normalize(uint32_t p[256]);
 void orc_dilithium_uniform(uint32_t p[256], const uint8_t seed[32], uint16_t nonce);
+int orc_dilithium_ball(int param, uint32_t p[256], const uint8_t *ctilde);
 const uint32_t *orc_dilithium_zetas(void);
 
 #ifdef __cplusplus

@@ -338,5 +338,12 @@ def dilithium_uniform(seed, nonce):
     lib().orc_dilithium_uniform(_p(r), _p(s), C.c_uint16(nonce)); return r
 
 
+def dilithium_ball(param, ctilde):
+    """PolyDeriveUniformBall(c~) -> uint32[256] (sample.go:299-339)"""
+    c = _u8(bytes(ctilde)); r = np.zeros(256, np.uint32)
+    assert lib().orc_dilithium_ball(param, _p(r), _p(c)) == 0
+    return r
+
+
 def dilithium_zetas():
     return np.ctypeslib.as_array(lib().orc_dilithium_zetas(), shape=(256,)).copy()

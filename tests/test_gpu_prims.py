@@ -163,3 +163,35 @@ def test_abi_error_codes():
     assert L.circl_hip_mlkem_encaps(768, p(a), p(b), p(c), p(b), p(s1), 0, 0) == nat.OK
     assert L.circl_hip_xof(100, 0x1f, 24, p(a), p(np.zeros(2, np.uint64)), p(c), 32, 1, 0) == nat.EPARAM   # not a sponge rate
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_keccak_coop_equals_lane_per_state_form():
+    # the wave-cooperative permutation (a rare serial path of the ML-DSA kernels) against the oracle and the main form
+    from circl_amd import hostapi
+    from oracle import orc
+    rng = np.random.default_rng(41)
+    st = rng.integers(0, 2**63, (300, 25), dtype=np.uint64) * 2 + rng.integers(0, 2, (300, 25), dtype=np.uint64)
+    st[0] = 0
+    a = hostapi.keccak_f1600_coop(st)
+    assert (a == hostapi.keccak_f1600(st)).all()
+    assert (a[:20] == np.stack([orc.keccak_f1600(s) for s in st[:20]])).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+def test_sample_in_ball_both_forms_vs_oracle(param):
+    # sample.go:299-339 PolyDeriveUniformBall: the block-parallel form the kernels use, the reference-order scan that is its
+    # fallback, and the oracle agree on random challenge seeds
+    from circl_amd import hostapi
+    from oracle import orc
+    rng = np.random.default_rng(param)
+    ct = {44: 32, 65: 48, 87: 64, 3: 32}[param]
+    seeds = rng.integers(0, 256, (4000, ct), dtype=np.uint8)
+    fast = hostapi.mldsa_sample_in_ball(param, seeds)
+    slow = hostapi.mldsa_sample_in_ball(param, seeds, sequential=True)
+    assert (fast == slow).all()
+    tau = {44: 39, 65: 49, 87: 60, 3: 49}[param]
+    assert ((fast != 0).sum(axis=1) == tau).all()
+    for i in range(0, 4000, 40):
+        assert (fast[i] == orc.dilithium_ball(param, seeds[i])).all()
