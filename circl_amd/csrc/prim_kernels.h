@@ -111,18 +111,32 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
     keccak_zero(s);
     size_t pos = 0;
     bool padded = false;
+    // Words that lie wholly inside the message come from aligned 64-bit loads (two of them and a funnel shift when the
+    // message starts at an odd address: the second one reaches at most 7 bytes past the message, inside the 16 bytes of
+    // slack every staged blob carries); only the words around the message's end are assembled byte by byte.  (The first
+    // version assembled every word from 8 checked byte loads: ~1.5 k instructions per block next to the 2.2 k of a
+    // 12-round permutation.)
+    const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(p) & 7);
+    const uint64_t *pa = reinterpret_cast<const uint64_t *>(p - mis);
     while (!padded) {
         // xor one block: message bytes, then the ds byte, then 0x80 at the end of the final block
 #pragma unroll
         for (int w = 0; w < 21; w++) {
             if (w < rate_words) {
+                const size_t k0 = pos + 8 * (size_t)w;
                 uint64_t v = 0;
-                for (int b = 0; b < 8; b++) {
-                    const size_t k = pos + 8 * (size_t)w + b;
-                    uint64_t byte = 0;
-                    if (k < inlen) byte = p[k];
-                    else if (k == inlen) byte = ds;
-                    v |= byte << (8 * b);
+                if (k0 + 8 <= inlen) {
+                    const uint64_t lo = pa[k0 >> 3];
+                    v = lo;
+                    if (mis) v = (lo >> (8 * mis)) | (pa[(k0 >> 3) + 1] << (64 - 8 * mis));
+                } else {
+                    for (int b = 0; b < 8; b++) {
+                        const size_t k = k0 + b;
+                        uint64_t byte = 0;
+                        if (k < inlen) byte = p[k];
+                        else if (k == inlen) byte = ds;
+                        v |= byte << (8 * b);
+                    }
                 }
                 s.lo[w] ^= (uint32_t)v;
                 s.hi[w] ^= (uint32_t)(v >> 32);
