@@ -62,7 +62,7 @@ template <int MODE> struct DG {
     static constexpr int LDS_XCH = 1024;
     static constexpr int LDS_MISC = 256;               // ball block bytes, positions
     // verify / keygen kernels: sampled matrix in global scratch
-    static constexpr int FIFO_STRIDE = 80;             // 16 dword slots + pad (bank spread)
+    static constexpr int FIFO_STRIDE = 80;             // bytes per lane the FIFO area is sized with (16 dword slots used, slot-major)
     static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;  // phase A; afterwards the staged z || hint bytes
     static constexpr int LDS_HINT1 = K * 32;           // one item's hint bitmap
     static constexpr int LDS_V_TOTAL = LDS_FIFO + LDS_XCH + LDS_HINT1 + LDS_MISC;
@@ -299,6 +299,11 @@ __device__ __forceinline__ void load_poly24(uint32_t (&c)[4], const uint32_t *ro
     c[3] = w2 >> 8;
 }
 
+// The 16-slot FIFOs of a wavefront are stored slot-major, fifo[slot][lane]: the acceptance rate is 0.999, so all 64 lanes
+// write the same slot at the same time, and with a row per lane (80-byte stride: 8 distinct banks) every write was an
+// 8-way bank conflict (SQ_LDS_BANK_CONFLICT 6.3e8 cycles per 2^18 verifications); slot-major, the lanes of a write hit
+// consecutive banks.  A lane's FIFO is fifo[slot * kFifoLanes], with `fifo` already offset by its lane.
+constexpr int kFifoLanes = 64;
 template <bool TAIL, bool NOSTORE = false, bool PACK24 = false>
 __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_t *fifo, uint32_t *row, int &cnt, int &flushed) {
     bool live = true;
@@ -310,11 +315,12 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
             uint32_t v;
             if constexpr (sh <= 8) v = (word(w) >> sh) & 0x7fffffu;
             else v = alignbit(word(w + 1), word(w), sh) & 0x7fffffu;
-            fifo[cnt & 15] = v;
+            fifo[(cnt & 15) * kFifoLanes] = v;
             cnt = min(cnt + (v < Q ? 1 : 0), 256);
             if constexpr (c % 4 == 3) {
                 if (cnt - flushed >= 4) {  // at most 7 pending here, so one flush per check suffices
-                    const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & 15));
+                    const uint32_t *fr = fifo + (flushed & 15) * kFifoLanes;
+                    const uint4 d = make_uint4(fr[0], fr[kFifoLanes], fr[2 * kFifoLanes], fr[3 * kFifoLanes]);
                     if constexpr (NOSTORE) { if (d.x == 0x7fffffffu) row[0] = d.y; }  // profiling aid: keep the LDS read, drop the store
                     else if constexpr (PACK24) {
                         uint32_t w[3];
@@ -345,7 +351,7 @@ __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *ro
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
     s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
-    uint32_t *fifo = reinterpret_cast<uint32_t *>(lds_fifo + lane * G::FIFO_STRIDE);
+    uint32_t *fifo = reinterpret_cast<uint32_t *>(lds_fifo) + lane;  // slot-major (parse23_block_fifo)
     uint32_t *row = rows + lane * kPackedRowDwords;  // 24-bit packed rows (pack24)
     int cnt = on ? 0 : 256, flushed = cnt;
     // 256 coefficients need at least 5 blocks of 56 candidates; the acceptance rate is q / 2^23 = 0.999

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256) sign_expand_a_kernel(const uint8_t *__res
     // accepted coefficients leave through a per-lane 16-slot LDS FIFO, four at a time (16-byte stores), with the
     // branch-free acceptance of the verify kernel's ExpandA (parse23_block_fifo)
     __shared__ __attribute__((aligned(16))) uint8_t fifo_lds[256 * DG<MODE>::FIFO_STRIDE];
-    uint32_t *fifo = reinterpret_cast<uint32_t *>(fifo_lds + threadIdx.x * DG<MODE>::FIFO_STRIDE);
+    // slot-major per wavefront (parse23_block_fifo): wave w owns 16 x 64 dwords
+    uint32_t *fifo = reinterpret_cast<uint32_t *>(fifo_lds) + (threadIdx.x >> 6) * (16 * kFifoLanes) + (threadIdx.x & 63);
     int cnt = on ? 0 : 256, flushed = cnt;
 #pragma unroll 1
     for (int blk = 0; blk < 5; blk++) {

@@ -1,22 +1,38 @@
 #!/bin/bash
-# usage: tools/pmc_any.sh <tag> <command...> : per-kernel instruction mix and cycles (two PMC passes)
+# SQ counters of every kernel matching $1 while running "$2..." under rocprofv3 --pmc (own passes, kernel-trace only)
+#   tools/pmc_any.sh mldsa_verify_kernel python tools/verify_only.py 65 18
 set -u
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
-OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -o a -- "$@" > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/b -o b -- "$@" > $OUT/b.log 2>&1
-cd $ROOT; python - <<PY
-import csv,collections,glob
-d=collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("$OUT/*/*counter_collection.csv"):
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; PAT=$1; shift
+OUT=$ROOT/gpurun_out/pmc_any; rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
+           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  ( cd "$ROOT" && cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -o g$i -- "$@" > "$OUT/g$i.log" 2>&1 )
+done
+cd "$ROOT" && python - "$PAT" <<'PY'
+import csv, glob, collections, sys
+pat = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_any/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k=r["Kernel_Name"].split("(")[0].replace("void ","").replace("circl::","")
-        d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k,v in sorted(d.items()):
-    m={c: sorted(x)[len(x)//2] for c,x in v.items()}
-    cyc=m.get("GRBM_GUI_ACTIVE",0)/8
-    if cyc < 1e5: continue
-    valu=m.get("SQ_INSTS_VALU",0)/1024
-    print(f"{k[:58]:58s} n={len(v['SQ_INSTS_VALU']):3d} cyc/XCD {cyc:.3e} VALU/SIMD {valu:.3e} cyc/VALU {cyc/max(valu,1):5.2f} SALU {m.get('SQ_INSTS_SALU',0)/1024:.2e} LDS {m.get('SQ_INSTS_LDS',0)/1024:.2e} VMEM {(m.get('SQ_INSTS_VMEM_RD',0)+m.get('SQ_INSTS_VMEM_WR',0))/1024:.2e} occ(waves/SIMD) {m.get('SQ_WAVE_CYCLES',0)*4/1024/max(cyc,1):.2f} wait_inst {m.get('SQ_WAIT_INST_ANY',0)/max(m.get('SQ_WAVE_CYCLES',1),1):.2f} lds_conf {m.get('SQ_LDS_BANK_CONFLICT',0)/max(m.get('SQ_ACTIVE_INST_LDS',1),1):.2f}")
+        k = r["Kernel_Name"]
+        if pat not in k: continue
+        agg[k.split("(")[0][:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_any/g1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]: dur[r["Kernel_Name"].split("(")[0][:80]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for k, d in agg.items():
+    print(k, " median duration %.3f ms" % (sorted(dur[k])[len(dur[k]) // 2] / 1e6 if dur.get(k) else -1))
+    med = {c: sorted(v)[len(v) // 2] for c, v in d.items()}
+    for c, v in sorted(med.items()): print(f"   {c:26s} {v:.4e}")
+    if "SQ_INSTS_VALU" in med and dur.get(k):
+        t = sorted(dur[k])[len(dur[k]) // 2] * 1e-9
+        print(f"   -> VALU wave-insts/s {med['SQ_INSTS_VALU'] / t:.3e}; cycles per VALU inst per SIMD at 2.4 GHz: {1024 * 2.4e9 * t / med['SQ_INSTS_VALU']:.2f}")
+    if "SQ_WAVE_CYCLES" in med and "SQ_BUSY_CYCLES" in med:
+        print(f"   -> resident waves per SIMD ~ {4 * med['SQ_WAVE_CYCLES'] / (med.get('GRBM_GUI_ACTIVE', 0) / 8 * 1024 + 1e-9):.2f} (4 x WAVE_CYCLES / (GUI_ACTIVE per XCD x 1024 SIMDs))")
 PY
