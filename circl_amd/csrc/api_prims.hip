@@ -121,10 +121,15 @@ int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const ui
 
 }  // extern "C"
 
-// KangarooTwelve draft -10 (xof/k12/k12.go), n independent computations.  Tree hashing maps onto the batched
-// sponge service as two or three TurboSHAKE128 batches: every 8192-byte leaf of every long message (D = 0x0B,
-// k12.go:136-160), then the final nodes of the long messages (D = 0x06, :141-142, :383-395) and the short
-// messages (|M| + |C| + |length_encode(|C|)| <= 8192, D = 0x07, :60-66).
+// KangarooTwelve draft -10 (xof/k12/k12.go), n independent computations.  Tree hashing maps onto the batched sponge service
+// as two or three TurboSHAKE128 batches: every 8192-byte leaf of every long message (D = 0x0B, k12.go:136-160), then the
+// final nodes of the long messages (D = 0x06, :141-142, :383-395) and the short messages (|M| + |C| + |length_encode(|C|)|
+// <= 8192, D = 0x07, :60-66).
+// The message bytes are not re-arranged on the host: the whole message blob goes to the device once and the leaves are
+// hashed in place as (offset, length) ranges of it -- with an empty context the trailing length_encode(0) byte is a
+// suffix the kernel appends, so short messages and last leaves are hashed in place too; only what does not lie inside a
+// message as it stands -- ranges that run into a non-empty C || length_encode(|C|), and the long messages' final nodes
+// (first chunk || chaining values) -- is assembled into a small side blob (at most ~8 KB + 32 B per leaf per message).
 namespace {
 void k12_length_encode(std::vector<uint8_t> &v, uint64_t x) {  // k12.go:333-342
     uint8_t be[8];
@@ -134,6 +139,16 @@ void k12_length_encode(std::vector<uint8_t> &v, uint64_t x) {  // k12.go:333-342
     v.insert(v.end(), be + nz, be + 8);
     v.push_back((uint8_t)(8 - nz));
 }
+
+// TurboSHAKE128 (12 rounds) over `cnt` ranges (off, len) of the device buffer `d_buf` -> outlen bytes each at d_out
+int k12_ranges(hipStream_t st, const uint8_t *d_buf, const uint64_t *d_off, const uint64_t *d_len, uint32_t ds, uint8_t *d_out, size_t outlen, size_t cnt) {
+    if (cnt == 0) return CIRCL_HIP_OK;
+    // suffix = 0x00 = length_encode(0): ranges flagged with one suffix byte end a message whose context is empty
+    hipLaunchKernelGGL(circl::prim::sponge_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, 168 / 8, ds, 12, d_buf, (size_t)0, d_off, d_out,
+                       outlen, cnt, d_len, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
 }  // namespace
 
 extern "C" int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *out,
@@ -141,67 +156,136 @@ extern "C" int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, c
     constexpr size_t CHUNK = 8192;
     if (outlen == 0) return CIRCL_HIP_EPARAM;
     if (n == 0) return CIRCL_HIP_OK;
-    // S_i = M_i || C_i || length_encode(|C_i|), first chunks and leaves gathered separately
-    std::vector<uint8_t> leaves, tail;
-    std::vector<uint64_t> leaf_off{0};
-    std::vector<std::vector<uint8_t>> head(n);   // S_0 of each message (whole S for short ones)
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    const int dev = device < 0 ? 0 : device;  // one tree per message: the batch is not split across devices
+    if (dev >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(dev));
+    const size_t base = (size_t)msg_off[0], msg_bytes = (size_t)(msg_off[n] - msg_off[0]);
+    // ---- pass 0 (host): where every leaf lives ----
+    // device buffer = [message blob (msg_bytes)] [side blob]; offsets below are relative to its start
+    std::vector<uint8_t> side, tail;
+    std::vector<uint64_t> leaf_off, leaf_len;       // every leaf of every long message, in message order
     std::vector<size_t> nleaves(n, 0);
+    std::vector<uint64_t> head_off(n), head_len(n); // S_0 of each message (whole S for short ones)
+    auto side_at = [&]() { return (uint64_t)(msg_bytes + 16 + side.size()); };  // (16 bytes of slack between the two parts)
     for (size_t i = 0; i < n; i++) {
+        const size_t mo = (size_t)msg_off[i] - base, ml = (size_t)(msg_off[i + 1] - msg_off[i]);
         const uint8_t *m = msg_blob + msg_off[i];
-        const size_t ml = (size_t)(msg_off[i + 1] - msg_off[i]);
         const uint8_t *c = ctx_blob ? ctx_blob + ctx_off[i] : nullptr;
         const size_t cl = ctx_blob ? (size_t)(ctx_off[i + 1] - ctx_off[i]) : 0;
         tail.clear();
         if (cl) tail.insert(tail.end(), c, c + cl);
         k12_length_encode(tail, cl);
         const size_t total = ml + tail.size();
-        auto byte_range = [&](size_t lo, size_t hi, std::vector<uint8_t> &dst) {  // S[lo, hi)
-            if (lo < ml) dst.insert(dst.end(), m + lo, m + std::min(hi, ml));
-            if (hi > ml) dst.insert(dst.end(), tail.begin() + (std::max(lo, ml) - ml), tail.begin() + (hi - ml));
+        // S[lo, hi): a range of the message as it lies in the blob, or assembled into the side blob when it reaches the tail
+        auto place = [&](size_t lo, size_t hi, uint64_t &o, uint64_t &l) {
+            l = hi - lo;
+            if (hi <= ml) { o = mo + lo; return; }
+            if (cl == 0 && lo <= ml) {  // the tail is the one byte length_encode(0) = 00: hashed in place with a suffix byte
+                o = mo + lo;
+                l = (uint64_t)(ml - lo) | (uint64_t(1) << 56);
+                return;
+            }
+            while (side.size() & 7) side.push_back(0);  // 8-byte aligned ranges: the sponge kernel's fast path
+            o = side_at();
+            if (lo < ml) side.insert(side.end(), m + lo, m + ml);
+            side.insert(side.end(), tail.begin() + (std::max(lo, ml) - ml), tail.begin() + (hi - ml));
         };
-        byte_range(0, std::min(total, CHUNK), head[i]);
-        for (size_t off = CHUNK; off < total; off += CHUNK) {
-            byte_range(off, std::min(total, off + CHUNK), leaves);
-            leaf_off.push_back(leaves.size());
+        place(0, std::min(total, CHUNK), head_off[i], head_len[i]);
+        for (size_t lo = CHUNK; lo < total; lo += CHUNK) {
+            uint64_t o, l;
+            place(lo, std::min(total, lo + CHUNK), o, l);
+            leaf_off.push_back(o);
+            leaf_len.push_back(l);
             nleaves[i]++;
         }
     }
-    const size_t total_leaves = leaf_off.size() - 1;
+    const size_t total_leaves = leaf_off.size();
+    size_t n_long = 0;
+    for (size_t i = 0; i < n; i++) n_long += nleaves[i] != 0;
+    // ---- device staging: one slot holds everything ----
+    const size_t side0 = msg_bytes + 16;
+    const size_t final_bytes = n_long * (CHUNK + 64) + 32 * total_leaves + 64;  // upper bound of the long messages' final nodes
+    const size_t o_side = side0, o_final = up256(o_side + side.size() + 16), o_desc = up256(o_final + final_bytes + 16);
+    const size_t desc_cnt = std::max(total_leaves, n);
+    const size_t o_out = up256(o_desc + 2 * 8 * desc_cnt), o_cv = up256(o_out + n * outlen), need = up256(o_cv + 32 * total_leaves + 16);
+    Slot *slot = slot_acquire(dev);
+    if (!slot) return CIRCL_HIP_EHIP;
+    struct Release {
+        Slot *s; hipStream_t st;
+        ~Release() { if (st) (void)hipStreamSynchronize(st); slot_release(s); }
+    } rel{slot, nullptr};
+    if (int rc = slot->ensure(need, 0, 0)) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t st; ~StreamGuard() { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } } sg{st};
+    uint8_t *d = slot->d;
+    if (msg_bytes) HIP_TRY(hipMemcpyAsync(d, msg_blob + base, msg_bytes, hipMemcpyHostToDevice, st));
+    if (!side.empty()) HIP_TRY(hipMemcpyAsync(d + o_side, side.data(), side.size(), hipMemcpyHostToDevice, st));
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(d + o_desc), *d_len = d_off + desc_cnt;
+    // ---- pass 1: chaining values of all leaves ----
     std::vector<uint8_t> cv(32 * total_leaves);
     if (total_leaves) {
-        leaves.resize(leaves.size() + 16);
-        const int rc = circl_hip_xof(168, 0x0B, 12, leaves.data(), leaf_off.data(), cv.data(), 32, total_leaves, device);
-        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_off, leaf_off.data(), 8 * total_leaves, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_len, leaf_len.data(), 8 * total_leaves, hipMemcpyHostToDevice, st));
+        if (int rc = k12_ranges(st, d, d_off, d_len, 0x0B, d + o_cv, 32, total_leaves)) return rc;
+        HIP_TRY(hipMemcpyAsync(cv.data(), d + o_cv, cv.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
-    // final nodes: long and short messages go out as two batches (different domain bytes)
+    // ---- pass 2: final nodes.  Short messages hash their S as it lies (D = 0x07); long ones S_0 || 03 0^7 || CVs ||
+    // length_encode(leaves) || FF FF (D = 0x06), assembled on the host around the first chunk ----
+    std::vector<uint64_t> f_off, f_len;
+    std::vector<size_t> f_idx;
+    std::vector<uint8_t> res(n * outlen);
     for (int pass = 0; pass < 2; pass++) {
-        std::vector<uint8_t> blob;
-        std::vector<uint64_t> off{0};
-        std::vector<size_t> idx;
+        std::vector<uint8_t> fin;
+        f_off.clear(); f_len.clear(); f_idx.clear();
         size_t cvpos = 0;
         for (size_t i = 0; i < n; i++) {
             const bool is_long = nleaves[i] != 0;
             if (is_long == (pass == 0)) {
-                blob.insert(blob.end(), head[i].begin(), head[i].end());
-                if (is_long) {
+                if (!is_long) {
+                    f_off.push_back(head_off[i]);
+                    f_len.push_back(head_len[i]);
+                } else {
+                    while (fin.size() & 7) fin.push_back(0);
+                    f_off.push_back(o_final + fin.size());
+                    const size_t start = fin.size();
+                    const uint8_t *m = msg_blob + msg_off[i];  // a long message's first chunk lies wholly inside M or reaches the tail
+                    const size_t ml = (size_t)(msg_off[i + 1] - msg_off[i]);
+                    if (ml >= CHUNK) fin.insert(fin.end(), m, m + CHUNK);
+                    else {  // |M| < 8192 < |S|: rebuild S_0 from M and the tail
+                        tail.clear();
+                        const size_t cl = ctx_blob ? (size_t)(ctx_off[i + 1] - ctx_off[i]) : 0;
+                        if (cl) tail.insert(tail.end(), ctx_blob + ctx_off[i], ctx_blob + ctx_off[i] + cl);
+                        k12_length_encode(tail, cl);
+                        fin.insert(fin.end(), m, m + ml);
+                        fin.insert(fin.end(), tail.begin(), tail.begin() + (CHUNK - ml));
+                    }
                     static const uint8_t sep[8] = {3, 0, 0, 0, 0, 0, 0, 0};
-                    blob.insert(blob.end(), sep, sep + 8);
-                    blob.insert(blob.end(), cv.begin() + 32 * cvpos, cv.begin() + 32 * (cvpos + nleaves[i]));
-                    k12_length_encode(blob, nleaves[i]);
-                    blob.push_back(0xff);
-                    blob.push_back(0xff);
+                    fin.insert(fin.end(), sep, sep + 8);
+                    fin.insert(fin.end(), cv.begin() + 32 * cvpos, cv.begin() + 32 * (cvpos + nleaves[i]));
+                    k12_length_encode(fin, nleaves[i]);
+                    fin.push_back(0xff);
+                    fin.push_back(0xff);
+                    f_len.push_back(fin.size() - start);
                 }
-                off.push_back(blob.size());
-                idx.push_back(i);
+                f_idx.push_back(i);
             }
             cvpos += nleaves[i];
         }
-        if (idx.empty()) continue;
-        blob.resize(blob.size() + 16);
-        std::vector<uint8_t> res(outlen * idx.size());
-        const int rc = circl_hip_xof(168, pass == 0 ? 0x06 : 0x07, 12, blob.data(), off.data(), res.data(), outlen, idx.size(), device);
-        if (rc) return rc;
-        for (size_t k = 0; k < idx.size(); k++) std::memcpy(out + idx[k] * outlen, &res[k * outlen], outlen);
+        if (f_idx.empty()) continue;
+        const size_t cnt = f_idx.size();
+        if (!fin.empty()) {
+            if (fin.size() > final_bytes) { g_err = "k12: final-node staging overflow"; return CIRCL_HIP_EHIP; }
+            HIP_TRY(hipMemcpyAsync(d + o_final, fin.data(), fin.size(), hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(hipMemcpyAsync(d_off, f_off.data(), 8 * cnt, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_len, f_len.data(), 8 * cnt, hipMemcpyHostToDevice, st));
+        if (int rc = k12_ranges(st, d, d_off, d_len, pass == 0 ? 0x06 : 0x07, d + o_out, outlen, cnt)) return rc;
+        HIP_TRY(hipMemcpyAsync(res.data(), d + o_out, cnt * outlen, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t k = 0; k < cnt; k++) std::memcpy(out + f_idx[k] * outlen, &res[k * outlen], outlen);
     }
     return CIRCL_HIP_OK;
 }

@@ -99,12 +99,19 @@ __global__ void __launch_bounds__(64) dilithium_ntt_kernel(uint32_t *polys, int 
 // (internal/sha3 State.Write / Read).  rate_words in {9, 17, 21}.
 // in_off == nullptr: equal-length messages of `inlen` bytes; otherwise message i is in[in_off[i] .. in_off[i+1]).
 // first_round = 0 for Keccak-f[1600], 12 for the 12-round TurboSHAKE permutation (shake.go:60-90).
+// Message i is in[in_off[i] .. in_off[i + 1]) (ragged, n + 1 offsets), or in[in_off[i] .. in_off[i] + in_len[i]) when in_len is
+// given (ranges of one resident buffer: the KangarooTwelve leaves, which lie inside their messages), or in[i * inlen_eq ..)
+// when there are no offsets (equal lengths).
 __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds, int first_round, const uint8_t *in, size_t inlen_eq,
-                                                     const uint64_t *in_off, uint8_t *out, size_t outlen, size_t n) {
+                                                     const uint64_t *in_off, uint8_t *out, size_t outlen, size_t n,
+                                                     const uint64_t *in_len = nullptr, uint64_t suffix = 0) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint8_t *p = in_off ? in + in_off[i] : in + i * inlen_eq;
-    const size_t inlen = in_off ? (size_t)(in_off[i + 1] - in_off[i]) : inlen_eq;
+    // in_len[i]: bits 0..55 the range's length, bits 56..63 how many bytes of `suffix` (little-endian) follow it in the
+    // message (KangarooTwelve's length_encode(|C|) after a message that is hashed where it lies)
+    const size_t body = in_len ? (size_t)(in_len[i] & 0x00ffffffffffffffull) : in_off ? (size_t)(in_off[i + 1] - in_off[i]) : inlen_eq;
+    const size_t inlen = body + (in_len ? (size_t)(in_len[i] >> 56) : 0);
     uint8_t *o = out + i * outlen;
     const size_t rate = (size_t)rate_words * 8;
     KeccakState s;
@@ -125,7 +132,7 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
             if (w < rate_words) {
                 const size_t k0 = pos + 8 * (size_t)w;
                 uint64_t v = 0;
-                if (k0 + 8 <= inlen) {
+                if (k0 + 8 <= body) {
                     const uint64_t lo = pa[k0 >> 3];
                     v = lo;
                     if (mis) v = (lo >> (8 * mis)) | (pa[(k0 >> 3) + 1] << (64 - 8 * mis));
@@ -133,7 +140,8 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
                     for (int b = 0; b < 8; b++) {
                         const size_t k = k0 + b;
                         uint64_t byte = 0;
-                        if (k < inlen) byte = p[k];
+                        if (k < body) byte = p[k];
+                        else if (k < inlen) byte = (suffix >> (8 * (k - body))) & 0xff;
                         else if (k == inlen) byte = ds;
                         v |= byte << (8 * b);
                     }

@@ -34,6 +34,13 @@ while time.time() < t_end:
     assert (cts == ct1).all() and (sss == ss1).all(), ("encaps shared", p, n)
     ssd, _ = hostapi.mlkem_decaps_shared(p, dk[:1], cts)
     assert (ssd == sss).all(), ("decaps shared", p, n)
+    nk = int(rng.integers(1, min(n, 50) + 1))
+    idx = rng.integers(0, nk, n).astype(np.uint32)
+    ctk, ssk, stk = hostapi.mlkem_encaps_keyed(p, ek[:nk], idx, m)
+    ctg, ssg, _ = orc.mlkem_encaps(p, ek[idx], m)
+    assert (ctk == ctg).all() and (ssk == ssg).all() and not stk.any(), ("encaps keyed", p, n, nk)
+    ssdk, stdk = hostapi.mlkem_decaps_keyed(p, dk[:nk], idx, ctk)
+    assert (ssdk == ssk).all() and not stdk.any(), ("decaps keyed", p, n, nk)
 
     d = int(rng.choice([44, 65, 87, 2, 3, 5]))
     n = int(rng.choice([1, 3, 15, 16, 17, 100, 513, 1025, 3000, 9000]))
@@ -50,4 +57,8 @@ while time.time() < t_end:
     sg = hostapi.mldsa_sign_shared(d, sk[:1], msgs)
     assert (sg == orc.mldsa_sign(d, np.tile(sk[:1], (n, 1)), msgs)).all(), ("sign shared", d, n)
     assert hostapi.mldsa_verify_shared(d, pk[:1], sg, msgs).all(), ("verify shared", d, n)
+    nk = int(rng.integers(1, min(n, 30) + 1))
+    idx = rng.integers(0, nk, n).astype(np.uint32)
+    okk = hostapi.mldsa_verify_keyed(d, pk[:nk], idx, sig, msgs)
+    assert okk.tolist() == orc.mldsa_verify(d, pk[idx], sig, msgs).tolist(), ("verify keyed", d, n, nk)
 print("stress ok:", it, "iterations")
