@@ -26,7 +26,10 @@ SYMBOLS = [
     "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_shared", "circl_hip_mldsa_verify_shared_dev", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
     "circl_hip_keccak_f1600", "circl_hip_keccak_f1600_coop", "circl_hip_mldsa_sample_in_ball", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_dilithium_ntt",
-    "circl_hip_shake", "circl_hip_xof", "circl_hip_k12", "circl_hip_alloc_host", "circl_hip_free_host",
+    "circl_hip_shake", "circl_hip_xof", "circl_hip_k12", "circl_hip_x25519", "circl_hip_x25519_dev",
+    "circl_hip_hybrid_seed_size", "circl_hip_hybrid_eseed_size", "circl_hip_hybrid_pk_size", "circl_hip_hybrid_sk_size", "circl_hip_hybrid_ct_size",
+    "circl_hip_hybrid_ss_size", "circl_hip_hybrid_workspace_size", "circl_hip_hybrid_keygen", "circl_hip_hybrid_encaps", "circl_hip_hybrid_decaps",
+    "circl_hip_hybrid_keygen_dev", "circl_hip_hybrid_encaps_dev", "circl_hip_hybrid_decaps_dev", "circl_hip_alloc_host", "circl_hip_free_host",
     "circl_hip_profile_enable", "circl_hip_profile_read",
 ]
 
@@ -131,6 +134,19 @@ def lib():
         L.circl_hip_shake.argtypes = [i, i, vp, sz, vp, sz, sz, i]
         L.circl_hip_xof.argtypes = [i, i, i, vp, vp, vp, sz, sz, i]
         L.circl_hip_k12.argtypes = [vp, vp, vp, vp, vp, sz, sz, i]
+        L.circl_hip_x25519.argtypes = [vp, vp, vp, vp, sz, i]
+        L.circl_hip_x25519_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        for f in ("seed", "eseed", "pk", "sk", "ct", "ss"):
+            fn = getattr(L, "circl_hip_hybrid_%s_size" % f)
+            fn.restype, fn.argtypes = sz, [i]
+        L.circl_hip_hybrid_workspace_size.restype = sz
+        L.circl_hip_hybrid_workspace_size.argtypes = [i, sz]
+        L.circl_hip_hybrid_keygen.argtypes = [i, vp, vp, vp, sz, i]
+        L.circl_hip_hybrid_encaps.argtypes = [i, vp, vp, vp, vp, vp, sz, i]
+        L.circl_hip_hybrid_decaps.argtypes = [i, vp, vp, vp, vp, sz, i]
+        L.circl_hip_hybrid_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_hybrid_encaps_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_hybrid_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_profile_enable.argtypes = [i]
         L.circl_hip_profile_read.argtypes = [i, vp, vp]
         _lib = L

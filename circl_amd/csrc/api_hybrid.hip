@@ -1,0 +1,235 @@
+// api_hybrid.hip -- the hybrid KEMs that carry ML-KEM-768 today, composed on the device behind the C ABI
+// (include/circl_hip.h):
+//   CIRCL_HIP_HYBRID_XWING            kem/xwing/xwing.go      (X25519 + ML-KEM-768, SHA3-256 combiner)
+//   CIRCL_HIP_HYBRID_X25519MLKEM768   kem/hybrid/hybrid.go    (ct_M || ct_X, ss_M || ss_X; X25519 as a KEM: xkem.go)
+// A call is a handful of launches per chunk over HBM-resident arrays: strided splits of the packed keys / ciphertexts,
+// seed expansion (SHAKE256, lane = item), the ML-KEM-768 batch kernels, two X25519 ladders per item (lane = item), the
+// combiner, strided joins.  Nothing is computed on the host.
+#include "host_common.h"
+#include "hybrid_kernels.h"
+
+using namespace circl::host;
+namespace hk = circl::hybridk;
+
+namespace {
+constexpr size_t EK = 1184, DK = 2400, CTM = 1088;
+
+struct Sizes { size_t seed, eseed, pk, sk, ct, ss; };
+bool sizes_of(int scheme, Sizes &s) {
+    if (scheme == CIRCL_HIP_HYBRID_XWING) { s = {32, 64, EK + 32, 32, CTM + 32, 32}; return true; }
+    if (scheme == CIRCL_HIP_HYBRID_X25519MLKEM768) { s = {64, 32, EK + 32, DK + 32, CTM + 32, 64}; return true; }
+    return false;
+}
+
+// temporaries of one call, carved from the caller's workspace in front of the ML-KEM workspace
+struct Carve {
+    uint8_t *p;
+    uint8_t *take(size_t bytes) {
+        uint8_t *r = p;
+        p += (bytes + 255) & ~size_t(255);
+        return r;
+    }
+};
+size_t tmp_bytes(size_t n) {  // upper bound over the three operations: ek, dk, ctm + a dozen 32/64-byte rows per item
+    auto r = [](size_t b) { return (b + 255) & ~size_t(255); };
+    return r(n * EK) + r(n * DK) + r(n * CTM) + 10 * r(n * 64) + r(n);
+}
+
+int copy_rows(hipStream_t st, void *dst, size_t dst_row, const void *src, size_t src_row, size_t width, size_t n) {
+    const size_t total = n * (width / 4);
+    if (total == 0) return CIRCL_HIP_OK;
+    hipLaunchKernelGGL(hk::rows_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(dst), dst_row / 4,
+                       static_cast<const uint32_t *>(src), src_row / 4, (unsigned)(width / 4), n);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+int zero_failed(hipStream_t st, void *dst, size_t row, const uint8_t *status, size_t n) {
+    const size_t total = n * (row / 4);
+    hipLaunchKernelGGL(hk::rows_zero_failed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(dst), row / 4,
+                       (unsigned)(row / 4), status, n);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+#define TRY(expr)                          \
+    do {                                   \
+        const int rc_ = (expr);            \
+        if (rc_ != CIRCL_HIP_OK) return rc_; \
+    } while (0)
+inline const uint32_t *w(const uint8_t *p) { return reinterpret_cast<const uint32_t *>(p); }
+inline uint32_t *w(uint8_t *p) { return reinterpret_cast<uint32_t *>(p); }
+inline dim3 g256(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+bool args_ok(const void *a, const void *b, const void *c, const void *d, const void *ws) {
+    return !((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d) |
+              reinterpret_cast<uintptr_t>(ws)) & 15);
+}
+}  // namespace
+
+extern "C" {
+
+size_t circl_hip_hybrid_seed_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.seed : 0; }
+size_t circl_hip_hybrid_eseed_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.eseed : 0; }
+size_t circl_hip_hybrid_pk_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.pk : 0; }
+size_t circl_hip_hybrid_sk_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.sk : 0; }
+size_t circl_hip_hybrid_ct_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.ct : 0; }
+size_t circl_hip_hybrid_ss_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.ss : 0; }
+
+size_t circl_hip_hybrid_workspace_size(int scheme, size_t n) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return 0;
+    return tmp_bytes(n) + circl_hip_mlkem_workspace_size(768, n);
+}
+
+int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_seed, d_pk, d_sk, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carve c{static_cast<uint8_t *>(d_ws)};
+    uint8_t *seedm = c.take(n * 64), *skx = c.take(n * 32), *pkx = c.take(n * 32), *ek = c.take(n * EK), *dk = c.take(n * DK);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
+    if (scheme == CIRCL_HIP_HYBRID_XWING)
+        hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
+    else
+        hipLaunchKernelGGL((hk::hybrid_expand_kernel<8, 8>), g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
+    HIP_TRY(hipGetLastError());
+    TRY(circl_hip_mlkem_keygen_dev(768, seedm, ek, dk, n, kws, kws_bytes, st));
+    TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, n, st));
+    TRY(copy_rows(st, d_pk, s.pk, ek, EK, EK, n));
+    TRY(copy_rows(st, d_pk + EK, s.pk, pkx, 32, 32, n));
+    if (scheme == CIRCL_HIP_HYBRID_XWING) {
+        TRY(copy_rows(st, d_sk, 32, d_seed, 32, 32, n));  // the packed private key is the seed (xwing.go:156-163)
+    } else {
+        TRY(copy_rows(st, d_sk, s.sk, dk, DK, DK, n));
+        TRY(copy_rows(st, d_sk + DK, s.sk, skx, 32, 32, n));
+    }
+    return CIRCL_HIP_OK;
+}
+
+int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *d_eseed, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                void *d_ws, size_t ws_bytes, void *stream) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_pk, d_eseed, d_ct, d_ss, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carve c{static_cast<uint8_t *>(d_ws)};
+    uint8_t *ek = c.take(n * EK), *pkx = c.take(n * 32), *m = c.take(n * 32), *ekx = c.take(n * 32), *ctm = c.take(n * CTM), *ssm = c.take(n * 32),
+            *ctx = c.take(n * 32), *ssx = c.take(n * 32), *okx = c.take(n);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
+    TRY(copy_rows(st, ek, EK, d_pk, s.pk, EK, n));
+    TRY(copy_rows(st, pkx, 32, d_pk + EK, s.pk, 32, n));
+    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // xwing.go:247-248: seedm = seed[:32], ekx = seed[32:]
+        TRY(copy_rows(st, m, 32, d_eseed, 64, 32, n));
+        TRY(copy_rows(st, ekx, 32, d_eseed + 32, 64, 32, n));
+    } else {
+        hipLaunchKernelGGL((hk::hybrid_expand_kernel<4, 4>), g256(n), dim3(256), 0, st, w(d_eseed), w(m), w(ekx), n);
+        HIP_TRY(hipGetLastError());
+    }
+    TRY(circl_hip_mlkem_encaps_dev(768, ek, m, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    TRY(circl_hip_x25519_dev(ekx, nullptr, ctx, nullptr, n, st));
+    TRY(circl_hip_x25519_dev(ekx, pkx, ssx, okx, n, st));
+    TRY(copy_rows(st, d_ct, s.ct, ctm, CTM, CTM, n));
+    TRY(copy_rows(st, d_ct + CTM, s.ct, ctx, 32, 32, n));
+    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // a low-order pk_X is not an error in X-Wing (xwing.go:251-254)
+        hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), d_status, w(d_ss), n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
+        HIP_TRY(hipGetLastError());
+        TRY(copy_rows(st, d_ss, 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + 32, 64, ssx, 32, 32, n));
+        TRY(zero_failed(st, d_ss, 64, d_status, n));
+    }
+    TRY(zero_failed(st, d_ct, s.ct, d_status, n));
+    return CIRCL_HIP_OK;
+}
+
+int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws,
+                                size_t ws_bytes, void *stream) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_sk, d_ct, d_ss, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carve c{static_cast<uint8_t *>(d_ws)};
+    uint8_t *dk = c.take(n * DK), *ek = c.take(n * EK), *skx = c.take(n * 32), *ctm = c.take(n * CTM), *ctx = c.take(n * 32), *ssm = c.take(n * 32),
+            *ssx = c.take(n * 32), *pkx = c.take(n * 32), *seedm = c.take(n * 64), *okx = c.take(n);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
+    TRY(copy_rows(st, ctm, CTM, d_ct, s.ct, CTM, n));
+    TRY(copy_rows(st, ctx, 32, d_ct + CTM, s.ct, 32, n));
+    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // the private key is the seed: re-derive (xwing.go:165-185 Unpack = deriveKeyPair)
+        hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_sk), w(seedm), w(skx), n);
+        HIP_TRY(hipGetLastError());
+        TRY(circl_hip_mlkem_keygen_dev(768, seedm, ek, dk, n, kws, kws_bytes, st));
+        TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, n, st));
+    } else {
+        TRY(copy_rows(st, dk, DK, d_sk, s.sk, DK, n));
+        TRY(copy_rows(st, skx, 32, d_sk + DK, s.sk, 32, n));
+    }
+    TRY(circl_hip_mlkem_decaps_dev(768, dk, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
+    if (scheme == CIRCL_HIP_HYBRID_XWING) {
+        hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), static_cast<const uint8_t *>(nullptr),
+                           w(d_ss), n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
+        HIP_TRY(hipGetLastError());
+        TRY(copy_rows(st, d_ss, 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + 32, 64, ssx, 32, 32, n));
+        TRY(zero_failed(st, d_ss, 64, d_status, n));
+    }
+    return CIRCL_HIP_OK;
+}
+
+// ---- host-buffer forms on the staging pipeline ----
+static PipeOpts hybrid_opts() {
+    PipeOpts o;
+    o.chunk_items = host_chunk_items(size_t(1) << 15);
+    o.wipe_device = true;
+    return o;
+}
+
+int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int device) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed + lo * s.seed, s.seed, true}}, {}, {{pk + lo * s.pk, s.pk}, {sk + lo * s.sk, s.sk, true}},
+                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(),
+                            [&](Chunk &c) { return circl_hip_hybrid_keygen_dev(scheme, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
+
+int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}}, {},
+                            {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                                return circl_hip_hybrid_encaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+
+int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
+    Sizes s;
+    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}}, {},
+                            {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                                return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+
+}  // extern "C"

@@ -338,3 +338,49 @@ def k12(msgs, outlen, ctxs=None, device=0):
         rc = nat.lib().circl_hip_k12(_p(mb), _p(mo), _p(cb), _p(co), _p(out), outlen, n, device)
     nat.check(rc, "k12")
     return out
+
+
+def x25519(scalar, point=None, device=0):
+    """Batch X25519 (dh/x25519): Shared(scalar_i, point_i), or KeyGen(scalar_i) when point is None.
+    Returns (out (n, 32), ok (n,)): ok = 0 where the reference's Shared reports a low-order public key."""
+    scalar = _u8(scalar, 32)
+    n = scalar.shape[0]
+    out = np.empty((n, 32), np.uint8)
+    ok = np.empty(n, np.uint8)
+    pt = None if point is None else _u8(point, 32)
+    nat.check(nat.lib().circl_hip_x25519(_p(scalar), None if pt is None else _p(pt), _p(out), _p(ok), n, device), "x25519")
+    return out, ok
+
+
+XWING, X25519MLKEM768 = 1, 2
+HYBRID_SIZES = {XWING: dict(seed=32, eseed=64, pk=1216, sk=32, ct=1120, ss=32), X25519MLKEM768: dict(seed=64, eseed=32, pk=1216, sk=2432, ct=1120, ss=64)}
+
+
+def hybrid_keygen(scheme, seeds, device=0):
+    """X-Wing DeriveKeyPairPacked / X25519MLKEM768 DeriveKeyPair for every seed -> (pk, sk)"""
+    S = HYBRID_SIZES[scheme]
+    seeds = _u8(seeds, S["seed"])
+    n = seeds.shape[0]
+    pk, sk = np.empty((n, S["pk"]), np.uint8), np.empty((n, S["sk"]), np.uint8)
+    nat.check(nat.lib().circl_hip_hybrid_keygen(scheme, _p(seeds), _p(pk), _p(sk), n, device), "hybrid keygen")
+    return pk, sk
+
+
+def hybrid_encaps(scheme, pk, eseeds, device=0):
+    """deterministic encapsulation -> (ct, ss, status)"""
+    S = HYBRID_SIZES[scheme]
+    pk, eseeds = _u8(pk, S["pk"]), _u8(eseeds, S["eseed"])
+    n = pk.shape[0]
+    ct, ss, st = np.empty((n, S["ct"]), np.uint8), np.empty((n, S["ss"]), np.uint8), np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_hybrid_encaps(scheme, _p(pk), _p(eseeds), _p(ct), _p(ss), _p(st), n, device), "hybrid encaps")
+    return ct, ss, st
+
+
+def hybrid_decaps(scheme, sk, ct, device=0):
+    """-> (ss, status)"""
+    S = HYBRID_SIZES[scheme]
+    sk, ct = _u8(sk, S["sk"]), _u8(ct, S["ct"])
+    n = sk.shape[0]
+    ss, st = np.empty((n, S["ss"]), np.uint8), np.empty(n, np.uint8)
+    nat.check(nat.lib().circl_hip_hybrid_decaps(scheme, _p(sk), _p(ct), _p(ss), _p(st), n, device), "hybrid decaps")
+    return ss, st

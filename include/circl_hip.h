@@ -310,6 +310,45 @@ int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const ui
 int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                   const uint64_t *ctx_off, uint8_t *out, size_t outlen, size_t n, int device);
 
+/* ---- X25519 (the Diffie-Hellman half of X25519MLKEM768 and X-Wing) -------
+ * Replaces dh/x25519: Shared(shared, secret, public) (key.go:41-47) with point != NULL, KeyGen(public, secret)
+ * (key.go:34-36) with point == NULL (base point u = 9).  scalar, point, out are n rows of 32 bytes; the scalar is
+ * clamped and bit 255 of the point is ignored, as the reference does.  ok[i] = 0 where Shared returns false (the point,
+ * reduced mod 2^255 - 19, is one of the five low-order u-coordinates of curve.go:71-96; out[i] is then all zero),
+ * 1 otherwise; ok may be NULL.  One Montgomery ladder per lane; device pointers 4-byte aligned. */
+int circl_hip_x25519(const uint8_t *scalar, const uint8_t *point, uint8_t *out, uint8_t *ok, size_t n, int device);
+int circl_hip_x25519_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out, uint8_t *d_ok, size_t n, void *stream);
+
+/* ---- hybrid KEMs around ML-KEM-768, composed on the device -------------------------------
+ * scheme = CIRCL_HIP_HYBRID_XWING: kem/xwing/xwing.go -- DeriveKeyPairPacked (:98-144), EncapsulateTo (:223-265),
+ *   DecapsulateTo (:270-299), combiner (:53-71).  seed 32, eseed 64 (seedm || ekx), pk 1216 (ek || pk_X), sk 32 (the
+ *   seed), ct 1120 (ct_M || ct_X), ss 32.  status[i] = 1 (kem.ErrPubKey) when the ML-KEM half of pk fails the
+ *   encapsulation-key check (xwing.go:301-311); a low-order X25519 point is not an error (xwing.go:251-254).
+ * scheme = CIRCL_HIP_HYBRID_X25519MLKEM768: kem/hybrid/hybrid.go (:236-323) with X25519 as a KEM (xkem.go:112-196).
+ *   seed 64, eseed 32, pk 1216 (ek || pk_X), sk 2432 (dk || sk_X), ct 1120, ss 64 (ss_M || ss_X).  status[i] = 1
+ *   (kem.ErrPubKey) for a non-canonical ek or a low-order X25519 point, 2 (kem.ErrPrivKey) for a private key failing its
+ *   hash check; the item's outputs are then zero (the reference returns nil, err).
+ * The deterministic forms only (EncapsulateDeterministically / DeriveKeyPair): randomness stays with the caller.
+ * status may be NULL on the host forms.  The _dev forms need circl_hip_hybrid_workspace_size(scheme, n) bytes, 16-byte
+ * aligned arrays, and a non-NULL d_status. */
+#define CIRCL_HIP_HYBRID_XWING 1
+#define CIRCL_HIP_HYBRID_X25519MLKEM768 2
+size_t circl_hip_hybrid_seed_size(int scheme);
+size_t circl_hip_hybrid_eseed_size(int scheme);
+size_t circl_hip_hybrid_pk_size(int scheme);
+size_t circl_hip_hybrid_sk_size(int scheme);
+size_t circl_hip_hybrid_ct_size(int scheme);
+size_t circl_hip_hybrid_ss_size(int scheme);
+size_t circl_hip_hybrid_workspace_size(int scheme, size_t n);
+int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int device);
+int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device);
+int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device);
+int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes, void *stream);
+int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *d_eseed, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
+                                void *d_ws, size_t ws_bytes, void *stream);
+int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws,
+                                size_t ws_bytes, void *stream);
+
 /* ---- kernel-level profiling (used by bench.py for the roofline figures) --------------------
  * While enabled, every *_dev call brackets each kernel it enqueues with HIP events recorded on
  * the caller's stream.  circl_hip_profile_read synchronises the pending events, returns the
@@ -325,6 +364,7 @@ int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_
 #define CIRCL_HIP_KERNEL_MLDSA_SIGN 8
 #define CIRCL_HIP_KERNEL_MLKEM_KEYTABLE 9  /* key tables: H(ek) + A^T per table entry */
 #define CIRCL_HIP_KERNEL_MLDSA_KEYTABLE 10 /* key tables: tr + ExpandA per table entry */
+#define CIRCL_HIP_KERNEL_X25519 11         /* X25519 ladder                            */
 #define CIRCL_HIP_KERNEL_COUNT 12
 int circl_hip_profile_enable(int on);
 int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);

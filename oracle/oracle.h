@@ -47,6 +47,11 @@ int orc_mlkem_encaps_batch(int param, const uint8_t *ek, const uint8_t *m, uint8
 int orc_mlkem_decaps_batch(int param, const uint8_t *dk, const uint8_t *ct, uint8_t *ss,
                            uint8_t *status, size_t n, int threads);
 
+/* ---- X25519 (dh/x25519), the DH half of the hybrid KEMs; see x25519.c ---- */
+int orc_x25519_shared(uint8_t shared[32], const uint8_t secret[32], const uint8_t public_[32]); /* 1 = valid public key */
+void orc_x25519_keygen(uint8_t public_[32], const uint8_t secret[32]);
+int orc_x25519_batch(const uint8_t *scalar, const uint8_t *point /* NULL = base point */, uint8_t *out, uint8_t *ok, size_t n);
+
 /* Kyber ring primitives */
 void orc_kyber_ntt(int16_t p[256]);
 void orc_kyber_invntt(int16_t p[256]);

@@ -21,7 +21,7 @@ DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 46
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("keccak.c", "kyber.c", "dilithium.c", "batch.c", "keccak.h", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("keccak.c", "kyber.c", "dilithium.c", "batch.c", "x25519.c", "keccak.h", "oracle.h")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -347,3 +347,16 @@ def dilithium_ball(param, ctilde):
 
 def dilithium_zetas():
     return np.ctypeslib.as_array(lib().orc_dilithium_zetas(), shape=(256,)).copy()
+
+
+# ---------------- X25519 (dh/x25519) ----------------
+def x25519(scalar, point=None):
+    """Batch X25519: scalar (n,32), point (n,32) or None for the base point (KeyGen).  Returns (out (n,32), ok (n,))
+    with ok = 0 where the reference's Shared reports a low-order public key."""
+    scalar = _u8(scalar).reshape(-1, 32)
+    n = scalar.shape[0]
+    out = np.zeros((n, 32), np.uint8)
+    ok = np.zeros(n, np.uint8)
+    pt = None if point is None else _u8(point).reshape(n, 32)
+    lib().orc_x25519_batch(_p(scalar), None if pt is None else _p(pt), _p(out), _p(ok), C.c_size_t(n))
+    return out, ok

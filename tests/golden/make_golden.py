@@ -23,6 +23,8 @@ reference's own tests read):
                        pke/kyber/internal/common/sample_test.go:23-138 (CBD3, CBD2, uniform; seed[i]=i),
                        sign/mldsa/mldsa65/internal/sample_test.go:12-63 (uniform, nonce 30000),
                        simd/keccakf1600/f1600x_test.go:9-19 (Keccak-f[1600] of the zero state).
+  x25519.json.gz       dh/x25519/testdata/{rfc7748_kat_test, rfc7748_times_test, wycheproof_kat}.json.gz, the vectors of
+                       dh/x25519/key_test.go:24-46 (TestRFC7748Kat), :53-84 (TestRFC7748Times), :114-150 (TestWycheproof).
 All binary fields are hex strings.
 """
 import re
@@ -174,8 +176,18 @@ def fixed():
     dump("fixed_vectors.json.gz", out)
 
 
+def x25519():
+    d = "dh/x25519/testdata/"
+    dump("x25519.json.gz", {
+        "rfc7748_kat": load_gz(d + "rfc7748_kat_test.json.gz"),
+        "rfc7748_times": load_gz(d + "rfc7748_times_test.json.gz"),
+        "wycheproof": [{k: v[k] for k in ("tcId", "public", "private", "shared", "result")} for v in load_gz(d + "wycheproof_kat.json.gz")],
+    })
+
+
 if __name__ == "__main__":
     fixed()
+    x25519()
     mlkem()
     mldsa()
     wycheproof()

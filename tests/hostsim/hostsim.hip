@@ -9,6 +9,7 @@
 
 #include "dilithium_dev.h"
 #include "kyber_dev.h"
+#include "x25519_dev.h"
 
 using namespace circl;
 
@@ -114,5 +115,59 @@ void hs_dil_decompose(uint32_t a, int gamma2_is_88, uint32_t *a0, uint32_t *a1) 
     else dilithium::decompose<261888>(a, *a0, *a1);
 }
 int hs_dil_exceeds(uint32_t x, uint32_t bound) { return dilithium::exceeds(x, bound) ? 1 : 0; }
+
+
+// ---- x25519_dev.h: limb arithmetic on raw (possibly un-carried) limbs, and the whole scalar multiplication ----
+void hs_fe_mul(uint32_t *r, const uint32_t *f, const uint32_t *g) {
+    x25519::Fe a, b;
+    for (int i = 0; i < 10; i++) { a.v[i] = f[i]; b.v[i] = g[i]; }
+    const x25519::Fe c = x25519::fe_mul(a, b);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_sqr(uint32_t *r, const uint32_t *f) {
+    x25519::Fe a;
+    for (int i = 0; i < 10; i++) a.v[i] = f[i];
+    const x25519::Fe c = x25519::fe_sqr(a);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_mul_small(uint32_t *r, const uint32_t *f, uint32_t k) {
+    x25519::Fe a;
+    for (int i = 0; i < 10; i++) a.v[i] = f[i];
+    const x25519::Fe c = x25519::fe_mul_small(a, k);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_sub(uint32_t *r, const uint32_t *f, const uint32_t *g) {
+    x25519::Fe a, b;
+    for (int i = 0; i < 10; i++) { a.v[i] = f[i]; b.v[i] = g[i]; }
+    const x25519::Fe c = x25519::fe_sub(a, b);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_inv(uint32_t *r, const uint32_t *f) {
+    x25519::Fe a;
+    for (int i = 0; i < 10; i++) a.v[i] = f[i];
+    const x25519::Fe c = x25519::fe_inv(a);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_from_words(uint32_t *r, const uint32_t *w) {
+    const x25519::Fe c = x25519::fe_from_words(w);
+    for (int i = 0; i < 10; i++) r[i] = c.v[i];
+}
+void hs_fe_to_words(uint32_t *w, const uint32_t *f) {
+    x25519::Fe a;
+    for (int i = 0; i < 10; i++) a.v[i] = f[i];
+    x25519::fe_to_words(w, a);
+}
+uint32_t hs_x25519_valid_public(const uint32_t *u) {
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++) w[i] = u[i];
+    w[7] &= 0x7fffffffu;
+    return x25519::valid_public(w);
+}
+void hs_x25519(uint32_t *out, const uint32_t *k, const uint32_t *u, int base, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (base) x25519::scalar_mult<true>(out + 8 * i, k + 8 * i, k + 8 * i);
+        else x25519::scalar_mult<false>(out + 8 * i, k + 8 * i, u + 8 * i);
+    }
+}
 
 }  // extern "C"

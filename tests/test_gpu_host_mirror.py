@@ -21,7 +21,7 @@ def _build_xwing():
     out = os.path.join(ROOT, "build", "xwing_test")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "xwing_test.cpp"),
-                           "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-lcrypto", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
+                           "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 
@@ -57,7 +57,7 @@ def _build_hybrid():
     out = os.path.join(ROOT, "build", "hybrid_test")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "hybrid_test.cpp"),
-                           "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-lcrypto", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
+                           "-L", os.path.join(ROOT, "circl_amd"), "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     return out
 

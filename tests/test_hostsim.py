@@ -19,7 +19,7 @@ Q, DQ = 3329, 8380417
 def hs():
     out = os.path.join(ROOT, "build", "libhostsim.so")
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.hip")
-    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h")]
+    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "x25519_dev.h")]
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
@@ -202,3 +202,82 @@ def test_decompose_use_hint_laws(hs, g88):
         up = hs.hs_dil_use_hint(a, 1, g88)
         assert up == ((a1.value + 1) % m if r0 > 0 else (a1.value - 1) % m)
     assert hs.hs_dil_exceeds(5, 6) == 0 and hs.hs_dil_exceeds(DQ - 6, 6) == 1 and hs.hs_dil_exceeds(6, 6) == 1
+
+
+# ---- x25519_dev.h (the GPU X25519 of SURVEY.md 8(f) row f2): the very source of the kernel, on the host ----
+P25519 = 2**255 - 19
+_POS = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+# the documented bounds: "carried" limbs, and the largest limbs a subtraction of two carried values can produce
+_CAR = [(1 << 26) + (1 << 18) if i % 2 == 0 else (1 << 25) + (1 << 18) for i in range(10)]
+_SUBMAX = [c + 2 * ((1 << 26) - 1 if i % 2 == 0 else (1 << 25) - 1) for i, c in enumerate(_CAR)]
+
+
+def _val(limbs):
+    return sum(int(x) << p for x, p in zip(limbs, _POS))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_x25519_field_arithmetic_at_its_bounds(hs):
+    # math/fp25519/fp_test.go's mul / sqr / sub / inv checks against exact integers, with every limb at the bound the
+    # ladder can reach (un-carried differences): the 64-bit column sums must not overflow
+    rng = np.random.default_rng(0)
+    r = np.zeros(10, np.uint32)
+    top = np.array(_SUBMAX, dtype=np.uint32)
+    for it in range(3000):
+        f = top - rng.integers(0, 4, 10).astype(np.uint32) if it % 2 == 0 else np.array([rng.integers(0, m + 1) for m in _SUBMAX], dtype=np.uint32)
+        g = top.copy() if it < 10 else np.array([rng.integers(0, m + 1) for m in _SUBMAX], dtype=np.uint32)
+        hs.hs_fe_mul(_ptr(r), _ptr(f), _ptr(g))
+        assert _val(r) % P25519 == _val(f) * _val(g) % P25519 and all(r[i] <= _CAR[i] for i in range(10))
+        hs.hs_fe_sqr(_ptr(r), _ptr(f))
+        assert _val(r) % P25519 == _val(f) ** 2 % P25519 and all(r[i] <= _CAR[i] for i in range(10))
+        hs.hs_fe_mul_small(_ptr(r), _ptr(f), 121666)
+        assert _val(r) % P25519 == _val(f) * 121666 % P25519 and all(r[i] <= _CAR[i] for i in range(10))
+        a = np.array([rng.integers(0, m + 1) for m in _CAR], dtype=np.uint32)
+        b = np.array(_CAR, dtype=np.uint32) if it < 10 else np.array([rng.integers(0, m + 1) for m in _CAR], dtype=np.uint32)
+        hs.hs_fe_sub(_ptr(r), _ptr(a), _ptr(b))
+        assert _val(r) % P25519 == (_val(a) - _val(b)) % P25519 and all(r[i] <= _SUBMAX[i] for i in range(10))
+
+
+def test_x25519_codec_and_inverse(hs):
+    rng = np.random.default_rng(1)
+    r, w = np.zeros(10, np.uint32), np.zeros(8, np.uint32)
+    for it in range(300):
+        a = np.array(_CAR, dtype=np.uint32) - np.uint32(it) if it < 40 else np.array([rng.integers(0, m + 1) for m in _CAR], dtype=np.uint32)
+        hs.hs_fe_to_words(_ptr(w), _ptr(a))
+        assert int.from_bytes(w.tobytes(), "little") == _val(a) % P25519
+        hs.hs_fe_inv(_ptr(r), _ptr(a))
+        assert _val(r) * _val(a) % P25519 == (1 if _val(a) % P25519 else 0)
+    for v in (0, 1, 18, 19, P25519 - 1, P25519, P25519 + 1, P25519 + 18, 2**255 - 1):
+        ww = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint32).copy()
+        hs.hs_fe_from_words(_ptr(r), _ptr(ww))
+        assert _val(r) == v
+        hs.hs_fe_to_words(_ptr(w), _ptr(r))
+        assert int.from_bytes(w.tobytes(), "little") == v % P25519
+
+
+def test_x25519_ladder_host_instantiation(hs):
+    # dh/x25519/key_test.go: RFC 7748 KATs, Wycheproof, TestBase -- on the device source compiled for the host
+    G = load_golden("x25519.json.gz")
+    hs.hs_x25519_valid_public.restype = C.c_uint32
+    o = np.zeros(32, np.uint8)
+    for v in G["rfc7748_kat"]:
+        k, u = (np.frombuffer(bytes.fromhex(v[t]), np.uint8).copy() for t in ("scalar", "input"))
+        hs.hs_x25519(_ptr(o), _ptr(k), _ptr(u), 0, C.c_size_t(1))
+        assert o.tobytes().hex() == v["output"]
+    for v in G["wycheproof"]:
+        k, u = (np.frombuffer(bytes.fromhex(v[t]), np.uint8).copy() for t in ("private", "public"))
+        hs.hs_x25519(_ptr(o), _ptr(k), _ptr(u), 0, C.c_size_t(1))
+        assert o.tobytes().hex() == v["shared"], v["tcId"]
+        assert hs.hs_x25519_valid_public(_ptr(u)) == orc.x25519(k, u)[1][0]
+    rng = np.random.default_rng(2)
+    n = 64
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    u = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    out = np.zeros((n, 32), np.uint8)
+    hs.hs_x25519(_ptr(out), _ptr(k), _ptr(u), 0, C.c_size_t(n))
+    assert (out == orc.x25519(k, u)[0]).all()
+    hs.hs_x25519(_ptr(out), _ptr(k), _ptr(u), 1, C.c_size_t(n))
+    assert (out == orc.x25519(k)[0]).all()
