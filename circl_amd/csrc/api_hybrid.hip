@@ -132,8 +132,7 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
         HIP_TRY(hipGetLastError());
     }
     TRY(circl_hip_mlkem_encaps_dev(768, ek, m, ctm, ssm, d_status, n, kws, kws_bytes, st));
-    TRY(circl_hip_x25519_dev(ekx, nullptr, ctx, nullptr, n, st));
-    TRY(circl_hip_x25519_dev(ekx, pkx, ssx, okx, n, st));
+    TRY(x25519_pair_dev(ekx, pkx, ctx, ssx, okx, n, st));  // ct_X = X25519(ekx, 9), ss_X = X25519(ekx, pk_X)
     TRY(copy_rows(st, d_ct, s.ct, ctm, CTM, CTM, n));
     TRY(copy_rows(st, d_ct + CTM, s.ct, ctx, 32, 32, n));
     if (scheme == CIRCL_HIP_HYBRID_XWING) {  // a low-order pk_X is not an error in X-Wing (xwing.go:251-254)
@@ -169,13 +168,13 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
         hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_sk), w(seedm), w(skx), n);
         HIP_TRY(hipGetLastError());
         TRY(circl_hip_mlkem_keygen_dev(768, seedm, ek, dk, n, kws, kws_bytes, st));
-        TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, n, st));
+        TRY(x25519_pair_dev(skx, ctx, pkx, ssx, okx, n, st));  // sk.xpk = X25519(sk_X, 9), ss_X = X25519(sk_X, ct_X)
     } else {
         TRY(copy_rows(st, dk, DK, d_sk, s.sk, DK, n));
         TRY(copy_rows(st, skx, 32, d_sk + DK, s.sk, 32, n));
+        TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
     }
     TRY(circl_hip_mlkem_decaps_dev(768, dk, ctm, ssm, d_status, n, kws, kws_bytes, st));
-    TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
     if (scheme == CIRCL_HIP_HYBRID_XWING) {
         hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), static_cast<const uint8_t *>(nullptr),
                            w(d_ss), n);
@@ -193,7 +192,8 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
 // ---- host-buffer forms on the staging pipeline ----
 static PipeOpts hybrid_opts() {
     PipeOpts o;
-    o.chunk_items = host_chunk_items(size_t(1) << 15);
+    o.chunk_items = host_chunk_items(size_t(1) << 16);  // 2 x 1024 ladder waves per launch: a ladder is 0.9 ms however few items
+    o.depth = 4;
     o.wipe_device = true;
     return o;
 }

@@ -5,6 +5,23 @@
 
 using namespace circl::host;
 
+namespace circl {
+namespace host {
+// internal (api_hybrid.hip): out_base[i] = X25519(scalar_i, 9) and out_shared[i] = X25519(scalar_i, point_i) in one launch
+int x25519_pair_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out_base, uint8_t *d_out_shared, uint8_t *d_ok, size_t n,
+                    hipStream_t st) {
+    if (n == 0) return CIRCL_HIP_OK;
+    const unsigned nb = (unsigned)((n + 63) / 64);
+    ProfScope ps(CIRCL_HIP_KERNEL_X25519, st);
+    hipLaunchKernelGGL(circl::x25519::x25519_pair_kernel, dim3(2 * nb), dim3(64), 0, st, reinterpret_cast<const uint32_t *>(d_scalar),
+                       reinterpret_cast<const uint32_t *>(d_point), reinterpret_cast<uint32_t *>(d_out_base), reinterpret_cast<uint32_t *>(d_out_shared), d_ok,
+                       n, nb);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+}  // namespace host
+}  // namespace circl
+
 extern "C" {
 
 int circl_hip_x25519_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out, uint8_t *d_ok, size_t n, void *stream) {

@@ -159,5 +159,10 @@ size_t host_chunk_items(size_t dflt);  // CIRCL_HIP_HOST_CHUNK overrides the def
 // Contiguous split of [0,n) over the visible devices, one host thread each (pinned to the device's NUMA node), no collective.
 int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn);
 
+
+// api_x25519.hip: both X25519 ladders of a hybrid KEM operation (base point and peer point, same scalar) in one launch
+int x25519_pair_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out_base, uint8_t *d_out_shared, uint8_t *d_ok, size_t n,
+                    hipStream_t st);
+
 }  // namespace host
 }  // namespace circl

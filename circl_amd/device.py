@@ -13,7 +13,7 @@ KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 
 DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 4627),  # pk, sk, sig
              2: (1312, 2528, 2420), 3: (1952, 4000, 3293), 5: (2592, 4864, 4595)}
 KERNELS = {"mlkem_hash": 0, "mlkem_encrypt": 1, "mlkem_decrypt": 2, "mlkem_keygen": 3, "mlkem_finish": 4,
-           "mldsa_hash": 5, "mldsa_verify": 6, "mldsa_keygen": 7, "mldsa_sign": 8, "mlkem_keytable": 9, "mldsa_keytable": 10}
+           "mldsa_hash": 5, "mldsa_verify": 6, "mldsa_keygen": 7, "mldsa_sign": 8, "mlkem_keytable": 9, "mldsa_keytable": 10, "x25519": 11}
 
 
 def _stream():
@@ -192,3 +192,47 @@ def profile_read(kernel):
     ms, cnt = C.c_double(0), C.c_uint64(0)
     nat.check(nat.lib().circl_hip_profile_read(KERNELS[kernel], C.byref(ms), C.byref(cnt)), "profile_read")
     return ms.value, cnt.value
+
+
+XWING, X25519MLKEM768 = 1, 2
+
+
+class HybridDevice:
+    """X-Wing / X25519MLKEM768 on resident tensors (circl_hip_hybrid_*_dev); x25519() is the bare ladder batch."""
+
+    def __init__(self, scheme, n, device="cuda"):
+        self.scheme, self.n = scheme, n
+        self.L = nat.lib()
+        self.S = {k: getattr(self.L, "circl_hip_hybrid_%s_size" % k)(scheme) for k in ("seed", "eseed", "pk", "sk", "ct", "ss")}
+        self.wsb = self.L.circl_hip_hybrid_workspace_size(scheme, n)
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=device)
+        self.pk = torch.empty((n, self.S["pk"]), dtype=torch.uint8, device=device)
+        self.sk = torch.empty((n, self.S["sk"]), dtype=torch.uint8, device=device)
+        self.ct = torch.empty((n, self.S["ct"]), dtype=torch.uint8, device=device)
+        self.ss = torch.empty((n, self.S["ss"]), dtype=torch.uint8, device=device)
+        self.ss2 = torch.empty((n, self.S["ss"]), dtype=torch.uint8, device=device)
+        self.status = torch.empty(n, dtype=torch.uint8, device=device)
+
+    def keygen(self, seeds):
+        nat.check(self.L.circl_hip_hybrid_keygen_dev(self.scheme, _chk(seeds, self.S["seed"]), _chk(self.pk), _chk(self.sk), self.n,
+                                                     self.ws.data_ptr(), self.wsb, _stream()), "hybrid_keygen_dev")
+        return self.pk, self.sk
+
+    def encaps(self, pk, eseeds):
+        nat.check(self.L.circl_hip_hybrid_encaps_dev(self.scheme, _chk(pk, self.S["pk"]), _chk(eseeds, self.S["eseed"]), _chk(self.ct), _chk(self.ss),
+                                                     _chk(self.status), self.n, self.ws.data_ptr(), self.wsb, _stream()), "hybrid_encaps_dev")
+        return self.ct, self.ss, self.status
+
+    def decaps(self, sk, ct):
+        nat.check(self.L.circl_hip_hybrid_decaps_dev(self.scheme, _chk(sk, self.S["sk"]), _chk(ct, self.S["ct"]), _chk(self.ss2), _chk(self.status),
+                                                     self.n, self.ws.data_ptr(), self.wsb, _stream()), "hybrid_decaps_dev")
+        return self.ss2, self.status
+
+
+def x25519(scalar, point=None, out=None, ok=None):
+    n = scalar.shape[0]
+    out = torch.empty_like(scalar) if out is None else out
+    ok = torch.empty(n, dtype=torch.uint8, device=scalar.device) if ok is None else ok
+    nat.check(nat.lib().circl_hip_x25519_dev(_chk(scalar, 32), None if point is None else _chk(point, 32), _chk(out, 32), _chk(ok), n, _stream()),
+              "x25519_dev")
+    return out, ok

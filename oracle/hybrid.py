@@ -1,9 +1,9 @@
-"""TEST INFRASTRUCTURE: X-Wing (kem/xwing/xwing.go) and X25519MLKEM768 (kem/hybrid/hybrid.go + xkem.go) restated over
+"""TEST INFRASTRUCTURE ONLY (see oracle.h): X-Wing (kem/xwing/xwing.go) and X25519MLKEM768 (kem/hybrid/hybrid.go + xkem.go) restated over
 the oracle's SHAKE256 / SHA3-256 / ML-KEM-768 / X25519.  X-Wing is pinned by the draft's transcript digest through
 tests/xwing_test.cpp (kem/xwing/xwing_test.go:38-85); the pieces are pinned by the tests/test_oracle_*.py files."""
 import numpy as np
 
-from oracle import orc
+from . import orc
 
 LABEL = b"\\.//^\\"
 

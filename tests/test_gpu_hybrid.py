@@ -1,5 +1,5 @@
 """The hybrid KEMs of SURVEY.md 8(f) row f2 through the C ABI (circl_hip_hybrid_*), batch level, against the oracle's
-restatement (tests/hybrid_oracle.py).  The X-Wing draft's test-vector transcript (kem/xwing/xwing_test.go:38-85) and the
+restatement (oracle/hybrid.py).  The X-Wing draft's test-vector transcript (kem/xwing/xwing_test.go:38-85) and the
 reference's xkem / schemes tests run through the C++ mirrors in tests/test_gpu_host_mirror.py, which sit on the same ABI."""
 import numpy as np
 import pytest
@@ -17,8 +17,8 @@ def api():
 
 @pytest.fixture(scope="module")
 def ho():
-    import hybrid_oracle
-    return hybrid_oracle
+    from oracle import hybrid
+    return hybrid
 
 
 @pytest.mark.parametrize("n", [1, 65, 1500])
