@@ -303,3 +303,67 @@ CIRCL_HD void scalar_mult(uint32_t out[8], const uint32_t k_in[8], const uint32_
 
 }  // namespace x25519
 }  // namespace circl
+
+#include "x25519_base_table.h"
+
+namespace circl {
+namespace x25519 {
+
+// KeyGen (key.go:34-36): X25519(k, 9) through the fixed-base comb of x25519_base_table.h instead of a ladder -- 64 mixed
+// additions on the twisted Edwards form (7 products each) against 255 ladder steps (4 products + 4 squarings + 2 small):
+// a third of the instructions.  The reference makes the same kind of trade with its own precomputation (a right-to-left
+// Montgomery ladder over a table of multiples, curve.go:9-45, table.go); the result is the same u-coordinate.
+// k B = sum_j e_j 16^j B with signed digits e_j in [-8, 8] (the clamped scalar has bit 255 clear, so the top digit needs no
+// carry out).  The eight candidates of a digit position are the same for every lane: they are read with wave-uniform
+// addresses and selected per lane by compares, so neither addresses nor control flow depend on the scalar.
+// P + Q for Q = ((y+x)/2, (y-x)/2, dxy):  A = (Y+X) q0, B = (Y-X) q1, C = T q2;  E = A-B, H = A+B, G = Z+C, F = Z-C;
+// (X, Y, Z, T) <- (E F, G H, F G, E H) -- the extended coordinates of the sum scaled by 1/4.  For -Q: q0 <-> q1, G <-> F.
+CIRCL_HD void base_mult(uint32_t out[8], const uint32_t k_in[8]) {
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = k_in[i];
+    k[0] &= ~7u;
+    k[7] = (k[7] & 0x7fffffffu) | 0x40000000u;
+    Fe X = fe_const(0), Y = fe_const(1), Z = fe_const(1), T = fe_const(0);
+    uint32_t carry = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int j = 0; j < 64; j++) {
+        const uint32_t d = (k[0] & 15u) + carry;  // 0..16
+#pragma unroll
+        for (int i = 0; i < 7; i++) k[i] = (k[i] >> 4) | (k[i + 1] << 28);
+        k[7] >>= 4;
+        carry = (j == 63) ? 0u : ((d + 8u) >> 4);
+        const int32_t e = (int32_t)d - (int32_t)(carry << 4);  // -8..8
+        const bool neg = e < 0;
+        const uint32_t m = (uint32_t)(neg ? -e : e);
+        Fe q0, q1, q2 = fe_const(0);  // the identity: ((1+0)/2, (1-0)/2, 0), 1/2 = 2^254 - 9
+#pragma unroll
+        for (int i = 0; i < 10; i++) q0.v[i] = q1.v[i] = (i == 0) ? (M26 - 8) : (i == 9) ? 0xffffffu : limb_mask(i);
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++) {
+            const uint32_t *t = base_comb_entry(j, mm);
+            const uint32_t mask = 0u - (((m ^ (uint32_t)(mm + 1)) - 1u) >> 31);  // all ones iff m == mm + 1; no branch
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                q0.v[i] ^= mask & (q0.v[i] ^ t[i]);
+                q1.v[i] ^= mask & (q1.v[i] ^ t[10 + i]);
+                q2.v[i] ^= mask & (q2.v[i] ^ t[20 + i]);
+            }
+        }
+        fe_cswap(q0, q1, neg ? 1u : 0u);
+        const Fe A = fe_mul(fe_add(Y, X), q0), B = fe_mul(fe_sub(Y, X), q1), C = fe_mul(T, q2);
+        const Fe E = fe_sub(A, B), H = fe_add(A, B);
+        Fe G = fe_add(Z, C), F = fe_sub(Z, C);
+        fe_cswap(G, F, neg ? 1u : 0u);
+        X = fe_mul(E, F);
+        Y = fe_mul(G, H);
+        Z = fe_mul(F, G);
+        T = fe_mul(E, H);
+    }
+    fe_to_words(out, fe_mul(fe_add(Z, Y), fe_inv(fe_sub(Z, Y))));  // u = (1 + y) / (1 - y)
+}
+
+}  // namespace x25519
+}  // namespace circl

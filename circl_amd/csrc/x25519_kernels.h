@@ -1,6 +1,7 @@
 // x25519_kernels.h -- batch X25519 (dh/x25519 KeyGen / Shared), one scalar multiplication per lane.
-// A wavefront is 64 independent Montgomery ladders: no LDS, no cross-lane traffic, 64 bytes in and 33 bytes out per item
-// against ~3.7 x 10^5 integer instructions -- the kernel is pure VALU issue (multiplier class).
+// A wavefront is 64 independent Montgomery ladders (Shared) or 64 fixed-base combs (KeyGen): no LDS, no cross-lane traffic,
+// 64 bytes in and 33 bytes out per item against ~3.9 x 10^5 (ladder) / ~1.2 x 10^5 (comb) integer instructions -- the
+// kernels are pure VALU issue (multiplier class).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,7 +31,8 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)
         m[7] &= 0x7fffffffu;
         ok[i] = BASE ? (uint8_t)1 : (uint8_t)valid_public(m);
     }
-    scalar_mult<BASE>(r, k, u);
+    if (BASE) base_mult(r, k);  // fixed-base comb (x25519_dev.h)
+    else scalar_mult<false>(r, k, u);
 #pragma unroll
     for (int j = 0; j < 8; j++) out[i * 8 + j] = r[j];
 }
@@ -61,7 +63,7 @@ static __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
         scalar_mult<false>(r, k, u);
     } else {
-        scalar_mult<true>(r, k, u);
+        base_mult(r, k);
     }
     uint32_t *out = shared ? out_shared : out_base;
 #pragma unroll

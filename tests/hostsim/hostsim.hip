@@ -165,7 +165,8 @@ uint32_t hs_x25519_valid_public(const uint32_t *u) {
 }
 void hs_x25519(uint32_t *out, const uint32_t *k, const uint32_t *u, int base, size_t n) {
     for (size_t i = 0; i < n; i++) {
-        if (base) x25519::scalar_mult<true>(out + 8 * i, k + 8 * i, k + 8 * i);
+        if (base == 2) x25519::base_mult(out + 8 * i, k + 8 * i);  // the fixed-base comb
+        else if (base) x25519::scalar_mult<true>(out + 8 * i, k + 8 * i, k + 8 * i);
         else x25519::scalar_mult<false>(out + 8 * i, k + 8 * i, u + 8 * i);
     }
 }

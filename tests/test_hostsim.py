@@ -19,7 +19,7 @@ Q, DQ = 3329, 8380417
 def hs():
     out = os.path.join(ROOT, "build", "libhostsim.so")
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.hip")
-    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "x25519_dev.h")]
+    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "x25519_dev.h", "x25519_base_table.h")]
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
@@ -281,3 +281,32 @@ def test_x25519_ladder_host_instantiation(hs):
     assert (out == orc.x25519(k, u)[0]).all()
     hs.hs_x25519(_ptr(out), _ptr(k), _ptr(u), 1, C.c_size_t(n))
     assert (out == orc.x25519(k)[0]).all()
+
+
+def test_x25519_fixed_base_comb_host_instantiation(hs):
+    # KeyGen through the Edwards comb (x25519_dev.h base_mult + the generated table) == Shared(k, 9): key_test.go:100-112
+    rng = np.random.default_rng(3)
+    n = 600
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, b in enumerate((0, 255, 0x88, 0x77, 0x08, 0xf8, 0x80, 0x7f)):  # digit patterns that exercise every carry / sign case
+        k[i] = b
+    out = np.zeros((n, 32), np.uint8)
+    hs.hs_x25519(_ptr(out), _ptr(k), _ptr(k), 2, C.c_size_t(n))
+    assert (out == orc.x25519(k)[0]).all()
+
+
+def test_x25519_base_table_is_what_the_generator_writes(tmp_path):
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(ROOT, "tools", "gen_x25519_base_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    hdr = os.path.join(ROOT, "circl_amd", "csrc", "x25519_base_table.h")
+    keep = tmp_path / "committed.h"
+    shutil.copy(hdr, keep)
+    try:
+        gen.main()
+        assert open(hdr).read() == open(keep).read()
+    finally:
+        shutil.copy(keep, hdr)
+        os.utime(hdr, (os.path.getmtime(keep), os.path.getmtime(keep)))
