@@ -18,6 +18,7 @@ The same JSON line carries, under "configs", a measured figure (own HIP-event ke
     config5       ML-KEM-1024 Encapsulate + ML-DSA-87 Verify submitted concurrently on two streams (per-GPU share 2^16 + 2^16)
     host_abi      the host-buffer C ABI end to end (H2D + kernels + D2H), page-locked and ordinary pageable buffers
     shared_key / keyed   one key for the batch / a table of 1000 keys (the reference's parsed-key cache)
+    hybrid               X-Wing and X25519MLKEM768 on resident arrays, 2^18 per GPU
 
 --mode config3 | config4 | config5 | host makes that workload the headline (metric / value / ms_per_step) instead; for
 N > 1 launch with torch.distributed.run (one rank per GPU): every rank owns its own batch (weak scaling), there is no
@@ -508,6 +509,35 @@ def main():
                             "keytable_ms_per_step": kk["mlkem_keytable"]["ms_per_step"], "equals_per_item_api_on_gathered_keys": same,
                             "note": "circl_hip_mlkem_encaps_keyed: 1000-key table + uniform random index per item; expansion once per table entry"}
         del ct_s, ss_s, st_s
+
+    # ---- the hybrid KEMs that carry ML-KEM-768 (X-Wing, X25519MLKEM768), composed on the device ----
+    if extras and args.mode == "encaps":
+        from circl_amd import device as cdev
+        nh = max(B // 4, 64)
+        gh = torch.Generator(device=dev).manual_seed(9000 + rank)
+        hyb = {}
+        for scheme, name in ((cdev.XWING, "xwing"), (cdev.X25519MLKEM768, "x25519mlkem768")):
+            h = cdev.HybridDevice(scheme, nh, dev)
+            seeds = torch.randint(0, 256, (nh, h.S["seed"]), dtype=torch.uint8, device=dev, generator=gh)
+            es = torch.randint(0, 256, (nh, h.S["eseed"]), dtype=torch.uint8, device=dev, generator=gh)
+            pk, sk = h.keygen(seeds)
+            th = Timer(ranks, ["x25519", "mlkem_hash", "mlkem_encrypt"])
+            el_e, ke = th.run(lambda: h.encaps(pk, es), 5, 1)
+            el_d, _ = th.run(lambda: h.decaps(sk, h.ct), 5, 1)
+            torch.cuda.synchronize()
+            agree = bool((h.ss == h.ss2).all().item()) and not bool(h.status.any().item())
+            from oracle import hybrid as ohyb
+            ns = min(nh, 1 << 10 if rank == 0 else 1 << 6)
+            pkc, esc, skc = pk[:ns].cpu().numpy(), es[:ns].cpu().numpy(), sk[:ns].cpu().numpy()
+            ct0, ss0, st0 = (ohyb.xwing_encaps if scheme == cdev.XWING else ohyb.hybrid_encaps)(pkc, esc)
+            exact = bool((h.ct[:ns].cpu().numpy() == ct0).all() and (h.ss[:ns].cpu().numpy() == ss0).all() and not st0.any())
+            hyb[name] = {"encaps_per_s": world * nh * 5 / ranks.max(el_e), "decaps_per_s": world * nh * 5 / ranks.max(el_d), "n_per_gpu": nh,
+                         "x25519_kernel_ms_per_encaps_step": ke["x25519"]["ms_per_step"],
+                         "parity": {"sampled_items": ns, "bit_exact_vs_oracle": exact, "all_items_ss_dec_equals_ss_enc": agree}}
+            del h
+        out_cfg["hybrid"] = dict(hyb, note="X25519 on the GPU (one ladder / fixed-base comb per lane), ML-KEM-768, SHAKE256 / SHA3-256 glue: "
+                                           "circl_hip_hybrid_*_dev on resident arrays; replaces kem/xwing and kem/hybrid's X25519MLKEM768")
+        torch.cuda.empty_cache()
 
     # ---- host-buffer ABI, end to end ----
     host = None
