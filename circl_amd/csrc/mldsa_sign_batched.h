@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
 // One entry's work is a function of its own (not inlined into the grid-stride loop of the kernel): inlined, the loop's
 // register allocation grew from 102 to 164 VGPRs (26-30 spilled under the 128-register cap of 4 waves per SIMD).
 template <int MODE>
-__device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
-                                               uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
+__device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
+                                                 uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
@@ -305,9 +305,16 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
     const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * kPackedRowDwords;
     uint32_t *w0 = st.w0 + slot * K * 256;
-    auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
-        uint32_t sv[4];
-        load_poly24(sv, row, lane);
+    uint32_t *best = st.best;
+    // Every loop below is software-pipelined by hand: the packed row of polynomial i + 1 (and its w0 / w1 words) is requested
+    // before the inverse transform of polynomial i, so the wave has loads in flight while it computes (the attempts are
+    // latency-bound chains: load, product, three LDS exchanges, compare).
+    auto load_row = [&](uint32_t (&raw)[3], const uint32_t *row) {
+        const uint32_t *p = row + 3 * lane;
+        raw[0] = p[0]; raw[1] = p[1]; raw[2] = p[2];
+    };
+    auto mul_c = [&](uint32_t (&t)[4], const uint32_t (&raw)[3]) {
+        const uint32_t sv[4] = {raw[0] & 0xffffffu, (raw[0] >> 24) | ((raw[1] & 0xffffu) << 8), (raw[1] >> 16) | ((raw[2] & 0xffu) << 16), raw[2] >> 8};
 #pragma unroll
         for (int r = 0; r < 4; r++) t[r] = dilithium::fold(dilithium::mont32(sv[r], chat[r]));
         dilithium::invntt(t, z, xch, lane);
@@ -318,38 +325,71 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
     // test 38 % (1280 against gamma1 - beta), so r0 first costs ~6.4 inverse transforms per attempt, z first ~7.8 (measured:
     // 14.7 vs 16.3 ms of finish kernels per 2^18 signatures).
     // w0 - c s2
-#pragma unroll 1
-    for (int i = 0; i < K; i++) {
-        uint32_t t[4];
-        mul_c(t, sec + (L + i) * kPackedRowDwords);
+    {
+        uint32_t raw[3], wv[4];
+        load_row(raw, sec + L * kPackedRowDwords);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int nidx = kyber::idx_l1(lane, r);
-            const uint32_t v = dilithium::normalize(w0[i * 256 + nidx] + (2 * Q - t[r]));
-            bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
-            w0[i * 256 + nidx] = v;
+        for (int r = 0; r < 4; r++) wv[r] = w0[kyber::idx_l1(lane, r)];
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint32_t raw_n[3] = {0, 0, 0}, wv_n[4] = {0, 0, 0, 0};
+            if (i + 1 < K) {
+                load_row(raw_n, sec + (L + i + 1) * kPackedRowDwords);
+#pragma unroll
+                for (int r = 0; r < 4; r++) wv_n[r] = w0[(i + 1) * 256 + kyber::idx_l1(lane, r)];
+            }
+            uint32_t t[4];
+            mul_c(t, raw);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t v = dilithium::normalize(wv[r] + (2 * Q - t[r]));
+                bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
+                w0[i * 256 + kyber::idx_l1(lane, r)] = v;
+            }
+            if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
+#pragma unroll
+            for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) wv[r] = wv_n[r];
         }
-        if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
     }
     if (__any(bad)) return;
     // z = y + c s1
     unsigned zfld[L][4];
+    {
+        auto load_y = [&](uint32_t (&yv)[4], int l) {
+            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
 #pragma unroll
-    for (int l = 0; l < L; l++) {
-        uint32_t t[4];
-        mul_c(t, sec + l * kPackedRowDwords);
-        const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+            for (int r = 0; r < 4; r++) yv[r] = gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+        };
+        uint32_t raw[3], yv[4];
+        load_row(raw, sec);
+        load_y(yv, 0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            uint32_t y = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
-            y += (uint32_t)((int32_t)y >> 31) & Q;
-            const uint32_t zz = dilithium::normalize(t[r] + y);
-            bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
-            uint32_t f = G::GAMMA1 - zz;
-            f += (uint32_t)((int32_t)f >> 31) & Q;
-            zfld[l][r] = f;
+        for (int l = 0; l < L; l++) {
+            uint32_t raw_n[3] = {0, 0, 0}, yv_n[4] = {0, 0, 0, 0};
+            if (l + 1 < L) {
+                load_row(raw_n, sec + (l + 1) * kPackedRowDwords);
+                load_y(yv_n, l + 1);
+            }
+            uint32_t t[4];
+            mul_c(t, raw);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t y = G::GAMMA1 - yv[r];
+                y += (uint32_t)((int32_t)y >> 31) & Q;
+                const uint32_t zz = dilithium::normalize(t[r] + y);
+                bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
+                uint32_t f = G::GAMMA1 - zz;
+                f += (uint32_t)((int32_t)f >> 31) & Q;
+                zfld[l][r] = f;
+            }
+            if (__any(bad)) break;
+#pragma unroll
+            for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) yv[r] = yv_n[r];
         }
-        if (__any(bad)) break;
     }
     if (__any(bad)) return;
     // z passed: bit-pack it as it will appear in the signature (pack.go:202-254) -- only now: most attempts never get here
@@ -363,26 +403,39 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
     __syncthreads();
     for (int i = lane; i < 24; i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
     __syncthreads();
+    {
+        uint32_t raw[3];
+        load_row(raw, sec + (L + K) * kPackedRowDwords);
 #pragma unroll 1
-    for (int i = 0; i < K; i++) {
-        uint32_t t[4];
-        mul_c(t, sec + (L + K + i) * kPackedRowDwords);
+        for (int i = 0; i < K; i++) {
+            uint32_t raw_n[3] = {0, 0, 0}, wv[4], r1v[4];
+            if (i + 1 < K) load_row(raw_n, sec + (L + K + i + 1) * kPackedRowDwords);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int nidx = kyber::idx_l1(lane, r);
-            const uint32_t ct0 = dilithium::csubq(t[r]);
-            bad |= dilithium::exceeds(ct0, P::GAMMA2);
-            const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
-            const uint32_t r1 = st.w1[(slot * K + i) * 256 + nidx];
-            const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
-            const unsigned long long mask = __ballot(hbit);
-            if (hbit) {
-                const unsigned hs = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
-                if (hs < (unsigned)P::OMEGA) hbytes[hs] = (uint8_t)nidx;
+            for (int r = 0; r < 4; r++) {
+                wv[r] = w0[i * 256 + kyber::idx_l1(lane, r)];
+                r1v[r] = st.w1[(slot * K + i) * 256 + kyber::idx_l1(lane, r)];
             }
-            pop += (unsigned)__popcll(mask);
+            uint32_t t[4];
+            mul_c(t, raw);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                const uint32_t ct0 = dilithium::csubq(t[r]);
+                bad |= dilithium::exceeds(ct0, P::GAMMA2);
+                const uint32_t v = dilithium::csubq(wv[r] + ct0);
+                const uint32_t r1 = r1v[r];
+                const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+                const unsigned long long mask = __ballot(hbit);
+                if (hbit) {
+                    const unsigned hs = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));
+                    if (hs < (unsigned)P::OMEGA) hbytes[hs] = (uint8_t)nidx;
+                }
+                pop += (unsigned)__popcll(mask);
+            }
+            if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
+#pragma unroll
+            for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
         }
-        if (lane == 0) hbytes[P::OMEGA + i] = (uint8_t)(pop < 255 ? pop : 255);
     }
     if (__any(bad) || pop > (unsigned)P::OMEGA) return;
     __syncthreads();       // every lane is done with w0
@@ -392,7 +445,17 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
     for (int b = lane; b < P::CT; b += 64) sg[b] = cb[b];
     for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
     for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
-    if (lane == 0) atomicMin(&st.best[item], off);
+    if (lane == 0) atomicMin(&best[item], off);
+}
+// The grid is (an upper estimate of) one workgroup per entry, so a workgroup normally handles exactly one: that one runs
+// inlined in the kernel.  Entries beyond the grid -- only when the schedule's estimate was too small -- go through a
+// non-inlined copy: inlined into a grid-stride loop the body made the loop's register allocation grow from 102 to 164 VGPRs,
+// and as a function it reaches its arrays through generic pointers (FLAT instructions, which also count against the LDS
+// counter: every wait for an LDS exchange then waits for the global loads in flight -- 8.2 cycles per VALU instruction).
+template <int MODE>
+__device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
+                                               uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
+    sign_finish_body<MODE>(st, cur, sig, slot, k, xch, zpk, hbytes, blk);
 }
 template <int MODE>
 __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
@@ -405,12 +468,15 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
     static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
     const size_t count = st.count[cur];
     const unsigned k = st.kk[cur];
-    // (static split: handing entries out through an atomic ticket -- per entry or in chunks of 8 -- balances the uneven
-    // attempts but measured slower, 17.5 and 14.6 ms against 12.3 ms per 2^16 ML-DSA-65 signatures)
+    if (blockIdx.x >= count) return;
+    sign_finish_body<MODE>(st, cur, sig, blockIdx.x, k, xch, zpk, hbytes, blk);
+    if ((size_t)blockIdx.x + gridDim.x >= count) return;
+    const SignState escaped = st;  // a copy for the call by reference: taking st's own address would turn every pointer field
+                                   // of the inlined path above into a generic pointer as well
 #pragma unroll 1
-    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    for (size_t slot = (size_t)blockIdx.x + gridDim.x; slot < count; slot += gridDim.x) {
         __syncthreads();  // the previous entry is done with the LDS buffers
-        sign_finish_entry<MODE>(st, cur, sig, slot, k, xch, zpk, hbytes, blk);
+        sign_finish_entry<MODE>(escaped, cur, sig, slot, k, xch, zpk, hbytes, blk);
     }
 }
 

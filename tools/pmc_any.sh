@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of every kernel matching $1 while running "$2..." under rocprofv3 --pmc (own passes, kernel-trace only)
 #   tools/pmc_any.sh mldsa_verify_kernel python tools/verify_only.py 65 18
+#   AGG=max ...: the largest invocation of each kernel instead of the median (round kernels of signing: the first round)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; PAT=$1; shift
 OUT=$ROOT/gpurun_out/pmc_any; rm -rf "$OUT"; mkdir -p "$OUT"
@@ -14,8 +15,9 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   ( cd "$ROOT" && cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -o g$i -- "$@" > "$OUT/g$i.log" 2>&1 )
 done
 cd "$ROOT" && python - "$PAT" <<'PY'
-import csv, glob, collections, sys
+import csv, glob, collections, sys, os
 pat = sys.argv[1]
+pick = (lambda v: max(v)) if os.environ.get("AGG") == "max" else (lambda v: sorted(v)[len(v) // 2])
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_any/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,11 +29,11 @@ for f in glob.glob("gpurun_out/pmc_any/g1/**/*kernel_trace.csv", recursive=True)
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]: dur[r["Kernel_Name"].split("(")[0][:80]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, d in agg.items():
-    print(k, " median duration %.3f ms" % (sorted(dur[k])[len(dur[k]) // 2] / 1e6 if dur.get(k) else -1))
-    med = {c: sorted(v)[len(v) // 2] for c, v in d.items()}
+    print(k, " duration %.3f ms" % (pick(dur[k]) / 1e6 if dur.get(k) else -1), "(%d launches)" % len(dur.get(k, [])))
+    med = {c: pick(v) for c, v in d.items()}
     for c, v in sorted(med.items()): print(f"   {c:26s} {v:.4e}")
     if "SQ_INSTS_VALU" in med and dur.get(k):
-        t = sorted(dur[k])[len(dur[k]) // 2] * 1e-9
+        t = pick(dur[k]) * 1e-9
         print(f"   -> VALU wave-insts/s {med['SQ_INSTS_VALU'] / t:.3e}; cycles per VALU inst per SIMD at 2.4 GHz: {1024 * 2.4e9 * t / med['SQ_INSTS_VALU']:.2f}")
     if "SQ_WAVE_CYCLES" in med and "SQ_BUSY_CYCLES" in med:
         print(f"   -> resident waves per SIMD ~ {4 * med['SQ_WAVE_CYCLES'] / (med.get('GRBM_GUI_ACTIVE', 0) / 8 * 1024 + 1e-9):.2f} (4 x WAVE_CYCLES / (GUI_ACTIVE per XCD x 1024 SIMDs))")
