@@ -164,16 +164,31 @@ template <uint32_t BOUND> CIRCL_HD void gs(uint32_t &a, uint32_t &b, uint32_t z)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// The exchange buffer is padded by four words after every 32 (word i lives at i + 4 (i >> 5), kXchWords in all): with the
+// plain layout the 32 lanes of a half-wave hit 8 distinct banks in layout L3 (4-way conflict on every access) and the
+// single-word accesses of L4 likewise; padded, L1 and L3 are conflict-free, L4 is one 16-byte access per lane, and only L2
+// keeps its 2-way conflict (no additive padding serves L2 and L3 at once).  The padding is additive in r for every layout,
+// so the four accesses of a lane still differ by immediate offsets from one address register.
+// LDS time per transform: 64 instead of 112-136 cycles.  Measured neutral on the kernels' run time (the exchanges are not on
+// their critical path: sign_w is HBM-bound, verify VALU-bound) -- kept because it frees LDS issue slots for nothing.
+constexpr int kXchWords = 256 + 4 * 8;
+__device__ __forceinline__ int xch_pad(int i) { return i + 4 * (i >> 5); }
 template <int FROM, int TO> __device__ __forceinline__ void relayout(uint32_t (&c)[4], uint32_t *xch, int lane) {
-    auto idx = [&](int which, int r) {
-        return which == 1 ? kyber::idx_l1(lane, r) : which == 2 ? kyber::idx_l2(lane, r) : which == 3 ? kyber::idx_l3(lane, r) : kyber::idx_l4(lane, r);
+    // padded position of coefficient r of this lane: base(lane) + an immediate per r
+    auto pos = [&](int which, int r) {
+        switch (which) {
+        case 1: return lane + 4 * (lane >> 5) + 72 * r;                                              // l + 64 r:  (l + 64 r) >> 5 = (l >> 5) + 2 r
+        case 2: return ((lane >> 4) * 72) + (lane & 15) + 16 * r + 4 * (r >> 1);                    // 64 a + 16 r + j:  >> 5 = 2 a + (r >> 1)
+        case 3: return ((lane >> 2) << 4) + 4 * (lane >> 3) + (lane & 3) + 4 * r;                   // 16 g + 4 r + j:  >> 5 = g >> 1
+        default: return 4 * lane + 4 * (lane >> 3) + r;                                             // 4 l + r:  >> 5 = l >> 3
+        }
     };
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) xch[idx(FROM, r)] = c[r];
+    for (int r = 0; r < 4; r++) xch[pos(FROM, r)] = c[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) c[r] = xch[idx(TO, r)];
+    for (int r = 0; r < 4; r++) c[r] = xch[pos(TO, r)];
 }
 
 // Poly.NTT (ntt.go:166-183).  In: layout L1, c < 2^32 - 16 q.  Out: layout L4, c < in + 16 q, plain residues.

@@ -59,7 +59,7 @@ template <int MODE> struct DG {
     static constexpr int STREAMS = K * L;
     static constexpr int IT = 64 / STREAMS;            // items per workgroup
     static constexpr int MUW1 = 64 + K * W1SZ;         // bytes of mu || w1 per item in the workspace
-    static constexpr int LDS_XCH = 1024;
+    static constexpr int LDS_XCH = 4 * dilithium::kXchWords;  // padded exchange buffer (dilithium_dev.h relayout)
     static constexpr int LDS_MISC = 256;               // ball block bytes, positions
     // verify / keygen kernels: sampled matrix in global scratch
     static constexpr int FIFO_STRIDE = 80;             // bytes per lane the FIFO area is sized with (16 dword slots used, slot-major)
@@ -516,7 +516,7 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
 template <int MODE>
 __global__ void __launch_bounds__(64) mldsa_sample_in_ball_kernel(const uint8_t *__restrict__ ctilde, uint32_t *__restrict__ polys, int sequential) {
     using P = DP<MODE>;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
     __shared__ __attribute__((aligned(16))) uint8_t st[200];
     __shared__ __attribute__((aligned(16))) uint8_t blk[144];
     const int lane = threadIdx.x;
@@ -926,7 +926,7 @@ template <int MODE> struct SG {
     static constexpr int LDS_MUW1 = G::MUW1 + 8;                        // mu || packed w1 (hashed as is)
     static constexpr int LDS_Z = L * G::ZSZ;                            // packed z
     static constexpr int LDS_H = 96;                                    // hint bytes (omega + K <= 84)
-    static constexpr int LDS_XCH = 1024;
+    static constexpr int LDS_XCH = 4 * dilithium::kXchWords;  // padded exchange buffer (dilithium_dev.h relayout)
     static constexpr int LDS_MISC = 256;                                // ball block (200 B)
     static constexpr int LDS_TOTAL = LDS_Y + LDS_W0 + LDS_W1 + LDS_MUW1 + LDS_Z + LDS_H + LDS_XCH + LDS_MISC;
     static constexpr int SPEC_STRIDE = (G::SIG + 15) & ~15;                // one parked signature of the speculative tail

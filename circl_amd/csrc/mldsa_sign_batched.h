@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
     using P = DP<MODE>;
     using Kg = KG<MODE>;
     constexpr int K = P::K, L = P::L;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
     const int lane = threadIdx.x;
     const size_t item = blockIdx.x;
     const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(sk + item * Kg::SK);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
     const int lane = threadIdx.x;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const size_t count = st.count[cur];
@@ -461,7 +461,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
     using G = DG<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
     __shared__ __attribute__((aligned(16))) uint8_t zpk[L * G::ZSZ];
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
     __shared__ __attribute__((aligned(16))) uint8_t blk[144];

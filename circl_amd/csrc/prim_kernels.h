@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) kyber_mulhat_kernel(int16_t *out, const in
 // returns 2^32/256 times the exact inverse (ntt.go:212-216); the device transform is exact, so the
 // factor 2^32 mod q is applied here to expose the reference's semantics.
 __global__ void __launch_bounds__(64) dilithium_ntt_kernel(uint32_t *polys, int inverse) {
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
     const int lane = threadIdx.x;
     uint32_t *p = polys + (size_t)blockIdx.x * 256;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
