@@ -321,6 +321,8 @@ struct SlotPool {
     std::once_flag copy_once;
     hipStream_t h2d = nullptr, d2h = nullptr, compute[2] = {nullptr, nullptr};
     std::atomic<unsigned> next_compute{0};
+    std::once_flag aux_once;
+    hipStream_t aux[2] = {nullptr, nullptr};
 };
 std::mutex g_slot_pools_mu;
 std::vector<SlotPool *> g_slot_pools;
@@ -344,6 +346,21 @@ int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *c
     *compute = p->compute[p->next_compute.fetch_add(1) & 1];
     return CIRCL_HIP_OK;
 }
+}  // namespace
+// two more non-blocking streams per device for device-resident calls that fork internally (batch signing runs its two halves
+// side by side: their latency-bound late rounds fill each other's gaps)
+int aux_streams(int dev, hipStream_t (&s)[2]) {
+    SlotPool *p = slot_pool_of(dev);
+    std::call_once(p->aux_once, [&] {
+        for (auto &a : p->aux)
+            if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) a = nullptr;
+    });
+    if (!p->aux[0] || !p->aux[1]) { g_err = "stream creation failed"; (void)hipGetLastError(); return CIRCL_HIP_EHIP; }
+    s[0] = p->aux[0];
+    s[1] = p->aux[1];
+    return CIRCL_HIP_OK;
+}
+namespace {
 int max_slots() {
     static const int v = env_int("CIRCL_HIP_HOST_SLOTS", 12, 1, 64);
     return v;
