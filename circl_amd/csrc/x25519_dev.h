@@ -149,13 +149,14 @@ CIRCL_HD Fe fe_mul_small(const Fe &f, uint32_t c) {
     return fe_carry64(h);
 }
 
+// per-lane select on the bit (two V_CNDMASK per limb on the device; no branch)
 CIRCL_HD void fe_cswap(Fe &a, Fe &b, uint32_t bit) {
-    const uint32_t m = 0u - bit;
+    const bool c = bit != 0;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        const uint32_t t = m & (a.v[i] ^ b.v[i]);
-        a.v[i] ^= t;
-        b.v[i] ^= t;
+        const uint32_t ta = a.v[i], tb = b.v[i];
+        a.v[i] = c ? tb : ta;
+        b.v[i] = c ? ta : tb;
     }
 }
 

@@ -7,6 +7,9 @@
 #   4. device-resident microbench of every operation at 2^18 and at the BASELINE sizes -> r02_microbench*.txt
 #   5. host-buffer path (page-locked / pageable) and the PCIe probe behind its design -> r02_host_path.txt, r02_pcie_probe.txt
 #   6. per-round trace of one batch signing call -> r02_sign_trace.txt
+#   7. SURVEY 8(f) rows f2 / f4: hybrid KEMs + X25519 and the XOF / K12 service: rates and rocprofv3 kernel stats
+#      -> r02_hybrid.txt, r02_xof.txt, r02_f2_f4_kernel_stats.txt
+#   8. SQ counters of the ML-DSA verify kernel and of the signing round kernels -> r02_pmc_mldsa.txt
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_r02
@@ -32,4 +35,18 @@ python tests/gpu_microbench.py 0 latency 2>&1 | grep -v amdgpu.ids > "$OUT/r02_l
 { python tools/host_path.py 20; CIRCL_HIP_HOST_AHEAD=0 python tools/host_path.py 20; CIRCL_HIP_HOST_CHUNK=14 python tools/host_path.py 20; CIRCL_HIP_HOST_CHUNK=16 python tools/host_path.py 20; CIRCL_HIP_HOST_THREADS=8 python tools/host_path.py 20; } 2>&1 | grep -v amdgpu.ids > "$OUT/r02_host_path.txt"
 tools/bin/pcie_probe > "$OUT/r02_pcie_probe.txt" 2>&1
 tools/sign_trace.sh 65 18 > "$OUT/r02_sign_trace.txt" 2>&1
+python tools/hybrid_bench.py 20 2>&1 | grep -v amdgpu.ids > "$OUT/r02_hybrid.txt"
+python tools/xof_bench.py 2>&1 | grep -v amdgpu.ids > "$OUT/r02_xof.txt"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/f2" -o f2 -- python $ROOT/tools/hybrid_bench.py 18 > "$OUT/f2.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/f4" -o f4 -- python $ROOT/tools/xof_bench.py > "$OUT/f4.log" 2>&1 )
+python - "$OUT" > "$OUT/r02_f2_f4_kernel_stats.txt" <<'PY'
+import csv, glob, sys
+for tag, what in (("f2", "tools/hybrid_bench.py 18 (X25519, X-Wing, X25519MLKEM768)"), ("f4", "tools/xof_bench.py (SHAKE128 batch, KangarooTwelve)")):
+    print("== rocprofv3 --kernel-trace --stats of", what)
+    for f in glob.glob(sys.argv[1] + "/" + tag + "/**/*kernel_stats.csv", recursive=True):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
+        for r in rows[:14]:
+            print(f"  {r['Name'].split('(')[0][:90]:90s} calls {int(r['Calls']):5d}  total {float(r['TotalDurationNs'])/1e6:9.3f} ms  avg {float(r['AverageNs'])/1e3:9.1f} us  {float(r['Percentage']):5.1f} %")
+PY
+{ AGG=max bash tools/pmc_any.sh sign_ python $ROOT/tools/sign_only.py 65 17; bash tools/pmc_any.sh mldsa_verify_kernel python $ROOT/tools/verify_only.py 65 18; } 2>&1 | grep -v amdgpu.ids > "$OUT/r02_pmc_mldsa.txt"
 tail -5 "$OUT/summary_r02.log"; head -c 600 "$OUT/r02_bench.json"; echo; cat "$OUT/r02_host_path.txt"

@@ -5,6 +5,7 @@
  *   - status == NULL where the bridge has no use for it,
  *   - blobs carry one spare byte and n + 1 uint64 offsets built by appending (VerifyBatch / SignBatch),
  *   - key tables + uint32 index vectors (EncapsulateKeyedBatch, VerifyKeyedBatch),
+ *   - the hybrid KEMs' packed keys and []x25519.Key arrays (kem/hybrid/hipbatch, dh/x25519/hipbatch),
  *   - the same call from several threads at once (goroutines on different OS threads).
  * Results are checked against the ABI's own other paths (keygen -> encaps -> decaps round trips; sign -> verify; keyed
  * == per-item); bit-exactness against the oracle is the job of the Python tests.  Prints OK.
@@ -80,6 +81,32 @@ static void dsa_round_trip(int param, size_t n, int device) {
     for (size_t i = 0; i < n; i++) CHECK(ok[i] == (i == n / 2 ? 0 : 1));
 }
 
+/* go/kem/hybrid/hipbatch + go/dh/x25519/hipbatch: packed keys / ciphertexts as byte-aligned sub-slices, NULL status */
+static void hybrid_round_trip(int scheme, size_t n, int device) {
+    const size_t SEED = circl_hip_hybrid_seed_size(scheme), ES = circl_hip_hybrid_eseed_size(scheme), PK = circl_hip_hybrid_pk_size(scheme),
+                 SK = circl_hip_hybrid_sk_size(scheme), CT = circl_hip_hybrid_ct_size(scheme), SS = circl_hip_hybrid_ss_size(scheme);
+    CHECK(SEED && PK == 1216 && CT == 1120);
+    uint8_t *seed = slice(SEED * n, 1), *es = slice(ES * n, 3), *pk = slice(PK * n, 5), *sk = slice(SK * n, 7), *ct = slice(CT * n, 9);
+    uint8_t *ss = slice(SS * n, 11), *ss2 = slice(SS * n, 13), *st = slice(n, 15);
+    fill(seed, SEED * n, (unsigned)scheme + 50);
+    fill(es, ES * n, (unsigned)scheme + 51);
+    CHECK(circl_hip_hybrid_keygen(scheme, seed, pk, sk, n, device) == 0);
+    CHECK(circl_hip_hybrid_encaps(scheme, pk, es, ct, ss, st, n, device) == 0);
+    CHECK(circl_hip_hybrid_decaps(scheme, sk, ct, ss2, NULL, n, device) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(st[i] == 0);
+    CHECK(memcmp(ss, ss2, SS * n) == 0);
+    /* the X25519 half alone: ct_X = KeyGen(ephemeral), and Shared agrees from both sides */
+    uint8_t *a = slice(32 * n, 1), *b = slice(32 * n, 2), *pa = slice(32 * n, 3), *pb = slice(32 * n, 5), *s1 = slice(32 * n, 7), *s2 = slice(32 * n, 9), *ok = slice(n, 1);
+    fill(a, 32 * n, 60);
+    fill(b, 32 * n, 61);
+    CHECK(circl_hip_x25519(a, NULL, pa, NULL, n, device) == 0);
+    CHECK(circl_hip_x25519(b, NULL, pb, NULL, n, device) == 0);
+    CHECK(circl_hip_x25519(a, pb, s1, ok, n, device) == 0);
+    CHECK(circl_hip_x25519(b, pa, s2, NULL, n, device) == 0);
+    CHECK(memcmp(s1, s2, 32 * n) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
+}
+
 static void *thread_main(void *arg) {
     kem_round_trip(768, 3000 + 100 * (size_t)(intptr_t)arg, 0);
     return NULL;
@@ -100,6 +127,12 @@ int main(void) {
     dsa_round_trip(44, 1, 0);
     dsa_round_trip(65, 333, CIRCL_HIP_ALL_DEVICES);
     dsa_round_trip(87, 100, 0);
+    CHECK(circl_hip_hybrid_encaps(CIRCL_HIP_HYBRID_XWING, NULL, NULL, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_x25519(NULL, NULL, NULL, NULL, 0, 0) == 0);
+    CHECK(circl_hip_hybrid_keygen(7, NULL, NULL, NULL, 0, 0) == CIRCL_HIP_EPARAM);
+    hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 1, 0);
+    hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 2051, CIRCL_HIP_ALL_DEVICES);
+    hybrid_round_trip(CIRCL_HIP_HYBRID_X25519MLKEM768, 777, 0);
     pthread_t th[3];
     for (intptr_t i = 0; i < 3; i++) CHECK(pthread_create(&th[i], NULL, thread_main, (void *)i) == 0);
     for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);

@@ -8,6 +8,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from circl_amd import device as cdev  # noqa: E402
 
+os.environ.setdefault("CIRCL_HIP_SIGN_NOSPLIT", "1")  # one stream: the counters of a round kernel belong to one launch
 param = int(sys.argv[1]) if len(sys.argv) > 1 else 65
 n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 17)
 g = torch.Generator(device="cuda").manual_seed(1)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # per-kernel and per-round time of one ML-DSA batch signing call under rocprofv3 --kernel-trace --stats
 #   tools/sign_trace.sh [param] [log2 n]
+# The trace runs with CIRCL_HIP_SIGN_NOSPLIT=1 (the whole batch on one stream) so that the kernels of a round follow each other;
+# the rate of the default path (two halves side by side) is printed first.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp
 PARAM=${1:-65}; LOGN=${2:-16}
 cat > /tmp/sg.py <<PY
@@ -18,7 +20,9 @@ for _ in range(2):
     t=time.perf_counter(); eng.sign(sk,msg,sig); te=time.perf_counter()-t; torch.cuda.synchronize(); dt=time.perf_counter()-t
     print(f"ML-DSA-{param} sign n={n}: enqueue {te*1e3:.2f} ms, complete {dt*1e3:.2f} ms -> {n/dt:.3e}/s")
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/sgt -o sgt -- python /tmp/sg.py 2>&1 | grep "ML-DSA"
+echo "default path (two halves on two streams), not profiled:"; python /tmp/sg.py 2>&1 | grep "ML-DSA"
+echo "one stream (CIRCL_HIP_SIGN_NOSPLIT=1), under rocprofv3 --kernel-trace:"
+CIRCL_HIP_SIGN_NOSPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/sgt -o sgt -- python /tmp/sg.py 2>&1 | grep "ML-DSA"
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("$ROOT/gpurun_out/sgt/sgt_kernel_stats.csv")))
