@@ -2,11 +2,13 @@
 (keygen -> encaps -> decaps round trip on all items, verification results of a tiled signed pool)
 plus bit-exact oracle parity on a uniform sample.  Device-resident (torch owns the HBM buffers)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_mlkem768_roundtrip_2p20_device_resident():
@@ -246,3 +248,55 @@ def test_sign_dev_is_asynchronous():
     assert bool(ok.all())
     print(f"sign+verify 2^16: enqueued in {t_enq * 1e3:.2f} ms, complete after {t_all * 1e3:.2f} ms")
     assert t_enq < 0.8 * t_all
+
+
+def test_sign_split_path_equals_single_stream_and_concurrent_callers():
+    # batches of >= 2^16 items are signed as two halves on two library-owned streams (api_mldsa.hip): same signatures as the
+    # one-stream path (CIRCL_HIP_SIGN_NOSPLIT=1, in a subprocess: the switch is read once), an odd batch size, and two
+    # callers on two streams of their own sharing the library's pair
+    import subprocess
+    import sys
+    import threading
+    import torch
+    from circl_amd import device as cdev
+    n = (1 << 16) + 37
+    g = torch.Generator(device="cuda").manual_seed(21)
+    eng = cdev.MLDSADevice(65, n, "cuda", msg_len=32, sign=True)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = eng.keygen(seeds)
+    msg = torch.randint(0, 256, (n * 32 + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    sig = eng.sign(sk, msg).clone()
+    assert bool(eng.verify(pk, sig, msg).all())
+    import hashlib
+    digest = hashlib.sha256(sig.cpu().numpy().tobytes()).hexdigest()
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
+        "from circl_amd import device as cdev\n"
+        "n = (1 << 16) + 37; g = torch.Generator(device='cuda').manual_seed(21)\n"
+        "eng = cdev.MLDSADevice(65, n, 'cuda', msg_len=32, sign=True)\n"
+        "seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device='cuda', generator=g)\n"
+        "pk, sk = eng.keygen(seeds)\n"
+        "msg = torch.randint(0, 256, (n * 32 + 16,), dtype=torch.uint8, device='cuda', generator=g)\n"
+        "print(hashlib.sha256(eng.sign(sk, msg).cpu().numpy().tobytes()).hexdigest())\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=dict(os.environ, CIRCL_HIP_SIGN_NOSPLIT="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().split("\n")[-1] == digest
+
+    # two concurrent callers, each with its own engine (workspace) and stream
+    engs = [cdev.MLDSADevice(65, n, "cuda", msg_len=32, sign=True) for _ in range(2)]
+    outs = [None, None]
+
+    def work(i):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                outs[i] = engs[i].sign(sk, msg)
+        s.synchronize()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert bool((outs[0] == sig).all()) and bool((outs[1] == sig).all())
