@@ -106,6 +106,10 @@ int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk
         TRY(copy_rows(st, d_sk, s.sk, dk, DK, DK, n));
         TRY(copy_rows(st, d_sk + DK, s.sk, skx, 32, 32, n));
     }
+    // nothing key-equivalent stays behind in the caller's workspace
+    HIP_TRY(hipMemsetAsync(seedm, 0, n * 64, st));
+    HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(dk, 0, n * DK, st));
     return CIRCL_HIP_OK;
 }
 
@@ -146,6 +150,10 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
     TRY(zero_failed(st, d_ct, s.ct, d_status, n));
+    HIP_TRY(hipMemsetAsync(m, 0, n * 32, st));  // the ephemeral secrets and the two half shared secrets
+    HIP_TRY(hipMemsetAsync(ekx, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(ssx, 0, n * 32, st));
     return CIRCL_HIP_OK;
 }
 
@@ -186,6 +194,11 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
         TRY(copy_rows(st, d_ss + 32, 64, ssx, 32, 32, n));
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
+    HIP_TRY(hipMemsetAsync(dk, 0, n * DK, st));
+    HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(ssx, 0, n * 32, st));
+    HIP_TRY(hipMemsetAsync(seedm, 0, n * 64, st));
     return CIRCL_HIP_OK;
 }
 

@@ -96,6 +96,8 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
 /* ---- ML-KEM, device-resident ------------------------------------------------------------
  * Same semantics; every pointer is a device pointer on the device `stream` belongs to.
  * `workspace` must hold circl_hip_mlkem_workspace_size(param, n) bytes.  status may NOT be NULL.
+ * After a call the workspace still holds per-item intermediates that are as secret as the call's secret inputs (the
+ * encryption coins r, the decrypted m'): a caller that hands the memory on should zero it (the host-buffer forms do).
  */
 size_t circl_hip_mlkem_workspace_size(int param, size_t n);
 int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct,
@@ -329,6 +331,8 @@ int circl_hip_x25519_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_
  *   (kem.ErrPubKey) for a non-canonical ek or a low-order X25519 point, 2 (kem.ErrPrivKey) for a private key failing its
  *   hash check; the item's outputs are then zero (the reference returns nil, err).
  * The deterministic forms only (EncapsulateDeterministically / DeriveKeyPair): randomness stays with the caller.
+ * The _dev forms zero the secret temporaries in the workspace (seeds, X25519 scalars, private keys, half secrets) before
+ * they return control of the stream; the ML-KEM workspace behind them follows the rules of the ML-KEM entry points.
  * status may be NULL on the host forms.  The _dev forms need circl_hip_hybrid_workspace_size(scheme, n) bytes, 16-byte
  * aligned arrays, and a non-NULL d_status. */
 #define CIRCL_HIP_HYBRID_XWING 1
