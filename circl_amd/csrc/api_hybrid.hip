@@ -2,6 +2,7 @@
 // (include/circl_hip.h):
 //   CIRCL_HIP_HYBRID_XWING            kem/xwing/xwing.go      (X25519 + ML-KEM-768, SHA3-256 combiner)
 //   CIRCL_HIP_HYBRID_X25519MLKEM768   kem/hybrid/hybrid.go    (ct_M || ct_X, ss_M || ss_X; X25519 as a KEM: xkem.go)
+//   CIRCL_HIP_HYBRID_KYBER768_X25519, _KYBER512_X25519   the same scheme type with X25519 first and round-3 Kyber second
 // A call is a handful of launches per chunk over HBM-resident arrays: strided splits of the packed keys / ciphertexts,
 // seed expansion (SHAKE256, lane = item), the ML-KEM-768 batch kernels, two X25519 ladders per item (lane = item), the
 // combiner, strided joins.  Nothing is computed on the host.
@@ -12,16 +13,56 @@ using namespace circl::host;
 namespace hk = circl::hybridk;
 
 namespace {
-constexpr size_t EK = 1184, DK = 2400, CTM = 1088;
-
-struct Sizes { size_t seed, eseed, pk, sk, ct, ss; };
-bool sizes_of(int scheme, Sizes &s) {
-    if (scheme == CIRCL_HIP_HYBRID_XWING) { s = {32, 64, EK + 32, 32, CTM + 32, 32}; return true; }
-    if (scheme == CIRCL_HIP_HYBRID_X25519MLKEM768) { s = {64, 32, EK + 32, DK + 32, CTM + 32, 64}; return true; }
-    return false;
+// one hybrid = one lattice KEM (ML-KEM or round-3 Kyber) + X25519, either of them first in every packed array
+struct Desc {
+    bool xwing;     // X-Wing: seed expansion, combiner and private-key format of kem/xwing; otherwise kem/hybrid's concatenation scheme
+    int param;      // 768 | 512
+    bool r3;        // round-3 Kyber (kem/kyber) instead of ML-KEM
+    bool x_first;   // X25519 is the `first` component of hybrid.go's scheme{name, first, second}
+    size_t EK, DK, CTM;
+    size_t seed, eseed, pk, sk, ct, ss;
+    // byte offsets of the two halves inside a packed row
+    size_t kem_off(size_t x_bytes) const { return x_first ? x_bytes : 0; }
+    size_t x_off(size_t kem_bytes) const { return x_first ? 0 : kem_bytes; }
+};
+bool desc_of(int scheme, Desc &d) {
+    auto lattice = [&](int param) {
+        d.param = param;
+        d.EK = circl_hip_mlkem_ek_size(param);
+        d.DK = circl_hip_mlkem_dk_size(param);
+        d.CTM = circl_hip_mlkem_ct_size(param);
+        d.pk = d.EK + 32;
+        d.ct = d.CTM + 32;
+    };
+    switch (scheme) {
+    case CIRCL_HIP_HYBRID_XWING:
+        d.xwing = true; d.r3 = false; d.x_first = false;
+        lattice(768);
+        d.seed = 32; d.eseed = 64; d.sk = 32; d.ss = 32;
+        return true;
+    case CIRCL_HIP_HYBRID_X25519MLKEM768:  // scheme{"X25519MLKEM768", mlkem768, x25519Kem}: hybrid.go:95-99
+        d.xwing = false; d.r3 = false; d.x_first = false;
+        lattice(768);
+        break;
+    case CIRCL_HIP_HYBRID_KYBER768_X25519:  // scheme{"Kyber768-X25519", x25519Kem, kyber768}: hybrid.go:77-81
+        d.xwing = false; d.r3 = true; d.x_first = true;
+        lattice(768);
+        break;
+    case CIRCL_HIP_HYBRID_KYBER512_X25519:  // scheme{"Kyber512-X25519", x25519Kem, kyber512}: hybrid.go:71-75
+        d.xwing = false; d.r3 = true; d.x_first = true;
+        lattice(512);
+        break;
+    default:
+        return false;
+    }
+    d.seed = 64;   // max of the components' seed sizes (hybrid.go:128-138): 64 for the lattice KEM, 32 for X25519
+    d.eseed = 32;  // hybrid.go:148-157
+    d.sk = d.DK + 32;
+    d.ss = 64;
+    return true;
 }
 
-// temporaries of one call, carved from the caller's workspace in front of the ML-KEM workspace
+// temporaries of one call, carved from the caller's workspace in front of the lattice KEM's workspace
 struct Carve {
     uint8_t *p;
     uint8_t *take(size_t bytes) {
@@ -30,9 +71,9 @@ struct Carve {
         return r;
     }
 };
-size_t tmp_bytes(size_t n) {  // upper bound over the three operations: ek, dk, ctm + a dozen 32/64-byte rows per item
+size_t tmp_bytes(const Desc &d, size_t n) {  // upper bound over the three operations: ek, dk, ctm + a dozen 32/64-byte rows per item
     auto r = [](size_t b) { return (b + 255) & ~size_t(255); };
-    return r(n * EK) + r(n * DK) + r(n * CTM) + 10 * r(n * 64) + r(n);
+    return r(n * d.EK) + r(n * d.DK) + r(n * d.CTM) + 10 * r(n * 64) + r(n);
 }
 
 int copy_rows(hipStream_t st, void *dst, size_t dst_row, const void *src, size_t src_row, size_t width, size_t n) {
@@ -63,93 +104,114 @@ bool args_ok(const void *a, const void *b, const void *c, const void *d, const v
     return !((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d) |
               reinterpret_cast<uintptr_t>(ws)) & 15);
 }
+
+// the lattice half: ML-KEM (per-item status) or round-3 Kyber (no per-item failure: status = 0)
+int kem_keygen(const Desc &d, const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, void *ws, size_t wsb, hipStream_t st) {
+    return d.r3 ? circl_hip_kyber_keygen_dev(d.param, seed64, ek, dk, n, ws, wsb, st) : circl_hip_mlkem_keygen_dev(d.param, seed64, ek, dk, n, ws, wsb, st);
+}
+int kem_encaps(const Desc &d, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t wsb,
+               hipStream_t st) {
+    if (!d.r3) return circl_hip_mlkem_encaps_dev(d.param, ek, m, ct, ss, status, n, ws, wsb, st);
+    HIP_TRY(hipMemsetAsync(status, 0, n, st));
+    return circl_hip_kyber_encaps_dev(d.param, ek, m, ct, ss, n, ws, wsb, st);
+}
+int kem_decaps(const Desc &d, const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws, size_t wsb, hipStream_t st) {
+    if (!d.r3) return circl_hip_mlkem_decaps_dev(d.param, dk, ct, ss, status, n, ws, wsb, st);
+    HIP_TRY(hipMemsetAsync(status, 0, n, st));
+    return circl_hip_kyber_decaps_dev(d.param, dk, ct, ss, n, ws, wsb, st);
+}
 }  // namespace
 
 extern "C" {
 
-size_t circl_hip_hybrid_seed_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.seed : 0; }
-size_t circl_hip_hybrid_eseed_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.eseed : 0; }
-size_t circl_hip_hybrid_pk_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.pk : 0; }
-size_t circl_hip_hybrid_sk_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.sk : 0; }
-size_t circl_hip_hybrid_ct_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.ct : 0; }
-size_t circl_hip_hybrid_ss_size(int scheme) { Sizes s; return sizes_of(scheme, s) ? s.ss : 0; }
+size_t circl_hip_hybrid_seed_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.seed : 0; }
+size_t circl_hip_hybrid_eseed_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.eseed : 0; }
+size_t circl_hip_hybrid_pk_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.pk : 0; }
+size_t circl_hip_hybrid_sk_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.sk : 0; }
+size_t circl_hip_hybrid_ct_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.ct : 0; }
+size_t circl_hip_hybrid_ss_size(int scheme) { Desc d; return desc_of(scheme, d) ? d.ss : 0; }
 
 size_t circl_hip_hybrid_workspace_size(int scheme, size_t n) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return 0;
-    return tmp_bytes(n) + circl_hip_mlkem_workspace_size(768, n);
+    Desc d;
+    if (!desc_of(scheme, d)) return 0;
+    return tmp_bytes(d, n) + circl_hip_mlkem_workspace_size(d.param, n);
 }
 
 int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc d;
+    if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_seed, d_pk, d_sk, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
-    uint8_t *seedm = c.take(n * 64), *skx = c.take(n * 32), *pkx = c.take(n * 32), *ek = c.take(n * EK), *dk = c.take(n * DK);
-    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
-    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
-    if (scheme == CIRCL_HIP_HYBRID_XWING)
+    uint8_t *seedm = c.take(n * 64), *skx = c.take(n * 32), *pkx = c.take(n * 32), *ek = c.take(n * d.EK), *dk = c.take(n * d.DK);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    if (d.xwing)
         hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
+    else if (d.x_first)
+        hipLaunchKernelGGL((hk::hybrid_expand_kernel<8, 8, true>), g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
     else
-        hipLaunchKernelGGL((hk::hybrid_expand_kernel<8, 8>), g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
+        hipLaunchKernelGGL((hk::hybrid_expand_kernel<8, 8, false>), g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
     HIP_TRY(hipGetLastError());
-    TRY(circl_hip_mlkem_keygen_dev(768, seedm, ek, dk, n, kws, kws_bytes, st));
+    TRY(kem_keygen(d, seedm, ek, dk, n, kws, kws_bytes, st));
     TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, n, st));
-    TRY(copy_rows(st, d_pk, s.pk, ek, EK, EK, n));
-    TRY(copy_rows(st, d_pk + EK, s.pk, pkx, 32, 32, n));
-    if (scheme == CIRCL_HIP_HYBRID_XWING) {
+    TRY(copy_rows(st, d_pk + d.kem_off(32), d.pk, ek, d.EK, d.EK, n));
+    TRY(copy_rows(st, d_pk + d.x_off(d.EK), d.pk, pkx, 32, 32, n));
+    if (d.xwing) {
         TRY(copy_rows(st, d_sk, 32, d_seed, 32, 32, n));  // the packed private key is the seed (xwing.go:156-163)
     } else {
-        TRY(copy_rows(st, d_sk, s.sk, dk, DK, DK, n));
-        TRY(copy_rows(st, d_sk + DK, s.sk, skx, 32, 32, n));
+        TRY(copy_rows(st, d_sk + d.kem_off(32), d.sk, dk, d.DK, d.DK, n));
+        TRY(copy_rows(st, d_sk + d.x_off(d.DK), d.sk, skx, 32, 32, n));
     }
     // nothing key-equivalent stays behind in the caller's workspace
     HIP_TRY(hipMemsetAsync(seedm, 0, n * 64, st));
     HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(dk, 0, n * DK, st));
+    HIP_TRY(hipMemsetAsync(dk, 0, n * d.DK, st));
     return CIRCL_HIP_OK;
 }
 
 int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *d_eseed, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
                                 void *d_ws, size_t ws_bytes, void *stream) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc d;
+    if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_pk, d_eseed, d_ct, d_ss, d_ws)) return CIRCL_HIP_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
-    uint8_t *ek = c.take(n * EK), *pkx = c.take(n * 32), *m = c.take(n * 32), *ekx = c.take(n * 32), *ctm = c.take(n * CTM), *ssm = c.take(n * 32),
+    uint8_t *ek = c.take(n * d.EK), *pkx = c.take(n * 32), *m = c.take(n * 32), *ekx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ssm = c.take(n * 32),
             *ctx = c.take(n * 32), *ssx = c.take(n * 32), *okx = c.take(n);
-    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
-    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
-    TRY(copy_rows(st, ek, EK, d_pk, s.pk, EK, n));
-    TRY(copy_rows(st, pkx, 32, d_pk + EK, s.pk, 32, n));
-    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // xwing.go:247-248: seedm = seed[:32], ekx = seed[32:]
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    TRY(copy_rows(st, ek, d.EK, d_pk + d.kem_off(32), d.pk, d.EK, n));
+    TRY(copy_rows(st, pkx, 32, d_pk + d.x_off(d.EK), d.pk, 32, n));
+    if (d.xwing) {  // xwing.go:247-248: seedm = seed[:32], ekx = seed[32:]
         TRY(copy_rows(st, m, 32, d_eseed, 64, 32, n));
         TRY(copy_rows(st, ekx, 32, d_eseed + 32, 64, 32, n));
     } else {
-        hipLaunchKernelGGL((hk::hybrid_expand_kernel<4, 4>), g256(n), dim3(256), 0, st, w(d_eseed), w(m), w(ekx), n);
+        if (d.x_first)
+            hipLaunchKernelGGL((hk::hybrid_expand_kernel<4, 4, true>), g256(n), dim3(256), 0, st, w(d_eseed), w(m), w(ekx), n);
+        else
+            hipLaunchKernelGGL((hk::hybrid_expand_kernel<4, 4, false>), g256(n), dim3(256), 0, st, w(d_eseed), w(m), w(ekx), n);
         HIP_TRY(hipGetLastError());
     }
-    TRY(circl_hip_mlkem_encaps_dev(768, ek, m, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    TRY(kem_encaps(d, ek, m, ctm, ssm, d_status, n, kws, kws_bytes, st));
     TRY(x25519_pair_dev(ekx, pkx, ctx, ssx, okx, n, st));  // ct_X = X25519(ekx, 9), ss_X = X25519(ekx, pk_X)
-    TRY(copy_rows(st, d_ct, s.ct, ctm, CTM, CTM, n));
-    TRY(copy_rows(st, d_ct + CTM, s.ct, ctx, 32, 32, n));
-    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // a low-order pk_X is not an error in X-Wing (xwing.go:251-254)
+    TRY(copy_rows(st, d_ct + d.kem_off(32), d.ct, ctm, d.CTM, d.CTM, n));
+    TRY(copy_rows(st, d_ct + d.x_off(d.CTM), d.ct, ctx, 32, 32, n));
+    if (d.xwing) {  // a low-order pk_X is not an error in X-Wing (xwing.go:251-254)
         hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), d_status, w(d_ss), n);
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
         HIP_TRY(hipGetLastError());
-        TRY(copy_rows(st, d_ss, 64, ssm, 32, 32, n));
-        TRY(copy_rows(st, d_ss + 32, 64, ssx, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.kem_off(32), 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.x_off(32), 64, ssx, 32, 32, n));
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
-    TRY(zero_failed(st, d_ct, s.ct, d_status, n));
+    TRY(zero_failed(st, d_ct, d.ct, d_status, n));
     HIP_TRY(hipMemsetAsync(m, 0, n * 32, st));  // the ephemeral secrets and the two half shared secrets
     HIP_TRY(hipMemsetAsync(ekx, 0, n * 32, st));
     HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
@@ -159,42 +221,42 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
 
 int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws,
                                 size_t ws_bytes, void *stream) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc d;
+    if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_sk, d_ct, d_ss, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
-    uint8_t *dk = c.take(n * DK), *ek = c.take(n * EK), *skx = c.take(n * 32), *ctm = c.take(n * CTM), *ctx = c.take(n * 32), *ssm = c.take(n * 32),
+    uint8_t *dk = c.take(n * d.DK), *ek = c.take(n * d.EK), *skx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ctx = c.take(n * 32), *ssm = c.take(n * 32),
             *ssx = c.take(n * 32), *pkx = c.take(n * 32), *seedm = c.take(n * 64), *okx = c.take(n);
-    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(n);
-    const size_t kws_bytes = ws_bytes - tmp_bytes(n);
-    TRY(copy_rows(st, ctm, CTM, d_ct, s.ct, CTM, n));
-    TRY(copy_rows(st, ctx, 32, d_ct + CTM, s.ct, 32, n));
-    if (scheme == CIRCL_HIP_HYBRID_XWING) {  // the private key is the seed: re-derive (xwing.go:165-185 Unpack = deriveKeyPair)
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    TRY(copy_rows(st, ctm, d.CTM, d_ct + d.kem_off(32), d.ct, d.CTM, n));
+    TRY(copy_rows(st, ctx, 32, d_ct + d.x_off(d.CTM), d.ct, 32, n));
+    if (d.xwing) {  // the private key is the seed: re-derive (xwing.go:165-185 Unpack = deriveKeyPair)
         hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_sk), w(seedm), w(skx), n);
         HIP_TRY(hipGetLastError());
-        TRY(circl_hip_mlkem_keygen_dev(768, seedm, ek, dk, n, kws, kws_bytes, st));
+        TRY(kem_keygen(d, seedm, ek, dk, n, kws, kws_bytes, st));
         TRY(x25519_pair_dev(skx, ctx, pkx, ssx, okx, n, st));  // sk.xpk = X25519(sk_X, 9), ss_X = X25519(sk_X, ct_X)
     } else {
-        TRY(copy_rows(st, dk, DK, d_sk, s.sk, DK, n));
-        TRY(copy_rows(st, skx, 32, d_sk + DK, s.sk, 32, n));
+        TRY(copy_rows(st, dk, d.DK, d_sk + d.kem_off(32), d.sk, d.DK, n));
+        TRY(copy_rows(st, skx, 32, d_sk + d.x_off(d.DK), d.sk, 32, n));
         TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
     }
-    TRY(circl_hip_mlkem_decaps_dev(768, dk, ctm, ssm, d_status, n, kws, kws_bytes, st));
-    if (scheme == CIRCL_HIP_HYBRID_XWING) {
+    TRY(kem_decaps(d, dk, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    if (d.xwing) {
         hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), static_cast<const uint8_t *>(nullptr),
                            w(d_ss), n);
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
         HIP_TRY(hipGetLastError());
-        TRY(copy_rows(st, d_ss, 64, ssm, 32, 32, n));
-        TRY(copy_rows(st, d_ss + 32, 64, ssx, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.kem_off(32), 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.x_off(32), 64, ssx, 32, 32, n));
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
-    HIP_TRY(hipMemsetAsync(dk, 0, n * DK, st));
+    HIP_TRY(hipMemsetAsync(dk, 0, n * d.DK, st));
     HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
     HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
     HIP_TRY(hipMemsetAsync(ssx, 0, n * 32, st));
@@ -212,8 +274,8 @@ static PipeOpts hybrid_opts() {
 }
 
 int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int device) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{seed + lo * s.seed, s.seed, true}}, {}, {{pk + lo * s.pk, s.pk}, {sk + lo * s.sk, s.sk, true}},
                             [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(),
@@ -222,8 +284,8 @@ int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_
 }
 
 int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}}, {},
                             {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
@@ -234,8 +296,8 @@ int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed,
 }
 
 int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
-    Sizes s;
-    if (!sizes_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}}, {},
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},

@@ -68,12 +68,16 @@ static __global__ __launch_bounds__(256) void xwing_expand_kernel(const uint32_t
     }
 }
 
-// X25519MLKEM768 seed expansion.  DeriveKeyPair (hybrid.go:236-250 + xkem.go:112-123): SHAKE256(seed[64]) -> seedm[64] ||
-// xseed[32], sk_X = SHAKE256(xseed)[:32].  EncapsulateDeterministically (hybrid.go:271-300 + xkem.go:160-178):
-// SHAKE256(seed[32]) -> m[32] || xseed[32], ephemeral sk_X = SHAKE256(xseed)[:32].  IN / FIRST in 64-bit words.
-template <int IN, int FIRST>
-static __global__ __launch_bounds__(256) void hybrid_expand_kernel(const uint32_t *__restrict__ seed, uint32_t *__restrict__ first,
+// kem/hybrid seed expansion (hybrid.go:236-250, :271-300; the X25519 half is a KEM of its own: xkem.go:112-123, :160-178).
+// ex = SHAKE256(seed) is cut into the first component's seed, then the second's; the X25519 component turns its 32 bytes into
+// the scalar sk_X = SHAKE256(xseed)[:32].  IN = seed words (8 for DeriveKeyPair, 4 for EncapsulateDeterministically), KEMW =
+// words of the lattice KEM's seed (8: d || z; 4: m), XFIRST = X25519 is the first component (Kyber768-X25519) or the second
+// (X25519MLKEM768).
+template <int IN, int KEMW, bool XFIRST>
+static __global__ __launch_bounds__(256) void hybrid_expand_kernel(const uint32_t *__restrict__ seed, uint32_t *__restrict__ kem_seed,
                                                                    uint32_t *__restrict__ skx, size_t n) {
+    constexpr int KEM_AT = XFIRST ? 4 : 0, X_AT = XFIRST ? 0 : KEMW;
+    static_assert(KEMW + 4 <= 17, "one squeeze block");
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     if (!live) i = n - 1;
@@ -82,13 +86,13 @@ static __global__ __launch_bounds__(256) void hybrid_expand_kernel(const uint32_
     state_load<0, IN>(s, seed + i * 2 * IN);
     shake256_pad<IN>(s);
     keccak_f1600(s);
-    if (live) state_store<0, FIRST>(first + i * 2 * FIRST, s);
+    if (live) state_store<KEM_AT, KEMW>(kem_seed + i * 2 * KEMW, s);
     KeccakState x;
     state_zero(x);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        x.lo[j] = s.lo[FIRST + j];
-        x.hi[j] = s.hi[FIRST + j];
+        x.lo[j] = s.lo[X_AT + j];
+        x.hi[j] = s.hi[X_AT + j];
     }
     shake256_pad<4>(x);
     keccak_f1600(x);

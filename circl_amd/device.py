@@ -194,7 +194,7 @@ def profile_read(kernel):
     return ms.value, cnt.value
 
 
-XWING, X25519MLKEM768 = 1, 2
+XWING, X25519MLKEM768, KYBER768_X25519, KYBER512_X25519 = 1, 2, 3, 4
 
 
 class HybridDevice:

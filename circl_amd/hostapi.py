@@ -352,8 +352,10 @@ def x25519(scalar, point=None, device=0):
     return out, ok
 
 
-XWING, X25519MLKEM768 = 1, 2
-HYBRID_SIZES = {XWING: dict(seed=32, eseed=64, pk=1216, sk=32, ct=1120, ss=32), X25519MLKEM768: dict(seed=64, eseed=32, pk=1216, sk=2432, ct=1120, ss=64)}
+XWING, X25519MLKEM768, KYBER768_X25519, KYBER512_X25519 = 1, 2, 3, 4
+HYBRID_SIZES = {XWING: dict(seed=32, eseed=64, pk=1216, sk=32, ct=1120, ss=32), X25519MLKEM768: dict(seed=64, eseed=32, pk=1216, sk=2432, ct=1120, ss=64),
+                KYBER768_X25519: dict(seed=64, eseed=32, pk=1216, sk=2432, ct=1120, ss=64),
+                KYBER512_X25519: dict(seed=64, eseed=32, pk=832, sk=1664, ct=800, ss=64)}
 
 
 def hybrid_keygen(scheme, seeds, device=0):

@@ -1,7 +1,7 @@
 //go:build cgo && hip
 
 // Package hipbatch is the cgo bridge a CIRCL maintainer would add next to kem/hybrid and kem/xwing to route batches of
-// the two hybrid KEMs that carry ML-KEM-768 -- "X25519MLKEM768" (kem/hybrid/hybrid.go) and "X-Wing" (kem/xwing) -- to
+// the X25519 hybrids -- "X25519MLKEM768", "Kyber768-X25519", "Kyber512-X25519" (kem/hybrid/hybrid.go) and "X-Wing" (kem/xwing) -- to
 // libcirclhip.so (MI355X).  Both halves run on the GPU: ML-KEM-768, the X25519 ladders (one lane per item), the seed
 // expansions and the X-Wing combiner; the kem.Scheme values stay untouched.
 //
@@ -27,7 +27,12 @@ import (
 // AllDevices splits a batch into contiguous shards, one per visible GPU (no collective).
 const AllDevices = -1
 
-var schemes = map[string]C.int{"X-Wing": C.CIRCL_HIP_HYBRID_XWING, "X25519MLKEM768": C.CIRCL_HIP_HYBRID_X25519MLKEM768}
+var schemes = map[string]C.int{
+	"X-Wing":          C.CIRCL_HIP_HYBRID_XWING,
+	"X25519MLKEM768":  C.CIRCL_HIP_HYBRID_X25519MLKEM768,
+	"Kyber768-X25519": C.CIRCL_HIP_HYBRID_KYBER768_X25519, // hybrid.Kyber768X25519(): X25519 first, round-3 Kyber768 second
+	"Kyber512-X25519": C.CIRCL_HIP_HYBRID_KYBER512_X25519,
+}
 
 func status(code C.int, where string) error {
 	if code == 0 {

@@ -330,6 +330,10 @@ int circl_hip_x25519_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_
  *   seed 64, eseed 32, pk 1216 (ek || pk_X), sk 2432 (dk || sk_X), ct 1120, ss 64 (ss_M || ss_X).  status[i] = 1
  *   (kem.ErrPubKey) for a non-canonical ek or a low-order X25519 point, 2 (kem.ErrPrivKey) for a private key failing its
  *   hash check; the item's outputs are then zero (the reference returns nil, err).
+ * scheme = CIRCL_HIP_HYBRID_KYBER768_X25519 / _KYBER512_X25519: the same hybrid.go scheme with X25519 as the FIRST component
+ *   and round-3 Kyber (kem/kyber) as the second: pk = pk_X || ek (1216 / 832), sk = sk_X || dk (2432 / 1664), ct = ct_X ||
+ *   ct_K (1120 / 800), ss = ss_X || ss_K (64); seed 64 (SHAKE256 -> 32 for X25519, then 64 for Kyber), eseed 32.  Round-3
+ *   Kyber has no per-item failure, so status is 1 only for a low-order X25519 point.
  * The deterministic forms only (EncapsulateDeterministically / DeriveKeyPair): randomness stays with the caller.
  * The _dev forms zero the secret temporaries in the workspace (seeds, X25519 scalars, private keys, half secrets) before
  * they return control of the stream; the ML-KEM workspace behind them follows the rules of the ML-KEM entry points.
@@ -337,6 +341,8 @@ int circl_hip_x25519_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_
  * aligned arrays, and a non-NULL d_status. */
 #define CIRCL_HIP_HYBRID_XWING 1
 #define CIRCL_HIP_HYBRID_X25519MLKEM768 2
+#define CIRCL_HIP_HYBRID_KYBER768_X25519 3 /* hybrid.Kyber768X25519(): X25519 first, round-3 Kyber768 second (hybrid.go:77-81) */
+#define CIRCL_HIP_HYBRID_KYBER512_X25519 4 /* hybrid.Kyber512X25519() (hybrid.go:71-75) */
 size_t circl_hip_hybrid_seed_size(int scheme);
 size_t circl_hip_hybrid_eseed_size(int scheme);
 size_t circl_hip_hybrid_pk_size(int scheme);

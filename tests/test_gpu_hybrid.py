@@ -77,7 +77,7 @@ def test_x25519mlkem768_against_oracle(api, ho, n):
         assert (ss2[8:] == ss[8:]).all() and (ss2[7] != ss[7]).any()
 
 
-@pytest.mark.parametrize("scheme", [1, 2])
+@pytest.mark.parametrize("scheme", [1, 2, 3, 4])
 def test_round_trip_full_chip_batch(api, scheme):
     n = 1 << 16
     S = api.HYBRID_SIZES[scheme]
@@ -87,3 +87,34 @@ def test_round_trip_full_chip_batch(api, scheme):
     ss2, st2 = api.hybrid_decaps(scheme, sk, ct)
     assert not st.any() and not st2.any() and (ss == ss2).all() and ss.any(axis=1).all()
     assert len(np.unique(ss[:, :8].copy().view(np.uint64))) == n
+
+
+@pytest.mark.parametrize("scheme", [3, 4])
+@pytest.mark.parametrize("n", [1, 300])
+def test_kyber_x25519_hybrids_against_oracle(api, ho, scheme, n):
+    # hybrid.Kyber768X25519() / Kyber512X25519() (hybrid.go:71-81): X25519 is the first component, round-3 Kyber the second
+    S = api.HYBRID_SIZES[scheme]
+    rng = np.random.default_rng(1000 * scheme + n)
+    seeds = rng.integers(0, 256, (n, S["seed"]), dtype=np.uint8)
+    es = rng.integers(0, 256, (n, S["eseed"]), dtype=np.uint8)
+    pk, sk = api.hybrid_keygen(scheme, seeds)
+    pk0, sk0 = ho.hybrid_keygen(seeds, scheme)
+    assert pk.shape[1] == S["pk"] and (pk == pk0).all() and (sk == sk0).all()
+    if n > 8:
+        pk[2, :32] = np.frombuffer(LOW_ORDER, np.uint8)   # low-order X25519 public key -> kem.ErrPubKey
+        pk[3, 32:34] = 0xff                               # round-3 Kyber reduces a coefficient >= q: not an error (kyber.go:248-262)
+    ct, ss, st = api.hybrid_encaps(scheme, pk, es)
+    ct0, ss0, st0 = ho.hybrid_encaps(pk, es, scheme)
+    assert (st == st0).all() and (ct == ct0).all() and (ss == ss0).all()
+    if n > 8:
+        assert st[2] == 1 and st.sum() == 1 and not ct[2].any()
+        ct[5, :32] = np.frombuffer(LOW_ORDER, np.uint8)   # low-order ciphertext point
+        ct[6, 40] ^= 1                                    # implicit rejection in the Kyber half
+    ss2, st2 = api.hybrid_decaps(scheme, sk, ct)
+    ss20, st20 = ho.hybrid_decaps(sk, ct, scheme)
+    assert (st2 == st20).all() and (ss2 == ss20).all()
+    if n > 8:
+        assert st2[5] == 1 and st2[2] == 1 and st2.sum() == 2   # item 2's ciphertext is all zero: its X25519 point is the low-order 0
+        assert (ss2[7:] == ss[7:]).all() and (ss2[6] != ss[6]).any()
+    else:
+        assert (ss2 == ss).all()
