@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from circl_amd import hostapi  # noqa: E402
-from oracle import orc  # noqa: E402
+from oracle import orc, hybrid as ohyb  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
@@ -61,4 +61,39 @@ while time.time() < t_end:
     idx = rng.integers(0, nk, n).astype(np.uint32)
     okk = hostapi.mldsa_verify_keyed(d, pk[:nk], idx, sig, msgs)
     assert okk.tolist() == orc.mldsa_verify(d, pk[idx], sig, msgs).tolist(), ("verify keyed", d, n, nk)
+    # X25519 and the hybrid KEMs (device composition, pair kernel, fixed-base comb)
+    n = int(rng.choice([1, 2, 63, 64, 65, 700, 5000]))
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    u = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    o, ok = hostapi.x25519(k, u)
+    o0, ok0 = orc.x25519(k, u)
+    assert (o == o0).all() and (ok == ok0).all(), ("x25519", n)
+    assert (hostapi.x25519(k)[0] == orc.x25519(k)[0]).all(), ("x25519 base", n)
+    sch = int(rng.choice([1, 2, 3, 4]))
+    S = hostapi.HYBRID_SIZES[sch]
+    n = int(rng.choice([1, 3, 65, 400]))
+    seeds = rng.integers(0, 256, (n, S["seed"]), dtype=np.uint8)
+    es = rng.integers(0, 256, (n, S["eseed"]), dtype=np.uint8)
+    pk, sk = hostapi.hybrid_keygen(sch, seeds)
+    if sch == 1:
+        pk0, sk0 = ohyb.xwing_keygen(seeds)[:2]
+        ct0, ss0, st0 = ohyb.xwing_encaps(pk0, es)
+    else:
+        pk0, sk0 = ohyb.hybrid_keygen(seeds, sch)
+        ct0, ss0, st0 = ohyb.hybrid_encaps(pk0, es, sch)
+    assert (pk == pk0).all() and (sk == sk0).all(), ("hybrid keygen", sch, n)
+    ct, ss, st = hostapi.hybrid_encaps(sch, pk, es)
+    assert (ct == ct0).all() and (ss == ss0).all() and (st == st0).all(), ("hybrid encaps", sch, n)
+    ss2, st2 = hostapi.hybrid_decaps(sch, sk, ct)
+    assert (ss2 == ss).all() and not st2.any(), ("hybrid decaps", sch, n)
+    if it % 7 == 0:  # the two-stream split of large signing batches, against the one-key oracle on a sample
+        d = int(rng.choice([44, 65, 87]))
+        n = (1 << 16) + int(rng.integers(0, 300))
+        s32 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pkd, skd = hostapi.mldsa_keygen(d, s32)
+        msgs = [bytes(rng.integers(0, 256, 20, dtype=np.uint8)) for _ in range(n)]
+        sig = hostapi.mldsa_sign(d, skd, msgs)
+        assert hostapi.mldsa_verify(d, pkd, sig, msgs).all(), ("big sign verify", d, n)
+        idx = rng.choice(n, 200, replace=False)
+        assert (sig[idx] == orc.mldsa_sign(d, skd[idx], [msgs[i] for i in idx])).all(), ("big sign oracle", d, n)
 print("stress ok:", it, "iterations")
