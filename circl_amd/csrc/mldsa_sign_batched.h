@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
 }
 
 // wave = entry: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88).
-// One entry's work is a function of its own (not inlined into the grid-stride loop of the kernel): inlined, the loop's
-// register allocation grew from 102 to 164 VGPRs (26-30 spilled under the 128-register cap of 4 waves per SIMD).
+// One entry's work (sign_finish_kernel below runs it inlined for a workgroup's first entry and through a non-inlined copy for
+// any further one).
 template <int MODE>
 __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
                                                  uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
