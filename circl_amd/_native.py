@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libcirclhip.so")
 
 # every symbol include/circl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "circl_hip_init", "circl_hip_device_count", "circl_hip_last_error", "circl_hip_version", "circl_hip_device_info",
+    "circl_hip_init", "circl_hip_device_count", "circl_hip_physical_device", "circl_hip_last_error", "circl_hip_version", "circl_hip_device_info",
     "circl_hip_mlkem_encaps_keyed", "circl_hip_mlkem_decaps_keyed", "circl_hip_mlkem_keyed_workspace_size",
     "circl_hip_mlkem_encaps_keyed_dev", "circl_hip_mlkem_decaps_keyed_dev",
     "circl_hip_mldsa_verify_keyed", "circl_hip_mldsa_keyed_workspace_size", "circl_hip_mldsa_verify_keyed_dev",
@@ -25,7 +25,7 @@ SYMBOLS = [
     "circl_hip_kyber_keygen", "circl_hip_kyber_encaps", "circl_hip_kyber_decaps",
     "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_shared", "circl_hip_mldsa_verify_shared_dev", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
-    "circl_hip_keccak_f1600", "circl_hip_keccak_f1600_coop", "circl_hip_mldsa_sample_in_ball", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_dilithium_ntt",
+    "circl_hip_keccak_f1600", "circl_hip_keccak_f1600_coop", "circl_hip_mldsa_sample_in_ball", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_lane_op", "circl_hip_kyber_sample_uniform", "circl_hip_kyber_sample_cbd", "circl_hip_mldsa_sample_uniform", "circl_hip_dilithium_ntt",
     "circl_hip_shake", "circl_hip_xof", "circl_hip_k12", "circl_hip_x25519", "circl_hip_x25519_dev",
     "circl_hip_hybrid_seed_size", "circl_hip_hybrid_eseed_size", "circl_hip_hybrid_pk_size", "circl_hip_hybrid_sk_size", "circl_hip_hybrid_ct_size",
     "circl_hip_hybrid_ss_size", "circl_hip_hybrid_workspace_size", "circl_hip_hybrid_keygen", "circl_hip_hybrid_encaps", "circl_hip_hybrid_decaps",
@@ -131,6 +131,10 @@ def lib():
         L.circl_hip_kyber_ntt.argtypes = [vp, sz, i, i]
         L.circl_hip_kyber_mulhat.argtypes = [vp, vp, vp, sz, i]
         L.circl_hip_dilithium_ntt.argtypes = [vp, sz, i, i]
+        L.circl_hip_lane_op.argtypes = [i, i, vp, vp, vp, vp, sz, i]
+        L.circl_hip_kyber_sample_uniform.argtypes = [vp, vp, vp, sz, i]
+        L.circl_hip_kyber_sample_cbd.argtypes = [i, vp, vp, sz, i]
+        L.circl_hip_mldsa_sample_uniform.argtypes = [vp, vp, vp, sz, i]
         L.circl_hip_shake.argtypes = [i, i, vp, sz, vp, sz, sz, i]
         L.circl_hip_xof.argtypes = [i, i, i, vp, vp, vp, sz, sz, i]
         L.circl_hip_k12.argtypes = [vp, vp, vp, vp, vp, sz, sz, i]

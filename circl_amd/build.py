@@ -22,7 +22,7 @@ UNITS = {
     "host_runtime.hip": [],
     "api_mlkem.hip": ["kyber_dev.h", "mlkem_kernels.h"],
     "api_mldsa.hip": ["kyber_dev.h", "dilithium_dev.h", "mlkem_kernels.h", "mldsa_kernels.h", "mldsa_sign_batched.h"],
-    "api_prims.hip": ["kyber_dev.h", "dilithium_dev.h", "prim_kernels.h"],
+    "api_prims.hip": ["kyber_dev.h", "dilithium_dev.h", "prim_kernels.h", "sampler_prims.h", "mlkem_kernels.h", "mldsa_kernels.h"],
     "api_x25519.hip": ["x25519_dev.h", "x25519_base_table.h", "x25519_kernels.h"],
     "api_hybrid.hip": ["hybrid_kernels.h"],
 }

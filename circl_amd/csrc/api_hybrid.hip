@@ -100,9 +100,34 @@ inline const uint32_t *w(const uint8_t *p) { return reinterpret_cast<const uint3
 inline uint32_t *w(uint8_t *p) { return reinterpret_cast<uint32_t *>(p); }
 inline dim3 g256(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// The secret temporaries of a call, zeroed on the call's stream on EVERY path: finish() on the way out of a successful call
+// (its failures are reported), the destructor behind any early error return.
+struct SecretWipe {
+    hipStream_t st;
+    struct R { uint8_t *p; size_t bytes; };
+    std::vector<R> regions;
+    bool done = false;
+    void add(uint8_t *p, size_t bytes) { regions.push_back({p, bytes}); }
+    int finish() {
+        done = true;
+        for (auto &r : regions) HIP_TRY(hipMemsetAsync(r.p, 0, r.bytes, st));
+        return CIRCL_HIP_OK;
+    }
+    ~SecretWipe() {
+        if (done) return;
+        for (auto &r : regions) (void)hipMemsetAsync(r.p, 0, r.bytes, st);
+        (void)hipGetLastError();
+    }
+};
+
 bool args_ok(const void *a, const void *b, const void *c, const void *d, const void *ws) {
     return !((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d) |
               reinterpret_cast<uintptr_t>(ws)) & 15);
+}
+
+int misaligned() {  // (the header's code for a misaligned device pointer; the message tells it from a short workspace)
+    g_err = "hybrid _dev entry point: device pointers must be 16-byte aligned";
+    return CIRCL_HIP_EWORKSPACE;
 }
 
 // the lattice half: ML-KEM (per-item status) or round-3 Kyber (no per-item failure: status = 0)
@@ -142,12 +167,16 @@ int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk
     if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_seed, d_pk, d_sk, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    if (!d_seed || !d_pk || !d_sk || !d_ws) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (!args_ok(d_seed, d_pk, d_sk, nullptr, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
     uint8_t *seedm = c.take(n * 64), *skx = c.take(n * 32), *pkx = c.take(n * 32), *ek = c.take(n * d.EK), *dk = c.take(n * d.DK);
     uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
     const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    SecretWipe wipe{st};  // nothing key-equivalent stays behind in the caller's workspace
+    wipe.add(seedm, n * 64); wipe.add(skx, n * 32); wipe.add(dk, n * d.DK);
     if (d.xwing)
         hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(n), dim3(256), 0, st, w(d_seed), w(seedm), w(skx), n);
     else if (d.x_first)
@@ -165,11 +194,7 @@ int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk
         TRY(copy_rows(st, d_sk + d.kem_off(32), d.sk, dk, d.DK, d.DK, n));
         TRY(copy_rows(st, d_sk + d.x_off(d.DK), d.sk, skx, 32, 32, n));
     }
-    // nothing key-equivalent stays behind in the caller's workspace
-    HIP_TRY(hipMemsetAsync(seedm, 0, n * 64, st));
-    HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(dk, 0, n * d.DK, st));
-    return CIRCL_HIP_OK;
+    return wipe.finish();
 }
 
 int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *d_eseed, uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
@@ -178,13 +203,17 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
     if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
-    if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_pk, d_eseed, d_ct, d_ss, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    if (!d_status || !d_pk || !d_eseed || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (!args_ok(d_pk, d_eseed, d_ct, d_ss, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
     uint8_t *ek = c.take(n * d.EK), *pkx = c.take(n * 32), *m = c.take(n * 32), *ekx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ssm = c.take(n * 32),
             *ctx = c.take(n * 32), *ssx = c.take(n * 32), *okx = c.take(n);
     uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
     const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    SecretWipe wipe{st};  // the ephemeral secrets and the two half shared secrets
+    wipe.add(m, n * 32); wipe.add(ekx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32);
     TRY(copy_rows(st, ek, d.EK, d_pk + d.kem_off(32), d.pk, d.EK, n));
     TRY(copy_rows(st, pkx, 32, d_pk + d.x_off(d.EK), d.pk, 32, n));
     if (d.xwing) {  // xwing.go:247-248: seedm = seed[:32], ekx = seed[32:]
@@ -212,11 +241,7 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
     TRY(zero_failed(st, d_ct, d.ct, d_status, n));
-    HIP_TRY(hipMemsetAsync(m, 0, n * 32, st));  // the ephemeral secrets and the two half shared secrets
-    HIP_TRY(hipMemsetAsync(ekx, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(ssx, 0, n * 32, st));
-    return CIRCL_HIP_OK;
+    return wipe.finish();
 }
 
 int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws,
@@ -225,13 +250,17 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
     if (!desc_of(scheme, d)) return CIRCL_HIP_EPARAM;
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
-    if (!d_status || ws_bytes < circl_hip_hybrid_workspace_size(scheme, n) || !args_ok(d_sk, d_ct, d_ss, nullptr, d_ws)) return CIRCL_HIP_EWORKSPACE;
+    if (!d_status || !d_sk || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (!args_ok(d_sk, d_ct, d_ss, nullptr, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
     uint8_t *dk = c.take(n * d.DK), *ek = c.take(n * d.EK), *skx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ctx = c.take(n * 32), *ssm = c.take(n * 32),
             *ssx = c.take(n * 32), *pkx = c.take(n * 32), *seedm = c.take(n * 64), *okx = c.take(n);
     uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
     const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    SecretWipe wipe{st};
+    wipe.add(dk, n * d.DK); wipe.add(skx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32); wipe.add(seedm, n * 64);
     TRY(copy_rows(st, ctm, d.CTM, d_ct + d.kem_off(32), d.ct, d.CTM, n));
     TRY(copy_rows(st, ctx, 32, d_ct + d.x_off(d.CTM), d.ct, 32, n));
     if (d.xwing) {  // the private key is the seed: re-derive (xwing.go:165-185 Unpack = deriveKeyPair)
@@ -256,12 +285,7 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
         TRY(copy_rows(st, d_ss + d.x_off(32), 64, ssx, 32, 32, n));
         TRY(zero_failed(st, d_ss, 64, d_status, n));
     }
-    HIP_TRY(hipMemsetAsync(dk, 0, n * d.DK, st));
-    HIP_TRY(hipMemsetAsync(skx, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(ssm, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(ssx, 0, n * 32, st));
-    HIP_TRY(hipMemsetAsync(seedm, 0, n * 64, st));
-    return CIRCL_HIP_OK;
+    return wipe.finish();
 }
 
 // ---- host-buffer forms on the staging pipeline ----
@@ -276,6 +300,7 @@ static PipeOpts hybrid_opts() {
 int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int device) {
     Desc s;
     if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n && (!seed || !pk || !sk)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{seed + lo * s.seed, s.seed, true}}, {}, {{pk + lo * s.pk, s.pk}, {sk + lo * s.sk, s.sk, true}},
                             [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(),
@@ -286,6 +311,7 @@ int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_
 int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
     Desc s;
     if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n && (!pk || !eseed || !ct || !ss)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}}, {},
                             {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
@@ -298,6 +324,7 @@ int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed,
 int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
     Desc s;
     if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n && (!sk || !ct || !ss)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}}, {},
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},

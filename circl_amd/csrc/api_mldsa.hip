@@ -389,14 +389,26 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     const size_t lo[2] = {0, h0}, cnt[2] = {h0, n - h0};
     uint8_t *wsp[2] = {static_cast<uint8_t *>(ws), static_cast<uint8_t *>(ws) + up256(SignLayout<MODE>(h0).total)};
     int rc = CIRCL_HIP_OK;
+    auto note = [&](hipError_t e, const char *what) {  // remember the first failure, keep going: both halves must be joined
+        if (e == hipSuccess) return true;
+        if (rc == CIRCL_HIP_OK) {
+            g_err = std::string("mldsa_sign_batched: ") + what + " -> " + hipGetErrorString(e);
+            rc = e == hipErrorOutOfMemory ? CIRCL_HIP_ENOMEM : CIRCL_HIP_EHIP;
+        }
+        (void)hipGetLastError();
+        return false;
+    };
     for (int p = 0; p < 2; p++) {
-        HIP_TRY(hipStreamWaitEvent(aux[p], fork, 0));
-        const int r = mldsa_sign_batched_part<MODE>(shared ? sk : sk + lo[p] * SK, msg_blob, msg_off + lo[p], ctx_blob, ctx_off ? ctx_off + lo[p] : nullptr,
-                                                    rnd + lo[p] * 32, internal, sig + lo[p] * SIG, cnt[p], wsp[p], aux[p], shared);
-        if (r != CIRCL_HIP_OK && rc == CIRCL_HIP_OK) rc = r;
-        // join on every path: whatever was enqueued on the library's streams is ordered before the caller's later work
-        HIP_TRY(hipEventRecord(done[p], aux[p]));
-        HIP_TRY(hipStreamWaitEvent(st, done[p], 0));
+        if (note(hipStreamWaitEvent(aux[p], fork, 0), "fork")) {
+            const int r = mldsa_sign_batched_part<MODE>(shared ? sk : sk + lo[p] * SK, msg_blob, msg_off + lo[p], ctx_blob, ctx_off ? ctx_off + lo[p] : nullptr,
+                                                        rnd + lo[p] * 32, internal, sig + lo[p] * SIG, cnt[p], wsp[p], aux[p], shared);
+            if (r != CIRCL_HIP_OK && rc == CIRCL_HIP_OK) rc = r;
+        }
+        // join on EVERY path: whatever was enqueued on the library's streams is ordered before the caller's later work (the
+        // caller may reuse sig / the workspace as soon as its own stream gets there); if the event calls themselves fail,
+        // wait for the library's stream on the host instead
+        if (!note(hipEventRecord(done[p], aux[p]), "join record") || !note(hipStreamWaitEvent(st, done[p], 0), "join wait"))
+            (void)hipStreamSynchronize(aux[p]);
     }
     return rc;
 }

@@ -309,10 +309,15 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     return CIRCL_HIP_OK;
 }
 
-PipeOpts kem_opts(bool secret) {
+// Every ML-KEM host-buffer call wipes what is secret in a chunk's device staging once its results are out.  encaps_only: the
+// secrets are m, ss and the per-item workspace slots (the coins r, G's output) -- the keys, the ciphertexts and the matrix
+// scratch are public -- so only those segments are zeroed; decapsulation and key generation (private keys in the staging)
+// zero the whole slot.
+PipeOpts kem_opts(bool encaps_only) {
     PipeOpts o;
     o.chunk_items = host_chunk_items(size_t(1) << 15);
-    o.wipe_device = secret;
+    o.wipe_device = true;
+    if (encaps_only) o.ws_secret_bytes = [](size_t cnt) { return up256(kKemWsPerItem * cnt); };
     return o;
 }
 std::function<size_t(size_t)> kem_ws_fn() {
@@ -409,7 +414,7 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false),
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true),
                             [&](Chunk &c) { return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -419,7 +424,7 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            kem_ws_fn(), kem_opts(true),
+                            kem_ws_fn(), kem_opts(false),
                             [&](Chunk &c) { return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -428,7 +433,7 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(true),
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(false),
                             [&](Chunk &c) { return circl_hip_mlkem_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -438,7 +443,7 @@ int circl_hip_mlkem_decaps_shared(int param, const uint8_t *dk, const uint8_t *c
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk, DK, true, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
+                            kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -449,7 +454,7 @@ int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek, EK, false, true}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -466,7 +471,7 @@ int circl_hip_mlkem_encaps_keyed(int param, const uint8_t *ek_table, size_t nkey
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek_table, EK * nkeys, false, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {m + lo * 32, 32, true}}, {},
                             {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(false), [&](Chunk &c) {
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(true), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
                                                                         c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -481,7 +486,7 @@ int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkey
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk_table, DK * nkeys, true, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {ct + lo * CT, CT}}, {},
                             {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(true), [&](Chunk &c) {
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(false), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
                                                                         c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -512,7 +517,7 @@ int circl_hip_kyber_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(true),
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(false),
                             [&](Chunk &c) { return circl_hip_kyber_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -521,7 +526,7 @@ int circl_hip_kyber_encaps(int param, const uint8_t *ek, const uint8_t *seed32, 
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {seed32 + lo * 32, 32, true}}, {}, {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}}, kem_ws_fn(),
-                            kem_opts(false),
+                            kem_opts(true),
                             [&](Chunk &c) { return circl_hip_kyber_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -529,7 +534,7 @@ int circl_hip_kyber_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}}, kem_ws_fn(), kem_opts(true),
+        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}}, kem_ws_fn(), kem_opts(false),
                             [&](Chunk &c) { return circl_hip_kyber_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }

@@ -3,6 +3,7 @@
 // nodes; every permutation runs on the device.
 #include "host_common.h"
 #include "prim_kernels.h"
+#include "sampler_prims.h"
 
 using namespace circl::host;
 
@@ -97,6 +98,73 @@ int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *
     });
 }
 
+// ---- lane-local arithmetic and the samplers as unit-level primitives (parity tests only; see prim_kernels.h / sampler_prims.h) ----
+int circl_hip_lane_op(int op, int arg, const uint32_t *a, const uint32_t *b, uint32_t *out0, uint32_t *out1, size_t n, int device) {
+    if (op < 1 || op >= CIRCL_HIP_LANE_OP_COUNT || !a || !out0) return CIRCL_HIP_EPARAM;
+    const uint8_t *pa = reinterpret_cast<const uint8_t *>(a), *pb = reinterpret_cast<const uint8_t *>(b);
+    uint8_t *p0 = reinterpret_cast<uint8_t *>(out0), *p1 = reinterpret_cast<uint8_t *>(out1);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        std::vector<HIn> ins = {{pa + lo * 4, 4}};
+        if (pb) ins.push_back({pb + lo * 4, 4});
+        return run_pipeline(dev, cnt, ins, {}, {{p0 + lo * 4, 4}, {p1 ? p1 + lo * 4 : nullptr, 4}}, no_ws, prim_opts(16), [&](Chunk &c) {
+            hipLaunchKernelGGL(circl::prim::lane_op_kernel, dim3((unsigned)((c.cnt + 255) / 256)), dim3(256), 0, c.st, op, arg,
+                               reinterpret_cast<const uint32_t *>(c.in[0]), pb ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr,
+                               reinterpret_cast<uint32_t *>(c.out[0]), p1 ? reinterpret_cast<uint32_t *>(c.out[1]) : nullptr, c.cnt);
+            HIP_TRY(hipGetLastError());
+            return CIRCL_HIP_OK;
+        });
+    });
+}
+
+int circl_hip_kyber_sample_uniform(const uint8_t *seed32, const uint8_t *xy, int16_t *polys, size_t n, int device) {
+    uint8_t *po = reinterpret_cast<uint8_t *>(polys);
+    PipeOpts o = prim_opts(512);
+    o.chunk_items = (o.chunk_items + 63) & ~size_t(63);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed32 + lo * 32, 32}, {xy + lo * 2, 2}}, {}, {{po + lo * 512, 512}}, no_ws, o, [&](Chunk &c) {
+            hipLaunchKernelGGL(circl::prim::kyber_uniform_prim_kernel, dim3((unsigned)((c.cnt + 63) / 64)), dim3(64), circl::mlkem::Geom<3>::LDS_FIFO, c.st,
+                               (const uint8_t *)c.in[0], (const uint8_t *)c.in[1], reinterpret_cast<int16_t *>(c.out[0]), c.cnt);
+            HIP_TRY(hipGetLastError());
+            return CIRCL_HIP_OK;
+        });
+    });
+}
+
+int circl_hip_kyber_sample_cbd(int eta, const uint8_t *seed32, int16_t *polys, size_t n, int device) {
+    if (eta != 2 && eta != 3) return CIRCL_HIP_EPARAM;
+    constexpr size_t ROW = 64 * 512;  // 64 nonces x 256 int16
+    uint8_t *po = reinterpret_cast<uint8_t *>(polys);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed32 + lo * 32, 32}}, {}, {{po + lo * ROW, ROW}}, no_ws, prim_opts(ROW), [&](Chunk &c) {
+            if (eta == 2)
+                hipLaunchKernelGGL(circl::prim::kyber_cbd_prim_kernel<3>, dim3((unsigned)c.cnt), dim3(64), 0, c.st, (const uint8_t *)c.in[0],
+                                   reinterpret_cast<int16_t *>(c.out[0]), c.cnt);
+            else
+                hipLaunchKernelGGL(circl::prim::kyber_cbd_prim_kernel<2>, dim3((unsigned)c.cnt), dim3(64), 0, c.st, (const uint8_t *)c.in[0],
+                                   reinterpret_cast<int16_t *>(c.out[0]), c.cnt);
+            HIP_TRY(hipGetLastError());
+            return CIRCL_HIP_OK;
+        });
+    });
+}
+
+int circl_hip_mldsa_sample_uniform(const uint8_t *seed32, const uint16_t *nonce, uint32_t *polys, size_t n, int device) {
+    uint8_t *po = reinterpret_cast<uint8_t *>(polys);
+    const uint8_t *pn = reinterpret_cast<const uint8_t *>(nonce);
+    PipeOpts o = prim_opts(1024);
+    o.chunk_items = (o.chunk_items + 63) & ~size_t(63);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{seed32 + lo * 32, 32}, {pn + lo * 2, 2}}, {}, {{po + lo * 1024, 1024}},
+                            [](size_t k) { return ((k + 63) & ~size_t(63)) * circl::mldsa::kPackedRowDwords * 4; }, o, [&](Chunk &c) {
+                                hipLaunchKernelGGL(circl::prim::mldsa_uniform_prim_kernel, dim3((unsigned)((c.cnt + 63) / 64)), dim3(64),
+                                                   circl::mldsa::DG<44>::LDS_FIFO, c.st, (const uint8_t *)c.in[0], reinterpret_cast<const uint16_t *>(c.in[1]),
+                                                   reinterpret_cast<uint32_t *>(c.ws), reinterpret_cast<uint32_t *>(c.out[0]), c.cnt);
+                                HIP_TRY(hipGetLastError());
+                                return CIRCL_HIP_OK;
+                            });
+    });
+}
+
 // Batched XOF service: n sponges over variable-length messages, 24 or 12 rounds.
 int circl_hip_xof(int rate, int ds, int rounds, const uint8_t *in_blob, const uint64_t *in_off, uint8_t *out, size_t outlen, size_t n,
                   int device) {
@@ -159,7 +227,7 @@ extern "C" int circl_hip_k12(const uint8_t *msg_blob, const uint64_t *msg_off, c
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     const int dev = device < 0 ? 0 : device;  // one tree per message: the batch is not split across devices
     if (dev >= ndev()) return CIRCL_HIP_ENODEV;
-    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipSetDevice(physical_device(dev)));
     const size_t base = (size_t)msg_off[0], msg_bytes = (size_t)(msg_off[n] - msg_off[0]);
     // ---- pass 0 (host): where every leaf lives ----
     // device buffer = [message blob (msg_bytes)] [side blob]; offsets below are relative to its start

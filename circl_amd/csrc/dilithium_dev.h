@@ -260,6 +260,19 @@ template <uint32_t GAMMA2> CIRCL_HD uint32_t use_hint(uint32_t a, uint32_t hint)
         return a1 == 0 ? 43 : a1 - 1;
     }
 }
+// rounding.go:56-70 makeHint for z0 = r0 - f in [0,q) and the unmodified high bits r1
+template <uint32_t GAMMA2> CIRCL_HD bool make_hint(uint32_t z0, uint32_t r1) {
+    return !(z0 <= GAMMA2 || z0 > Q - GAMMA2 || (z0 == Q - GAMMA2 && r1 == 0));
+}
+// field.go:35-52 power2round for a in [0,q): a = a1 2^D + a0 with -2^(D-1) < a0 <= 2^(D-1); returns a0 + q like the reference
+CIRCL_HD void power2round(uint32_t a, uint32_t &a0plusq, uint32_t &a1) {
+    uint32_t a0 = a & ((1u << D) - 1);
+    a0 -= (1u << (D - 1)) + 1;
+    a0 += (uint32_t)((int32_t)a0 >> 31) & (1u << D);
+    a0 -= (1u << (D - 1)) - 1;   // now the signed a0 (two's complement)
+    a1 = (a - a0) >> D;
+    a0plusq = Q + a0;
+}
 // poly.go:51-71 exceeds for one coefficient x in [0,q)
 CIRCL_HD bool exceeds(uint32_t x, uint32_t bound) {
     int32_t t = (int32_t)((Q - 1) / 2) - (int32_t)x;

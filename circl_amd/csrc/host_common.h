@@ -46,7 +46,9 @@ inline size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- devices ----------------------------------------------------------------------------------
-int ndev();                      // visible HIP devices (0 if none), fixed at first call
+int ndev();                      // LOGICAL devices (0 if none), fixed at first call: the HIP devices of the process unless
+                                 // CIRCL_HIP_LOGICAL_DEVICES says otherwise (host_runtime.hip); every `dev` below is logical
+int physical_device(int dev);    // the HIP device a logical device runs on (dev % HIP device count)
 struct DeviceInfo {
     int cus = 256;               // compute units
     int numa = -1;               // NUMA node of the PCIe function, -1 unknown
@@ -149,6 +151,10 @@ struct PipeOpts {
     size_t chunk_items = size_t(1) << 15;
     int depth = 6;            // chunks in flight per call (staging slots held)
     bool wipe_device = false; // zero the device staging of every chunk once its results are out
+    // With wipe_device: how much of a chunk's WORKSPACE is secret (from its start).  Unset = all of it.  Set (ML-KEM:
+    // the per-item slots m', r', K', J; the matrix scratch behind them is public) = only the secret inputs, the secret
+    // outputs and that prefix are zeroed, a few hundred KB instead of the 134 MB scratch.
+    std::function<size_t(size_t)> ws_secret_bytes;
 };
 // Runs items [0, n) on device `dev`: per chunk  stage-in (host threads) -> H2D -> launch -> D2H -> stage-out (host threads),
 // with `depth` chunks in flight on separate streams.  ws_bytes(cnt) = workspace the launch needs for cnt items.

@@ -22,7 +22,8 @@ thread_local std::string g_err;
 namespace {
 
 struct DeviceTable {
-    int n = 0;
+    int n = 0;       // LOGICAL devices: what every index of the ABI, every per-device pool and shard() count in
+    int nphys = 0;   // HIP devices behind them; logical device d runs on HIP device d % nphys
     std::vector<DeviceInfo> info;
     int max_cus = 256;
 };
@@ -42,11 +43,24 @@ std::vector<int> parse_cpulist(const std::string &s) {  // "0-15,128-143"
     return out;
 }
 
+int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo || v > hi ? dflt : v;
+}
+
 void init_devices() {
     auto *t = new DeviceTable;  // never freed: worker threads may outlive static destruction
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
-    t->n = n;
+    t->nphys = n;
+    // CIRCL_HIP_LOGICAL_DEVICES=L presents L devices whatever the box has (logical d -> HIP device d % n): a node with
+    // one GPU then runs the all-devices branch of shard(), L staging pools, L sets of streams and L mover pools -- every
+    // piece of per-device host state of an L-GPU node -- and an 8-GPU node can be driven as 16 half-batches.
+    // (never fewer than the HIP devices: device-resident callers index per-device state with their current HIP device)
+    const int logical = n > 0 ? std::max(n, env_int("CIRCL_HIP_LOGICAL_DEVICES", n, 1, 64)) : 0;
+    t->n = logical;
     t->info.resize(n > 0 ? n : 0);
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
@@ -73,6 +87,7 @@ void init_devices() {
         }
     }
     if (mx > 0) t->max_cus = mx;
+    for (int d = n; d < logical; d++) t->info.push_back(t->info[d % n]);
     g_devs = t;
 }
 const DeviceTable &devs() {
@@ -88,16 +103,13 @@ void pin_to(const std::vector<int> &cpus) {
     (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
 
-int env_int(const char *name, int dflt, int lo, int hi) {
-    const char *e = getenv(name);
-    if (!e || !*e) return dflt;
-    const int v = atoi(e);
-    return v < lo || v > hi ? dflt : v;
-}
-
 }  // namespace
 
 int ndev() { return devs().n; }
+int physical_device(int dev) {
+    const DeviceTable &t = devs();
+    return t.nphys > 0 && dev >= 0 ? dev % t.nphys : 0;
+}
 const DeviceInfo &dev_info(int dev) {
     static const DeviceInfo fallback;
     const DeviceTable &t = devs();
@@ -462,7 +474,11 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
                  const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch) {
     if (n == 0) return CIRCL_HIP_OK;
     if (dev < 0 || dev >= ndev()) return CIRCL_HIP_ENODEV;
-    HIP_TRY(hipSetDevice(dev));
+    for (auto &in : ins)
+        if (!in.p && in.row) { g_err = "a required input pointer is NULL"; return CIRCL_HIP_EPARAM; }
+    for (auto &b : blobs)
+        if (b.blob && !b.off) { g_err = "a blob without offsets"; return CIRCL_HIP_EPARAM; }
+    HIP_TRY(hipSetDevice(physical_device(dev)));
     const size_t chunk = std::max<size_t>(1, std::min(n, opts.chunk_items));
     static const int depth_env = env_int("CIRCL_HIP_HOST_DEPTH", 0, 1, 32);  // tuning aid: chunks in flight per call
     const size_t depth = (size_t)std::max(1, (depth_env && opts.depth > 1) ? depth_env : opts.depth);
@@ -478,15 +494,25 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     struct Drain {
         std::deque<InFlight> &q;
         hipStream_t h2d, d2h, st;
+        const std::vector<HOut> &outs;
+        bool wipe_device;
         ~Drain() {
             if (q.empty()) return;
             (void)hipStreamSynchronize(h2d);
             (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(d2h);
-            for (auto &f : q) slot_release(f.slot);
+            // a failed call leaves nothing secret behind either: the staging copies of secret inputs / outputs of every chunk
+            // still in flight, and (for calls that wipe the device staging) the whole device slot
+            for (auto &f : q) {
+                for (auto &s : f.secret_in) memset(f.slot->hin + s.hofs, 0, s.bytes);
+                for (size_t k = 0; k < outs.size() && k < f.out.size(); k++)
+                    if (outs[k].secret && f.out[k].staged) memset(f.slot->hout + f.out[k].hofs, 0, f.out[k].bytes);
+                if (wipe_device && f.slot->d) (void)hipMemset(f.slot->d, 0, f.slot->d_cap);
+                slot_release(f.slot);
+            }
             (void)hipGetLastError();
         }
-    } drain{inflight, h2d, d2h, st};
+    } drain{inflight, h2d, d2h, st, outs, opts.wipe_device};
 
     // stage-out of a finished chunk = copy jobs (staging -> caller memory), then wipe jobs (secret staging areas)
     auto out_jobs = [&](InFlight &f, std::vector<CopyJob> &jobs) {
@@ -637,7 +663,18 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             void *dst = cur.out[k].staged ? (void *)(slot->hout + cur.out[k].hofs) : (void *)(outs[k].p + lo * outs[k].row);
             HIP_TRY(hipMemcpyAsync(dst, slot->d + cur.out[k].dofs, cur.out[k].bytes, hipMemcpyDeviceToHost, d2h));
         }
-        if (opts.wipe_device) HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, d2h));  // keys, seeds and intermediates do not outlive the chunk
+        if (opts.wipe_device) {  // keys, seeds and intermediates do not outlive the chunk
+            if (!opts.ws_secret_bytes) {
+                HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, d2h));
+            } else {
+                for (size_t k = 0; k < ins.size(); k++)
+                    if (ins[k].secret && sin[k].bytes) HIP_TRY(hipMemsetAsync(slot->d + sin[k].dofs, 0, sin[k].bytes, d2h));
+                for (size_t k = 0; k < outs.size(); k++)
+                    if (outs[k].secret && cur.out[k].bytes) HIP_TRY(hipMemsetAsync(slot->d + cur.out[k].dofs, 0, cur.out[k].bytes, d2h));
+                const size_t sec = std::min(up256(wsb), opts.ws_secret_bytes(cnt));
+                if (sec) HIP_TRY(hipMemsetAsync(slot->d + ws_ofs, 0, sec, d2h));
+            }
+        }
         HIP_TRY(hipEventRecord(slot->done, d2h));
     }
     while (!inflight.empty()) {
@@ -690,7 +727,8 @@ int circl_hip_init(void) {
 }
 int circl_hip_device_count(void) { return std::max(ndev(), 0); }
 const char *circl_hip_last_error(void) { return g_err.c_str(); }
-const char *circl_hip_version(void) { return "circl-hip 0.2 (gfx950)"; }
+const char *circl_hip_version(void) { return "circl-hip 0.3 (gfx950)"; }
+int circl_hip_physical_device(int device) { return device >= 0 && device < ndev() ? physical_device(device) : CIRCL_HIP_ENODEV; }
 
 int circl_hip_device_info(int device, int *cus, int *numa_node) {
     if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;

@@ -336,20 +336,23 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
     });
 }
 
-template <int MODE, bool NOSTORE = false, int GA = DG<MODE>::IT>
+// NONCE_ARG (the unit-level primitive circl_hip_mldsa_sample_uniform only): lane = item, the stream's 16-bit nonce comes
+// from nonces[item] instead of (i << 8) + j -- PolyDeriveUniform(p, seed, nonce) for arbitrary nonces, sample.go:92-123.
+template <int MODE, bool NOSTORE = false, int GA = DG<MODE>::IT, bool NONCE_ARG = false>
 __device__ __forceinline__ void expand_a_scratch(uint8_t *lds_fifo, uint32_t *rows, const uint8_t *__restrict__ rho, size_t rho_stride,
-                                                 size_t item0, size_t n, int lane) {
+                                                 size_t item0, size_t n, int lane, const uint16_t *__restrict__ nonces = nullptr) {
     using G = DG<MODE>;
     constexpr int L = G::L;
-    const bool on = lane < GA * G::STREAMS;
-    const int g = on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
+    const bool on = NONCE_ARG ? item0 + lane < n : lane < GA * G::STREAMS;
+    const int g = NONCE_ARG ? lane : on ? lane / G::STREAMS : 0, p = on ? lane % G::STREAMS : 0;
     const int i = p / L, j = p % L;
     size_t item = item0 + g;
     if (item >= n) item = n - 1;
     KeccakState s;
     keccak_zero(s);
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
-    s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
+    if constexpr (NONCE_ARG) s.lo[4] = (uint32_t)nonces[item] | (kDsShake << 16);
+    else s.lo[4] = (uint32_t)j | ((uint32_t)i << 8) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
     uint32_t *fifo = reinterpret_cast<uint32_t *>(lds_fifo) + lane;  // slot-major (parse23_block_fifo)
     uint32_t *row = rows + lane * kPackedRowDwords;  // 24-bit packed rows (pack24)
@@ -868,13 +871,10 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             for (int r = 0; r < 4; r++) {
                 const int v = s2[kyber::idx_l1(lane, r)];
                 const uint32_t a = dilithium::csubq(dilithium::fold(w[r] + (v < 0 ? Q + v : (uint32_t)v)));
-                // field.go:35-52 power2round
-                uint32_t a0 = a & ((1u << dilithium::D) - 1);
-                a0 -= (1u << (dilithium::D - 1)) + 1;
-                a0 += (uint32_t)((int32_t)a0 >> 31) & (1u << dilithium::D);
-                a0 -= (1u << (dilithium::D - 1)) - 1;
-                t1[r] = (a - a0) >> dilithium::D;
-                t0[r] = ((1u << (dilithium::D - 1)) - a0) & ((1u << dilithium::D) - 1);  // pack.go:23-50 PackT0 field
+                uint32_t a0q, a1;
+                dilithium::power2round(a, a0q, a1);  // field.go:35-52
+                t1[r] = a1;
+                t0[r] = ((1u << (dilithium::D - 1)) - (a0q - Q)) & ((1u << dilithium::D) - 1);  // pack.go:23-50 PackT0 field
             }
             mlkem::stage_bits_l1<10>(xch, t1, lane);
             mlkem::store_staged<10>(reinterpret_cast<uint32_t *>(pkp + 32 + 320 * i), xch, lane, false);
@@ -1236,7 +1236,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                     const uint32_t v = dilithium::csubq(w0[i * 256 + nidx] + ct0);
                     const uint32_t r1 = w1b[i * 256 + nidx];
                     // rounding.go:55-62 makeHint
-                    const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+                    const bool hbit = dilithium::make_hint<P::GAMMA2>(v, r1);
                     const unsigned long long mask = __ballot(hbit);  // coefficients 64 r .. 64 r + 63, ascending
                     if (hbit) {
                         const unsigned slot = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));

@@ -450,7 +450,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
                 bad |= dilithium::exceeds(ct0, P::GAMMA2);
                 const uint32_t v = dilithium::csubq(wv[r] + ct0);
                 const uint32_t r1 = r1v[r];
-                const bool hbit = !(v <= P::GAMMA2 || v > Q - P::GAMMA2 || (v == Q - P::GAMMA2 && r1 == 0));
+                const bool hbit = dilithium::make_hint<P::GAMMA2>(v, r1);
                 const unsigned long long mask = __ballot(hbit);
                 if (hbit) {
                     const unsigned hs = pop + (unsigned)__popcll(mask & ((1ull << lane) - 1));

@@ -356,19 +356,22 @@ __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, 
     });
 }
 
-template <int K, bool TRANSPOSED, int GA = Geom<K>::G>
+// XY_ARG (the unit-level primitive circl_hip_kyber_sample_uniform only): lane = item, the stream's (x, y) bytes come from
+// xy[2 item], xy[2 item + 1] -- Poly.DeriveUniform(seed, x, y) for arbitrary coordinates, sample.go:192-236.
+template <int K, bool TRANSPOSED, int GA = Geom<K>::G, bool XY_ARG = false>
 __device__ __forceinline__ void sample_matrix_scratch(uint8_t *lds_fifo, int16_t *rows, const uint8_t *__restrict__ rho,
-                                                      size_t rho_stride, size_t item0, size_t n, int lane) {
+                                                      size_t rho_stride, size_t item0, size_t n, int lane, const uint8_t *__restrict__ xy = nullptr) {
     using Gm = Geom<K>;
-    const bool on = lane < GA * Gm::PAIRS;
-    const int g = on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
+    const bool on = XY_ARG ? item0 + lane < n : lane < GA * Gm::PAIRS;
+    const int g = XY_ARG ? lane : on ? lane / Gm::PAIRS : 0, p = on ? lane % Gm::PAIRS : 0;
     const int i = p / K, j = p % K;
     size_t item = item0 + g;
     if (item >= n) item = n - 1;
     KeccakState s;
     keccak_zero(s);
     xor_words<0, 4>(s, reinterpret_cast<const uint64_t *>(rho + item * rho_stride));
-    s.lo[4] = (TRANSPOSED ? (uint32_t)i | ((uint32_t)j << 8) : (uint32_t)j | ((uint32_t)i << 8)) | (kDsShake << 16);
+    if constexpr (XY_ARG) s.lo[4] = (uint32_t)xy[2 * item] | ((uint32_t)xy[2 * item + 1] << 8) | (kDsShake << 16);
+    else s.lo[4] = (TRANSPOSED ? (uint32_t)i | ((uint32_t)j << 8) : (uint32_t)j | ((uint32_t)i << 8)) | (kDsShake << 16);
     s.hi[20] = 0x80000000u;
     int16_t *fifo = reinterpret_cast<int16_t *>(lds_fifo + lane * Gm::FIFO_STRIDE);
     int16_t *row = rows + lane * 256;

@@ -5,6 +5,7 @@
 #pragma once
 #include "kyber_dev.h"
 #include "dilithium_dev.h"
+#include "lane_ops.h"
 
 namespace circl {
 namespace prim {
@@ -174,6 +175,24 @@ __global__ void __launch_bounds__(256) sponge_kernel(int rate_words, uint32_t ds
         done += rate;
         if (done < outlen) keccak_f1600(s, first_round);
     }
+}
+
+
+// ---- lane-local arithmetic, one element per lane -------------------------------------------------------------------------
+// The coefficient-level functions of kyber_dev.h / dilithium_dev.h applied elementwise by the DEVICE instantiation (which
+// uses __mul24, __umulhi, V_BITOP3, V_ALIGNBIT, V_DOT2 where the host instantiation of the same source uses plain C), so
+// that the parity tests can sweep their whole domains on the GPU: compress / decompress = exact rounding for every
+// representative (pke/kyber/internal/common/poly_test.go:351-378), decompose / useHint / makeHint / power2round for every
+// a < q and both gamma2 (sign/mldsa/mldsa65/internal/rounding_test.go:14-67), the Montgomery products at their bounds.
+// op codes: include/circl_hip.h (CIRCL_HIP_LANE_*).
+__global__ void __launch_bounds__(256) lane_op_kernel(int op, int arg, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                      uint32_t *__restrict__ out0, uint32_t *__restrict__ out1, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r0, r1;
+    lane_op_eval(op, arg, a[i], b ? b[i] : 0u, r0, r1);
+    out0[i] = r0;
+    if (out1) out1[i] = r1;
 }
 
 }  // namespace prim

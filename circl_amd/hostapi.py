@@ -308,6 +308,49 @@ def dilithium_ntt(polys, inverse=False, device=0):
     return a
 
 
+LANE_OPS = dict(KYBER_COMPRESS=1, KYBER_DECOMPRESS=2, KYBER_MSG_BIT=3, KYBER_MULC=4, KYBER_REDUCE32=5, KYBER_NORMALIZE=6, KYBER_CBD2_WORD=7,
+                KYBER_DOT2=8, DIL_DECOMPOSE=9, DIL_USE_HINT=10, DIL_MAKE_HINT=11, DIL_POWER2ROUND=12, DIL_MONT32=13, DIL_MONT64=14,
+                DIL_NORMALIZE=15, DIL_EXCEEDS=16)
+
+
+def lane_op(op, a, b=None, arg=0, two=False, device=0):
+    """The DEVICE instantiation of a coefficient-level function, elementwise over uint32 arrays -> out0 (, out1 with two=True)"""
+    a = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1)
+    n = len(a)
+    bb = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.uint32), a.shape))
+    o0 = np.empty(n, np.uint32)
+    o1 = np.empty(n, np.uint32) if two else None
+    nat.check(nat.lib().circl_hip_lane_op(LANE_OPS[op], int(arg), _p(a), None if bb is None else _p(bb), _p(o0), None if o1 is None else _p(o1), n, device),
+              "lane_op " + op)
+    return (o0, o1) if two else o0
+
+
+def kyber_sample_uniform(seeds, xy, device=0):
+    """Poly.DeriveUniform(seed_i, x_i, y_i) -> (n, 256) int16 in [0, q)"""
+    seeds, xy = _u8(seeds, 32), _u8(xy, 2)
+    out = np.empty((len(seeds), 256), np.int16)
+    nat.check(nat.lib().circl_hip_kyber_sample_uniform(_p(seeds), _p(xy), _p(out), len(seeds), device), "kyber_sample_uniform")
+    return out
+
+
+def kyber_sample_cbd(eta, seeds, device=0):
+    """Poly.DeriveNoise(seed_i, nonce, eta) for nonce 0..63 -> (n, 64, 256) int16 in [-eta, eta]"""
+    seeds = _u8(seeds, 32)
+    out = np.empty((len(seeds), 64, 256), np.int16)
+    nat.check(nat.lib().circl_hip_kyber_sample_cbd(eta, _p(seeds), _p(out), len(seeds), device), "kyber_sample_cbd")
+    return out
+
+
+def mldsa_sample_uniform(seeds, nonces, device=0):
+    """PolyDeriveUniform(seed_i, nonce_i) -> (n, 256) uint32 in [0, q)"""
+    seeds = _u8(seeds, 32)
+    nonces = np.ascontiguousarray(nonces, dtype=np.uint16).reshape(-1)
+    assert len(nonces) == len(seeds)
+    out = np.empty((len(seeds), 256), np.uint32)
+    nat.check(nat.lib().circl_hip_mldsa_sample_uniform(_p(seeds), _p(nonces), _p(out), len(seeds), device), "mldsa_sample_uniform")
+    return out
+
+
 def shake(rate, ds, msgs, outlen, device=0):
     """msgs: (n, inlen) uint8 (equal lengths) -> (n, outlen)"""
     msgs = np.ascontiguousarray(msgs, dtype=np.uint8)

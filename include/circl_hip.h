@@ -64,6 +64,13 @@ const char *circl_hip_last_error(void); /* thread-local message for the last CIR
 const char *circl_hip_version(void);
 /* compute units and NUMA node (-1 unknown) of one device; either pointer may be NULL */
 int circl_hip_device_info(int device, int *cus, int *numa_node);
+/* Device indices of this ABI are LOGICAL.  By default they are the process's HIP devices.  With the environment variable
+ * CIRCL_HIP_LOGICAL_DEVICES=L (read once, at the first call; never fewer than the HIP devices) the library presents L
+ * devices, logical device d running on HIP device d mod the HIP device count, each with its own staging pool, copy /
+ * compute streams and byte movers: a one-GPU box then executes exactly the host-side code of an L-GPU node
+ * (CIRCL_HIP_ALL_DEVICES splits into L contiguous shards driven by L threads), and an 8-GPU node can be driven as 16
+ * half-shards.  Returns the HIP device behind a logical one, or CIRCL_HIP_ENODEV. */
+int circl_hip_physical_device(int device);
 
 /* ---- sizes (kem.Scheme.PublicKeySize etc., kem/kem.go:33-82; sign/sign.go:48-94) -------- */
 size_t circl_hip_mlkem_ek_size(int param); /* 512|768|1024 -> 800|1184|1568, 0 if unknown */
@@ -297,6 +304,41 @@ int circl_hip_mldsa_sample_in_ball(int param, const uint8_t *ctilde, uint32_t *p
                                    int device);
 int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device);
 int circl_hip_kyber_mulhat(int16_t *out, const int16_t *a, const int16_t *b, size_t n, int device);
+
+/* Lane-local arithmetic of the device code, elementwise over uint32 arrays (parity tests: the reference checks these
+ * functions over their whole domains -- pke/kyber/internal/common/poly_test.go:351-378 compress = exact rounding,
+ * sign/mldsa/mldsa65/internal/rounding_test.go:14-67 decompose / makeHint / useHint, field_test.go Montgomery / Barrett --
+ * and the GPU instantiation uses different instructions than the host one).  out1 may be NULL; b may be NULL when unused. */
+#define CIRCL_HIP_LANE_KYBER_COMPRESS 1    /* arg = d in {4,5,10,11}: out0 = round(a 2^d / q) mod 2^d for ANY representative a < 4q (poly.go:248-332) */
+#define CIRCL_HIP_LANE_KYBER_DECOMPRESS 2  /* arg = d in {1,4,5,10,11}: out0 = round(a q / 2^d) (poly.go:170-243) */
+#define CIRCL_HIP_LANE_KYBER_MSG_BIT 3     /* out0 = message bit of a in [0,q) (poly.go:150-165) */
+#define CIRCL_HIP_LANE_KYBER_MULC 4        /* out0 = a b mod q in [0,q) for a < 2^32/q, via the R = 2^32 constant product (field.go:4-32 replaced) */
+#define CIRCL_HIP_LANE_KYBER_REDUCE32 5    /* out0 = -a 2^-32 mod q in [0,q) for any 32-bit a */
+#define CIRCL_HIP_LANE_KYBER_NORMALIZE 6   /* a = int16 in the low half: out0 = Normalize (poly.go:35-39), out1 = barrettReduce (field.go:45-64) */
+#define CIRCL_HIP_LANE_KYBER_CBD2_WORD 7   /* out0 = the eight biased eta = 2 samples of the PRF word a, one per nibble (sample.go:67-95) */
+#define CIRCL_HIP_LANE_KYBER_DOT2 8        /* out0 = lo16(a) lo16(b) + hi16(a) hi16(b) + arg (signed 16-bit halves): MulHat's multiply-accumulate */
+#define CIRCL_HIP_LANE_DIL_DECOMPOSE 9     /* arg = gamma2 (95232 | 261888): out0 = a0 + q, out1 = a1 (rounding.go:13-43) */
+#define CIRCL_HIP_LANE_DIL_USE_HINT 10     /* arg = gamma2, b = hint: out0 = useHint(a, b) (rounding.go:72-81) */
+#define CIRCL_HIP_LANE_DIL_MAKE_HINT 11    /* arg = gamma2, a = z0, b = r1: out0 = makeHint (rounding.go:56-70) */
+#define CIRCL_HIP_LANE_DIL_POWER2ROUND 12  /* out0 = a0 + q, out1 = a1 (sign/internal/dilithium/field.go:35-52) */
+#define CIRCL_HIP_LANE_DIL_MONT32 13       /* out0 = a b 2^-32 mod q in (0, 2q) for a b < 2^32 q (field.go:20-24) */
+#define CIRCL_HIP_LANE_DIL_MONT64 14       /* the same reduction of the 64-bit value b 2^32 + a < 2^32 q */
+#define CIRCL_HIP_LANE_DIL_NORMALIZE 15    /* out0 = a mod q for any 32-bit a, out1 = the partial reduction fold(a) < 2^24 (field.go:5-13, :27-31) */
+#define CIRCL_HIP_LANE_DIL_EXCEEDS 16      /* b = bound: out0 = 1 iff the centred |a| >= bound, a in [0,q) (poly.go:51-71) */
+#define CIRCL_HIP_LANE_OP_COUNT 17
+int circl_hip_lane_op(int op, int arg, const uint32_t *a, const uint32_t *b, uint32_t *out0, uint32_t *out1, size_t n, int device);
+
+/* The samplers of the fused kernels with caller-chosen arguments (parity tests: the reference's fixed vectors use arguments the
+ * fused kernels never do -- pke/kyber/internal/common/sample_test.go:23-138, sign/mldsa/mldsa65/internal/sample_test.go:12-63).
+ * circl_hip_kyber_sample_uniform: Poly.DeriveUniform(seed_i, x_i, y_i) (sample.go:192-236), xy = n pairs of bytes ->
+ *   polys[n][256] int16 in coefficient order, values in [0,q).
+ * circl_hip_kyber_sample_cbd: Poly.DeriveNoise(seed_i, nonce, eta) for every nonce 0..63 (sample.go:17-95) ->
+ *   polys[n][64][256] int16, centred values in [-eta, eta]; eta in {2, 3}.
+ * circl_hip_mldsa_sample_uniform: PolyDeriveUniform(seed_i, nonce_i) (sign/mldsa/mldsa65/internal/sample.go:92-123) ->
+ *   polys[n][256] uint32 in [0,q). */
+int circl_hip_kyber_sample_uniform(const uint8_t *seed32, const uint8_t *xy, int16_t *polys, size_t n, int device);
+int circl_hip_kyber_sample_cbd(int eta, const uint8_t *seed32, int16_t *polys, size_t n, int device);
+int circl_hip_mldsa_sample_uniform(const uint8_t *seed32, const uint16_t *nonce, uint32_t *polys, size_t n, int device);
 int circl_hip_dilithium_ntt(uint32_t *polys, size_t n, int inverse, int device);
 int circl_hip_shake(int rate, int ds, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen,
                     size_t n, int device);

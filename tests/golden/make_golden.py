@@ -99,8 +99,9 @@ def mldsa():
     groups, res = acvp("sign/mldsa/testdata/ML-DSA-sigGen-FIPS204")
     for g in groups:
         ps = out[g["parameterSet"]]
-        # keep 4 cases per group (sk + message are large); all use Sign_internal
-        for t in g["tests"][:4]:
+        # all 10 cases of both groups per parameter set (deterministic and hedged), as sign/mldsa/mldsa65/acvp_test.go:81-120
+        # runs them; all use Sign_internal
+        for t in g["tests"]:
             r = res[t["tcId"]]
             ps["siggen"].append({"sk": t["sk"], "message": t["message"],
                                  "rnd": t.get("rnd", "00" * 32) if not g["deterministic"] else "00" * 32,

@@ -9,6 +9,7 @@
 
 #include "dilithium_dev.h"
 #include "kyber_dev.h"
+#include "lane_ops.h"
 #include "x25519_dev.h"
 
 using namespace circl;
@@ -168,6 +169,16 @@ void hs_x25519(uint32_t *out, const uint32_t *k, const uint32_t *u, int base, si
         if (base == 2) x25519::base_mult(out + 8 * i, k + 8 * i);  // the fixed-base comb
         else if (base) x25519::scalar_mult<true>(out + 8 * i, k + 8 * i, k + 8 * i);
         else x25519::scalar_mult<false>(out + 8 * i, k + 8 * i, u + 8 * i);
+    }
+}
+
+// the switch behind circl_hip_lane_op, host instantiation, elementwise
+void hs_lane_op_array(int op, int arg, const uint32_t *a, const uint32_t *b, uint32_t *out0, uint32_t *out1, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t r0, r1;
+        prim::lane_op_eval(op, arg, a[i], b ? b[i] : 0u, r0, r1);
+        out0[i] = r0;
+        if (out1) out1[i] = r1;
     }
 }
 

@@ -1,0 +1,158 @@
+// tests/race_driver.cpp -- the concurrency test of the host runtime, meant to run under ThreadSanitizer / AddressSanitizer
+// (`make tsan`, `make asan`; tests/test_gpu_sanitizers.py).  The reference's counterpart is `go test -race`
+// (Makefile:44-47 of cloudflare/circl); SURVEY.md section 5 asks for a sanitizer build of the C ABI's host side.
+//
+// It drives exactly the state the functional tests cannot judge: staging-slot pools, byte-mover pools, the per-device copy /
+// compute streams, call_once device tables, shard()'s thread-per-device branch (with CIRCL_HIP_LOGICAL_DEVICES > 1), the
+// profiling records, and the error-path Drain guard -- from several caller threads at once.  Results are compared with a
+// single-threaded, single-device reference run of the same library, so a race that corrupts data fails even without a
+// sanitizer report.  Environment (set by the test): CIRCL_HIP_LOGICAL_DEVICES, CIRCL_HIP_HOST_SLOTS, CIRCL_HIP_HOST_THREADS.
+//
+//   usage: race_driver [callers=3] [rounds=2] [n_kem=20000] [n_dsa=600]
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "circl_hip.h"
+
+#define CHECK(c)                                                                                                      \
+    do {                                                                                                              \
+        if (!(c)) {                                                                                                   \
+            fprintf(stderr, "%s:%d: check failed: %s (%s)\n", __FILE__, __LINE__, #c, circl_hip_last_error());        \
+            exit(1);                                                                                                  \
+        }                                                                                                             \
+    } while (0)
+
+static std::vector<uint8_t> bytes(size_t n, unsigned seed) {
+    std::vector<uint8_t> v(n + 1);  // (one spare byte: the blobs of the Go bridge carry one)
+    uint32_t x = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        v[i] = (uint8_t)(x >> 24);
+    }
+    return v;
+}
+
+struct Kem {
+    int param;
+    size_t n, EK, DK, CT;
+    std::vector<uint8_t> seed, m, ek, dk, ct, ss, ssd, st;
+    Kem(int p, size_t n_) : param(p), n(n_) {
+        EK = circl_hip_mlkem_ek_size(p); DK = circl_hip_mlkem_dk_size(p); CT = circl_hip_mlkem_ct_size(p);
+        seed = bytes(64 * n, 1); m = bytes(32 * n, 2);
+        ek.resize(EK * n); dk.resize(DK * n); ct.resize(CT * n); ss.resize(32 * n); ssd.resize(32 * n); st.resize(n);
+        CHECK(circl_hip_mlkem_keygen(p, seed.data(), ek.data(), dk.data(), n, 0) == 0);
+        CHECK(circl_hip_mlkem_encaps(p, ek.data(), m.data(), ct.data(), ss.data(), st.data(), n, 0) == 0);
+        CHECK(circl_hip_mlkem_decaps(p, dk.data(), ct.data(), ssd.data(), st.data(), n, 0) == 0);
+        CHECK(ss == ssd);
+    }
+    void again(int device) const {
+        std::vector<uint8_t> ek2(EK * n), dk2(DK * n), ct2(CT * n), ss2(32 * n), ss3(32 * n), st2(n);
+        CHECK(circl_hip_mlkem_keygen(param, seed.data(), ek2.data(), dk2.data(), n, device) == 0);
+        CHECK(ek2 == ek && dk2 == dk);
+        CHECK(circl_hip_mlkem_encaps(param, ek.data(), m.data(), ct2.data(), ss2.data(), st2.data(), n, device) == 0);
+        CHECK(ct2 == ct && ss2 == ss);
+        CHECK(circl_hip_mlkem_decaps(param, dk.data(), ct.data(), ss3.data(), nullptr, n, device) == 0);
+        CHECK(ss3 == ss);
+    }
+};
+
+struct Dsa {
+    int param;
+    size_t n, PK, SK, SIG;
+    std::vector<uint8_t> seed, pk, sk, sig, mblob, cblob;
+    std::vector<uint64_t> moff, coff;
+    Dsa(int p, size_t n_) : param(p), n(n_) {
+        PK = circl_hip_mldsa_pk_size(p); SK = circl_hip_mldsa_sk_size(p); SIG = circl_hip_mldsa_sig_size(p);
+        seed = bytes(32 * n, 3);
+        pk.resize(PK * n); sk.resize(SK * n); sig.resize(SIG * n + 4);
+        moff.resize(n + 1); coff.resize(n + 1);
+        size_t mt = 0, ctot = 0;
+        for (size_t i = 0; i < n; i++) { moff[i] = mt; coff[i] = ctot; mt += 1 + (i * 37) % 300; ctot += i % 11; }
+        moff[n] = mt; coff[n] = ctot;
+        mblob = bytes(mt, 4); cblob = bytes(ctot, 5);
+        CHECK(circl_hip_mldsa_keygen(p, seed.data(), pk.data(), sk.data(), n, 0) == 0);
+        CHECK(circl_hip_mldsa_sign(p, sk.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig.data(), n, 0) == 0);
+    }
+    void again(int device) const {
+        std::vector<uint8_t> sig2(SIG * n + 4), ok(n);
+        CHECK(circl_hip_mldsa_sign(param, sk.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig2.data(), n, device) == 0);
+        CHECK(memcmp(sig2.data(), sig.data(), SIG * n) == 0);
+        sig2[SIG * (n / 3) + 50] ^= 2;
+        CHECK(circl_hip_mldsa_verify(param, pk.data(), sig2.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), ok.data(), n, device) == 0);
+        for (size_t i = 0; i < n; i++) CHECK(ok[i] == (i == n / 3 ? 0 : 1));
+    }
+};
+
+struct Hyb {
+    int scheme;
+    size_t n, SEED, ES, PK, SK, CT, SS;
+    std::vector<uint8_t> seed, es, pk, sk, ct, ss;
+    Hyb(int s, size_t n_) : scheme(s), n(n_) {
+        SEED = circl_hip_hybrid_seed_size(s); ES = circl_hip_hybrid_eseed_size(s); PK = circl_hip_hybrid_pk_size(s);
+        SK = circl_hip_hybrid_sk_size(s); CT = circl_hip_hybrid_ct_size(s); SS = circl_hip_hybrid_ss_size(s);
+        seed = bytes(SEED * n, 6); es = bytes(ES * n, 7);
+        pk.resize(PK * n); sk.resize(SK * n); ct.resize(CT * n); ss.resize(SS * n);
+        std::vector<uint8_t> st(n);
+        CHECK(circl_hip_hybrid_keygen(s, seed.data(), pk.data(), sk.data(), n, 0) == 0);
+        CHECK(circl_hip_hybrid_encaps(s, pk.data(), es.data(), ct.data(), ss.data(), st.data(), n, 0) == 0);
+    }
+    void again(int device) const {
+        std::vector<uint8_t> ct2(CT * n), ss2(SS * n), ss3(SS * n), st(n);
+        CHECK(circl_hip_hybrid_encaps(scheme, pk.data(), es.data(), ct2.data(), ss2.data(), st.data(), n, device) == 0);
+        CHECK(ct2 == ct && ss2 == ss);
+        CHECK(circl_hip_hybrid_decaps(scheme, sk.data(), ct.data(), ss3.data(), st.data(), n, device) == 0);
+        CHECK(ss3 == ss);
+    }
+};
+
+int main(int argc, char **argv) {
+    const int callers = argc > 1 ? atoi(argv[1]) : 3;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 2;
+    const size_t n_kem = argc > 3 ? (size_t)atol(argv[3]) : 20000, n_dsa = argc > 4 ? (size_t)atol(argv[4]) : 600;
+    const int nd = circl_hip_init();
+    if (nd <= 0) { fprintf(stderr, "race_driver: no HIP device\n"); return 2; }
+    printf("race_driver: %d (logical) devices, %d callers x %d rounds, %zu ML-KEM items, %zu ML-DSA items\n", nd, callers, rounds, n_kem, n_dsa);
+    const Kem kem768(768, n_kem), kem1024(1024, n_kem / 4 + 3);
+    const Dsa dsa65(65, n_dsa), dsa44(44, 9);  // 9 items: shards below the 16-item switch of the signer, and empty shards
+    const Hyb xwing(1, n_kem / 8 + 5);
+    circl_hip_profile_enable(1);  // the profiling records are shared state too
+    std::atomic<int> started{0};
+    std::vector<std::thread> th;
+    for (int c = 0; c < callers; c++) {
+        th.emplace_back([&, c] {
+            started.fetch_add(1);
+            while (started.load() < callers) std::this_thread::yield();  // everybody enters the library together
+            for (int r = 0; r < rounds; r++) {
+                const int device = (c + r) % 3 == 2 ? nd - 1 : CIRCL_HIP_ALL_DEVICES;  // mostly all devices; now and then one device alone
+                switch ((c + r) % 4) {
+                case 0: kem768.again(device); break;
+                case 1: dsa65.again(device); dsa44.again(CIRCL_HIP_ALL_DEVICES); break;
+                case 2: kem1024.again(device); xwing.again(device); break;
+                case 3: kem768.again(device); dsa44.again(device); break;
+                }
+                // an error path in the middle of everything: the Drain guard must give its slots back
+                uint8_t junk[64] = {0};
+                CHECK(circl_hip_mlkem_encaps(768, nullptr, junk, junk, junk, junk, 1, 0) == CIRCL_HIP_EPARAM);
+                CHECK(circl_hip_mlkem_encaps(768, junk, junk, junk, junk, junk, 1, nd) == CIRCL_HIP_ENODEV);
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    double ms = 0;
+    uint64_t launches = 0;
+    for (int k = 0; k < CIRCL_HIP_KERNEL_COUNT; k++) {
+        double m1 = 0;
+        uint64_t l1 = 0;
+        CHECK(circl_hip_profile_read(k, &m1, &l1) == 0);
+        ms += m1;
+        launches += l1;
+    }
+    circl_hip_profile_enable(0);
+    printf("race_driver ok: %llu profiled launch groups, %.1f ms of kernels\n", (unsigned long long)launches, ms);
+    return 0;
+}

@@ -153,6 +153,7 @@ def test_acvp_siggen(name):
     import hashlib
     p = PARAMS[name]
     cases = load_golden("mldsa_acvp.json.gz")[name]["siggen"]
+    assert len(cases) == 20  # every case of both groups
     sk = b"".join(hx(c["sk"]) for c in cases)
     msgs = [hx(c["message"]) for c in cases]
     rnd = np.frombuffer(b"".join(hx(c["rnd"]) for c in cases), np.uint8).reshape(-1, 32)

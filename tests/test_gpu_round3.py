@@ -1,0 +1,90 @@
+"""Round-3 GPU tests: the multi-device host paths executed on whatever box runs the tests (logical devices), BASELINE
+configs[2] in its stated shape, bench.py with 8 ranks, and the randomised soak as a bounded test.
+
+SURVEY.md 8(e): contiguous split per device, one host thread per device, no collective.  The shape of the work is the
+reference's kem/schemes/schemes_test.go:28-51 (Encapsulate / Decapsulate over a scheme), sharded."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "logical_worker.py")
+
+
+def run_worker(args, logical, extra_env=None, timeout=1500):
+    env = dict(os.environ, CIRCL_HIP_LOGICAL_DEVICES=str(logical))
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, WORKER] + [str(a) for a in args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_eight_logical_devices_equal_one_device_everywhere():
+    # device = -1 over 8 logical devices (shard()'s thread-per-device branch, 8 staging pools / stream sets / mover pools)
+    # == device 0 == the last logical device alone, bit for bit: ML-KEM keygen / encaps / decaps (+ shared, keyed, round 3),
+    # ML-DSA keygen / sign / verify (+ shared, keyed), hybrids, X25519, primitives, XOF; ragged n incl. n < 8; oracle samples
+    rep = run_worker(["parity"], 8)
+    assert rep["logical_devices"] == 8 and rep["checks"] > 150
+
+
+def test_three_logical_devices_uneven_split():
+    rep = run_worker(["parity"], 3, {"CIRCL_HIP_HOST_SLOTS": "2", "CIRCL_HIP_HOST_CHUNK": "10"})  # tiny chunks, two slots per device
+    assert rep["logical_devices"] == 3
+
+
+def test_concurrent_callers_over_eight_logical_devices():
+    rep = run_worker(["concurrent"], 8)
+    assert rep["callers"] == 4
+    # and with one staging slot per device and no mover threads (the caller thread of each shard does everything)
+    run_worker(["concurrent"], 8, {"CIRCL_HIP_HOST_SLOTS": "1", "CIRCL_HIP_HOST_THREADS": "0"})
+
+
+def test_config3_stated_shape_through_one_call():
+    # BASELINE configs[2]: ML-KEM-768 Encaps + Decaps, 2^23 items, 8 contiguous shards of 2^20, ONE circl_hip_mlkem_* call each.
+    # Needs ~45 GB of host memory for the key / ciphertext arrays; a smaller box runs the largest power of two that fits.
+    import psutil
+    avail = psutil.virtual_memory().available
+    lg = 23
+    while lg > 16 and (1 << lg) * 5600 > 0.7 * avail:  # 64 + 1184 + 2400 + 32 + 1088 + 2 * 32 + staging ~ 5.6 KB per item
+        lg -= 1
+    rep = run_worker(["config3", lg], 8, timeout=2400)
+    assert rep["n"] == 1 << lg and rep["shard_items"] == (1 << lg) // 8
+    assert rep["all_items_ss_dec_equals_ss_enc"] and rep["bit_exact_vs_oracle"] and rep["oracle_sample"] >= min(1 << 16, 1 << lg)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "config3_stated_shape.json"), "w") as f:
+        json.dump(rep, f)
+
+
+@pytest.mark.parametrize("mode", ["config3", "config5"])
+def test_bench_py_eight_ranks(mode):
+    # bench.py --gpus 8 as the driver launches it, with the process group on gloo and the 8 ranks sharing this box's GPU(s):
+    # per-rank batches, barriers, max-over-ranks timing, whole-job aggregation, per-rank gathers, ONE JSON line from rank 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", str(1 << 12),
+                        "--mode", mode, "--no-pmc"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["mode"] == mode and out["value"] > 0
+    cfg = out["configs"]
+    if mode == "config3":
+        assert cfg["decaps"]["parity"]["ranks_failing"] == 0 and out["parity"]["ranks_failing"] == 0
+    else:
+        assert cfg["config5"]["parity"]["ranks_failing"] == 0 and len(cfg["config5"]["per_rank_per_s"]) == 8
+
+
+def test_randomised_soak_against_the_oracle():
+    # tools/stress.py: random parameter sets and batch sizes through every host-buffer path (ML-KEM, ML-DSA incl. the
+    # round-based signer and its speculative tail, X25519, the hybrids), each result compared with the oracle; bounded to ~50 s
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "20260924", "50"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

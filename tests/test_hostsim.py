@@ -19,7 +19,7 @@ Q, DQ = 3329, 8380417
 def hs():
     out = os.path.join(ROOT, "build", "libhostsim.so")
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.hip")
-    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "x25519_dev.h", "x25519_base_table.h")]
+    hdrs = [os.path.join(ROOT, "circl_amd", "csrc", h) for h in ("keccak_dev.h", "kyber_dev.h", "dilithium_dev.h", "x25519_dev.h", "x25519_base_table.h", "lane_ops.h")]
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not os.path.exists(out) or any(os.path.getmtime(p) > os.path.getmtime(out) for p in [src] + hdrs):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
@@ -310,3 +310,46 @@ def test_x25519_base_table_is_what_the_generator_writes(tmp_path):
     finally:
         shutil.copy(keep, hdr)
         os.utime(hdr, (os.path.getmtime(keep), os.path.getmtime(keep)))
+
+
+# ---- the laws of tests/lane_laws.py on the HOST instantiation (tests/test_gpu_lane_prims.py runs them on the GPU) ----------
+import lane_laws as laws  # noqa: E402
+
+
+def _host_lane(hs):
+    from circl_amd.hostapi import LANE_OPS
+
+    def lane(op, a, b=None, arg=0, two=False):
+        a = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1)
+        bb = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.uint32), a.shape))
+        o0 = np.empty(len(a), np.uint32)
+        o1 = np.empty(len(a), np.uint32) if two else None
+        vp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        hs.hs_lane_op_array(LANE_OPS[op], int(arg), vp(a), vp(bb), vp(o0), vp(o1), C.c_size_t(len(a)))
+        return (o0, o1) if two else o0
+    return lane
+
+
+@pytest.mark.parametrize("d", [4, 5, 10, 11])
+def test_lane_law_compress(hs, d):
+    laws.law_compress_is_exact_rounding_for_every_representative(_host_lane(hs), d)
+    laws.law_decompress_and_round_trip_bound(_host_lane(hs), d)
+
+
+def test_lane_laws_kyber(hs):
+    lane = _host_lane(hs)
+    laws.law_decompress_and_round_trip_bound(lane, 1)
+    laws.law_message_bit_normalize_barrett(lane)
+    laws.law_mulc_and_reduce32_at_their_bounds(lane)
+    laws.law_cbd2_word_and_dot2(lane)
+
+
+@pytest.mark.parametrize("gamma2", [95232, 261888])
+def test_lane_laws_dilithium_rounding(hs, gamma2):
+    laws.law_decompose_law_for_every_a(_host_lane(hs), gamma2)
+    laws.law_make_hint_use_hint_law(_host_lane(hs), gamma2)
+
+
+def test_lane_laws_dilithium_field(hs):
+    laws.law_power2round_exceeds_normalize(_host_lane(hs))
+    laws.law_montgomery_products_at_their_bounds(_host_lane(hs))
