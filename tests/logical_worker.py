@@ -198,16 +198,24 @@ def config3(lg):
     t0 = time.perf_counter()
     seeds = np.random.default_rng(3).integers(0, 256, (n, 64), dtype=np.uint8)
     m = np.random.default_rng(4).integers(0, 256, (n, 32), dtype=np.uint8)
-    t = time.perf_counter()
-    ek, dk = hostapi.mlkem_keygen(768, seeds, device=ALL)
-    t_kg = time.perf_counter() - t
-    hostapi.mlkem_encaps(768, ek[:1 << 16], m[:1 << 16], device=ALL)  # staging pools of every device exist
-    t = time.perf_counter()
-    ct, ss, st = hostapi.mlkem_encaps(768, ek, m, device=ALL)
-    t_enc = time.perf_counter() - t
-    t = time.perf_counter()
-    ss2, st2 = hostapi.mlkem_decaps(768, dk, ct, device=ALL)
-    t_dec = time.perf_counter() - t
+    # outputs allocated and touched once, calls timed on their second run: the figures below are the host path itself, not the
+    # kernel's first-touch page faults of 40 GB of fresh numpy memory
+    L = nat.lib()
+    P = hostapi._p
+    ek, dk = np.zeros((n, 1184), np.uint8), np.zeros((n, 2400), np.uint8)
+    ct, ss, ss2 = np.zeros((n, 1088), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+    st, st2 = np.ones(n, np.uint8), np.ones(n, np.uint8)
+    t_kg = t_enc = t_dec = 0.0
+    for rep in range(2):
+        t = time.perf_counter()
+        nat.check(L.circl_hip_mlkem_keygen(768, P(seeds), P(ek), P(dk), n, ALL), "keygen")
+        t_kg = time.perf_counter() - t
+        t = time.perf_counter()
+        nat.check(L.circl_hip_mlkem_encaps(768, P(ek), P(m), P(ct), P(ss), P(st), n, ALL), "encaps")
+        t_enc = time.perf_counter() - t
+        t = time.perf_counter()
+        nat.check(L.circl_hip_mlkem_decaps(768, P(dk), P(ct), P(ss2), P(st2), n, ALL), "decaps")
+        t_dec = time.perf_counter() - t
     assert not st.any() and not st2.any()
     all_equal = bool((ss == ss2).all())
     assert all_equal
