@@ -217,16 +217,28 @@ constexpr int kSignBlocksPerCU = 8;
 
 constexpr size_t kSignBatchedMin = 16;  // below this the single persistent kernel has less launch overhead
 
+// CIRCL_HIP_SIGN_PAIR=1: the long rounds try two attempts per item with shared matrix reads (lazy pairs, sign_next_k in
+// mldsa_sign_batched.h).  Measured on MI355X (profiles/r03_sign_sweep.txt): the w kernel's HBM traffic per attempt falls by 35 %
+// and its time by 17 %, which the 10.8 % extra masks and products eat: 8.39e6 against 8.35e6 sig/s for ML-DSA-65 at 2^18, with
+// twice the per-attempt workspace -- so the default stays one attempt per item.
+inline bool sign_pair_mode() {
+    static const bool v = [] {
+        const char *e = getenv("CIRCL_HIP_SIGN_PAIR");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
 // The carving of a signing workspace (one definition for the size query and for the launches).
 template <int MODE> struct SignLayout {
     using S = circl::mldsa::SG<MODE>;
     using B = circl::mldsa::SB<MODE>;
     size_t n, E, tail_units;
     size_t o_mr, o_work, o_scratch;                 // persistent kernel (also the tail of the batched path)
-    size_t o_A, o_sec, o_y, o_w0, o_w1, o_muw1, o_cb, o_attempts, o_best, o_list0, o_list1, o_ctl, o_secret_end;  // batched path
+    size_t o_A, o_sec, o_y, o_w0, o_muw1, o_cb, o_attempts, o_best, o_list0, o_list1, o_ctl, o_secret_end;  // batched path
     size_t o_dead, total;
     explicit SignLayout(size_t n_) : n(n_) {
-        E = std::max(n, circl::mldsa::kMinEntryCapacity);
+        E = std::max((sign_pair_mode() ? 2 : 1) * n, circl::mldsa::kMinEntryCapacity);  // lazy pairs: two attempts per item in the long rounds
         tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
         size_t o = 0;
         auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
@@ -238,7 +250,6 @@ template <int MODE> struct SignLayout {
             o_sec = take(n * B::SEC_BYTES);
             o_y = take(E * B::Y_BYTES);
             o_w0 = take(E * B::W0_BYTES);
-            o_w1 = take(E * B::W1_BYTES);
             o_muw1 = take(E * B::MUW1_BYTES);
             o_cb = take(E * B::CB_BYTES);
             o_secret_end = o;
@@ -248,7 +259,7 @@ template <int MODE> struct SignLayout {
             o_list1 = take(4 * E);
             o_ctl = take(256);
         } else {
-            o_A = o_sec = o_y = o_w0 = o_w1 = o_muw1 = o_cb = o_secret_end = o_attempts = o_best = o_list0 = o_list1 = o_ctl = o;
+            o_A = o_sec = o_y = o_w0 = o_muw1 = o_cb = o_secret_end = o_attempts = o_best = o_list0 = o_list1 = o_ctl = o;
         }
         o_dead = take(n);  // one byte per item: the "context refused" flags of mldsa_sign_prep_kernel
         total = o;
@@ -286,7 +297,6 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     S.sec = reinterpret_cast<uint32_t *>(base + lay.o_sec);
     S.y = reinterpret_cast<uint32_t *>(base + lay.o_y);
     S.w0 = reinterpret_cast<uint32_t *>(base + lay.o_w0);
-    S.w1 = base + lay.o_w1;
     S.muw1 = base + lay.o_muw1;
     S.cb = base + lay.o_cb;
     S.attempts = reinterpret_cast<uint32_t *>(base + lay.o_attempts);
@@ -308,10 +318,12 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         return (uint32_t)(x >= 0 && x <= 4096 ? x : 128);  // plateau 96 .. 256 at 2^16 items
     }();
     S.spec_target = (uint32_t)std::min<size_t>((size_t)cus * spec_per_cu, lay.E);
-    const unsigned k0 = sign_next_k(n, S.spec_target);
+    S.pair = sign_pair_mode() ? 1u : 0u;
+    const unsigned k0 = sign_next_k(n, S.spec_target, S.pair);
     constexpr int kMaxRounds = 400;
     size_t entries_upper[kMaxRounds];
-    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, entries_upper, kMaxRounds);
+    bool lazy[kMaxRounds];
+    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, S.pair, entries_upper, lazy, kMaxRounds);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -327,19 +339,32 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     // grids: the kernels loop over the device-side count, so any grid is correct; the schedule's upper estimate of a
     // round's entries gives (nearly) one workgroup per entry while the lists are long, and small launches for the late and
     // the empty rounds
+    static const int w_waves = [] { const char *e = getenv("CIRCL_HIP_SIGN_W_WAVES"); return e ? atoi(e) : 4; }();  // tuning aids
+    static const int f_waves = [] { const char *e = getenv("CIRCL_HIP_SIGN_F_WAVES"); return e ? atoi(e) : 4; }();
     const size_t lane_cap = (size_t)cus * 10;
+    const unsigned small = (unsigned)cus * 4;  // grid of the kernels that usually have nothing to do (grid-stride loops: any grid is correct)
     for (int round = 0; round < rounds; round++) {
         const int cur = round & 1;
         const size_t upper = std::min(round == 0 ? n * k0 : entries_upper[round], lay.E);
-        const unsigned gw = (unsigned)std::max<size_t>(1, upper);
+        // a pass of a lazy round handles every other entry; the schedule's plan picks the grid, the device-side counts decide
+        const size_t pass0 = lazy[round] ? (upper + 1) / 2 : upper, pass1 = lazy[round] ? (upper + 1) / 2 : 0;
+        const unsigned gw = (unsigned)std::max<size_t>(1, (upper + 1) / 2);
         const unsigned gm = (unsigned)std::max<size_t>(1, std::min((upper * L + 255) / 256, lane_cap));
         const unsigned gc = (unsigned)std::max<size_t>(1, std::min((upper + 255) / 256, lane_cap));
+        auto g256 = [&](size_t work) { return (unsigned)std::max<size_t>(1, std::min((work + 255) / 256, lane_cap)); };
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3(gm), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(gc), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
-        hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur, sig);
+        if (w_waves == 6) hipLaunchKernelGGL((sign_w_kernel<MODE, 6>), dim3(gw), dim3(64), 0, st, S, cur);
+        else if (w_waves == 5) hipLaunchKernelGGL((sign_w_kernel<MODE, 5>), dim3(gw), dim3(64), 0, st, S, cur);
+        else hipLaunchKernelGGL((sign_w_kernel<MODE, 4>), dim3(gw), dim3(64), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
+        if (f_waves == 6) hipLaunchKernelGGL((sign_finish_kernel<MODE, 6>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
+        else if (f_waves == 5) hipLaunchKernelGGL((sign_finish_kernel<MODE, 5>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
+        else hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
+        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
+        hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
+        hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(lazy[round] ? small : std::min<unsigned>((unsigned)std::max<size_t>(1, upper), (unsigned)cus * 32)),
+                           dim3(64), 0, st, S, cur, sig);
         hipLaunchKernelGGL(sign_compact_kernel, dim3(gc), dim3(256), 0, st, S, cur, round == rounds - 1 ? 1 : 0);
     }
     {

@@ -232,6 +232,59 @@ __device__ __forceinline__ void invntt(uint32_t (&c)[4], const LaneZetas &z, uin
 #pragma unroll
     for (int r = 0; r < 4; r++) c[r] = mont32(c[r], FINAL);
 }
+// ---- two polynomials at a time -------------------------------------------------------------------------------------------
+// A transform is a chain of 4 register-local stages separated by 3 exchanges through LDS, and a lone wavefront waits out the
+// full latency of every exchange (write, read back, ~100+ cycles) with nothing else to issue: the batch-signing kernels, one
+// wavefront per attempt at 4 waves per SIMD, ran at 6.7 cycles per VALU instruction.  Two INDEPENDENT polynomials with an
+// exchange buffer each go through the stages in lock step -- both buffers are written, then both are read -- so every
+// wait covers two transforms.  Same arithmetic, same layouts and bounds as ntt / invntt above.
+template <int FROM, int TO> __device__ __forceinline__ void relayout2(uint32_t (&c0)[4], uint32_t (&c1)[4], uint32_t *xch0, uint32_t *xch1, int lane) {
+    auto pos = [&](int which, int r) {
+        switch (which) {
+        case 1: return lane + 4 * (lane >> 5) + 72 * r;
+        case 2: return ((lane >> 4) * 72) + (lane & 15) + 16 * r + 4 * (r >> 1);
+        case 3: return ((lane >> 2) << 4) + 4 * (lane >> 3) + (lane & 3) + 4 * r;
+        default: return 4 * lane + 4 * (lane >> 3) + r;
+        }
+    };
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { xch0[pos(FROM, r)] = c0[r]; xch1[pos(FROM, r)] = c1[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c0[r] = xch0[pos(TO, r)]; c1[r] = xch1[pos(TO, r)]; }
+}
+__device__ __forceinline__ void ntt2(uint32_t (&a)[4], uint32_t (&b)[4], const LaneZetas &z, uint32_t *xch0, uint32_t *xch1, int lane) {
+    const uint32_t z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
+    ct(a[0], a[2], z1); ct(a[1], a[3], z1); ct(b[0], b[2], z1); ct(b[1], b[3], z1);
+    ct(a[0], a[1], z2); ct(a[2], a[3], z3); ct(b[0], b[1], z2); ct(b[2], b[3], z3);
+    relayout2<1, 2>(a, b, xch0, xch1, lane);
+    ct(a[0], a[2], z.f2); ct(a[1], a[3], z.f2); ct(b[0], b[2], z.f2); ct(b[1], b[3], z.f2);
+    ct(a[0], a[1], z.f3a); ct(a[2], a[3], z.f3b); ct(b[0], b[1], z.f3a); ct(b[2], b[3], z.f3b);
+    relayout2<2, 3>(a, b, xch0, xch1, lane);
+    ct(a[0], a[2], z.f4); ct(a[1], a[3], z.f4); ct(b[0], b[2], z.f4); ct(b[1], b[3], z.f4);
+    ct(a[0], a[1], z.f5a); ct(a[2], a[3], z.f5b); ct(b[0], b[1], z.f5a); ct(b[2], b[3], z.f5b);
+    relayout2<3, 4>(a, b, xch0, xch1, lane);
+    ct(a[0], a[2], z.f6); ct(a[1], a[3], z.f6); ct(b[0], b[2], z.f6); ct(b[1], b[3], z.f6);
+    ct(a[0], a[1], z.f7a); ct(a[2], a[3], z.f7b); ct(b[0], b[1], z.f7a); ct(b[2], b[3], z.f7b);
+}
+template <uint32_t FINAL = INV256_R>
+__device__ __forceinline__ void invntt2(uint32_t (&a)[4], uint32_t (&b)[4], const LaneZetas &z, uint32_t *xch0, uint32_t *xch1, int lane) {
+    gs<2>(a[0], a[1], z.i7a); gs<2>(a[2], a[3], z.i7b); gs<2>(b[0], b[1], z.i7a); gs<2>(b[2], b[3], z.i7b);
+    gs<4>(a[0], a[2], z.i6); gs<4>(a[1], a[3], z.i6); gs<4>(b[0], b[2], z.i6); gs<4>(b[1], b[3], z.i6);
+    relayout2<4, 3>(a, b, xch0, xch1, lane);
+    gs<8>(a[0], a[1], z.i5a); gs<8>(a[2], a[3], z.i5b); gs<8>(b[0], b[1], z.i5a); gs<8>(b[2], b[3], z.i5b);
+    gs<16>(a[0], a[2], z.i4); gs<16>(a[1], a[3], z.i4); gs<16>(b[0], b[2], z.i4); gs<16>(b[1], b[3], z.i4);
+    relayout2<3, 2>(a, b, xch0, xch1, lane);
+    gs<32>(a[0], a[1], z.i3a); gs<32>(a[2], a[3], z.i3b); gs<32>(b[0], b[1], z.i3a); gs<32>(b[2], b[3], z.i3b);
+    gs<64>(a[0], a[2], z.i2); gs<64>(a[1], a[3], z.i2); gs<64>(b[0], b[2], z.i2); gs<64>(b[1], b[3], z.i2);
+    relayout2<2, 1>(a, b, xch0, xch1, lane);
+    const uint32_t z1 = zeta(1), z2 = zeta(2), z3 = zeta(3);
+    gs<128>(a[0], a[1], z3); gs<128>(a[2], a[3], z2); gs<128>(b[0], b[1], z3); gs<128>(b[2], b[3], z2);
+    gs<256>(a[0], a[2], z1); gs<256>(a[1], a[3], z1); gs<256>(b[0], b[2], z1); gs<256>(b[1], b[3], z1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { a[r] = mont32(a[r], FINAL); b[r] = mont32(b[r], FINAL); }
+}
 #endif
 
 // rounding.go:13-43 decompose for a in [0,q): returns a1, and a0+q through the reference's formula

@@ -4,13 +4,15 @@
 // full lanes: the rejection loop of sign/mldsa/mldsa65/internal/dilithium.go:371-455 is executed as
 // rounds over the list of still-unsigned items.  Per-item state lives in the workspace:
 //   A rows (K L KB), s1-hat / s2-hat / t0-hat ((L+2K) KB), y bytes, w0, w1, mu || w1, c~ + ball sponge.
-// One round = five launches over the active list:
-//   mask   lane = (entry, l)            ExpandMask streams, 64 useful lanes per wave
-//   w      wave = entry                 y-hat, w = InvNTT(A y-hat), Decompose, w1 packing
-//   chal   lane = entry                 c~ = H(mu || w1), first SampleInBall block
-//   finish wave = entry                 c s2 / z / c t0 / hints; a success lowers best[item]
-//   commit wave = entry                 (k > 1 only) the lowest successful attempt's signature -> sig
-//   compact lane = entry                survivors -> next list
+// One round = eight launches over the active list:
+//   mask     lane = (entry, l)          ExpandMask streams, 64 useful lanes per wave
+//   w        wave = 2 entries           y-hat, w = InvNTT(A y-hat), Decompose, w1 packing; two entries of one item share the matrix reads
+//   chal 0/1 lane = entry               c~ = H(mu || w1), first SampleInBall block
+//   finish 0/1 wave = entry             c s2 / z / c t0 / hints; a success lowers best[item]
+//   commit   wave = entry               (speculative rounds only) the lowest successful attempt's signature -> sig
+//   compact  lane = entry               survivors -> next list
+// (chal / finish run as two passes: in a LAZY round -- pairs of attempts, sign_next_k -- the second attempt's challenge and norm
+// tests run only for the items whose first attempt was rejected; in every other round pass 1 finds nothing to do.)
 // An ENTRY of the active list is (item, off): attempt number attempts[item] + off of that item.  Early rounds have one
 // entry per item.  Once so few items are left that a round is latency-bound (five dependent launches whatever the
 // count), the list carries k <= 64 consecutive attempts per item, tried in the same round: the signature is the one of
@@ -41,11 +43,10 @@ template <int MODE> struct SB {
     static constexpr size_t Y_BYTES = (size_t)L * (G::ZSZ + 64);   // ZSZ payload + slack, per polynomial
     static constexpr int YROW_DW = (G::ZSZ + 64) / 4;
     static constexpr size_t W0_BYTES = (size_t)K * 1024;
-    static constexpr size_t W1_BYTES = (size_t)K * 256;
     static constexpr size_t MUW1_BYTES = ((G::MUW1 + 63) / 64) * 64;
     static constexpr size_t CB_BYTES = 320;                          // c~ (<= 64 B), 56 B pad, ball state (200 B)
     static constexpr size_t PER_ITEM = A_BYTES + SEC_BYTES + 128 /* mu, rho'' */;                   // per item (key material)
-    static constexpr size_t PER_ENTRY = Y_BYTES + W0_BYTES + W1_BYTES + MUW1_BYTES + CB_BYTES;      // per list entry (one attempt)
+    static constexpr size_t PER_ENTRY = Y_BYTES + W0_BYTES + MUW1_BYTES + CB_BYTES;                 // per list entry (one attempt)
 };
 
 struct SignState {          // device pointers into the workspace, passed by value to the kernels
@@ -54,7 +55,6 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t *sec;          // n x (L + 2K) x 256
     uint32_t *y;            // n x L x YROW_DW
     uint32_t *w0;           // n x K x 256
-    uint8_t *w1;            // n x K x 256
     uint8_t *muw1;          // n x MUW1_BYTES
     uint8_t *cb;            // n x 320
     uint32_t *attempts;     // n: attempts already spent on the item
@@ -65,6 +65,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once)
     uint32_t spec_target;   // rounds speculate (k > 1) once at most this many entries would result
     uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
+    uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
 };
 
 constexpr uint32_t kNoSuccess = 0xffffffffu;
@@ -74,12 +75,23 @@ constexpr unsigned kMaxSpec = 64;  // 6 bits of `off`
 constexpr size_t kMinEntryCapacity = 2048;  // small batches may still try many attempts per item and round
 
 // attempts per item of the NEXT list when `items` items may survive into it (the same rule on the host, which sizes the
-// schedule, and on the device, which applies it to the real counts)
-__host__ __device__ inline unsigned sign_next_k(unsigned long long items, unsigned spec_target) {
-    if (items == 0 || items > spec_target) return 1u;
+// schedule, and on the device, which applies it to the real counts).
+//   items <= spec_target / 2   k = spec_target / items (<= 64): the rounds are latency-bound, every attempt of a round runs at once
+//   otherwise                  k = 2 (`pair`) -- a LAZY PAIR: ExpandMask and w = A y-hat of attempts a and a + 1 are computed
+//                              together, because the w kernel is bound by reading the item's 23 KB of matrix rows and one read
+//                              then serves two attempts; challenge and the norm tests of attempt a + 1 run in a second pass and
+//                              only for the items whose attempt a was rejected.  Expected work per signature (p = success
+//                              probability of an attempt, 0.196 for ML-DSA-65): 2 / (1 - (1-p)^2) = 5.65 masks and w products
+//                              instead of 1 / p = 5.1, 2.83 matrix reads instead of 5.1, the same 5.1 challenges / finishes,
+//                              half the rounds.
+__host__ __device__ inline unsigned sign_next_k(unsigned long long items, unsigned spec_target, unsigned pair) {
+    if (items == 0) return 1u;
+    if (2 * items > spec_target) return pair ? 2u : 1u;
     const unsigned long long k = spec_target / items;
     return (unsigned)(k < 1 ? 1 : k > kMaxSpec ? kMaxSpec : k);
 }
+// a round is LAZY when its list holds pairs that are too many to run all at once
+__host__ __device__ inline bool sign_round_lazy(unsigned long long count, unsigned k, unsigned spec_target) { return k == 2 && count > spec_target; }
 
 // ---- setup ---------------------------------------------------------------------------------------
 
@@ -225,79 +237,169 @@ __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     }
 }
 
-// wave = entry: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398)
-template <int MODE>
-__global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
+// wave = one or two entries: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398).
+// Two consecutive list entries that belong to the SAME item (attempts a, a + 1 of a lazy pair, or neighbours of a speculative
+// round) are processed by one wavefront and every matrix row read (K L rows of 768 bytes, 23 KB for ML-DSA-65) serves both.
+// The kernel is a chain of L + K transforms per attempt, each with three exchanges through LDS whose latency a lone wavefront
+// waits out (measured: 6.7 cycles per VALU instruction, 1.83 ms per 2^18 ML-DSA-65 attempts, whether the matrix reads are
+// shared or not): transforms therefore run TWO AT A TIME (dilithium::ntt2 / invntt2) -- both attempts' polynomial l, both
+// attempts' output polynomial i; a single entry pairs its own polynomials (l, l + 1) and (i, i + 1).
+// The transformed masks do not stay in registers (up to 2 L polynomials): each lane parks its 4 coefficients of every y-hat,
+// folded to 24 bits, in its own 12 bytes of LDS (no other lane touches them).
+template <int MODE, int T>
+__device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot, size_t item, uint32_t *xch0, uint32_t *xch1, uint32_t *yl,
+                                               const dilithium::LaneZetas &z, int lane) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
+    static_assert(K % 2 == 0, "output polynomials are processed in pairs");
+#pragma unroll
+    for (int t = 0; t < T; t++)
+        if (lane < 16)  // mu in front of the w1 bytes that follow
+            reinterpret_cast<uint32_t *>(st.muw1 + (slot + t) * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
+    auto load_y = [&](uint32_t (&yh)[4], size_t sl, int l) {
+        const uint32_t *yrow = st.y + (sl * L + l) * B::YROW_DW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+            x += (uint32_t)((int32_t)x >> 31) & Q;
+            yh[r] = x;
+        }
+    };
+    auto park = [&](const uint32_t (&yh)[4], int row) {  // plain y-hat < 17q, folded below 2^24
+        const uint32_t f[4] = {dilithium::fold(yh[0]), dilithium::fold(yh[1]), dilithium::fold(yh[2]), dilithium::fold(yh[3])};
+        store_poly24(yl + row * kPackedRowDwords, f, lane);
+    };
+    if constexpr (T == 2) {
+#pragma unroll 1
+        for (int l = 0; l < L; l++) {
+            uint32_t ya[4], yb[4];
+            load_y(ya, slot, l);
+            load_y(yb, slot + 1, l);
+            dilithium::ntt2(ya, yb, z, xch0, xch1, lane);
+            park(ya, l);
+            park(yb, L + l);
+        }
+    } else {
+#pragma unroll 1
+        for (int l = 0; l + 1 < L; l += 2) {
+            uint32_t ya[4], yb[4];
+            load_y(ya, slot, l);
+            load_y(yb, slot, l + 1);
+            dilithium::ntt2(ya, yb, z, xch0, xch1, lane);
+            park(ya, l);
+            park(yb, l + 1);
+        }
+        if constexpr (L % 2 == 1) {
+            uint32_t ya[4];
+            load_y(ya, slot, L - 1);
+            dilithium::ntt(ya, z, xch0, lane);
+            park(ya, L - 1);
+        }
+    }
+    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+    // Decompose, the low part to w0, the high part packed behind mu (PackW1, pack.go:256-270: the challenge hash absorbs it from
+    // there and the hint computation of the finish kernel reads its fields back)
+    auto emit = [&](uint32_t (&w)[4], size_t sl, int i, uint32_t *stage) {
+        unsigned w1v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t a0, a1;
+            dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
+            st.w0[(sl * K + i) * 256 + kyber::idx_l1(lane, r)] = a0;
+            w1v[r] = a1;
+        }
+        mlkem::stage_bits_l1<G::W1BITS>(stage, w1v, lane);
+        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + sl * B::MUW1_BYTES + 64 + G::W1SZ * i), stage, lane, false);
+    };
+    // lazy 64-bit dot products (a < 2^23, y-hat < 2^24, L <= 7 terms), one reduction per coefficient
+#pragma unroll 1
+    for (int i = 0; i < K; i += (T == 2 ? 1 : 2)) {
+        uint64_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            uint32_t a[4], b[4], y0[4], y1[4];
+            load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
+            load_poly24(y0, yl + j * kPackedRowDwords, lane);
+            if constexpr (T == 2) load_poly24(y1, yl + (L + j) * kPackedRowDwords, lane);
+            else load_poly24(b, arows + ((i + 1) * L + j) * kPackedRowDwords, lane);
+            // Keep y opaque.  With BOTH factors visibly below 2^24 (two load_poly24 results) the AMDGPU backend of ROCm 7.2
+            // selects 24-bit multiplies, drops the `& 0xffffff` of the unpacking as implied by them -- and then fuses the
+            // products into V_MAD_U64_U32 on the UNMASKED dwords (seen in the ISA of this loop: v_mad_u64_u32 on the raw
+            // ds_read / global_load registers): wrong products for every term but the first.  Found by the signing parity
+            // tests; an operand of unknown width keeps the masks and the full 32 x 32 -> 64 multiply-add.
+            asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]));
+            if constexpr (T == 2) asm volatile("" : "+v"(y1[0]), "+v"(y1[1]), "+v"(y1[2]), "+v"(y1[3]));
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc0[r] += (uint64_t)a[r] * y0[r];
+                if constexpr (T == 2) acc1[r] += (uint64_t)a[r] * y1[r];
+                else acc1[r] += (uint64_t)b[r] * y0[r];
+            }
+        }
+        uint32_t wa[4], wb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { wa[r] = dilithium::mont64(acc0[r]); wb[r] = dilithium::mont64(acc1[r]); }
+        dilithium::invntt2<dilithium::INV256_RR>(wa, wb, z, xch0, xch1, lane);
+        emit(wa, slot, i, xch0);
+        if constexpr (T == 2) emit(wb, slot + 1, i, xch1);
+        else emit(wb, slot, i + 1, xch1);
+    }
+    __syncthreads();  // the exchange buffers are reused by the next entry
+}
+template <int MODE, int WAVES = 4>
+__global__ void __launch_bounds__(64, WAVES) sign_w_kernel(SignState st, int cur) {
+    constexpr int L = DP<MODE>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t xch0[dilithium::kXchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t xch1[dilithium::kXchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t yl[2 * L * kPackedRowDwords];
     const int lane = threadIdx.x;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const size_t count = st.count[cur];
 #pragma unroll 1
-    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
-        const size_t item = st.list[cur][slot] & kEntryItemMask;
-        if (lane < 16)  // mu in front of the w1 bytes that follow
-            reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
-        uint32_t yh[L][4];
-#pragma unroll
-        for (int l = 0; l < L; l++) {
-            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
-                x += (uint32_t)((int32_t)x >> 31) & Q;
-                yh[l][r] = x;
-            }
-            dilithium::ntt(yh[l], z, xch, lane);  // plain y-hat, < 17q
+    for (size_t s0 = 2 * (size_t)blockIdx.x; s0 < count; s0 += 2 * (size_t)gridDim.x) {
+        const size_t item0 = st.list[cur][s0] & kEntryItemMask;
+        const bool two = s0 + 1 < count;
+        const size_t item1 = two ? (size_t)(st.list[cur][s0 + 1] & kEntryItemMask) : item0;
+        if (two && item1 == item0) {
+            sign_w_entries<MODE, 2>(st, s0, item0, xch0, xch1, yl, z, lane);
+        } else {
+            sign_w_entries<MODE, 1>(st, s0, item0, xch0, xch1, yl, z, lane);
+            if (two) sign_w_entries<MODE, 1>(st, s0 + 1, item1, xch0, xch1, yl, z, lane);
         }
-        const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
-        // (requesting rows of output polynomial i + 1 before the inverse transform of polynomial i was tried: the registers it
-        // takes cost more than the extra bytes in flight give, 9.1 -> 9.8 ms per 2^18 ML-DSA-65 signatures)
-#pragma unroll 1
-        for (int i = 0; i < K; i++) {
-            uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient (see mac_rows)
-#pragma unroll
-            for (int j = 0; j < L; j++) {
-                uint32_t a[4];
-                load_poly24(a, arows + (i * L + j) * kPackedRowDwords, lane);
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * yh[j][r];
-            }
-            uint32_t w[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
-            dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);
-            unsigned w1v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int nidx = kyber::idx_l1(lane, r);
-                uint32_t a0, a1;
-                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
-                st.w0[(slot * K + i) * 256 + nidx] = a0;
-                st.w1[(slot * K + i) * 256 + nidx] = (uint8_t)a1;
-                w1v[r] = a1;
-            }
-            mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
-            mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
-        }
-        __syncthreads();  // xch is reused by the next entry
     }
 }
 
+// Which entries a pass of the challenge / finish kernels handles.  A LAZY round (pairs, sign_round_lazy) runs them twice: pass 0
+// takes the first attempt of every pair, pass 1 the second -- and only of the items whose first attempt was rejected (best is
+// still kNoSuccess); every other round does everything in pass 0.  Pairs start at even slots (the compaction reserves k
+// entries per survivor from a counter that starts at zero), so in a lazy round the slot's parity is the entry's `off`.
+struct PassMap {
+    size_t nwork;   // entries of this pass
+    bool lazy;
+    int pass;
+    __device__ __forceinline__ PassMap(const SignState &st, int cur, int pass_) : pass(pass_) {
+        const size_t count = st.count[cur];
+        lazy = sign_round_lazy(count, st.kk[cur], st.spec_target);
+        nwork = lazy ? (count + 1 - (size_t)pass) / 2 : (pass == 0 ? count : 0);
+    }
+    __device__ __forceinline__ size_t slot(size_t a) const { return lazy ? 2 * a + (size_t)pass : a; }
+};
+
 // lane = entry: c~ = SHAKE256(mu || w1)[:CT] and the first SampleInBall block (dilithium.go:400-405)
 template <int MODE>
-__global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int cur) {
+__global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int cur, int pass) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
-    const size_t count = st.count[cur];
+    const PassMap pm(st, cur, pass);
 #pragma unroll 1
-    for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {
-        const size_t a = base + threadIdx.x;
-        if (a >= count) continue;
+    for (size_t base = (size_t)blockIdx.x * 256; base < pm.nwork; base += (size_t)gridDim.x * 256) {
+        if (base + threadIdx.x >= pm.nwork) continue;
+        const size_t a = pm.slot(base + threadIdx.x);
+        const uint32_t e = st.list[cur][a];
+        if (st.best[e & kEntryItemMask] < (e >> kEntryShift)) continue;  // a lower attempt of the item has already succeeded
         KeccakState s;
         sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
         uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
@@ -315,7 +417,7 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
 // One entry's work (sign_finish_kernel below runs it inlined for a workgroup's first entry and through a non-inlined copy for
 // any further one).
 template <int MODE>
-__device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
+__device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, bool direct, uint32_t *xch,
                                                  uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
     using G = DG<MODE>;
     using P = DP<MODE>;
@@ -326,6 +428,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     const uint32_t e = st.list[cur][slot];
     const size_t item = e & kEntryItemMask;
     const uint32_t off = e >> kEntryShift;
+    if (st.best[item] < off) return;  // a lower attempt of the item has already succeeded (the challenge kernel skipped it too)
     const uint8_t *cb = st.cb + slot * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
@@ -439,7 +542,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 wv[r] = w0[i * 256 + kyber::idx_l1(lane, r)];
-                r1v[r] = st.w1[(slot * K + i) * 256 + kyber::idx_l1(lane, r)];
+                r1v[r] = get_bits32<G::W1BITS>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i, kyber::idx_l1(lane, r));  // w1 as packed by the w kernel
             }
             uint32_t t[4];
             mul_c(t, raw);
@@ -465,26 +568,27 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     }
     if (__any(bad) || pop > (unsigned)P::OMEGA) return;
     __syncthreads();       // every lane is done with w0
-    // with one attempt per item the signature goes straight out; with several, this one is parked in the slot's w0
-    // area and the commit kernel copies the lowest successful attempt's
-    uint8_t *sg = k == 1 ? sig + item * G::SIG : reinterpret_cast<uint8_t *>(w0);
+    // `direct`: this attempt is the lowest one of its item that can still succeed (one attempt per item, or a lazy pair,
+    // whose second attempt only runs after the first was rejected): the signature goes straight out.  Otherwise it is parked
+    // in the slot's w0 area and the commit kernel copies the lowest successful attempt's.
+    uint8_t *sg = direct ? sig + item * G::SIG : reinterpret_cast<uint8_t *>(w0);
     for (int b = lane; b < P::CT; b += 64) sg[b] = cb[b];
     for (int b = lane; b < L * G::ZSZ; b += 64) sg[P::CT + b] = zpk[b];
     for (int b = lane; b < P::OMEGA + K; b += 64) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
     if (lane == 0) atomicMin(&best[item], off);
 }
-// The grid is (an upper estimate of) one workgroup per entry, so a workgroup normally handles exactly one: that one runs
-// inlined in the kernel.  Entries beyond the grid -- only when the schedule's estimate was too small -- go through a
+// The grid is (an upper estimate of) one workgroup per entry of the pass, so a workgroup normally handles exactly one: that one
+// runs inlined in the kernel.  Entries beyond the grid -- only when the schedule's estimate was too small -- go through a
 // non-inlined copy: inlined into a grid-stride loop the body made the loop's register allocation grow from 102 to 164 VGPRs,
 // and as a function it reaches its arrays through generic pointers (FLAT instructions, which also count against the LDS
 // counter: every wait for an LDS exchange then waits for the global loads in flight -- 8.2 cycles per VALU instruction).
 template <int MODE>
-__device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, unsigned k, uint32_t *xch,
+__device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, bool direct, uint32_t *xch,
                                                uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
-    sign_finish_body<MODE>(st, cur, sig, slot, k, xch, zpk, hbytes, blk);
+    sign_finish_body<MODE>(st, cur, sig, slot, direct, xch, zpk, hbytes, blk);
 }
-template <int MODE>
-__global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+template <int MODE, int WAVES = 4>
+__global__ void __launch_bounds__(64, WAVES) sign_finish_kernel(SignState st, int cur, int pass, uint8_t *__restrict__ sig) {
     using G = DG<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
     __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
@@ -492,17 +596,17 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
     __shared__ __attribute__((aligned(16))) uint8_t blk[144];
     static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
-    const size_t count = st.count[cur];
-    const unsigned k = st.kk[cur];
-    if (blockIdx.x >= count) return;
-    sign_finish_body<MODE>(st, cur, sig, blockIdx.x, k, xch, zpk, hbytes, blk);
-    if ((size_t)blockIdx.x + gridDim.x >= count) return;
+    const PassMap pm(st, cur, pass);
+    const bool direct = pm.lazy || st.kk[cur] == 1;
+    if (blockIdx.x >= pm.nwork) return;
+    sign_finish_body<MODE>(st, cur, sig, pm.slot(blockIdx.x), direct, xch, zpk, hbytes, blk);
+    if ((size_t)blockIdx.x + gridDim.x >= pm.nwork) return;
     const SignState escaped = st;  // a copy for the call by reference: taking st's own address would turn every pointer field
                                    // of the inlined path above into a generic pointer as well
 #pragma unroll 1
-    for (size_t slot = (size_t)blockIdx.x + gridDim.x; slot < count; slot += gridDim.x) {
+    for (size_t a = (size_t)blockIdx.x + gridDim.x; a < pm.nwork; a += gridDim.x) {
         __syncthreads();  // the previous entry is done with the LDS buffers
-        sign_finish_entry<MODE>(escaped, cur, sig, slot, k, xch, zpk, hbytes, blk);
+        sign_finish_entry<MODE>(escaped, cur, sig, pm.slot(a), direct, xch, zpk, hbytes, blk);
     }
 }
 
@@ -512,8 +616,8 @@ template <int MODE>
 __global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
     using G = DG<MODE>;
     constexpr int K = DP<MODE>::K;
-    if (st.kk[cur] == 1) return;
     const size_t count = st.count[cur];
+    if (st.kk[cur] == 1 || sign_round_lazy(count, st.kk[cur], st.spec_target)) return;  // those rounds wrote their signatures directly
 #pragma unroll 1
     for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
         const uint32_t e = st.list[cur][slot];
@@ -536,7 +640,7 @@ __global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, 
 __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, int last) {
     const size_t count = st.count[cur];
     const unsigned k = st.kk[cur];
-    const unsigned k_next = last ? 1u : sign_next_k((count + k - 1) / k, st.spec_target);
+    const unsigned k_next = last ? 1u : sign_next_k((count + k - 1) / k, st.spec_target, st.pair);
     if (blockIdx.x == 0 && threadIdx.x == 0) st.kk[cur ^ 1] = k_next;
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
@@ -566,7 +670,8 @@ __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur
 // that entered it; with success probability p per attempt an item survives k attempts with (1 - p)^k.  The schedule follows
 // the EXPECTED survivor count (with a pessimistic p and a safety margin on the count that drives k) until it is below
 // 2^-40; the persistent tail kernel behind the schedule makes the result independent of that estimate.
-template <int MODE> inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target, size_t *entries_upper, int max_rounds) {
+template <int MODE>
+inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target, unsigned pair, size_t *entries_upper, bool *lazy, int max_rounds) {
     // expected attempts per signature 4.25 / 5.1 / 3.85 (FIPS 204 table 1): success probability per attempt, times 0.85
     const double p = 0.85 * (DP<MODE>::K == 4 ? 0.235 : DP<MODE>::K == 6 ? 0.196 : 0.26);
     double items = (double)n;
@@ -577,9 +682,10 @@ template <int MODE> inline int sign_round_schedule(size_t n, unsigned k0, unsign
         // unevenly long attempts; workgroups beyond the real count leave at once, and the kernels' grid-stride loops keep a
         // too-small estimate correct)
         entries_upper[rounds] = (size_t)(items * k * 1.03) + 64;
+        lazy[rounds] = sign_round_lazy((unsigned long long)(items * k), k, spec_target);
         const double survive = __builtin_pow(1.0 - p, (double)k);
         // the device derives the next k from the items that ENTERED this round
-        k = sign_next_k((unsigned long long)(items * 1.25 + 8.0), spec_target);
+        k = sign_next_k((unsigned long long)(items * 1.25 + 8.0), spec_target, pair);
         items *= survive;
         rounds++;
     }

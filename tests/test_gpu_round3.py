@@ -88,3 +88,19 @@ def test_randomised_soak_against_the_oracle():
     # round-based signer and its speculative tail, X25519, the hybrids), each result compared with the oracle; bounded to ~50 s
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "20260924", "50"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- batch signing: every round mode against the oracle ---------------------------------------------------------------------
+@pytest.mark.parametrize("env_extra", [{"CIRCL_HIP_SIGN_SPEC": "1", "CIRCL_HIP_SIGN_PAIR": "1"}, {"CIRCL_HIP_SIGN_SPEC": "1"},
+                                       {"CIRCL_HIP_SIGN_SPEC": "4", "CIRCL_HIP_SIGN_PAIR": "1"}, {}],
+                         ids=["lazy-pairs", "single-attempts", "pairs-then-speculation", "default"])
+@pytest.mark.parametrize("param,n,shared", [(65, 1500, ""), (44, 777, ""), (87, 600, ""), (3, 640, ""), (65, 900, "shared")])
+def test_sign_round_modes(env_extra, param, n, shared):
+    # sign/mldsa/mldsa65/internal/dilithium.go:340-470: the signature is the one of the FIRST attempt that passes the norm tests,
+    # whatever the round structure: lazy pairs (two attempts share the matrix reads, the second one's tests run only after the
+    # first was rejected), single attempts, wide speculation (lowest successful attempt wins), and the mixes a real batch goes through
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sign_worker.py"), str(param), str(n)] + ([shared] if shared else []), cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sign worker ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]

@@ -7,10 +7,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; PAT=$1; shift
 OUT=$ROOT/gpurun_out/pmc_any; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
+# GROUPS="A B|C D" overrides the counter groups (one rocprofv3 pass per |-separated group)
+if [ -n "${GROUPS_OVERRIDE:-}" ]; then IFS='|' read -ra GRPS <<< "$GROUPS_OVERRIDE"; else GRPS=(); fi
+for grp in "${GRPS[@]:-}" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
            "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD" \
            "FETCH_SIZE" "WRITE_SIZE"; do
+  [ -z "$grp" ] && continue
   i=$((i+1))
   ( cd "$ROOT" && cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -o g$i -- "$@" > "$OUT/g$i.log" 2>&1 )
 done
