@@ -12,7 +12,28 @@ namespace {
 // ML-KEM workspace: 129 B per item + one 32 KB scratch slice per resident workgroup
 constexpr size_t kKemWsPerItem = 129;  // four 32-byte slots + one status byte (round-3 decapsulation has no caller-side status)
 size_t kem_scratch_bytes() { return 256 + max_resident_blocks() * 64 * 512; }
-size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
+// Small batches (encapsulation): hashing and matrix expansion run side by side in one launch and the encrypt kernel takes its
+// rows from a cache behind the scratch slices (mlkem_small_pre_kernel).  CIRCL_HIP_KEM_SMALL = log2 of the largest such batch
+// (0 = never); the cache is sized for the largest parameter set (K = 4: 8 KB per item, whole groups).
+size_t kem_small_batch() {
+    static const size_t v = [] {
+        const char *e = getenv("CIRCL_HIP_KEM_SMALL");
+        const int lg = e ? atoi(e) : 14;
+        return lg <= 0 ? size_t(0) : size_t(1) << std::min(lg, 20);
+    }();
+    return v;
+}
+size_t kem_coop_batch() {
+    static const size_t v = [] {
+        const char *e = getenv("CIRCL_HIP_KEM_COOP");  // log2 of the largest batch hashed two items per wavefront (0 = never)
+        const int lg = e ? atoi(e) : 12;
+        return lg <= 0 ? size_t(0) : size_t(1) << std::min(lg, 20);
+    }();
+    return v;
+}
+size_t kem_small_table_bytes(size_t n) { return n && n <= kem_small_batch() ? up256((n + 15) / 16 * 16 * size_t(16 * 512)) : 0; }
+size_t kem_small_table_ofs(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
+size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes() + kem_small_table_bytes(n); }
 
 int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
 
@@ -61,6 +82,28 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     uint8_t *r_ws = w.slot0, *m_ws = w.slot1;
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
+    if (!R3 && n <= kem_small_batch()) {
+        // small batch: [H(ek), G] and [A^T] side by side in one launch, then PRF + ring phase with the rows from the cache
+        int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
+        // up to kem_coop_batch() items the hashes run two items per wavefront (25 lanes per state): shorter chains while the chip
+        // has SIMDs to spare (n / 2 hashing wavefronts); beyond it, one item per lane
+        const int coop = n <= kem_coop_batch() ? 1 : 0;
+        const unsigned nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G), nb_hash = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64);
+        static_assert(Gm::LDS_FIFO >= 108 * 8, "the cooperative hash's exchange area fits the FIFO area");
+        {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+            hipLaunchKernelGGL(mlkem_small_pre_kernel<K>, dim3(nb_hash + nb_expand), dim3(64), Gm::LDS_FIFO, st, ek, m, ss, r_ws, key_rows, n, nb_hash, coop);
+        }
+        auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
+        // about two groups per SIMD: one item per workgroup up to 2 x 4 x CUs items, then as few per group as that allows
+        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)key_rows);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         if (R3) hipLaunchKernelGGL(kyber_r3_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, m_ws, n);

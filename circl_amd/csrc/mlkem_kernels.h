@@ -811,7 +811,11 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     int16_t *rows = KM == KM_KEYED ? nullptr : reinterpret_cast<int16_t *>(scratch + (size_t)blockIdx.x * Gm::SCRATCH_BYTES);
     const int lane = threadIdx.x;
     constexpr int GI = SHARED ? Gm::GS : Gm::G;  // items per group
-    const size_t ngroups = (n + GI - 1) / GI;
+    // Shared-key / key-table modes: a launch with at least one workgroup per default group (a small batch on a mostly idle
+    // chip) spreads the items over ALL its workgroups -- fewer items per group, down to one: the PRF pass costs the same
+    // whether its lanes are full or not, and the ring phases of a group run one after the other.
+    const unsigned gi = (SHARED && (size_t)gridDim.x * GI >= n) ? (unsigned)((n + gridDim.x - 1) / gridDim.x) : (unsigned)GI;
+    const size_t ngroups = (n + gi - 1) / gi;
     if constexpr (KM == KM_SHARED) {
         sample_matrix_scratch<K, true, 1>(lds_a, rows, ek + 384 * K, 0, 0, 1, lane);  // rows 0 .. K^2 - 1, once
         __threadfence_block();
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
-    const size_t item0 = grp * GI;
+    const size_t item0 = grp * gi;
     if constexpr (SHARED) {
         __syncthreads();  // phase C of the previous group is done with the noise
         prf_streams<K, Gm::NOISE, K, Gm::GS>(lds_noise, r_ws, 32, item0, n, lane);
@@ -854,7 +858,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     asm volatile("" : "+v"(lane_ring));
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane_ring);
 #pragma unroll 1
-    for (int g = 0; g < ((ABLATE & 4) ? 0 : GI); g++) {
+    for (int g = 0; g < ((ABLATE & 4) ? 0 : (int)gi); g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
         if constexpr (Gm::HALVES > 1 && !SHARED) {
@@ -864,7 +868,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 __syncthreads();
             }
         }
-        const size_t kq = KM == KM_KEYED ? (size_t)key_idx[item] : item;  // wave-uniform
+        const size_t kq = (KM == KM_KEYED && key_idx) ? (size_t)key_idx[item] : item;  // wave-uniform; a key table without an index vector is the batch's own keys
         const uint8_t *ekp = ek + kq * ek_stride;
         const int16_t *krows = KM == KM_KEYED ? key_rows + kq * (size_t)(K * K * 256) : nullptr;
         const uint8_t *noise = lds_noise + (SHARED ? g : g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
@@ -978,6 +982,91 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_expand_keys_
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const size_t e0 = (size_t)blockIdx.x * Gm::G;
     sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), keys + rho_off, stride, e0, nkeys, threadIdx.x);
+}
+
+// ---- small batches: hashing and matrix expansion side by side ----------------------------------------------------
+// Below ~2^14 items an encapsulation is a latency chain, not a throughput problem: H(ek) || G is ten dependent permutations
+// on one lane (~100 us for a lone wavefront at ~5.4 cycles per instruction), and only then do the three matrix blocks, the
+// PRF and the ring phase of the encrypt kernel start (another ~60 us), on a chip that is mostly idle.  The matrix does not
+// depend on the hashes, so for small batches ONE launch runs both in different workgroups -- [0, nb_hash): H(ek), G(m || H(ek))
+// of 64 items each, exactly mlkem_hash_kernel; the rest: A^T of G items each into the key-table cache, exactly
+// mlkem_expand_keys_kernel -- and the key-table form of the encrypt kernel (PRF + ring phase, rows from the cache) follows:
+// max(hash, expansion) + PRF + ring instead of their sum.  Results are bit-identical (same device functions).
+// H(ek), G(m || H(ek)) of items item0 and item0 + 1 by ONE wavefront (keccak_f1600_coop2: 25 lanes per state).  Same values as
+// mlkem_hash_kernel: SHA3-256 over the EK / 8 words of ek (rate 17 words, suffix 0x06), SHA3-512 over m || h (one block of
+// rate 9 words); K' -> ss, r -> r_ws.
+template <int K>
+__device__ __forceinline__ void mlkem_hash_coop2(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ m, uint8_t *__restrict__ ss,
+                                                 uint8_t *__restrict__ r_ws, size_t item0, size_t n, uint64_t *ws, int lane) {
+    using Gm = Geom<K>;
+    constexpr int NW = Gm::EK / 8, FULL = NW / 17, REM = NW % 17;
+    const CoopLane c = coop_lane(ws, lane);
+    uint64_t *hx = ws + 100;  // 2 x 4 words: h on its way from lanes 0..3 to lanes 4..7
+    const int half = lane >> 5, j = lane & 31;
+    size_t item = item0 + half;
+    const bool live = item < n;
+    if (!live) item = n - 1;  // both halves run in lock step; the duplicate is not stored
+    const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ek + item * Gm::EK);
+    uint32_t vlo = 0, vhi = 0;
+    uint64_t next = j < 17 ? ekw[j] : 0;  // the block after the current one is requested before the permutation
+#pragma unroll 1
+    for (int b = 0; b < FULL; b++) {
+        vlo ^= (uint32_t)next;
+        vhi ^= (uint32_t)(next >> 32);
+        next = (j < 17 && 17 * (b + 1) + j < NW) ? ekw[17 * (b + 1) + j] : 0;
+        keccak_f1600_coop2(vlo, vhi, c);
+    }
+    vlo ^= (uint32_t)next;  // the REM words of the last block (zero beyond them)
+    vhi ^= (uint32_t)(next >> 32);
+    if (j == REM) vlo ^= kDsSha3;
+    if (j == 16) vhi ^= 0x80000000u;
+    keccak_f1600_coop2(vlo, vhi, c);
+    // G: words 0..3 = m, 4..7 = h, word 8 = suffix and final bit
+    __syncthreads();
+    if (j < 4) hx[4 * half + j] = ((uint64_t)vhi << 32) | vlo;
+    __syncthreads();
+    uint64_t g = 0;
+    if (j < 4) g = reinterpret_cast<const uint64_t *>(m + item * 32)[j];
+    else if (j < 8) g = hx[4 * half + j - 4];
+    else if (j == 8) g = 0x8000000000000000ull | kDsSha3;
+    vlo = (uint32_t)g;
+    vhi = (uint32_t)(g >> 32);
+    keccak_f1600_coop2(vlo, vhi, c);
+    if (live && j < 8) {
+        uint64_t *dst = reinterpret_cast<uint64_t *>((j < 4 ? ss : r_ws) + item * 32);
+        dst[j & 3] = ((uint64_t)vhi << 32) | vlo;
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_pre_kernel(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ m,
+                                                                                    uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws,
+                                                                                    int16_t *__restrict__ key_rows, size_t n, unsigned nb_hash, int coop) {
+    using Gm = Geom<K>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (blockIdx.x >= nb_hash) {
+        const size_t e0 = (size_t)(blockIdx.x - nb_hash) * Gm::G;
+        sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), ek + 384 * K, (size_t)Gm::EK, e0, n, threadIdx.x);
+        return;
+    }
+    // The hashing wavefronts are the critical path (ten dependent permutations against three or four): they are dispatched
+    // first and issue ahead of the expansion wavefronts that share their SIMD (measured at 2^14 items without the priority: the
+    // launch took as long as hashing and expansion one after the other).
+    __builtin_amdgcn_s_setprio(3);
+    if (coop) {  // very small batches: two items per wavefront, ~2.5 x shorter chain (keccak_f1600_coop2)
+        mlkem_hash_coop2<K>(ek, m, ss, r_ws, 2 * (size_t)blockIdx.x, n, reinterpret_cast<uint64_t *>(smem), threadIdx.x);
+        return;
+    }
+    size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;  // keep the wave converged; the duplicate result is not stored
+    KeccakState h, g;
+    sha3_256_words<Gm::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek + idx * Gm::EK));
+    sha3_512_m_h(g, reinterpret_cast<const uint64_t *>(m + idx * 32), h);
+    if (live) {
+        store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
+        store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
+    }
 }
 
 // ---- decapsulation ---------------------------------------------------------------------------
