@@ -305,20 +305,156 @@ def cpu_baseline(work, budget_s=10.0):
                       "restatement of CIRCL's generic Go (Go toolchain absent, so not CIRCL's AVX2 path)"}
 
 
+GO_HARNESS = r'''// Written by circl-hip's bench.py and placed into kem/schemes by `go test -overlay` (nothing is written into the
+// reference tree).  BASELINE.md section 5: all cores, distinct key: UnmarshalBinaryPublicKey + EncapsulateDeterministically
+// per item on the same synthetic arrays the GPU run used.
+package schemes_test
+
+import (
+	"encoding/binary"
+	"os"
+	"sync/atomic"
+	"testing"
+
+	"github.com/cloudflare/circl/kem/schemes"
+)
+
+func circlHipInputs(tb testing.TB) (int, []byte, []byte) {
+	raw, err := os.ReadFile(os.Getenv("CIRCL_HIP_BENCH_INPUT"))
+	if err != nil {
+		tb.Fatal(err)
+	}
+	n := int(binary.LittleEndian.Uint64(raw[:8]))
+	return n, raw[8 : 8+n*1184], raw[8+n*1184 : 8+n*1184+n*32]
+}
+
+func BenchmarkCirclHipDistinctKey(b *testing.B) {
+	s := schemes.ByName("ML-KEM-768")
+	n, ek, m := circlHipInputs(b)
+	var ctr int64
+	b.ResetTimer()
+	b.RunParallel(func(pb *testing.PB) {
+		for pb.Next() {
+			i := int(atomic.AddInt64(&ctr, 1)) % n
+			pk, err := s.UnmarshalBinaryPublicKey(ek[i*1184 : (i+1)*1184])
+			if err != nil {
+				b.Fatal(err)
+			}
+			if _, _, err = s.EncapsulateDeterministically(pk, m[i*32:(i+1)*32]); err != nil {
+				b.Fatal(err)
+			}
+		}
+	})
+}
+
+func TestCirclHipParity(t *testing.T) {
+	s := schemes.ByName("ML-KEM-768")
+	n, ek, m := circlHipInputs(t)
+	if n > 256 {
+		n = 256
+	}
+	out := make([]byte, 0, n*(1088+32))
+	for i := 0; i < n; i++ {
+		pk, err := s.UnmarshalBinaryPublicKey(ek[i*1184 : (i+1)*1184])
+		if err != nil {
+			t.Fatal(err)
+		}
+		ct, ss, err := s.EncapsulateDeterministically(pk, m[i*32:(i+1)*32])
+		if err != nil {
+			t.Fatal(err)
+		}
+		out = append(append(out, ct...), ss...)
+	}
+	if err := os.WriteFile(os.Getenv("CIRCL_HIP_BENCH_OUTPUT"), out, 0o600); err != nil {
+		t.Fatal(err)
+	}
+}
+'''
+
+
+def cpu_baseline_reference(work, budget_s=8.0):
+    """BASELINE.md section 5 option A: CIRCL itself, when the box has a Go toolchain and $CIRCL_REFERENCE points at a checkout
+    (nothing here reads /root/reference): the reference's own BenchmarkEncapsulate/ML-KEM-768 (one core, parsed key; AVX2 and
+    -tags purego) and an all-cores distinct-key harness over the first items of this very batch, placed into kem/schemes by
+    `go test -overlay`; its first 256 ciphertexts / shared secrets are compared with the GPU's.  Returns None (and says why on
+    stderr) when any of that is unavailable: the caller then times the oracle ('port')."""
+    import re
+    import tempfile
+    go, ref = shutil.which("go"), os.environ.get("CIRCL_REFERENCE")
+    if not go or not ref or not os.path.isdir(os.path.join(ref, "kem", "schemes")):
+        return None
+    tmp = tempfile.mkdtemp(prefix="circl_go_", dir="/tmp")
+    try:
+        nsamp = min(work.B, 1 << 16)
+        ek, m = work.ek[:nsamp].cpu().numpy(), work.m[:nsamp].cpu().numpy()
+        with open(os.path.join(tmp, "in.bin"), "wb") as f:
+            f.write(nsamp.to_bytes(8, "little") + ek.tobytes() + m.tobytes())
+        with open(os.path.join(tmp, "zz_circl_hip_test.go"), "w") as f:
+            f.write(GO_HARNESS)
+        with open(os.path.join(tmp, "overlay.json"), "w") as f:
+            json.dump({"Replace": {os.path.join(ref, "kem", "schemes", "zz_circl_hip_test.go"): os.path.join(tmp, "zz_circl_hip_test.go")}}, f)
+        env = dict(os.environ, CIRCL_HIP_BENCH_INPUT=os.path.join(tmp, "in.bin"), CIRCL_HIP_BENCH_OUTPUT=os.path.join(tmp, "out.bin"),
+                   GOFLAGS=os.environ.get("GOFLAGS", "-mod=mod"), GOCACHE=os.path.join(tmp, "gocache"))
+        cores = len(os.sched_getaffinity(0))
+
+        def gotest(args, timeout):
+            r = subprocess.run([go, "test"] + args + ["./kem/schemes"], cwd=ref, env=env, capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                raise RuntimeError((r.stdout + r.stderr)[-600:])
+            return r.stdout
+
+        def ns_per_op(out, name):
+            mm = re.search(re.escape(name) + r"\S*\s+\d+\s+([0-9.]+) ns/op", out)
+            if not mm:
+                raise RuntimeError("no ns/op for " + name)
+            return float(mm.group(1))
+        bt = "%ds" % max(1, int(budget_s / 4))
+        single = ns_per_op(gotest(["-run", "^$", "-bench", "BenchmarkEncapsulate/ML-KEM-768$", "-benchtime", bt], 300), "BenchmarkEncapsulate/ML-KEM-768")
+        purego = ns_per_op(gotest(["-tags", "purego", "-run", "^$", "-bench", "BenchmarkEncapsulate/ML-KEM-768$", "-benchtime", bt], 300),
+                           "BenchmarkEncapsulate/ML-KEM-768")
+        ov = ["-overlay", os.path.join(tmp, "overlay.json")]
+        gotest(ov + ["-run", "TestCirclHipParity", "-count", "1"], 300)
+        ref_out = np.fromfile(os.path.join(tmp, "out.bin"), np.uint8).reshape(-1, 1088 + 32)
+        k = len(ref_out)
+        same = bool((ref_out[:, :1088] == work.eng.ct[:k].cpu().numpy()).all() and (ref_out[:, 1088:] == work.eng.ss[:k].cpu().numpy()).all())
+        par = ns_per_op(gotest(ov + ["-run", "^$", "-bench", "BenchmarkCirclHipDistinctKey", "-benchtime", bt, "-cpu", str(cores)], 300), "BenchmarkCirclHipDistinctKey")
+        ver = subprocess.run([go, "version"], capture_output=True, text=True).stdout.strip()
+        return {"value": 1e9 / par, "unit": "encaps/s", "cores": cores, "kind": "reference", "cpu": cpu_model(), "go": ver,
+                "gpu_equals_reference_on_first_items": {"items": int(k), "bit_exact": same},
+                "single_core_parsed_key": {"avx2_ns_per_op": single, "purego_ns_per_op": purego, "value": 1e9 / single, "unit": "encaps/s",
+                                           "what": "go test -bench BenchmarkEncapsulate/ML-KEM-768 ./kem/schemes (kem/schemes/schemes_test.go:28-38)"},
+                "sample": f"cloudflare/circl at $CIRCL_REFERENCE, {ver}: b.RunParallel over the first {nsamp} items of the same batch (UnmarshalBinaryPublicKey + "
+                          f"EncapsulateDeterministically per item), GOMAXPROCS={cores}, benchtime {bt}"}
+    except Exception as e:  # noqa: BLE001 -- the reference path is optional; the port is the fallback
+        print("bench.py: the Go reference baseline was attempted and failed (%s: %s); timing the C oracle instead" % (type(e).__name__, str(e)[-400:]), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # PMC: HBM-side traffic and VALU instruction counts of the dominant kernel, measured by a fresh rocprofv3 pass
 # ------------------------------------------------------------------------------------------------------------------
-def pmc_live(batch, timeout_s=240):
+PMC_KERNELS = {  # name in the JSON line -> substring of the rocprofv3 kernel name
+    "mlkem768_encrypt": "mlkem_encrypt_kernel<3, 0",
+    "mlkem1024_encrypt": "mlkem_encrypt_kernel<4, 0",
+    "mldsa65_verify": "mldsa_verify_kernel<65",
+    "mldsa87_verify": "mldsa_verify_kernel<87",
+}
+
+
+def pmc_live(batch, timeout_s=300):
     """Runs `bench.py --pmc-child` under rocprofv3 --pmc (own passes, kernel-trace only, as MI355X_MICROARCH.md prescribes)
-    and returns per-launch medians for mlkem_encrypt_kernel<3, ENCAPS>: read bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports
-    half of a wide coalesced stream), write bytes = WRITE_SIZE x 1024 (uncalibrated), SQ_INSTS_VALU."""
+    and returns per-launch medians for the dominant kernel of every BASELINE config (PMC_KERNELS): read bytes =
+    2 x FETCH_SIZE x 1024 (gfx950 reports half of a wide coalesced stream), write bytes = WRITE_SIZE x 1024 (uncalibrated),
+    SQ_INSTS_VALU.  The child launches each kernel at the batch size its config is quoted on."""
     import csv
     import glob
     import tempfile
     rp = shutil.which("rocprofv3")
     if not rp:
         return None, "rocprofv3 not found"
-    res = {}
+    res = {k: {} for k in PMC_KERNELS}
     base = tempfile.mkdtemp(prefix="circl_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     t_end = time.time() + timeout_s
@@ -331,36 +467,72 @@ def pmc_live(batch, timeout_s=240):
             cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(batch)]
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=left, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            vals = []
+            vals = {k: [] for k in PMC_KERNELS}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") != counter:
+                            continue
                         name = r.get("Kernel_Name", "")
-                        if "mlkem_encrypt_kernel<3, 0" in name and r.get("Counter_Name") == counter:
-                            vals.append(float(r["Counter_Value"]))
-            if not vals:
+                        for k, pat in PMC_KERNELS.items():
+                            if pat in name:
+                                vals[k].append(float(r["Counter_Value"]))
+            if not vals["mlkem768_encrypt"]:
                 return None, f"no {counter} rows for the encrypt kernel"
-            res[counter] = float(np.median(vals))
+            for k, v in vals.items():
+                if v:
+                    res[k][counter] = float(np.median(v))  # (the child's launches of a kernel all have the same batch size)
     except Exception as e:  # noqa: BLE001 -- any failure of the optional pass falls back to the committed figures
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(base, ignore_errors=True)
-    return {"read_bytes": 2.0 * res["FETCH_SIZE"] * 1024.0, "write_bytes": res["WRITE_SIZE"] * 1024.0,
-            "bytes": 2.0 * res["FETCH_SIZE"] * 1024.0 + res["WRITE_SIZE"] * 1024.0, "valu_insts": res["SQ_INSTS_VALU"],
-            "method": "live rocprofv3 --pmc passes of this very library inside this bench run (kernel-trace only, one counter per pass); "
-                      "read = 2 x FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB (uncalibrated); L2<->fabric bytes incl. Infinity-Cache hits"}, None
+    out = {}
+    for k, c in res.items():
+        if len(c) == 3:
+            out[k] = {"read_bytes": 2.0 * c["FETCH_SIZE"] * 1024.0, "write_bytes": c["WRITE_SIZE"] * 1024.0,
+                      "bytes": 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0, "valu_insts": c["SQ_INSTS_VALU"]}
+    out["method"] = ("live rocprofv3 --pmc passes of this very library inside this bench run (kernel-trace only, one counter per pass); "
+                     "read = 2 x FETCH_SIZE KB (gfx950 correction), write = WRITE_SIZE KB (uncalibrated); L2<->fabric bytes incl. Infinity-Cache hits")
+    return out, None
 
 
 def pmc_committed():
+    """profiles/traffic.json + valu.json: the figures of an earlier live pass (written by a run with CIRCL_BENCH_WRITE_PMC set),
+    used only when they carry the SHA-256 of the library that is loaded now."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
             v = json.load(f)
+        kern = {}
+        for k in PMC_KERNELS:
+            tk, vk = (t.get("kernels") or {}).get(k), (v.get("kernels") or {}).get(k)
+            if tk and vk:
+                kern[k] = {"bytes": tk["bytes"], "read_bytes": tk.get("read_bytes"), "write_bytes": tk.get("write_bytes"), "valu_insts": vk["valu_insts"]}
         return {"bytes": t.get("mlkem768_encrypt_bytes_per_launch_2p20"), "valu_insts": v.get("mlkem768_encrypt_valu_insts_per_launch_2p20"),
-                "lib_sha256": t.get("lib_sha256")}
+                "lib_sha256": t.get("lib_sha256"), "kernels": kern}
     except Exception:  # noqa: BLE001
         return None
+
+
+def pmc_write(live_all, sha, batch):
+    """CIRCL_BENCH_WRITE_PMC=<dir>: keep the live figures as traffic.json / valu.json (copied into profiles/ by hand)."""
+    d = os.environ.get("CIRCL_BENCH_WRITE_PMC")
+    if not d or not live_all:
+        return
+    os.makedirs(d, exist_ok=True)
+    kern = {k: v for k, v in live_all.items() if isinstance(v, dict)}
+    with open(os.path.join(d, "traffic.json"), "w") as f:
+        json.dump({"mlkem768_encrypt_bytes_per_launch_2p20": kern["mlkem768_encrypt"]["bytes"] if batch == 1 << 20 else None,
+                   "batch": batch, "kernels": {k: {kk: v[kk] for kk in ("bytes", "read_bytes", "write_bytes")} for k, v in kern.items()},
+                   "lib_sha256": sha, "method": live_all["method"]}, f, indent=1)
+    with open(os.path.join(d, "valu.json"), "w") as f:
+        json.dump({"mlkem768_encrypt_valu_insts_per_launch_2p20": kern["mlkem768_encrypt"]["valu_insts"] if batch == 1 << 20 else None,
+                   "batch": batch, "kernels": {k: {"valu_insts": v["valu_insts"]} for k, v in kern.items()}, "lib_sha256": sha,
+                   "method": "rocprofv3 --pmc SQ_INSTS_VALU (own pass, kernel-trace only), median over the launches of bench.py --pmc-child"}, f, indent=1)
+
+
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2 cycles per wave64 VALU op, 2.4 GHz = 1.229e12
 
 
 def valu_issue(insts, launch_ms):
@@ -369,6 +541,8 @@ def valu_issue(insts, launch_ms):
     simds, nominal_hz = 1024, 2.4e9
     per_s = insts / (launch_ms * 1e-3)
     return {"wave_insts_per_launch": insts, "achieved_Ginst_per_s": per_s / 1e9,
+            "peak_Ginst_per_s": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "frac": per_s / VALU_PEAK_WAVE_INSTS_PER_S,
+            "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
             "cycles_per_inst_per_simd_at_2.4GHz": simds * nominal_hz / per_s,
             "keccak_probe_cycles_per_inst": {"4_waves_per_simd": 4.12, "8_waves_per_simd": 3.43},
             "resident_waves_per_simd": 4}
@@ -402,10 +576,24 @@ def main():
     B = args.batch
     extras = not args.no_extras
 
-    if args.pmc_child:  # a few launches of the headline kernels for the counter passes, nothing else
+    if args.pmc_child:  # a few launches of the dominant kernel of every BASELINE config for the counter passes, nothing else
         w = KemWork(768, B, 0, dev, shake_inputs=False)
         for _ in range(3):
             w.encaps()
+        torch.cuda.synchronize()
+        del w
+        torch.cuda.empty_cache()
+        d65 = DsaWork(65, max(B // 4, 64), 0, dev)
+        for _ in range(3):
+            d65.verify()
+        torch.cuda.synchronize()
+        del d65
+        torch.cuda.empty_cache()
+        k1024 = KemWork(1024, max(B // 16, 64), 0, dev, shake_inputs=False)
+        d87 = DsaWork(87, max(B // 16, 64), 0, dev)
+        for _ in range(3):
+            k1024.encaps()
+            d87.verify()
         torch.cuda.synchronize()
         return
 
@@ -611,16 +799,29 @@ def main():
     if args.mode == "host":
         headline = {"elapsed": B / host["pageable"]["value"] * args.steps, "value": host["pageable"]["whole_job_value"], "kern": {}}
 
-    # ---- PMC: traffic / VALU instructions of the dominant kernel ----
+    # ---- PMC: traffic / VALU instructions of the dominant kernels ----
     traffic, valu, pmc_note = None, None, None
     if rank == 0 and enc_kern is not None:
         enc_avg_ms = enc_kern["mlkem_encrypt"]["ms_per_step"]
-        live, why = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_live(B)
+        live_all, why = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_live(B)
+        live = live_all.get("mlkem768_encrypt") if live_all else None
         committed = pmc_committed()
         sha = lib_sha256()
+        pmc_write(live_all, sha, B)
+        other = live_all if live_all else ((committed or {}).get("kernels") if (committed or {}).get("lib_sha256") == sha else None)
+        if other:  # the other configs' dominant kernels: traffic and VALU fraction next to their HBM rooflines
+            live_all_or_committed = other
+            for cfg_key, roof_key, pk in (("config4", "roofline", "mldsa65_verify"), ("config5", "roofline_mlkem1024", "mlkem1024_encrypt"),
+                                          ("config5", "roofline_mldsa87", "mldsa87_verify")):
+                r = (out_cfg.get(cfg_key) or {}).get(roof_key)
+                if r and live_all_or_committed.get(pk):
+                    r["traffic"] = live_all_or_committed[pk]["bytes"]
+                    r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
+                    r["valu"] = valu_issue(live_all_or_committed[pk]["valu_insts"], r["avg_launch_ms"])
+                    r["pmc_source"] = "live" if live_all else "profiles/traffic.json + valu.json (this very build)"
         if live:
             traffic, valu = live["bytes"], valu_issue(live["valu_insts"], enc_avg_ms)
-            pmc_note = {"source": "live", "method": live["method"], "read_bytes": live["read_bytes"], "write_bytes": live["write_bytes"]}
+            pmc_note = {"source": "live", "method": live_all["method"], "read_bytes": live["read_bytes"], "write_bytes": live["write_bytes"]}
             if committed and committed.get("bytes"):
                 dev_pct = abs(committed["bytes"] - traffic) / traffic * 100.0
                 pmc_note["committed_profiles_traffic_json_deviates_pct"] = dev_pct
@@ -667,13 +868,19 @@ def main():
             r["launches"] = enc_kern["mlkem_encrypt"]["launch_groups"]
             r["hash_kernel_avg_ms"] = enc_kern["mlkem_hash"]["ms_per_step"]
             r["valu"] = valu
+            if traffic:
+                r["traffic_over_algorithmic"] = traffic / r["algorithmic_bytes_per_launch"]
             r["pmc"] = pmc_note
             r["status_nonzero"] = status_sum
             out["roofline"] = r
         else:
             out["roofline"] = (out_cfg.get(args.mode) or {}).get("roofline")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kem)
+            # the reference itself when this box can run it (Go toolchain + $CIRCL_REFERENCE), the C oracle otherwise; with the
+            # reference, the oracle's figure stays in the line as `port` for comparison across boxes
+            refb = cpu_baseline_reference(kem)
+            port = cpu_baseline(kem, budget_s=10.0 if refb is None else 4.0)
+            out["cpu_baseline"] = dict(refb, port=port) if refb else port
         print(json.dumps(out))
     ranks.close()
 

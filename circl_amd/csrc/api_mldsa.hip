@@ -37,8 +37,23 @@ template <int MODE> size_t mldsa_item_ws_bytes(size_t n) {
     using G = circl::mldsa::DG<MODE>;
     return up256(n * G::MUW1) + up256(n * circl::mldsa::kBallStateBytes) + up256(n);
 }
+constexpr size_t kLongCtlBytes = (sizeof(circl::mldsa::LongCtl) + 255) & ~size_t(255);
 template <int MODE> size_t mldsa_ws_bytes(size_t n) {
-    return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES + 256;  // + tr of a shared key
+    return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES + 256 + kLongCtlBytes;  // + tr of a shared key + long-message list
+}
+// mu of the batch's long messages ahead of the per-lane kernels (mldsa_kernels.h, kLongMsg): scan, then two messages per wavefront
+template <int TRW>
+int mldsa_long_prepass(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
+                       const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *mu_out,
+                       size_t mu_stride, circl::mldsa::LongCtl *ctl, size_t n, hipStream_t st) {
+    using namespace circl::mldsa;
+    HIP_TRY(hipMemsetAsync(ctl, 0, 256, st));
+    hipLaunchKernelGGL(mldsa_long_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msg_off, ctx_blob, ctx_off, internal, n, ctl);
+    const unsigned grid = (unsigned)std::min<size_t>((std::min<size_t>(n, kLongCap) + 1) / 2, (size_t)cu_count() * 8);
+    hipLaunchKernelGGL(mldsa_mu_long_kernel<TRW>, dim3(grid), dim3(64), 0, st, tr_base, tr_stride, key_idx, pk, pk_stride, pk_words, msg_blob, msg_off,
+                       ctx_blob, ctx_off, internal, mu_out, mu_stride, (const LongCtl *)ctl);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
 }
 template <class Kern> unsigned dsa_resident_blocks(Kern kern, int lds_bytes) {
     const unsigned occ = resident_blocks(kern, lds_bytes);  // CUs of the current device * min(occupancy, kMaxBlocksPerCU)
@@ -71,6 +86,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     unsigned *work = reinterpret_cast<unsigned *>(muw1 + mldsa_item_ws_bytes<MODE>(n));
     uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
     uint8_t *tr = scratch + mldsa_scratch_blocks<MODE>(n) * G::SCRATCH_BYTES;  // shared key: 64 bytes behind the scratch slices
+    LongCtl *lctl = reinterpret_cast<LongCtl *>(tr + 256);
     uint32_t *key_rows = nullptr;
     const uint8_t *tr_arg = nullptr;
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
@@ -90,8 +106,17 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
             hipLaunchKernelGGL(mldsa_tr_kernel<MODE>, dim3(1), dim3(64), 0, st, pk, tr);
             tr_arg = tr;
         }
+        {
+            const int internal_eff = DP<MODE>::NIST ? internal : 1;  // round 3: mu = CRH(tr || msg)
+            const uint32_t *kidx = KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr;
+            const int rc = tr_arg ? mldsa_long_prepass<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+                                                                         internal_eff, muw1, G::MUW1, lctl, n, st)
+                                  : mldsa_long_prepass<DP<MODE>::TR / 8>(nullptr, 0, nullptr, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
+                                                                         muw1, G::MUW1, lctl, n, st);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, muw1, ball,
-                           fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr);
+                           fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr, (const LongCtl *)lctl);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
@@ -236,7 +261,7 @@ template <int MODE> struct SignLayout {
     size_t n, E, tail_units;
     size_t o_mr, o_work, o_scratch;                 // persistent kernel (also the tail of the batched path)
     size_t o_A, o_sec, o_y, o_w0, o_muw1, o_cb, o_attempts, o_best, o_list0, o_list1, o_ctl, o_secret_end;  // batched path
-    size_t o_dead, total;
+    size_t o_dead, o_long, total;
     explicit SignLayout(size_t n_) : n(n_) {
         E = std::max((sign_pair_mode() ? 2 : 1) * n, circl::mldsa::kMinEntryCapacity);  // lazy pairs: two attempts per item in the long rounds
         tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
@@ -262,6 +287,7 @@ template <int MODE> struct SignLayout {
             o_A = o_sec = o_y = o_w0 = o_muw1 = o_cb = o_secret_end = o_attempts = o_best = o_list0 = o_list1 = o_ctl = o;
         }
         o_dead = take(n);  // one byte per item: the "context refused" flags of mldsa_sign_prep_kernel
+        o_long = take(kLongCtlBytes);  // the list of long messages (mldsa_kernels.h, kLongMsg)
         total = o;
     }
 };
@@ -327,8 +353,12 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, shared ? 0 : KG<MODE>::SK, nullptr, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+                                                          DP<MODE>::NIST ? internal : 1, S.mr, 128, lctl, n, st))
+            return rc;
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                           S.mr, n, shared ? 1 : 0, dead);
+                           S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
@@ -455,8 +485,12 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, shared ? 0 : KG<MODE>::SK, nullptr, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+                                                          DP<MODE>::NIST ? internal : 1, mr, 128, lctl, n, st))
+            return rc;
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sk, msg_blob,
-                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead);
+                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl);
     }
     {
         auto kern = mldsa_sign_kernel<MODE>;

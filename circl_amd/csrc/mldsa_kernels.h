@@ -100,12 +100,59 @@ template <int NWORDS> __device__ __forceinline__ void sponge17_words(KeccakState
 // therefore gathered in a rolled loop into the lane's row of an LDS staging area (kStageStride dwords apart: an odd
 // stride, so the 64 rows of a wave hit distinct banks) and xor-ed into the state from there.
 constexpr int kStageStride = 35;
-template <int TRW>
-__device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const uint8_t *mp, size_t mlen, const uint8_t *cp,
-                                                           size_t clen, int internal, uint32_t *stage) {
-    const size_t pre = internal ? 0 : 2;
-    const size_t total = pre + (internal ? 0 : clen) + mlen;  // length of M'
-    auto mbyte = [&](size_t k) -> uint32_t {
+
+// ---- long messages ------------------------------------------------------------------------------------------------------
+// One sponge per lane means one LONG message keeps its lane -- and the 63 idle ones of its wavefront, and the whole launch --
+// busy for a block per ~10 us: a 64 KB message among 2^14 32-byte ones made verification 8 x slower (tools/msglen_bench.py).
+// Messages whose M' exceeds kLongMsg bytes are therefore listed by a scan kernel and, when there are at most kLongCap of them,
+// hashed ahead of the per-lane kernels by mldsa_mu_long_kernel: two messages per wavefront on the two-state cooperative
+// permutation (keccak_f1600_coop2, ~2.5 x shorter chain), every long message on its own half-wave in parallel.  The per-lane
+// kernels then take mu ready-made for those items.  With more long messages than kLongCap the batch is throughput-bound and
+// the per-lane form (64 sponges per wavefront) is the right one: the pre-pass does nothing.
+constexpr size_t kLongMsg = 2048;
+constexpr uint32_t kLongCap = 4096;
+struct LongCtl {
+    uint32_t count;          // long messages found by the scan (may exceed kLongCap: then nothing is pre-hashed)
+    uint32_t pad[63];
+    uint32_t list[kLongCap]; // their item indices
+};
+__device__ __forceinline__ bool long_premade(const LongCtl *ctl, size_t total) { return ctl && total > kLongMsg && ctl->count <= kLongCap; }
+__device__ __forceinline__ size_t mprime_total(const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, size_t idx) {
+    const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+    const size_t clen = (ctx_blob && !internal) ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+    return (internal ? 0 : 2) + clen + mlen;
+}
+// lane = item: which items have a long M'
+static __global__ void __launch_bounds__(256) mldsa_long_scan_kernel(const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
+                                                                     const uint64_t *__restrict__ ctx_off, int internal, size_t n, LongCtl *__restrict__ ctl) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    if (mprime_total(msg_off, ctx_blob, ctx_off, internal, idx) > kLongMsg) {
+        const uint32_t p = atomicAdd(&ctl->count, 1u);
+        if (p < kLongCap) ctl->list[p] = (uint32_t)idx;
+    }
+}
+
+// The eight bytes of M' = [0 || len(ctx) ||] ctx || msg at stream offset `base` (a multiple of 8), with the SHAKE suffix byte
+// behind the last one and zeros beyond: aligned 64-bit loads and a funnel shift where the word lies wholly inside the message
+// (the second aligned word of a misaligned load holds the word's own last byte, so nothing beyond the message's last 8-byte
+// granule is read), byte by byte around the prefix / context and the end.
+struct MPrime {
+    const uint8_t *mp, *cp;
+    size_t clen, total, m_begin;
+    int internal;
+    const uint64_t *pa;
+    unsigned mis;
+    __device__ __forceinline__ MPrime(const uint8_t *mp_, size_t mlen, const uint8_t *cp_, size_t clen_, int internal_)
+        : mp(mp_), cp(cp_), clen(internal_ ? 0 : clen_), internal(internal_) {
+        const size_t pre = internal ? 0 : 2;
+        m_begin = pre + clen;
+        total = m_begin + mlen;
+        const uint8_t *vp = mp - m_begin;  // M' byte k of the message region is vp[k]
+        mis = (unsigned)(reinterpret_cast<uintptr_t>(vp) & 7);
+        pa = reinterpret_cast<const uint64_t *>(vp - mis);
+    }
+    __device__ __forceinline__ uint32_t byte(size_t k) const {
         if (k > total) return 0;
         if (k == total) return kDsShake;
         if (!internal) {
@@ -115,19 +162,36 @@ __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const
             return mp[k - 2 - clen];
         }
         return mp[k];
-    };
+    }
+    __device__ __forceinline__ void word(size_t base, uint32_t &lo, uint32_t &hi) const {
+        if (base >= m_begin && base + 8 <= total) {
+            uint64_t v = pa[base >> 3];
+            if (mis) v = (v >> (8 * mis)) | (pa[(base >> 3) + 1] << (64 - 8 * mis));
+            lo = (uint32_t)v;
+            hi = (uint32_t)(v >> 32);
+            return;
+        }
+        lo = hi = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            lo |= byte(base + b) << (8 * b);
+            hi |= byte(base + 4 + b) << (8 * b);
+        }
+    }
+};
+
+template <int TRW>
+__device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const uint8_t *mp, size_t mlen, const uint8_t *cp,
+                                                           size_t clen, int internal, uint32_t *stage) {
+    const MPrime mpr(mp, mlen, cp, clen, internal);
+    const size_t total = mpr.total;  // length of M'
     size_t pos = 0;   // M' bytes consumed
     int w0 = TRW;     // the first block's words 0..TRW-1 hold tr
     for (;;) {
 #pragma unroll 1
         for (int w = w0; w < 17; w++) {
-            const size_t base = pos + 8 * (size_t)(w - w0);
-            uint32_t lo = 0, hi = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                lo |= mbyte(base + b) << (8 * b);
-                hi |= mbyte(base + 4 + b) << (8 * b);
-            }
+            uint32_t lo, hi;
+            mpr.word(pos + 8 * (size_t)(w - w0), lo, hi);
             stage[2 * w] = lo;
             stage[2 * w + 1] = hi;
         }
@@ -145,6 +209,79 @@ __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const
         if (last) break;
         pos += span;
         w0 = 0;
+    }
+}
+
+// mu = SHAKE256(tr || M')[:64] of the long messages the scan listed, two per wavefront (see kLongMsg above).  tr of item t:
+// TRW words at tr_base + q * tr_stride with q = key_idx ? key_idx[t] : t (tr_stride 0: one key for the batch) -- or, when pk
+// is given, SHAKE256(pk_t)[:8 TRW] computed here (pk_words 64-bit words at pk + t * pk_stride).  mu -> mu_out + t * mu_stride.
+template <int TRW>
+__global__ void __launch_bounds__(64) mldsa_mu_long_kernel(const uint8_t *__restrict__ tr_base, size_t tr_stride, const uint32_t *__restrict__ key_idx,
+                                                          const uint8_t *__restrict__ pk, size_t pk_stride, int pk_words,
+                                                          const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
+                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off, int internal,
+                                                          uint8_t *__restrict__ mu_out, size_t mu_stride, const LongCtl *__restrict__ ctl) {
+    __shared__ uint64_t ws[100];
+    const uint32_t count = ctl->count;
+    if (count == 0 || count > kLongCap) return;
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+#pragma unroll 1
+    for (uint32_t pair = blockIdx.x; 2 * pair < count; pair += gridDim.x) {
+        const uint32_t e = 2 * pair + (uint32_t)half;
+        const bool live = e < count;
+        const size_t idx = ctl->list[live ? e : count - 1];  // the odd one out is done twice, stored once
+        uint32_t vlo = 0, vhi = 0;
+        if (pk) {  // tr = SHAKE256(pk)[:TR] (dilithium.go:123-125)
+            const uint64_t *pw = reinterpret_cast<const uint64_t *>(pk + idx * pk_stride);
+            const int full = pk_words / 17, rem = pk_words % 17;
+            uint64_t next = j < 17 ? pw[j] : 0;
+#pragma unroll 1
+            for (int b = 0; b < full; b++) {
+                vlo ^= (uint32_t)next;
+                vhi ^= (uint32_t)(next >> 32);
+                next = (j < 17 && 17 * (b + 1) + j < pk_words) ? pw[17 * (b + 1) + j] : 0;
+                keccak_f1600_coop2(vlo, vhi, c);
+            }
+            vlo ^= (uint32_t)next;
+            vhi ^= (uint32_t)(next >> 32);
+            if (j == rem) vlo ^= kDsShake;
+            if (j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2(vlo, vhi, c);
+            if (j >= TRW) vlo = vhi = 0;  // the mu sponge starts from tr || 0
+        } else if (j < TRW) {
+            const size_t q = key_idx ? (size_t)key_idx[idx] : idx;
+            const uint64_t w = reinterpret_cast<const uint64_t *>(tr_base + q * tr_stride)[j];
+            vlo = (uint32_t)w;
+            vhi = (uint32_t)(w >> 32);
+        }
+        const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+        const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
+        const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+        const MPrime mpr(msg_blob + msg_off[idx], mlen, cp, clen, internal);
+        size_t pos = 0;
+        int w0 = TRW;
+        bool done = false;  // this half's mu is out (the other half may still have blocks to absorb: it keeps both permuting)
+#pragma unroll 1
+        for (;;) {
+            if (!done && j >= w0 && j < 17) {
+                uint32_t lo, hi;
+                mpr.word(pos + 8 * (size_t)(j - w0), lo, hi);
+                vlo ^= lo;
+                vhi ^= hi;
+            }
+            const size_t span = 8 * (size_t)(17 - w0);
+            const bool last = mpr.total < pos + span;
+            if (!done && last && j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2(vlo, vhi, c);
+            if (!done && last) {
+                if (live && j < 8) reinterpret_cast<uint64_t *>(mu_out + idx * mu_stride)[j] = ((uint64_t)vhi << 32) | vlo;
+                done = true;
+            }
+            if (!__any(!done)) break;
+            pos += span;
+            w0 = 0;
+        }
     }
 }
 
@@ -175,7 +312,7 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                          int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
                                                          uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared,
-                                                         const uint32_t *__restrict__ key_idx) {
+                                                         const uint32_t *__restrict__ key_idx, const LongCtl *__restrict__ long_ctl) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     __shared__ uint32_t stage_lds[256 * kStageStride];
@@ -188,20 +325,22 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
     // tr = SHAKE256(pk)[:TR]  (dilithium.go:123-125); shared-key batches bring it ready-made (mldsa_tr_kernel), key-table
     // batches one 64-byte slot per table entry (mldsa_tr_table_kernel), selected by key_idx.  ONE sponge state is live at
     // a time (tr, then mu, then the SampleInBall sponge reuse `s`): two states side by side cost 204 VGPRs = 2 waves per SIMD.
-    if (tr_shared) {  // kernel-uniform
-        keccak_zero(s);
-        xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
-    } else {
-        sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
-#pragma unroll
-        for (int i = P::TR / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }
-    }
     const uint8_t *mp = msg_blob + msg_off[idx];
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze<P::TR / 8>(s, mp, mlen, cp, clen, internal, stage);
-    store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), s);  // mu
+    if (!long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx))) {  // (a long message's mu is already there: mldsa_mu_long_kernel)
+        if (tr_shared) {  // kernel-uniform
+            keccak_zero(s);
+            xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
+        } else {
+            sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
+#pragma unroll
+            for (int i = P::TR / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }
+        }
+        absorb_message_and_squeeze<P::TR / 8>(s, mp, mlen, cp, clen, internal, stage);
+        store_words<0, 8>(reinterpret_cast<uint64_t *>(muw1_ws + idx * G::MUW1), s);  // mu
+    }
     // SampleInBall's sponge: SHAKE256(c~), first block (sample.go:299-306); the whole state is
     // parked so that the verify kernel can squeeze further blocks in the (rare) case it must.
     const uint8_t *sg = sig + idx * G::SIG;
@@ -938,7 +1077,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
                                                               int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key,
-                                                              uint8_t *__restrict__ dead_ws) {
+                                                              uint8_t *__restrict__ dead_ws, const LongCtl *__restrict__ long_ctl) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
     __shared__ uint32_t stage_lds[256 * kStageStride];
@@ -961,8 +1100,13 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal, stage);
-    store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128), h);  // mu
+    if (long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx))) {  // a long message: mu is already there (mldsa_mu_long_kernel)
+        keccak_zero(h);
+        xor_words<0, 8>(h, reinterpret_cast<const uint64_t *>(mr_ws + idx * 128));
+    } else {
+        absorb_message_and_squeeze<P::TR / 8>(h, mp, mlen, cp, clen, internal, stage);
+        store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128), h);  // mu
+    }
     // rho'' = H(key || rnd || mu): built in the same state (mu moves up from words 0..7), one sponge live at a time
     constexpr int MU0 = P::NIST ? 8 : 4;                                       // round 3: rho'' = CRH(key || mu), no rnd (dilithium.go:357-364)
 #pragma unroll

@@ -49,6 +49,22 @@ def kernel_stats(raw, tag):
         lines.append(f"# {os.path.relpath(f, raw)} (derived from trace; VGPR/AGPR/SGPR/LDS/grid/wg of last launch)")
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             lines.append(f"{short(k):72s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e6:10.4f} {min(v)/1e6:10.4f} {max(v)/1e6:10.4f}  {meta[k]}")
+            # One persistent grid serves every batch size, so the line above blends 2^15-item chunks of the host path, 2^18 and
+            # 2^20 launches.  Launches of one batch size have nearly equal durations: split the sorted durations wherever two
+            # neighbours differ by more than 1.35x and report each class (>= 3 launches) on its own -- the 2^20 class of the
+            # dominant kernel is the figure bench.py's roofline.avg_launch_ms must agree with.
+            d = sorted(v)
+            classes, cur = [], [d[0]]
+            for x in d[1:]:
+                if x > 1.35 * cur[-1]:
+                    classes.append(cur)
+                    cur = []
+                cur.append(x)
+            classes.append(cur)
+            if len(classes) > 1:
+                for c in classes:
+                    if len(c) >= 3:
+                        lines.append(f"{'    duration class':72s} {len(c):6d} {sum(c)/1e6:10.3f} {sum(c)/len(c)/1e6:10.4f} {c[0]/1e6:10.4f} {c[-1]/1e6:10.4f}  median {c[len(c)//2]/1e6:.4f} ms")
     open(os.path.join(raw, f"{tag}_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

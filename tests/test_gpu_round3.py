@@ -104,3 +104,45 @@ def test_sign_round_modes(env_extra, param, n, shared):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sign_worker.py"), str(param), str(n)] + ([shared] if shared else []), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sign worker ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+
+
+# ---- long and ragged messages ---------------------------------------------------------------------------
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+def test_long_and_ragged_messages_against_the_oracle(param):
+    # mu = SHAKE256(tr || M') (sign/mldsa/mldsa65/dilithium.go:115-132) over messages from empty to 70 KB in one batch, lengths on
+    # both sides of the 136-byte block edges and of the long-message threshold (2048 bytes of M': those items are hashed two per
+    # wavefront ahead of the per-lane kernels), contexts of every length class; sign and verify, per-item / one key / key table
+    import numpy as np
+    from circl_amd import hostapi
+    from oracle import orc
+    rng = np.random.default_rng(1000 + param)
+    r3 = param in (2, 3, 5)
+    lens = [0, 1, 70, 71, 72, 73, 135, 136, 137, 207, 208, 209, 2043, 2044, 2045, 2046, 2047, 2048, 2049, 2050, 2100, 2181, 2182, 2183, 4096, 5000, 8191, 70001]
+    lens += [int(x) for x in rng.integers(0, 400, 60)] + [int(x) for x in rng.integers(1900, 2300, 20)]
+    n = len(lens)
+    msgs = [bytes(rng.integers(0, 256, k, dtype=np.uint8)) for k in lens]
+    ctxs = None if r3 else [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.choice([0, 1, 5, 54, 55, 56, 255], n)]
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    sig = hostapi.mldsa_sign(param, sk, msgs, ctxs=ctxs)
+    assert (sig == orc.mldsa_sign(param, sk, msgs, ctxs=ctxs)).all()
+    bad = sig.copy()
+    bad[::5, 37] ^= 1
+    want = np.ones(n, np.uint8)
+    want[::5] = 0
+    assert (hostapi.mldsa_verify(param, pk, bad, msgs, ctxs=ctxs) == want).all()
+    assert hostapi.mldsa_verify(param, pk, sig, msgs, ctxs=ctxs).tolist() == orc.mldsa_verify(param, pk, sig, msgs, ctxs=ctxs).tolist()
+    # one key for the batch, and a key table
+    sg1 = hostapi.mldsa_sign_shared(param, sk[:1], msgs, ctxs=ctxs)
+    assert (sg1 == orc.mldsa_sign(param, np.tile(sk[:1], (n, 1)), msgs, ctxs=ctxs)).all()
+    assert hostapi.mldsa_verify_shared(param, pk[:1], sg1, msgs, ctxs=ctxs).all()
+    idx = rng.integers(0, 7, n).astype(np.uint32)
+    okk = hostapi.mldsa_verify_keyed(param, pk[:7], idx, sig, msgs, ctxs=ctxs)
+    assert (okk == (idx == np.arange(n)).astype(np.uint8)).all()
+    # more long messages than the pre-pass takes (4096): everything through the per-lane kernels again
+    if param == 65:
+        n2 = 4200
+        pk2, sk2 = orc.mldsa_keygen(65, rng.integers(0, 256, (1, 32), dtype=np.uint8))
+        m2 = [bytes(rng.integers(0, 256, 2100 + (i % 7), dtype=np.uint8)) for i in range(n2)]
+        sg2 = hostapi.mldsa_sign_shared(65, sk2, m2)
+        assert (sg2[:64] == orc.mldsa_sign(65, np.tile(sk2, (64, 1)), m2[:64])).all()
+        assert hostapi.mldsa_verify_shared(65, pk2, sg2, m2).all()
