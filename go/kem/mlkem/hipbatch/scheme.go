@@ -84,6 +84,7 @@ func (s *Scheme) DecapsulateBatch(sks []kem.PrivateKey, cts [][]byte, device int
 		return nil, nil, kem.ErrCiphertextSize
 	}
 	dks := make([]byte, 0, n*s.PrivateKeySize())
+	defer func() { clear(dks[:cap(dks)]) }() // the marshalled private keys are this wrapper's own copies: they do not outlive the call
 	ctRows := make([]byte, 0, n*s.CiphertextSize())
 	for i, sk := range sks {
 		if sk.Scheme().Name() != s.Name() {
@@ -97,6 +98,7 @@ func (s *Scheme) DecapsulateBatch(sks []kem.PrivateKey, cts [][]byte, device int
 			return nil, nil, e
 		}
 		dks = append(dks, b...)
+		clear(b)
 		ctRows = append(ctRows, cts[i]...)
 	}
 	ss, errs, err := DecapsulateBatch(s.Scheme, dks, ctRows, device)

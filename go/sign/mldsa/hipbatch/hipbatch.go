@@ -83,6 +83,7 @@ func SignBatch(s sign.Scheme, sks [][]byte, msgs [][]byte, ctxs []string, rnd []
 	}
 	n := len(sks)
 	skRows := make([]byte, 0, n*s.PrivateKeySize())
+	defer func() { clear(skRows[:cap(skRows)]) }() // the contiguous copy of the private keys does not outlive the call
 	var msgBlob, ctxBlob []byte
 	msgOff := make([]uint64, 1, n+1)
 	ctxOff := make([]uint64, 1, n+1)

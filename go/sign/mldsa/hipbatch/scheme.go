@@ -81,6 +81,13 @@ func (s *Scheme) SignBatch(sks []sign.PrivateKey, msgs [][]byte, ctxs []string, 
 		}
 		raw[i] = b
 	}
+	// the marshalled private keys are this wrapper's own copies: they do not outlive the call (the native library wipes its
+	// staging and device copies; without this the Go heap would keep n packed private keys until the collector reuses them)
+	defer func() {
+		for _, b := range raw {
+			clear(b)
+		}
+	}()
 	return SignBatch(s.Scheme, raw, msgs, ctxs, nil, device)
 }
 

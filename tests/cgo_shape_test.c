@@ -112,6 +112,34 @@ static void *thread_main(void *arg) {
     return NULL;
 }
 
+/* go/xof/hipbatch + go/simd/keccakf1600/hipbatch: blobs with spare capacity behind the last message, n + 1 offsets, nil contexts,
+ * plain [25]uint64 states */
+static void xof_shapes(int device) {
+    const size_t n = 333, len = 200, outlen = 48;
+    uint8_t *blob = slice(n * len + 16, 3), *eq = slice(n * len, 5), *o1 = slice(n * outlen, 7), *o2 = slice(n * outlen, 9), *o3 = slice(n * outlen, 11);
+    uint64_t *off = (uint64_t *)slice(8 * (n + 1), 8), *zoff = (uint64_t *)slice(8 * (n + 1), 8);
+    fill(blob, n * len, 91);
+    memcpy(eq, blob, n * len);
+    for (size_t i = 0; i <= n; i++) { off[i] = i * len; zoff[i] = 0; }
+    CHECK(circl_hip_xof(136, 0x1f, 24, blob, off, o1, outlen, n, device) == 0);       /* SumBatch(xof.SHAKE256, ...) */
+    CHECK(circl_hip_shake(136, 0x1f, eq, len, o2, outlen, n, device) == 0);           /* the equal-length form of the same sponges */
+    CHECK(memcmp(o1, o2, n * outlen) == 0);
+    CHECK(circl_hip_xof(168, 0x07, 12, blob, off, o1, outlen, n, device) == 0);       /* TurboShakeBatch(128, 0x07, ...) */
+    CHECK(circl_hip_k12(blob, off, NULL, NULL, o2, outlen, n, device) == 0);          /* K12Batch(msgs, nil, ...) */
+    uint8_t *cb = slice(16, 1);
+    CHECK(circl_hip_k12(blob, off, cb, zoff, o3, outlen, n, device) == 0);            /* explicit empty contexts: the same digests */
+    CHECK(memcmp(o2, o3, n * outlen) == 0);
+    CHECK(memcmp(o1, o2, n * outlen) != 0);  /* (K12 hashes msg || 0x00 -- length_encode(0) -- where TurboSHAKE128 above hashed msg) */
+    uint64_t *st = (uint64_t *)slice(8 * 25 * 77, 8), *st2 = (uint64_t *)slice(8 * 25 * 77, 8);
+    fill((uint8_t *)st, 8 * 25 * 77, 17);
+    memcpy(st2, st, 8 * 25 * 77);
+    CHECK(circl_hip_keccak_f1600(st, 77, 24, device) == 0);                           /* PermuteBatch(states, false, ...) */
+    CHECK(circl_hip_keccak_f1600(st2, 77, 24, CIRCL_HIP_ALL_DEVICES) == 0);
+    CHECK(memcmp(st, st2, 8 * 25 * 77) == 0);
+    CHECK(circl_hip_keccak_f1600(st, 77, 12, device) == 0);                           /* turbo */
+    CHECK(circl_hip_keccak_f1600(st, 77, 7, device) == CIRCL_HIP_EPARAM);
+}
+
 int main(void) {
     CHECK(circl_hip_init() > 0);
     /* zero-length batches: nil slices become NULL pointers */
@@ -133,6 +161,9 @@ int main(void) {
     hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 1, 0);
     hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 2051, CIRCL_HIP_ALL_DEVICES);
     hybrid_round_trip(CIRCL_HIP_HYBRID_X25519MLKEM768, 777, 0);
+    CHECK(circl_hip_xof(168, 0x1f, 24, NULL, NULL, NULL, 32, 0, 0) == 0);
+    CHECK(circl_hip_keccak_f1600(NULL, 0, 24, 0) == 0);
+    xof_shapes(0);
     pthread_t th[3];
     for (intptr_t i = 0; i < 3; i++) CHECK(pthread_create(&th[i], NULL, thread_main, (void *)i) == 0);
     for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);
