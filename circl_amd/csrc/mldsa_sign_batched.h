@@ -258,6 +258,51 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
     for (int t = 0; t < T; t++)
         if (lane < 16)  // mu in front of the w1 bytes that follow
             reinterpret_cast<uint32_t *>(st.muw1 + (slot + t) * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
+    if constexpr (T == 1) {
+        // One entry alone (the long rounds by default): y-hat in registers, single transforms -- measured 1.83 ms per 2^18
+        // ML-DSA-65 attempts against 1.94 ms for the paired-transform form below on (l, l + 1) / (i, i + 1): with one attempt
+        // per wavefront the kernel sits on its matrix reads (4.4 TB/s, profiles/r03_sign_pmc.txt), not on exchange latency.
+        uint32_t yh[L][4];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+                x += (uint32_t)((int32_t)x >> 31) & Q;
+                yh[l][r] = x;
+            }
+            dilithium::ntt(yh[l], z, xch0, lane);  // plain y-hat, < 17q
+        }
+        const uint32_t *arows1 = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                uint32_t a[4];
+                load_poly24(a, arows1 + (i * L + j) * kPackedRowDwords, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * yh[j][r];
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
+            dilithium::invntt<dilithium::INV256_RR>(w, z, xch0, lane);
+            unsigned w1v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t a0, a1;
+                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
+                st.w0[(slot * K + i) * 256 + kyber::idx_l1(lane, r)] = a0;
+                w1v[r] = a1;
+            }
+            mlkem::stage_bits_l1<G::W1BITS>(xch0, w1v, lane);
+            mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch0, lane, false);
+        }
+        __syncthreads();  // xch is reused by the next entry
+        return;
+    }
     auto load_y = [&](uint32_t (&yh)[4], size_t sl, int l) {
         const uint32_t *yrow = st.y + (sl * L + l) * B::YROW_DW;
 #pragma unroll
