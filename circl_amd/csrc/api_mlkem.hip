@@ -211,6 +211,27 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
     uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
+    if (n <= kem_small_batch()) {
+        // small batch under one key: J(z || ct) per item, the key's hash check (one workgroup) and Decrypt + G side by side, then the
+        // shared-key re-encryption with as few items per workgroup as the idle SIMDs allow
+        const int coop = n <= kem_coop_batch() ? 1 : 0;
+        const unsigned nb_j = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64);
+        {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+            hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(nb_j + 1 + (unsigned)n), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)0, ct, mprime, kbar, r_ws,
+                               ssrej, status, key_status, (int16_t *)nullptr, n, nb_j, 1u, coop);
+            hipLaunchKernelGGL(mlkem_fill_status_kernel, dim3(hb), dim3(256), 0, st, status, (const uint8_t *)key_status, n);
+        }
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_SHARED>;
+        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
+                           (const uint32_t *)nullptr, (const int16_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
         hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)0, ct, mprime, n, (const uint32_t *)nullptr);
@@ -295,6 +316,27 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     if (R3) status = w.status_slot;
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
+    if (!R3 && n <= kem_small_batch()) {
+        // small batch: J(z || ct), the key's hash check, Decrypt + G and A^T side by side in one launch, then the key-table form
+        // of the re-encryption (mlkem_small_decaps_pre_kernel)
+        int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
+        const int coop = n <= kem_coop_batch() / 2 ? 1 : 0;  // two sponges per item here: half the encapsulation's threshold (measured: 2^11)
+        const unsigned nb_hash = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64), nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G);
+        {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+            hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(2 * nb_hash + (unsigned)n + nb_expand), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)Gm::DK, ct,
+                               mprime, kbar, r_ws, ssrej, status, (uint8_t *)nullptr, key_rows, n, nb_hash, nb_hash, coop);
+        }
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
+        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
+                           (const uint32_t *)nullptr, (const int16_t *)key_rows);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
         hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)Gm::DK, ct, mprime, n, (const uint32_t *)nullptr);

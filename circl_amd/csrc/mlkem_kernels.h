@@ -123,6 +123,27 @@ template <int FIRST, int COUNT> __device__ __forceinline__ void store_words(uint
     });
 }
 
+// A cooperative SHA3-256 / SHAKE256 sponge (rate 17 words) over `nwords` 64-bit words delivered by `src(k)`; returns with the
+// squeezed state in the lanes (word j in lane j of the half).
+template <class Src>
+__device__ __forceinline__ void coop_sponge17(uint32_t &vlo, uint32_t &vhi, Src &&src, int nwords, uint32_t ds, const CoopLane &c, int j) {
+    const int full = nwords / 17, rem = nwords % 17;
+    vlo = vhi = 0;
+    uint64_t next = j < 17 ? src(j) : 0;  // the block after the current one is requested before the permutation
+#pragma unroll 1
+    for (int b = 0; b < full; b++) {
+        vlo ^= (uint32_t)next;
+        vhi ^= (uint32_t)(next >> 32);
+        next = (j < 17 && 17 * (b + 1) + j < nwords) ? src(17 * (b + 1) + j) : 0;
+        keccak_f1600_coop2(vlo, vhi, c);
+    }
+    vlo ^= (uint32_t)next;
+    vhi ^= (uint32_t)(next >> 32);
+    if (j == rem) vlo ^= ds;
+    if (j == 16) vhi ^= 0x80000000u;
+    keccak_f1600_coop2(vlo, vhi, c);
+}
+
 // ---- kernel 1: H(ek), G(m || H(ek)) -----------------------------------------------------------
 
 template <int K>
@@ -144,22 +165,30 @@ __global__ void __launch_bounds__(256) mlkem_hash_kernel(const uint8_t *__restri
 // ---- shared-key decapsulation: the private key's hash check (kyber.go:219-228), once -------------------
 template <int K>
 __global__ void __launch_bounds__(64) mlkem_dk_check_kernel(const uint8_t *__restrict__ dk, uint8_t *__restrict__ key_status) {
-    KeccakState h;
-    sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(dk + 384 * K));
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+    const uint64_t *ekw = reinterpret_cast<const uint64_t *>(dk + 384 * K);
     const uint64_t *stored = reinterpret_cast<const uint64_t *>(dk + 768 * K + 32);
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
-    if (threadIdx.x == 0) *key_status = ok ? 0 : 2;
+    uint32_t vlo, vhi;
+    coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Geom<K>::EK / 8, kDsSha3, c, j);
+    const bool mine = j >= 4 || ((((uint64_t)vhi << 32) | vlo) == stored[j & 3]);
+    const unsigned long long bad = __ballot(!mine);  // (both halves carry the same state)
+    if (lane == 0) *key_status = (bad & 0xfull) == 0 ? 0 : 2;
 }
 
 // ---- shared-key encapsulation: H(ek) once, then (K, r) = G(m || H(ek)) per item ------------------
 
 template <int K>
 __global__ void __launch_bounds__(64) mlkem_hek_kernel(const uint8_t *__restrict__ ek, uint8_t *__restrict__ h_ws) {
-    KeccakState h;
-    sha3_256_words<Geom<K>::EK / 8>(h, reinterpret_cast<const uint64_t *>(ek));
-    if (threadIdx.x == 0) store_words<0, 4>(reinterpret_cast<uint64_t *>(h_ws), h);
+    // one hash per call, in front of everything else: on the cooperative permutation (~36 us instead of ~97 for a lone lane)
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+    const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ek);
+    uint32_t vlo, vhi;
+    coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Geom<K>::EK / 8, kDsSha3, c, j);
+    if (lane < 4) reinterpret_cast<uint64_t *>(h_ws)[lane] = ((uint64_t)vhi << 32) | vlo;
 }
 
 // ---- key tables (grouped keys): what the reference caches in a parsed key object, once per table entry ----------
@@ -1071,18 +1100,11 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_pre_ke
 
 // ---- decapsulation ---------------------------------------------------------------------------
 
-// K-PKE.Decrypt (cpapke.go:113-130), one item per single-wave workgroup: m' -> workspace.
+// K-PKE.Decrypt (cpapke.go:113-130) of one item by one wavefront: m' -> 32 bytes at `mprime`.
 template <int K>
-__global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
-                                                          uint8_t *__restrict__ mprime_ws, size_t n, const uint32_t *__restrict__ key_idx) {
-    using Gm = Geom<K>;
+__device__ __forceinline__ void mlkem_decrypt_item(const uint8_t *__restrict__ dkp, const uint8_t *__restrict__ ctp, uint8_t *__restrict__ mprime,
+                                                   uint32_t *xch, int lane) {
     using P = Params<K>;
-    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
-    const int lane = threadIdx.x;
-    const size_t item = blockIdx.x;
-    // dk_stride = 0: one private key for the whole batch; key_idx: item t uses entry key_idx[t] of a key table
-    const uint8_t *dkp = dk + (key_idx ? (size_t)key_idx[item] : item) * dk_stride;
-    const uint8_t *ctp = ct + item * Gm::CT;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
     int acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1106,8 +1128,19 @@ __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__rest
         const int d = v - acc[r];  // in (-q, q)
         const unsigned bit = kyber::msg_bit(d + ((d >> 31) & Q));
         const unsigned long long mask = __ballot(bit != 0);  // bits of coefficients 64r .. 64r+63
-        if (lane == 0) reinterpret_cast<unsigned long long *>(mprime_ws + item * 32)[r] = mask;
+        if (lane == 0) reinterpret_cast<unsigned long long *>(mprime)[r] = mask;
     }
+}
+// one item per single-wave workgroup: m' -> workspace
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
+                                                          uint8_t *__restrict__ mprime_ws, size_t n, const uint32_t *__restrict__ key_idx) {
+    using Gm = Geom<K>;
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    const size_t item = blockIdx.x;
+    // dk_stride = 0: one private key for the whole batch; key_idx: item t uses entry key_idx[t] of a key table
+    const uint8_t *dkp = dk + (key_idx ? (size_t)key_idx[item] : item) * dk_stride;
+    mlkem_decrypt_item<K>(dkp, ct + item * Gm::CT, mprime_ws + item * 32, xch, threadIdx.x);
 }
 
 // lane = item: the three sponges of decapsulation.
@@ -1167,6 +1200,113 @@ __global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *_
     h.hi[16] ^= 0x80000000u;
     keccak_f1600(h);
     if (live) store_words<0, 4>(reinterpret_cast<uint64_t *>(ssrej_ws + idx * 32), h);
+}
+
+// ---- small batches: decapsulation ------------------------------------------------------------------------------------
+// The same reasoning as mlkem_small_pre_kernel, for decapsulation: per item there are three independent chains -- K-PKE.Decrypt
+// followed by G(m' || hpk) (G takes the STORED hash, kyber.go:158-162, so it does not wait for the key's hash check), the check
+// H(ek) == hpk itself (9 permutations), J(z || ct) (9 permutations) -- plus, for distinct keys, A^T for the re-encryption; the
+// big-batch route runs decrypt, then all three sponges on one lane (19 dependent permutations, ~185 us), then the re-encryption.
+// For small batches ONE launch runs them in different workgroups (J and H first: they are the long ones, at raised priority),
+// two sponges per wavefront on the cooperative permutation while the chip has SIMDs to spare (`coop`), and the key-table form
+// of the re-encryption follows.  dk_stride = 0: one private key for the batch (its hash check: ONE workgroup, verdict to
+// *key_status; the per-item status bytes are filled by mlkem_fill_status_kernel).
+template <int K>
+__global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps_pre_kernel(
+    const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct, uint8_t *__restrict__ mprime_ws, uint8_t *__restrict__ kbar_ws,
+    uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ status, uint8_t *__restrict__ key_status,
+    int16_t *__restrict__ key_rows, size_t n, unsigned nb_j, unsigned nb_h, int coop) {
+    using Gm = Geom<K>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    unsigned b = blockIdx.x;
+    constexpr int CTW = Gm::CT / 8;
+    if (b < nb_j + nb_h) {
+        __builtin_amdgcn_s_setprio(3);
+        const bool is_j = b < nb_j;
+        if (!is_j) b -= nb_j;
+        const size_t per = coop ? 2 : 64;
+        const size_t nitems = (!is_j && dk_stride == 0) ? 1 : n;  // one key: one hash check
+        size_t idx = (size_t)b * per + (coop ? (size_t)half : (size_t)lane);
+        const bool live = idx < nitems;
+        if (!live) idx = nitems - 1;
+        const uint8_t *dkp = dk + idx * dk_stride;
+        const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
+        if (is_j) {  // ss_rej = J(z || ct) = SHAKE256(z || ct)[:32] (kyber.go:171-174)
+            const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
+            const uint64_t *cw = reinterpret_cast<const uint64_t *>(ct + idx * Gm::CT);
+            if (coop) {
+                const CoopLane c = coop_lane(reinterpret_cast<uint64_t *>(smem), lane);
+                uint32_t vlo, vhi;
+                coop_sponge17(vlo, vhi, [&](int k) { return k < 4 ? zw[k] : cw[k - 4]; }, 4 + CTW, kDsShake, c, j);
+                if (live && j < 4) reinterpret_cast<uint64_t *>(ssrej_ws + idx * 32)[j] = ((uint64_t)vhi << 32) | vlo;
+            } else {
+                constexpr int TOTAL = 4 + CTW, FULL = TOTAL / 17, REM = TOTAL % 17;
+                KeccakState h;
+                keccak_zero(h);
+                xor_words<0, 4>(h, zw);
+                xor_words<4, 13>(h, cw);
+                keccak_f1600(h);
+#pragma unroll 1
+                for (int bb = 1; bb < FULL; bb++) {
+                    xor_words<0, 17>(h, cw + 17 * bb - 4);
+                    keccak_f1600(h);
+                }
+                xor_words<0, REM>(h, cw + 17 * FULL - 4);
+                h.lo[REM] ^= kDsShake;
+                h.hi[16] ^= 0x80000000u;
+                keccak_f1600(h);
+                if (live) store_words<0, 4>(reinterpret_cast<uint64_t *>(ssrej_ws + idx * 32), h);
+            }
+        } else {  // H(ek) over the ek embedded in dk against the stored hash -> status 2 (kyber.go:219-228)
+            const uint64_t *ekw = reinterpret_cast<const uint64_t *>(dkp + 384 * K);
+            bool ok = true;
+            if (coop) {
+                const CoopLane c = coop_lane(reinterpret_cast<uint64_t *>(smem), lane);
+                uint32_t vlo, vhi;
+                coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
+                const bool mine = j >= 4 || ((((uint64_t)vhi << 32) | vlo) == stored[j & 3]);
+                // all four words of the half must match: lanes 0..3 of half 0 are bits 0..3 of the ballot, of half 1 bits 32..35
+                const unsigned long long bad = __ballot(!mine);
+                ok = ((bad >> (32 * half)) & 0xfull) == 0;
+                if (live && j == 0) (dk_stride == 0 ? key_status : status)[dk_stride == 0 ? 0 : idx] = ok ? 0 : 2;
+            } else {
+                KeccakState h;
+                sha3_256_words<Gm::EK / 8>(h, ekw);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ok &= (((uint64_t)h.hi[i] << 32) | h.lo[i]) == stored[i];
+                if (live) (dk_stride == 0 ? key_status : status)[dk_stride == 0 ? 0 : idx] = ok ? 0 : 2;
+            }
+        }
+        return;
+    }
+    b -= nb_j + nb_h;
+    if ((size_t)b < n) {  // K-PKE.Decrypt, then (K', r') = G(m' || hpk) by the same wavefront (one state on the cooperative permutation)
+        const size_t item = b;
+        const uint8_t *dkp = dk + item * dk_stride;
+        uint32_t *xch = reinterpret_cast<uint32_t *>(smem);
+        mlkem_decrypt_item<K>(dkp, ct + item * Gm::CT, mprime_ws + item * 32, xch, lane);
+        __threadfence_block();
+        __syncthreads();  // m' is visible to the lanes that absorb it; the exchange buffer is free
+        const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
+        const CoopLane c = coop_lane(reinterpret_cast<uint64_t *>(smem), lane);
+        uint64_t g = 0;
+        if (j < 4) g = reinterpret_cast<const volatile uint64_t *>(mprime_ws + item * 32)[j];
+        else if (j < 8) g = stored[j - 4];
+        else if (j == 8) g = 0x8000000000000000ull | kDsSha3;
+        uint32_t vlo = (uint32_t)g, vhi = (uint32_t)(g >> 32);
+        keccak_f1600_coop2(vlo, vhi, c);  // (both halves carry the same state; half 0 stores)
+        if (half == 0 && j < 8) reinterpret_cast<uint64_t *>((j < 4 ? kbar_ws : r_ws) + item * 32)[j & 3] = ((uint64_t)vhi << 32) | vlo;
+        return;
+    }
+    b -= (unsigned)n;  // A^T of G items each into the cache (distinct keys only: the grid has no such workgroups for one key)
+    const size_t e0 = (size_t)b * Gm::G;
+    sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), dk + 768 * K, dk_stride, e0, n, lane);
+}
+// one key for the batch: every item's status byte is the key's verdict
+static __global__ void __launch_bounds__(256) mlkem_fill_status_kernel(uint8_t *__restrict__ status, const uint8_t *__restrict__ key_status, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) status[i] = *key_status;
 }
 
 // ---- key generation ---------------------------------------------------------------------------

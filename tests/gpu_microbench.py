@@ -147,7 +147,7 @@ def latency_curve(param=768):
     plus the wall-clock latency of a batch of one through the host-buffer ABI."""
     from circl_amd import hostapi
     rng = np.random.default_rng(1)
-    for logn in (0, 6, 10, 12, 13, 14, 15, 16, 18, 20):
+    for logn in (0, 6, 10, 11, 12, 13, 14, 15, 16, 18, 20):
         n = 1 << logn
         eng = cdev.MLKEMDevice(param, n)
         seeds = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()
@@ -157,6 +157,13 @@ def latency_curve(param=768):
         ss = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
         ms = timeit(lambda: eng.encaps(ek, m, ct, ss), 20 if n < (1 << 18) else 5)
         print(f"ML-KEM-{param} encaps  n=2^{logn:<2d}: {ms * 1e3:10.1f} us per call -> {n / ms * 1e3:.3e}/s")
+        if os.environ.get("CIRCL_LATENCY_ALL"):  # the other operations a TLS front-end batches: decapsulation, per-item and under ONE key
+            ss2 = torch.empty_like(ss)
+            md = timeit(lambda: eng.decaps(dk, ct, ss2), 20 if n < (1 << 18) else 5)
+            ms1 = timeit(lambda: eng.encaps_shared(ek[:1], m, ct, ss), 20 if n < (1 << 18) else 5)
+            mds = timeit(lambda: eng.decaps_shared(dk[:1], ct, ss2), 20 if n < (1 << 18) else 5)
+            print(f"ML-KEM-{param}    decaps {md * 1e3:8.1f} us ({n / md * 1e3:.3e}/s) | encaps, one key {ms1 * 1e3:8.1f} us ({n / ms1 * 1e3:.3e}/s) | "
+                  f"decaps, one key {mds * 1e3:8.1f} us ({n / mds * 1e3:.3e}/s)")
     ek1, _ = orc.mlkem_keygen(param, rng.integers(0, 256, (1, 64), dtype=np.uint8))
     m1 = rng.integers(0, 256, (1, 32), dtype=np.uint8)
     hostapi.mlkem_encaps(param, ek1, m1)
