@@ -127,7 +127,10 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
-        hipLaunchKernelGGL(mldsa_final_kernel<MODE>, dim3(hb), dim3(256), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
+        if (n <= kSmallMu)
+            hipLaunchKernelGGL(mldsa_final_coop_kernel<MODE>, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
+        else
+            hipLaunchKernelGGL(mldsa_final_kernel<MODE>, dim3(hb), dim3(256), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -263,7 +266,9 @@ template <int MODE> struct SignLayout {
     size_t o_A, o_sec, o_y, o_w0, o_muw1, o_cb, o_attempts, o_best, o_list0, o_list1, o_ctl, o_secret_end;  // batched path
     size_t o_dead, o_long, total;
     explicit SignLayout(size_t n_) : n(n_) {
-        E = std::max((sign_pair_mode() ? 2 : 1) * n, circl::mldsa::kMinEntryCapacity);  // lazy pairs: two attempts per item in the long rounds
+        // entries: one per item (two with lazy pairs) in the long rounds; small batches get room for up to 64 attempts per item
+        // and round, capped at kMinEntryCapacity entries
+        E = std::max((sign_pair_mode() ? 2 : 1) * n, std::min(circl::mldsa::kMinEntryCapacity, 64 * n));
         tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
         size_t o = 0;
         auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };

@@ -111,12 +111,18 @@ constexpr int kStageStride = 35;
 // the per-lane form (64 sponges per wavefront) is the right one: the pre-pass does nothing.
 constexpr size_t kLongMsg = 2048;
 constexpr uint32_t kLongCap = 4096;
+// A small batch is a latency chain like a long message: tr = H(pk) alone is 15 dependent permutations on one lane (~145 us)
+// in front of everything else.  Batches of at most kSmallMu items send EVERY item through the pre-pass (tr and mu two items per
+// wavefront on the cooperative permutation, ~4 us per block instead of ~10).
+constexpr size_t kSmallMu = 1024;
 struct LongCtl {
     uint32_t count;          // long messages found by the scan (may exceed kLongCap: then nothing is pre-hashed)
     uint32_t pad[63];
     uint32_t list[kLongCap]; // their item indices
 };
-__device__ __forceinline__ bool long_premade(const LongCtl *ctl, size_t total) { return ctl && total > kLongMsg && ctl->count <= kLongCap; }
+__device__ __forceinline__ bool long_premade(const LongCtl *ctl, size_t total, size_t n) {
+    return ctl && (total > kLongMsg || n <= kSmallMu) && ctl->count <= kLongCap;
+}
 __device__ __forceinline__ size_t mprime_total(const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, size_t idx) {
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const size_t clen = (ctx_blob && !internal) ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
@@ -127,7 +133,7 @@ static __global__ void __launch_bounds__(256) mldsa_long_scan_kernel(const uint6
                                                                      const uint64_t *__restrict__ ctx_off, int internal, size_t n, LongCtl *__restrict__ ctl) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
-    if (mprime_total(msg_off, ctx_blob, ctx_off, internal, idx) > kLongMsg) {
+    if (n <= kSmallMu || mprime_total(msg_off, ctx_blob, ctx_off, internal, idx) > kLongMsg) {
         const uint32_t p = atomicAdd(&ctl->count, 1u);
         if (p < kLongCap) ctl->list[p] = (uint32_t)idx;
     }
@@ -329,7 +335,7 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    if (!long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx))) {  // (a long message's mu is already there: mldsa_mu_long_kernel)
+    if (!long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx), n)) {  // (otherwise mu is already there: mldsa_mu_long_kernel)
         if (tr_shared) {  // kernel-uniform
             keccak_zero(s);
             xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
@@ -850,6 +856,34 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     expand_a_scratch<MODE>(smem, key_rows + e0 * (size_t)(G::STREAMS * kPackedRowDwords), pk_table, (size_t)G::PK, e0, nkeys, threadIdx.x);
 }
 
+// c' = SHAKE256(mu || w1)[:CT] against the signature's c~, two items per wavefront on the cooperative permutation: the small-batch
+// form of mldsa_final_kernel below (seven dependent permutations on one lane are ~68 us; here ~28)
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_final_coop_kernel(const uint8_t *__restrict__ sig, const uint8_t *__restrict__ muw1_ws,
+                                                             const uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ ok, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+    size_t idx = 2 * (size_t)blockIdx.x + half;
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    const uint64_t *mw = reinterpret_cast<const uint64_t *>(muw1_ws + idx * G::MUW1);
+    uint32_t vlo, vhi;
+    mlkem::coop_sponge17(vlo, vhi, [&](int k) { return mw[k]; }, G::MUW1 / 8, kDsShake, c, j);
+    const uint8_t *sg = sig + idx * G::SIG;
+    bool mine = true;
+    if (j < P::CT / 8) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)sg[8 * j + b] << (8 * b);
+        mine = v == (((uint64_t)vhi << 32) | vlo);
+    }
+    const unsigned long long bad = __ballot(!mine);
+    const bool same = ((bad >> (32 * half)) & 0xffffffffull) == 0;
+    if (live && j == 0) ok[idx] = (same && fail_ws[idx] == 0) ? 1 : 0;
+}
+
 // ---- kernel F -----------------------------------------------------------------------------------
 
 template <int MODE>
@@ -1100,7 +1134,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
     const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
     const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
     const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
-    if (long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx))) {  // a long message: mu is already there (mldsa_mu_long_kernel)
+    if (long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx), n)) {  // a long message or a small batch: mu is already there (mldsa_mu_long_kernel)
         keccak_zero(h);
         xor_words<0, 8>(h, reinterpret_cast<const uint64_t *>(mr_ws + idx * 128));
     } else {

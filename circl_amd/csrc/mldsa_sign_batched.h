@@ -72,7 +72,10 @@ constexpr uint32_t kNoSuccess = 0xffffffffu;
 constexpr int kEntryShift = 26;
 constexpr uint32_t kEntryItemMask = (1u << kEntryShift) - 1;
 constexpr unsigned kMaxSpec = 64;  // 6 bits of `off`
-constexpr size_t kMinEntryCapacity = 2048;  // small batches may still try many attempts per item and round
+// Small and medium batches speculate widely: a round is four dependent Keccak-latency launches (~250 us) whatever its length, so a
+// batch of 2^10 items with room for only 2 attempts per item and round took 1.8 ms in ~8 rounds; with 32 k entries it tries
+// 32 attempts per item at once and is done in two rounds.  (11 KB of workspace per entry: 360 MB at most.)
+constexpr size_t kMinEntryCapacity = 32768;
 
 // attempts per item of the NEXT list when `items` items may survive into it (the same rule on the host, which sizes the
 // schedule, and on the device, which applies it to the real counts).
