@@ -25,7 +25,7 @@ SYMBOLS = [
     "circl_hip_kyber_keygen", "circl_hip_kyber_encaps", "circl_hip_kyber_decaps",
     "circl_hip_kyber_keygen_dev", "circl_hip_kyber_encaps_dev", "circl_hip_kyber_decaps_dev",
     "circl_hip_mldsa_verify", "circl_hip_mldsa_verify_shared", "circl_hip_mldsa_verify_shared_dev", "circl_hip_mldsa_verify_internal", "circl_hip_mldsa_workspace_size", "circl_hip_mldsa_verify_dev",
-    "circl_hip_keccak_f1600", "circl_hip_keccak_f1600_coop", "circl_hip_mldsa_sample_in_ball", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_lane_op", "circl_hip_kyber_sample_uniform", "circl_hip_kyber_sample_cbd", "circl_hip_mldsa_sample_uniform", "circl_hip_dilithium_ntt",
+    "circl_hip_keccak_f1600", "circl_hip_keccak_f1600_coop", "circl_hip_keccak_f1600_split", "circl_hip_mldsa_sample_in_ball", "circl_hip_kyber_ntt", "circl_hip_kyber_mulhat", "circl_hip_lane_op", "circl_hip_kyber_sample_uniform", "circl_hip_kyber_sample_cbd", "circl_hip_mldsa_sample_uniform", "circl_hip_dilithium_ntt",
     "circl_hip_shake", "circl_hip_xof", "circl_hip_k12", "circl_hip_x25519", "circl_hip_x25519_dev",
     "circl_hip_hybrid_seed_size", "circl_hip_hybrid_eseed_size", "circl_hip_hybrid_pk_size", "circl_hip_hybrid_sk_size", "circl_hip_hybrid_ct_size",
     "circl_hip_hybrid_ss_size", "circl_hip_hybrid_workspace_size", "circl_hip_hybrid_keygen", "circl_hip_hybrid_encaps", "circl_hip_hybrid_decaps",
@@ -127,6 +127,7 @@ def lib():
         L.circl_hip_mldsa_verify_dev.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_keccak_f1600.argtypes = [vp, sz, i, i]
         L.circl_hip_keccak_f1600_coop.argtypes = [vp, sz, i]
+        L.circl_hip_keccak_f1600_split.argtypes = [vp, sz, i]
         L.circl_hip_mldsa_sample_in_ball.argtypes = [i, vp, vp, sz, i, i]
         L.circl_hip_kyber_ntt.argtypes = [vp, sz, i, i]
         L.circl_hip_kyber_mulhat.argtypes = [vp, vp, vp, sz, i]

@@ -41,20 +41,69 @@ constexpr size_t kLongCtlBytes = (sizeof(circl::mldsa::LongCtl) + 255) & ~size_t
 template <int MODE> size_t mldsa_ws_bytes(size_t n) {
     return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES + 256 + kLongCtlBytes;  // + tr of a shared key + long-message list
 }
-// mu of the batch's long messages ahead of the per-lane kernels (mldsa_kernels.h, kLongMsg): scan, then two messages per wavefront
+// mu of the batch's long messages ahead of the per-lane kernels (mldsa_kernels.h, kLongMsg): scan, then two messages per wavefront.
+// The two halves are separate so that a small verification batch can run the second one beside its other kernels (SideStream).
+inline int mldsa_long_scan(const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, circl::mldsa::LongCtl *ctl, size_t n,
+                           hipStream_t st) {
+    using namespace circl::mldsa;
+    HIP_TRY(hipMemsetAsync(ctl, 0, 256, st));
+    hipLaunchKernelGGL(mldsa_long_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msg_off, ctx_blob, ctx_off, internal, n, ctl);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+template <int TRW>
+int mldsa_long_mu(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
+                  const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *mu_out,
+                  size_t mu_stride, const circl::mldsa::LongCtl *ctl, size_t n, hipStream_t st) {
+    using namespace circl::mldsa;
+    const unsigned grid = (unsigned)std::min<size_t>((std::min<size_t>(n, kLongCap) + 1) / 2, (size_t)cu_count() * 8);
+    hipLaunchKernelGGL(mldsa_mu_long_kernel<TRW>, dim3(grid), dim3(64), 0, st, tr_base, tr_stride, key_idx, pk, pk_stride, pk_words, msg_blob, msg_off,
+                       ctx_blob, ctx_off, internal, mu_out, mu_stride, ctl);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
 template <int TRW>
 int mldsa_long_prepass(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
                        const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *mu_out,
                        size_t mu_stride, circl::mldsa::LongCtl *ctl, size_t n, hipStream_t st) {
-    using namespace circl::mldsa;
-    HIP_TRY(hipMemsetAsync(ctl, 0, 256, st));
-    hipLaunchKernelGGL(mldsa_long_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msg_off, ctx_blob, ctx_off, internal, n, ctl);
-    const unsigned grid = (unsigned)std::min<size_t>((std::min<size_t>(n, kLongCap) + 1) / 2, (size_t)cu_count() * 8);
-    hipLaunchKernelGGL(mldsa_mu_long_kernel<TRW>, dim3(grid), dim3(64), 0, st, tr_base, tr_stride, key_idx, pk, pk_stride, pk_words, msg_blob, msg_off,
-                       ctx_blob, ctx_off, internal, mu_out, mu_stride, (const LongCtl *)ctl);
-    HIP_TRY(hipGetLastError());
-    return CIRCL_HIP_OK;
+    if (int rc = mldsa_long_scan(msg_off, ctx_blob, ctx_off, internal, ctl, n, st)) return rc;
+    return mldsa_long_mu<TRW>(tr_base, tr_stride, key_idx, pk, pk_stride, pk_words, msg_blob, msg_off, ctx_blob, ctx_off, internal, mu_out, mu_stride, ctl, n, st);
 }
+// One of the library's auxiliary streams borrowed for the length of a call: begin() orders it after what the caller's stream
+// holds so far, join() orders the caller's stream after it; the destructor joins on every path that did not (error returns),
+// falling back to a host-side wait if the event calls themselves fail.
+struct SideStream {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+    bool open = false;
+    bool begin(hipStream_t st) {
+        hipStream_t aux[2];
+        if (aux_streams(current_device(), aux) != CIRCL_HIP_OK) return false;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_fork, st) != hipSuccess ||
+            hipStreamWaitEvent(aux[0], ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;  // (nothing was enqueued on the side stream: the caller stays on its own stream)
+        }
+        main = st;
+        side = aux[0];
+        open = true;
+        return true;
+    }
+    void join() {
+        if (!open) return;
+        open = false;
+        if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(main, ev_done, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(side);
+        }
+    }
+    ~SideStream() {
+        join();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+    }
+};
 template <class Kern> unsigned dsa_resident_blocks(Kern kern, int lds_bytes) {
     const unsigned occ = resident_blocks(kern, lds_bytes);  // CUs of the current device * min(occupancy, kMaxBlocksPerCU)
     return std::min<unsigned>(occ, (unsigned)(cu_count() * dsa_blocks_per_cu()));
@@ -89,6 +138,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     LongCtl *lctl = reinterpret_cast<LongCtl *>(tr + 256);
     uint32_t *key_rows = nullptr;
     const uint8_t *tr_arg = nullptr;
+    SideStream side;  // (declared ahead of every early return below: its destructor joins)
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (KM == KM_KEYED) {
@@ -102,19 +152,27 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        const int internal_eff = DP<MODE>::NIST ? internal : 1;  // round 3: mu = CRH(tr || msg)
+        const uint32_t *kidx = KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr;
+        if (int rc = mldsa_long_scan(msg_off, ctx_blob, ctx_off, internal_eff, lctl, n, st)) return rc;
+        // small batches: every mu comes from the cooperative pre-pass (kSmallMu), and nothing before the final hash reads it --
+        // so tr and mu run on a side stream next to SampleInBall's sponge and the verify kernel (n=1: ~75 us off the chain)
+        static const bool no_side = getenv("CIRCL_HIP_DSA_NOSIDE") != nullptr;  // tuning aid
+        hipStream_t mu_st = st;
+        if (n <= kSmallMu && !no_side && side.begin(st)) mu_st = side.side;
         if (KM == KM_SHARED) {
-            hipLaunchKernelGGL(mldsa_tr_kernel<MODE>, dim3(1), dim3(64), 0, st, pk, tr);
+            hipLaunchKernelGGL(mldsa_tr_kernel<MODE>, dim3(1), dim3(64), 0, mu_st, pk, tr);
             tr_arg = tr;
         }
         {
-            const int internal_eff = DP<MODE>::NIST ? internal : 1;  // round 3: mu = CRH(tr || msg)
-            const uint32_t *kidx = KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr;
-            const int rc = tr_arg ? mldsa_long_prepass<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
-                                                                         internal_eff, muw1, G::MUW1, lctl, n, st)
-                                  : mldsa_long_prepass<DP<MODE>::TR / 8>(nullptr, 0, nullptr, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
-                                                                         muw1, G::MUW1, lctl, n, st);
+            const int rc = tr_arg ? mldsa_long_mu<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+                                                                    internal_eff, muw1, G::MUW1, lctl, n, mu_st)
+                                  : mldsa_long_mu<DP<MODE>::TR / 8>(nullptr, 0, nullptr, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
+                                                                    muw1, G::MUW1, lctl, n, mu_st);
             if (rc) return rc;
         }
+        // (with the side stream open, prep never takes its own mu path: n <= kSmallMu means every mu is pre-made, or -- more than
+        // kLongCap items cannot occur below kSmallMu -- none is; so it does not read tr before the side stream wrote it)
         hipLaunchKernelGGL(mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, muw1, ball,
                            fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr, (const LongCtl *)lctl);
     }
@@ -125,6 +183,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n, key_idx,
                            (const uint32_t *)key_rows);
     }
+    side.join();
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         if (n <= kSmallMu)

@@ -18,7 +18,7 @@ size_t kem_scratch_bytes() { return 256 + max_resident_blocks() * 64 * 512; }
 size_t kem_small_batch() {
     static const size_t v = [] {
         const char *e = getenv("CIRCL_HIP_KEM_SMALL");
-        const int lg = e ? atoi(e) : 14;
+        const int lg = e ? atoi(e) : 15;
         return lg <= 0 ? size_t(0) : size_t(1) << std::min(lg, 20);
     }();
     return v;
@@ -26,14 +26,37 @@ size_t kem_small_batch() {
 size_t kem_coop_batch() {
     static const size_t v = [] {
         const char *e = getenv("CIRCL_HIP_KEM_COOP");  // log2 of the largest batch hashed two items per wavefront (0 = never)
-        const int lg = e ? atoi(e) : 12;
+        const int lg = e ? atoi(e) : 11;
         return lg <= 0 ? size_t(0) : size_t(1) << std::min(lg, 20);
     }();
     return v;
 }
-size_t kem_small_table_bytes(size_t n) { return n && n <= kem_small_batch() ? up256((n + 15) / 16 * 16 * size_t(16 * 512)) : 0; }
+// How the hashing wavefronts of a small batch hold their sponges: 1 = two per wavefront on the cooperative permutation (shortest
+// chain, LDS-bound beyond a few thousand), 2 = one per lane pair (keccak_f1600_split), 0 = one per lane (CIRCL_HIP_KEM_SPLIT=0).
+int kem_hash_form(size_t n, size_t coop_max) {
+    static const bool split = env_int("CIRCL_HIP_KEM_SPLIT", 1, 0, 1) != 0;  // tuning aid
+    return n <= coop_max ? 1 : split ? 2 : 0;
+}
+unsigned kem_hash_blocks(size_t n, int form) { return (unsigned)(form == 1 ? (n + 1) / 2 : form == 2 ? (n + 31) / 32 : (n + 63) / 64); }
+// One-key batches keep ONE entry in that cache (G copies of it), so their small-batch routes reach further (measured: the
+// encapsulation wins up to 2^17 items, the decapsulation -- a workgroup per item for K-PKE.Decrypt -- up to 2^15):
+// CIRCL_HIP_KEM_SMALL_SHARED / CIRCL_HIP_KEM_SMALL_SHARED_DECAPS = log2 of the largest such batch.
+size_t kem_small_shared_batch(bool decaps) {
+    static const size_t enc = size_t(1) << env_int("CIRCL_HIP_KEM_SMALL_SHARED", 17, 0, 24);
+    static const size_t dec = size_t(1) << env_int("CIRCL_HIP_KEM_SMALL_SHARED_DECAPS", 15, 0, 24);
+    return decaps ? dec : enc;  // (log2 0 = batches of one only)
+}
+size_t kem_small_table_bytes(size_t n) { return up256(((n && n <= kem_small_batch() ? n : 1) + 15) / 16 * 16 * size_t(16 * 512)); }
 size_t kem_small_table_ofs(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
 size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes() + kem_small_table_bytes(n); }
+
+// Items per ring-phase workgroup of a small batch: about two groups per SIMD -- one item per workgroup up to 2 x 4 x CUs items,
+// then as few per group as that allows (measured 2^11 .. 2^15: 8 groups per CU up to 2^14 items, 16 beyond)
+size_t kem_small_group(size_t n) {
+    static const size_t per_cu_env = (size_t)env_int("CIRCL_HIP_KEM_SMALL_WGS", 0, 1, 32);  // tuning aid
+    const size_t per_cu = per_cu_env ? per_cu_env : (n <= (size_t(1) << 14) ? 8 : 16);
+    return std::max<size_t>(1, (n + per_cu * (size_t)cu_count() - 1) / (per_cu * (size_t)cu_count()));
+}
 
 int kem_k(int param) { return param == 512 ? 2 : param == 768 ? 3 : param == 1024 ? 4 : 0; }
 
@@ -80,23 +103,23 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *m_ws = w.slot1;
-    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (!R3 && n <= kem_small_batch()) {
         // small batch: [H(ek), G] and [A^T] side by side in one launch, then PRF + ring phase with the rows from the cache
         int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
         // up to kem_coop_batch() items the hashes run two items per wavefront (25 lanes per state): shorter chains while the chip
         // has SIMDs to spare (n / 2 hashing wavefronts); beyond it, one item per lane
-        const int coop = n <= kem_coop_batch() ? 1 : 0;
-        const unsigned nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G), nb_hash = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64);
+        // (beyond that an item per lane pair, keccak_f1600_split: 2/3 of the chain at 4/3 of the issue slots)
+        const int coop = kem_hash_form(n, kem_coop_batch());
+        const unsigned nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G), nb_hash = kem_hash_blocks(n, coop);
         static_assert(Gm::LDS_FIFO >= 108 * 8, "the cooperative hash's exchange area fits the FIFO area");
+        const size_t want = kem_small_group(n);
+        HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
         {
             ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
             hipLaunchKernelGGL(mlkem_small_pre_kernel<K>, dim3(nb_hash + nb_expand), dim3(64), Gm::LDS_FIFO, st, ek, m, ss, r_ws, key_rows, n, nb_hash, coop);
         }
         auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
-        // about two groups per SIMD: one item per workgroup up to 2 x 4 x CUs items, then as few per group as that allows
-        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
@@ -104,6 +127,7 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         if (R3) hipLaunchKernelGGL(kyber_r3_hash_kernel<K>, dim3(hb), dim3(256), 0, st, ek, m, ss, r_ws, m_ws, n);
@@ -138,6 +162,23 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *h_ws = w.slot1;
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    if (n <= kem_small_shared_batch(false)) {
+        // small batch: [A^T of the key] and [H(ek), G] side by side in one launch, then PRF + ring phase with the rows from the cache
+        int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
+        static_assert(Gm::LDS_FIFO >= 108 * 8, "the cooperative hash's exchange area fits the FIFO area");
+        {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+            hipLaunchKernelGGL(mlkem_small_shared_pre_kernel<K>, dim3(1 + (unsigned)((n + 31) / 32)), dim3(64), Gm::LDS_FIFO, st, ek, m, ss, r_ws, key_rows, n);
+        }
+        auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
+        const size_t want = kem_small_group(n);
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)0, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)key_rows);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(mlkem_hek_kernel<K>, dim3(1), dim3(64), 0, st, ek, h_ws);
@@ -211,24 +252,27 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
     uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
-    if (n <= kem_small_batch()) {
+    if (n <= kem_small_shared_batch(true)) {
         // small batch under one key: J(z || ct) per item, the key's hash check (one workgroup) and Decrypt + G side by side, then the
         // shared-key re-encryption with as few items per workgroup as the idle SIMDs allow
-        const int coop = n <= kem_coop_batch() ? 1 : 0;
-        const unsigned nb_j = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64);
+        const int coop = kem_hash_form(n, kem_coop_batch());
+        const unsigned nb_j = kem_hash_blocks(n, coop);
         {
             ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-            hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(nb_j + 1 + (unsigned)n), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)0, ct, mprime, kbar, r_ws,
-                               ssrej, status, key_status, (int16_t *)nullptr, n, nb_j, 1u, coop);
+            // (+ ONE expansion workgroup behind the n decrypting ones: the key's A^T into the row cache, G copies -- stride 0)
+            int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
+            hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(nb_j + 1 + (unsigned)n + 1), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)0, ct, mprime, kbar, r_ws,
+                               ssrej, status, key_status, key_rows, n, nb_j, 1u, coop);
             hipLaunchKernelGGL(mlkem_fill_status_kernel, dim3(hb), dim3(256), 0, st, status, (const uint8_t *)key_status, n);
         }
-        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_SHARED>;
-        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
+        const int16_t *key_rows = reinterpret_cast<const int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
+        const size_t want = kem_small_group(n);
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
                            const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
-                           (const uint32_t *)nullptr, (const int16_t *)nullptr);
+                           (const uint32_t *)nullptr, key_rows);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -320,15 +364,15 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
         // small batch: J(z || ct), the key's hash check, Decrypt + G and A^T side by side in one launch, then the key-table form
         // of the re-encryption (mlkem_small_decaps_pre_kernel)
         int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
-        const int coop = n <= kem_coop_batch() / 2 ? 1 : 0;  // two sponges per item here: half the encapsulation's threshold (measured: 2^11)
-        const unsigned nb_hash = (unsigned)(coop ? (n + 1) / 2 : (n + 63) / 64), nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G);
+        const int coop = kem_hash_form(n, kem_coop_batch() / 2);  // two sponges per item here: half the encapsulation's threshold
+        const unsigned nb_hash = kem_hash_blocks(n, coop), nb_expand = (unsigned)((n + Gm::G - 1) / Gm::G);
         {
             ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
             hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(2 * nb_hash + (unsigned)n + nb_expand), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)Gm::DK, ct,
                                mprime, kbar, r_ws, ssrej, status, (uint8_t *)nullptr, key_rows, n, nb_hash, nb_hash, coop);
         }
         auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
-        const size_t want = std::max<size_t>(1, (n + 8 * (size_t)cu_count() - 1) / (8 * (size_t)cu_count()));
+        const size_t want = kem_small_group(n);
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,

@@ -44,6 +44,19 @@ int circl_hip_keccak_f1600_coop(uint64_t *states, size_t n, int device) {
     });
 }
 
+int circl_hip_keccak_f1600_split(uint64_t *states, size_t n, int device) {
+    uint8_t *p = reinterpret_cast<uint8_t *>(states);
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{p + lo * 200, 200}}, {}, {{p + lo * 200, 200}}, no_ws, prim_opts(200), [&](Chunk &c) {
+            HIP_TRY(hipMemcpyAsync(c.out[0], c.in[0], c.cnt * 200, hipMemcpyDeviceToDevice, c.st));
+            hipLaunchKernelGGL(circl::prim::keccak_f1600_split_kernel, dim3((unsigned)((2 * c.cnt + 255) / 256)), dim3(256), 0, c.st,
+                               reinterpret_cast<uint64_t *>(c.out[0]), c.cnt);
+            HIP_TRY(hipGetLastError());
+            return CIRCL_HIP_OK;
+        });
+    });
+}
+
 int circl_hip_kyber_ntt(int16_t *polys, size_t n, int inverse, int device) {
     uint8_t *p = reinterpret_cast<uint8_t *>(polys);
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {

@@ -58,6 +58,7 @@ const DeviceInfo &dev_info(int dev);
 int current_device();            // hipGetDevice, 0 on failure
 inline int cu_count() { return dev_info(current_device()).cus; }  // of the CURRENT device (launch geometry)
 int max_cu_count();              // over all visible devices (workspace sizing: valid whichever device runs the call)
+int env_int(const char *name, int dflt, int lo, int hi);  // an integer tuning knob from the environment, clamped
 int usable_cpus();               // affinity mask capped by the cgroup CPU quota
 
 // ---- persistent-launch geometry for the scratch-based kernels -----------------------------------

@@ -19,6 +19,13 @@ namespace host {
 thread_local std::string g_err;
 
 // ---- devices ----------------------------------------------------------------------------------
+int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo || v > hi ? dflt : v;
+}
+
 namespace {
 
 struct DeviceTable {
@@ -41,13 +48,6 @@ std::vector<int> parse_cpulist(const std::string &s) {  // "0-15,128-143"
         for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) out.push_back(c);
     }
     return out;
-}
-
-int env_int(const char *name, int dflt, int lo, int hi) {
-    const char *e = getenv(name);
-    if (!e || !*e) return dflt;
-    const int v = atoi(e);
-    return v < lo || v > hi ? dflt : v;
 }
 
 void init_devices() {

@@ -176,6 +176,55 @@ __device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
     }
 }
 
+// Keccak-f[1600] with a state on TWO ADJACENT LANES, for latency-bound chains on a mostly idle chip (hashing of a small or
+// medium batch): the even lane holds the low 32-bit halves of the 25 words, the odd lane the high halves -- the natural
+// little-endian dword order, so absorbing and squeezing are plain 32-bit loads and stores at dword 2 k + (lane & 1).  All of
+// theta, chi and the column sums are lane-local; only a 64-bit rotation needs the other half, fetched by a DPP move from the
+// partner lane (quad_perm [1,0,3,2], full rate, no LDS): rol64 by n < 32 is alignbit(own, other, 32 - n) IN BOTH LANES, by
+// n > 32 alignbit(other, own, 64 - n) in both.  One round is
+//     theta : 10 bitop3 (column sums) + 5 dpp + 5 alignbit (rol 1) + 25 bitop3
+//     rho/pi: 24 dpp + 24 alignbit
+//     chi   : 25 bitop3,   iota: 2
+// = 120 instructions per lane against 180 of the lane-per-state form: a lone wavefront, which issues an instruction every ~5.4
+// cycles whatever it is, finishes a permutation in 2/3 of the time, at 4/3 of the total issue slots (twice the wavefronts).
+// Worth it while the lane-per-state form leaves the SIMDs at or below one wavefront each.
+struct SplitState {
+    uint32_t w[25];
+};
+__device__ __forceinline__ uint32_t split_partner(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
+template <int N> __device__ __forceinline__ uint32_t split_rol64(uint32_t own) {
+    if constexpr (N == 0) {
+        return own;
+    } else {
+        static_assert(N != 32, "no rho offset is 32");
+        const uint32_t oth = split_partner(own);
+        if constexpr (N < 32) return alignbit(own, oth, 32 - N);
+        else return alignbit(oth, own, 64 - N);
+    }
+}
+__device__ __forceinline__ void keccak_f1600_split(SplitState &s, bool hi_lane) {
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        const RcPair rc = rc_pair(r);
+        uint32_t c[5], rl[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) c[x] = bitop3_xor(bitop3_xor(s.w[x], s.w[x + 5], s.w[x + 10]), s.w[x + 15], s.w[x + 20]);
+#pragma unroll
+        for (int x = 0; x < 5; x++) rl[x] = split_rol64<1>(c[x]);
+        detail::static_for<0, 25>([&](auto ic) {
+            constexpr int i = decltype(ic)::v, x = i % 5, y = i / 5;
+            const uint32_t t = bitop3_xor(s.w[i], c[(x + 4) % 5], rl[(x + 1) % 5]);
+            constexpr int d = y + 5 * ((2 * x + 3 * y) % 5);  // pi
+            b[d] = split_rol64<detail::rho_of(i)>(t);
+        });
+#pragma unroll
+        for (int y = 0; y < 25; y += 5)
+#pragma unroll
+            for (int x = 0; x < 5; x++) s.w[x + y] = bitop3_chi(b[x + y], b[(x + 1) % 5 + y], b[(x + 2) % 5 + y]);
+        s.w[0] ^= hi_lane ? rc.hi : rc.lo;
+    }
+}
+
 // Keccak-f[1600] on TWO states by one wavefront, for latency-bound chains (H(ek) || G of a small ML-KEM batch: ten dependent
 // permutations).  Lanes 0..24 hold the 25 lanes of state A, lanes 32..56 those of state B, each as a (lo, hi) register pair
 // that STAYS in its lane across rounds and across absorbed blocks; a round is ~25 VALU instructions and two exchanges through

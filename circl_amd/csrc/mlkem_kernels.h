@@ -116,6 +116,63 @@ __device__ __forceinline__ void sha3_512_m_h(KeccakState &g, const uint64_t *m, 
     keccak_f1600(g);
 }
 
+// ---- the same sponges with a state on two adjacent lanes (keccak_f1600_split): the even lane of a pair holds and loads the
+// low dword of every 64-bit word, the odd lane the high one -- `p32` below is the item's data as dwords, already offset by the
+// lane's parity.  The next block's words are requested before the permutation of the current one.
+template <int NWORDS, class Src> __device__ __forceinline__ void split_sponge17_src(SplitState &s, Src &&src, uint32_t ds, bool hi_lane) {
+    constexpr int FULL = NWORDS / 17, REM = NWORDS % 17;  // src(k) = this lane's dword of 64-bit word k
+    uint32_t nx[17];
+#pragma unroll
+    for (int j = 0; j < 25; j++) s.w[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 17; j++) nx[j] = (FULL > 0 || j < REM) ? src(j) : 0;
+#pragma unroll 1
+    for (int b = 0; b < FULL; b++) {
+#pragma unroll
+        for (int j = 0; j < 17; j++) s.w[j] ^= nx[j];
+        const bool last = b + 1 == FULL;  // the block behind the last full one has REM words
+#pragma unroll
+        for (int j = 0; j < 17; j++) nx[j] = (!last || j < REM) ? src(17 * (b + 1) + j) : 0;
+        keccak_f1600_split(s, hi_lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 17; j++) s.w[j] ^= nx[j];
+    s.w[REM] ^= hi_lane ? 0u : ds;  // REM < 17 for every input size used
+    s.w[16] ^= hi_lane ? 0x80000000u : 0u;
+    keccak_f1600_split(s, hi_lane);
+}
+template <int NWORDS> __device__ __forceinline__ void split_sponge17(SplitState &s, const uint32_t *p32, uint32_t ds, bool hi_lane) {
+    split_sponge17_src<NWORDS>(s, [&](int k) { return p32[2 * k]; }, ds, hi_lane);
+}
+// (K, r) = G(m || h) on a lane pair: h = this lane's dwords of the four hash words; K -> ss, r -> r_ws (kyber.go:163-181)
+__device__ __forceinline__ void mlkem_g_split(const uint32_t (&h)[4], const uint8_t *__restrict__ m, uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws,
+                                              size_t item, bool live, int parity) {
+    const bool hi_lane = parity != 0;
+    const uint32_t *mw = reinterpret_cast<const uint32_t *>(m + item * 32) + parity;
+    SplitState s;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { s.w[j] = mw[2 * j]; s.w[4 + j] = h[j]; }
+    s.w[8] = hi_lane ? 0x80000000u : kDsSha3;  // one block of rate 9 words: suffix and final bit both in word 8
+#pragma unroll
+    for (int j = 9; j < 25; j++) s.w[j] = 0;
+    keccak_f1600_split(s, hi_lane);
+    if (live) {
+        uint32_t *kd = reinterpret_cast<uint32_t *>(ss + item * 32) + parity, *rd = reinterpret_cast<uint32_t *>(r_ws + item * 32) + parity;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { kd[2 * j] = s.w[j]; rd[2 * j] = s.w[4 + j]; }
+    }
+}
+// H(ek), then G, item `item` on this lane pair
+template <int K>
+__device__ __forceinline__ void mlkem_hash_split(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ m, uint8_t *__restrict__ ss,
+                                                 uint8_t *__restrict__ r_ws, size_t item, bool live, int parity) {
+    using Gm = Geom<K>;
+    SplitState s;
+    split_sponge17<Gm::EK / 8>(s, reinterpret_cast<const uint32_t *>(ek + item * Gm::EK) + parity, kDsSha3, parity != 0);
+    const uint32_t h[4] = {s.w[0], s.w[1], s.w[2], s.w[3]};
+    mlkem_g_split(h, m, ss, r_ws, item, live, parity);
+}
+
 template <int FIRST, int COUNT> __device__ __forceinline__ void store_words(uint64_t *p, const KeccakState &s) {
     detail::static_for<0, COUNT>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
@@ -791,10 +848,14 @@ template <int D> __device__ __forceinline__ unsigned get_bits(const uint8_t *p, 
 // the launch): equal finish times without a static schedule.  work == nullptr means one group per
 // workgroup (grid = number of groups).
 __device__ __forceinline__ size_t next_group(unsigned *work, int lane, bool first, size_t ngroups) {
-    if (work == nullptr) return first ? (size_t)blockIdx.x : ngroups;  // wave-uniform
+    // The first group of a workgroup is its own index, later ones come from the ticket counter (offset by the grid).  A launch
+    // with a workgroup per group never touches the counter: ~2000 workgroups hitting one address at the same instant cost a
+    // small batch ~40 us (20 ns per same-address atomic, twice per workgroup) -- measured on the small-batch ML-KEM routes.
+    if (first) return (size_t)blockIdx.x;                                // wave-uniform
+    if (work == nullptr || (size_t)gridDim.x >= ngroups) return ngroups;
     unsigned t = 0;
     if (lane == 0) t = atomicAdd(work, 1u);
-    return (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    return (size_t)gridDim.x + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
 }
 
 // ---- kernel 2: K-PKE.Encrypt ------------------------------------------------------------------
@@ -897,7 +958,8 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 __syncthreads();
             }
         }
-        const size_t kq = (KM == KM_KEYED && key_idx) ? (size_t)key_idx[item] : item;  // wave-uniform; a key table without an index vector is the batch's own keys
+        // wave-uniform; a key table without an index vector is the batch's own keys -- or, with stride 0, ONE key (entry 0)
+        const size_t kq = KM == KM_KEYED ? (key_idx ? (size_t)key_idx[item] : (ek_stride ? item : size_t(0))) : item;
         const uint8_t *ekp = ek + kq * ek_stride;
         const int16_t *krows = KM == KM_KEYED ? key_rows + kq * (size_t)(K * K * 256) : nullptr;
         const uint8_t *noise = lds_noise + (SHARED ? g : g % Gm::GH) * Gm::NOISE * Gm::NOISE_STRIDE;
@@ -1082,8 +1144,15 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_pre_ke
     // first and issue ahead of the expansion wavefronts that share their SIMD (measured at 2^14 items without the priority: the
     // launch took as long as hashing and expansion one after the other).
     __builtin_amdgcn_s_setprio(3);
-    if (coop) {  // very small batches: two items per wavefront, ~2.5 x shorter chain (keccak_f1600_coop2)
+    if (coop == 1) {  // very small batches: two items per wavefront, ~2.5 x shorter chain (keccak_f1600_coop2)
         mlkem_hash_coop2<K>(ek, m, ss, r_ws, 2 * (size_t)blockIdx.x, n, reinterpret_cast<uint64_t *>(smem), threadIdx.x);
+        return;
+    }
+    if (coop == 2) {  // the rest of the small-batch range: an item per lane pair, 2/3 of the chain (keccak_f1600_split)
+        size_t item = (size_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+        const bool live = item < n;
+        if (!live) item = n - 1;  // keep the wave converged; the duplicate result is not stored
+        mlkem_hash_split<K>(ek, m, ss, r_ws, item, live, threadIdx.x & 1);
         return;
     }
     size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1096,6 +1165,40 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_pre_ke
         store_words<0, 4>(reinterpret_cast<uint64_t *>(ss + idx * 32), g);
         store_words<4, 4>(reinterpret_cast<uint64_t *>(r_ws + idx * 32), g);
     }
+}
+
+// Small batches under ONE public key (the reference's BenchmarkEncapsulate shape): workgroup 0 expands the key's A^T into
+// entry 0 of the row cache; every other workgroup computes H(ek) itself on the cooperative permutation (the same nine
+// permutations in every workgroup: no dependence between workgroups, and the chip is idle anyway) and then G for 32 items on
+// lane pairs.  The key-table encrypt kernel follows (stride 0: every item takes entry 0) -- instead of H(ek), then G, then a
+// kernel whose every workgroup samples A^T first: three dependent stages became max(expansion, H + G) and the ring phase.
+template <int K>
+__global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_shared_pre_kernel(const uint8_t *__restrict__ ek, const uint8_t *__restrict__ m,
+                                                                                           uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws,
+                                                                                           int16_t *__restrict__ key_rows, size_t n) {
+    using Gm = Geom<K>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
+    if (blockIdx.x == 0) {
+        sample_matrix_scratch<K, true, 1>(smem, key_rows, ek + 384 * K, 0, 0, 1, lane);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t *ws = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *hx = reinterpret_cast<uint32_t *>(ws + 100);  // 8 dwords: H(ek) on its way from lanes 0..3 to every lane pair
+    const CoopLane c = coop_lane(ws, lane);
+    const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ek);
+    uint32_t vlo, vhi;
+    coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, lane & 31);
+    __syncthreads();
+    if (lane < 4) { hx[2 * lane] = vlo; hx[2 * lane + 1] = vhi; }
+    __syncthreads();
+    const int parity = lane & 1;
+    size_t item = (size_t)(blockIdx.x - 1) * 32 + (lane >> 1);
+    const bool live = item < n;
+    if (!live) item = n - 1;
+    const uint32_t h[4] = {hx[parity], hx[2 + parity], hx[4 + parity], hx[6 + parity]};
+    mlkem_g_split(h, m, ss, r_ws, item, live, parity);
 }
 
 // ---- decapsulation ---------------------------------------------------------------------------
@@ -1225,9 +1328,10 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
         __builtin_amdgcn_s_setprio(3);
         const bool is_j = b < nb_j;
         if (!is_j) b -= nb_j;
-        const size_t per = coop ? 2 : 64;
+        const size_t per = coop == 1 ? 2 : coop == 2 ? 32 : 64;  // 1: two sponges per wavefront; 2: a sponge per lane pair; 0: per lane
         const size_t nitems = (!is_j && dk_stride == 0) ? 1 : n;  // one key: one hash check
-        size_t idx = (size_t)b * per + (coop ? (size_t)half : (size_t)lane);
+        size_t idx = (size_t)b * per + (coop == 1 ? (size_t)half : coop == 2 ? (size_t)(lane >> 1) : (size_t)lane);
+        const int parity = lane & 1;
         const bool live = idx < nitems;
         if (!live) idx = nitems - 1;
         const uint8_t *dkp = dk + idx * dk_stride;
@@ -1235,11 +1339,20 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
         if (is_j) {  // ss_rej = J(z || ct) = SHAKE256(z || ct)[:32] (kyber.go:171-174)
             const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
             const uint64_t *cw = reinterpret_cast<const uint64_t *>(ct + idx * Gm::CT);
-            if (coop) {
+            if (coop == 1) {
                 const CoopLane c = coop_lane(reinterpret_cast<uint64_t *>(smem), lane);
                 uint32_t vlo, vhi;
                 coop_sponge17(vlo, vhi, [&](int k) { return k < 4 ? zw[k] : cw[k - 4]; }, 4 + CTW, kDsShake, c, j);
                 if (live && j < 4) reinterpret_cast<uint64_t *>(ssrej_ws + idx * 32)[j] = ((uint64_t)vhi << 32) | vlo;
+            } else if (coop == 2) {
+                const uint32_t *z32 = reinterpret_cast<const uint32_t *>(zw) + parity, *c32 = reinterpret_cast<const uint32_t *>(cw) + parity;
+                SplitState h;
+                split_sponge17_src<4 + CTW>(h, [&](int k) { return k < 4 ? z32[2 * k] : c32[2 * (k - 4)]; }, kDsShake, parity != 0);
+                if (live) {
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(ssrej_ws + idx * 32) + parity;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) dst[2 * i] = h.w[i];
+                }
             } else {
                 constexpr int TOTAL = 4 + CTW, FULL = TOTAL / 17, REM = TOTAL % 17;
                 KeccakState h;
@@ -1261,7 +1374,7 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
         } else {  // H(ek) over the ek embedded in dk against the stored hash -> status 2 (kyber.go:219-228)
             const uint64_t *ekw = reinterpret_cast<const uint64_t *>(dkp + 384 * K);
             bool ok = true;
-            if (coop) {
+            if (coop == 1) {
                 const CoopLane c = coop_lane(reinterpret_cast<uint64_t *>(smem), lane);
                 uint32_t vlo, vhi;
                 coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
@@ -1270,6 +1383,15 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
                 const unsigned long long bad = __ballot(!mine);
                 ok = ((bad >> (32 * half)) & 0xfull) == 0;
                 if (live && j == 0) (dk_stride == 0 ? key_status : status)[dk_stride == 0 ? 0 : idx] = ok ? 0 : 2;
+            } else if (coop == 2) {
+                SplitState h;
+                split_sponge17<Gm::EK / 8>(h, reinterpret_cast<const uint32_t *>(ekw) + parity, kDsSha3, parity != 0);
+                const uint32_t *st32 = reinterpret_cast<const uint32_t *>(stored) + parity;
+                uint32_t diff = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) diff |= h.w[i] ^ st32[2 * i];
+                diff |= split_partner(diff);  // both halves of every word must match
+                if (live && parity == 0) (dk_stride == 0 ? key_status : status)[dk_stride == 0 ? 0 : idx] = diff == 0 ? 0 : 2;
             } else {
                 KeccakState h;
                 sha3_256_words<Gm::EK / 8>(h, ekw);

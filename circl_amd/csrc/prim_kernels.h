@@ -34,6 +34,24 @@ __global__ void __launch_bounds__(64) keccak_f1600_coop_kernel(uint64_t *states)
     if (lane < 25) p[lane] = ws[lane];
 }
 
+// The two-lanes-per-state form (keccak_f1600_split): lane pair t of the grid owns state t.
+__global__ void __launch_bounds__(256) keccak_f1600_split_kernel(uint64_t *states, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t item = lane >> 1;
+    const int p = (int)(lane & 1);
+    const bool live = item < n;
+    if (!live) item = n - 1;  // both lanes of a pair stay in step; the duplicate is not stored
+    uint32_t *w = reinterpret_cast<uint32_t *>(states + item * 25);
+    SplitState s;
+#pragma unroll
+    for (int k = 0; k < 25; k++) s.w[k] = w[2 * k + p];
+    keccak_f1600_split(s, p != 0);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 25; k++) w[2 * k + p] = s.w[k];
+    }
+}
+
 // One polynomial per single-wave workgroup, int16[256] in standard order, in place.
 // Outputs are normalised to [0,q).  The inverse carries the reference's factor: Poly.InvNTT returns 2^16 times the
 // exact inverse (ntt.go:145-193; ntt_test.go:83-109 checks InvNTT(NTT(p)) = p * 2^16).

@@ -279,6 +279,12 @@ def keccak_f1600_coop(states, device=0):
     return a
 
 
+def keccak_f1600_split(states, device=0):
+    a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25).copy()
+    nat.check(nat.lib().circl_hip_keccak_f1600_split(_p(a), len(a), device), "keccak_f1600_split")
+    return a
+
+
 def mldsa_sample_in_ball(param, ctilde, sequential=False, device=0):
     """c~ rows -> (n, 256) uint32 challenge polynomials (PolyDeriveUniformBall)"""
     ct = {44: 32, 65: 48, 87: 64, 2: 32, 3: 32, 5: 32}[param]

@@ -297,6 +297,9 @@ int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device);
 /* the same 24-round permutation through the wave-cooperative form (one state per wavefront, lanes exchange through LDS)
  * that the ML-DSA kernels use on a rare serial path; exported so that the parity tests can pin it */
 int circl_hip_keccak_f1600_coop(uint64_t *states, size_t n, int device);
+/* the same through the two-lanes-per-state form (low halves on the even lane, high halves on the odd one, DPP exchange for
+ * the rotations) that the small- and medium-batch hashing paths use; exported so that the parity tests can pin it */
+int circl_hip_keccak_f1600_split(uint64_t *states, size_t n, int device);
 /* sign/mldsa/mldsa65/internal/sample.go:299-339 PolyDeriveUniformBall: n challenge seeds c~ (32 / 48 / 64 bytes for
  * ML-DSA-44 / 65 / 87, 32 for the round-3 modes) -> n polynomials uint32[256] with tau coefficients in {1, q-1}.
  * sequential != 0 runs the reference-order byte scan (otherwise the fallback of the block-parallel form). */

@@ -147,7 +147,8 @@ def latency_curve(param=768):
     plus the wall-clock latency of a batch of one through the host-buffer ABI."""
     from circl_amd import hostapi
     rng = np.random.default_rng(1)
-    for logn in (0, 6, 10, 11, 12, 13, 14, 15, 16, 18, 20):
+    logns = [int(x) for x in os.environ["CIRCL_LATENCY_LOGNS"].split(",")] if os.environ.get("CIRCL_LATENCY_LOGNS") else (0, 6, 10, 11, 12, 13, 14, 15, 16, 18, 20)
+    for logn in logns:
         n = 1 << logn
         eng = cdev.MLKEMDevice(param, n)
         seeds = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8)).cuda()

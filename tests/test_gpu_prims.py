@@ -179,6 +179,22 @@ def test_keccak_coop_equals_lane_per_state_form():
 
 
 @pytest.mark.gpu
+def test_keccak_split_equals_lane_per_state_form():
+    # the two-lanes-per-state permutation (hashing of small and medium batches) against the oracle and the main form; an odd
+    # count leaves a lane pair without a state, 301 states span more than one workgroup
+    from circl_amd import hostapi
+    from oracle import orc
+    rng = np.random.default_rng(43)
+    st = rng.integers(0, 2**63, (301, 25), dtype=np.uint64) * 2 + rng.integers(0, 2, (301, 25), dtype=np.uint64)
+    st[0] = 0
+    st[1] = 0xFFFFFFFFFFFFFFFF
+    a = hostapi.keccak_f1600_split(st)
+    assert (a == hostapi.keccak_f1600(st)).all()
+    assert (a[:20] == np.stack([orc.keccak_f1600(s) for s in st[:20]])).all()
+    assert (hostapi.keccak_f1600_split(st[:1]) == a[:1]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("param", [44, 65, 87, 3])
 def test_sample_in_ball_both_forms_vs_oracle(param):
     # sample.go:299-339 PolyDeriveUniformBall: the block-parallel form the kernels use, the reference-order scan that is its
