@@ -106,6 +106,22 @@ def test_sign_round_modes(env_extra, param, n, shared):
     assert r.returncode == 0 and "sign worker ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
 
 
+# ---- ML-KEM: every batch route against the oracle ----------------------------------------------------------------------------
+@pytest.mark.parametrize("env_extra", [{}, {"CIRCL_HIP_KEM_COOP": "0"}, {"CIRCL_HIP_KEM_COOP": "15"}, {"CIRCL_HIP_KEM_COOP": "0", "CIRCL_HIP_KEM_SPLIT": "0"},
+                                       {"CIRCL_HIP_KEM_SMALL": "0", "CIRCL_HIP_KEM_SMALL_SHARED": "0", "CIRCL_HIP_KEM_SMALL_SHARED_DECAPS": "0"},
+                                       {"CIRCL_HIP_KEM_SMALL_WGS": "1"}],
+                         ids=["default", "lane-pairs", "two-per-wavefront", "lane-per-sponge", "big-batch-routes", "many-items-per-group"])
+@pytest.mark.parametrize("param", [512, 768, 1024])
+def test_kem_batch_routes(env_extra, param):
+    # kem/mlkem/mlkem768/kyber.go:150-232 EncapsulateTo / DecapsulateTo: the same bytes whichever way a batch is laid over the
+    # chip -- the routes switch on the batch size, so the environment forces each of them at sizes the oracle finishes quickly
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "kem_routes_worker.py"), str(param)], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "kem routes ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+
+
 # ---- long and ragged messages ---------------------------------------------------------------------------
 @pytest.mark.parametrize("param", [44, 65, 87, 3])
 def test_long_and_ragged_messages_against_the_oracle(param):
