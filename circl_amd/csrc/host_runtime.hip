@@ -26,6 +26,50 @@ int env_int(const char *name, int dflt, int lo, int hi) {
     return v < lo || v > hi ? dflt : v;
 }
 
+// Page-locked staging memory.  ThreadSanitizer builds (tests/test_gpu_sanitizers.py) take it from mmap + hipHostRegister instead of
+// hipHostMalloc: the ROCm runtime maps its own host memory behind TSan's back, so a staging buffer that lands on the address
+// range of a finished thread's unmapped stack inherited that thread's access history, and the first write to it was reported as
+// a race with the dead thread (seen with the no-worker configuration, one run in three).  TSan sees mmap and clears the range.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define CIRCL_TSAN 1
+#endif
+#endif
+#ifdef CIRCL_TSAN
+}  // namespace host
+}  // namespace circl
+#include <sys/mman.h>
+#include <map>
+namespace circl {
+namespace host {
+static std::mutex g_pinned_mu;
+static std::map<void *, size_t> g_pinned_sizes;
+static hipError_t pinned_alloc(void **p, size_t bytes) {
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return hipErrorOutOfMemory;
+    const hipError_t e = hipHostRegister(m, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { munmap(m, bytes); return e; }
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned_sizes[m] = bytes;
+    *p = m;
+    return hipSuccess;
+}
+static hipError_t pinned_free(void *p) {
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        bytes = g_pinned_sizes[p];
+        g_pinned_sizes.erase(p);
+    }
+    const hipError_t e = hipHostUnregister(p);
+    munmap(p, bytes);
+    return e;
+}
+#else
+static hipError_t pinned_alloc(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault); }  // default placement: the device's NUMA node
+static hipError_t pinned_free(void *p) { return hipHostFree(p); }
+#endif
+
 namespace {
 
 struct DeviceTable {
@@ -388,17 +432,17 @@ int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
         d_cap = want;
     }
     if (hin_bytes > hin_cap) {
-        if (hin) HIP_TRY(hipHostFree(hin));
+        if (hin) HIP_TRY(pinned_free(hin));
         hin = nullptr; hin_cap = 0;
         const size_t want = up256(hin_bytes + hin_bytes / 8);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hin), want, hipHostMallocDefault));  // default placement: the device's NUMA node
+        HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hin), want));
         hin_cap = want;
     }
     if (hout_bytes > hout_cap) {
-        if (hout) HIP_TRY(hipHostFree(hout));
+        if (hout) HIP_TRY(pinned_free(hout));
         hout = nullptr; hout_cap = 0;
         const size_t want = up256(hout_bytes + hout_bytes / 8);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hout), want, hipHostMallocDefault));
+        HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hout), want));
         hout_cap = want;
     }
     return CIRCL_HIP_OK;
