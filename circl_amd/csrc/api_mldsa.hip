@@ -37,6 +37,8 @@ template <int MODE> size_t mldsa_item_ws_bytes(size_t n) {
     using G = circl::mldsa::DG<MODE>;
     return up256(n * G::MUW1) + up256(n * circl::mldsa::kBallStateBytes) + up256(n);
 }
+// up to here a lane per item leaves the SIMDs at or below one wavefront each: hash chains go on lane pairs (keccak_f1600_split)
+constexpr size_t kMidBatch = size_t(1) << 14;
 constexpr size_t kLongCtlBytes = (sizeof(circl::mldsa::LongCtl) + 255) & ~size_t(255);
 template <int MODE> size_t mldsa_ws_bytes(size_t n) {
     return mldsa_item_ws_bytes<MODE>(n) + 256 + mldsa_scratch_blocks<MODE>(n) * circl::mldsa::DG<MODE>::SCRATCH_BYTES + 256 + kLongCtlBytes;  // + tr of a shared key + long-message list
@@ -173,8 +175,15 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         }
         // (with the side stream open, prep never takes its own mu path: n <= kSmallMu means every mu is pre-made, or -- more than
         // kLongCap items cannot occur below kSmallMu -- none is; so it does not read tr before the side stream wrote it)
+        // medium batches of distinct keys: tr on lane pairs first (into the items' ball slots, which prep reads before it writes them)
+        size_t tr_stride = 0;
+        if (KM == KM_ITEM && n > kSmallMu && n <= kMidBatch) {
+            hipLaunchKernelGGL(mldsa_tr_split_kernel<MODE>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, pk, ball, (size_t)kBallStateBytes, n);
+            tr_arg = ball;
+            tr_stride = kBallStateBytes;
+        }
         hipLaunchKernelGGL(mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, muw1, ball,
-                           fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr, (const LongCtl *)lctl);
+                           fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr, (const LongCtl *)lctl, tr_stride);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
@@ -188,6 +197,8 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         if (n <= kSmallMu)
             hipLaunchKernelGGL(mldsa_final_coop_kernel<MODE>, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
+        else if (n <= kMidBatch)
+            hipLaunchKernelGGL(mldsa_final_split_kernel<MODE>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
         else
             hipLaunchKernelGGL(mldsa_final_kernel<MODE>, dim3(hb), dim3(256), 0, st, sig, (const uint8_t *)muw1, (const uint8_t *)fail, ok, n);
     }
@@ -219,7 +230,10 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
-        hipLaunchKernelGGL(mldsa_keygen_finish_kernel<MODE>, dim3(hb), dim3(256), 0, st, (const uint8_t *)pk, sk, n);
+        // tr = H(pk): up to 2^14 keys the chain of a lone lane is the launch (two keys per wavefront up to kSmallMu, lane pairs beyond)
+        if (n <= kSmallMu) hipLaunchKernelGGL(mldsa_keygen_finish_small_kernel<MODE>, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, (const uint8_t *)pk, sk, n, 1);
+        else if (n <= kMidBatch) hipLaunchKernelGGL(mldsa_keygen_finish_small_kernel<MODE>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, (const uint8_t *)pk, sk, n, 2);
+        else hipLaunchKernelGGL(mldsa_keygen_finish_kernel<MODE>, dim3(hb), dim3(256), 0, st, (const uint8_t *)pk, sk, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

@@ -432,7 +432,11 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_FINISH, st);
-        hipLaunchKernelGGL(mlkem_keygen_finish_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, (const uint8_t *)ek, dk, n);
+        // H(ek): nine permutations per key.  Up to 2^15 keys a lane per key leaves the SIMDs at or below one wavefront each, and
+        // the chain is the launch: two keys per wavefront / a key per lane pair there (kem_hash_form, as for the encapsulation)
+        const int form = n <= (size_t(1) << 15) ? kem_hash_form(n, kem_coop_batch()) : 0;
+        if (form) hipLaunchKernelGGL(mlkem_keygen_finish_small_kernel<K>, dim3(kem_hash_blocks(n, form)), dim3(64), 0, st, seed64, (const uint8_t *)ek, dk, n, form);
+        else hipLaunchKernelGGL(mlkem_keygen_finish_kernel<K>, dim3(hb), dim3(256), 0, st, seed64, (const uint8_t *)ek, dk, n);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

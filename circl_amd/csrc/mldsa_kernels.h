@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                          int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
                                                          uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared,
-                                                         const uint32_t *__restrict__ key_idx, const LongCtl *__restrict__ long_ctl) {
+                                                         const uint32_t *__restrict__ key_idx, const LongCtl *__restrict__ long_ctl,
+                                                         size_t tr_item_stride = 0) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     __shared__ uint32_t stage_lds[256 * kStageStride];
@@ -349,7 +350,8 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
     if (!long_premade(long_ctl, mprime_total(msg_off, ctx_blob, ctx_off, internal, idx), n)) {  // (otherwise mu is already there: mldsa_mu_long_kernel)
         if (tr_shared) {  // kernel-uniform
             keccak_zero(s);
-            xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : 0)));
+            // (tr_item_stride != 0: every item's own tr, made by mldsa_tr_split_kernel -- it may lie in this item's ball slot, read here before that is written)
+            xor_words<0, P::TR / 8>(s, reinterpret_cast<const uint64_t *>(tr_shared + (key_idx ? (size_t)key_idx[idx] * 64 : idx * tr_item_stride)));
         } else {
             sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
 #pragma unroll
@@ -897,6 +899,47 @@ __global__ void __launch_bounds__(64) mldsa_final_coop_kernel(const uint8_t *__r
 
 // ---- kernel F -----------------------------------------------------------------------------------
 
+// The same with an item per lane pair (keccak_f1600_split), for the batches between the cooperative form's range and the
+// sizes where a lane per item fills the chip.
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_final_split_kernel(const uint8_t *__restrict__ sig, const uint8_t *__restrict__ muw1_ws,
+                                                              const uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ ok, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    const int lane = threadIdx.x, parity = lane & 1;
+    size_t idx = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    SplitState s;
+    mlkem::split_sponge17<G::MUW1 / 8>(s, reinterpret_cast<const uint32_t *>(muw1_ws + idx * G::MUW1) + parity, kDsShake, parity != 0);
+    const uint8_t *sg = sig + idx * G::SIG + 4 * parity;  // (signatures are byte-aligned rows)
+    uint32_t diff = 0;
+#pragma unroll
+    for (int w = 0; w < P::CT / 8; w++) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) v |= (uint32_t)sg[8 * w + b] << (8 * b);
+        diff |= v ^ s.w[w];
+    }
+    diff |= split_partner(diff);
+    if (live && parity == 0) ok[idx] = (diff == 0 && fail_ws[idx] == 0) ? 1 : 0;
+}
+// tr = SHAKE256(pk)[:TR] of every item on a lane pair, 64 bytes at tr_out + item * stride: in front of mldsa_prep_kernel for
+// the same batches (15 of its 18 dependent permutations are tr)
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_tr_split_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ tr_out, size_t stride, size_t n) {
+    using G = DG<MODE>;
+    const int lane = threadIdx.x, parity = lane & 1;
+    size_t idx = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    SplitState s;
+    mlkem::split_sponge17<G::PK / 8>(s, reinterpret_cast<const uint32_t *>(pk + idx * G::PK) + parity, kDsShake, parity != 0);
+    if (live) {
+        uint32_t *tr = reinterpret_cast<uint32_t *>(tr_out + idx * stride) + parity;
+#pragma unroll
+        for (int i = 0; i < 8; i++) tr[2 * i] = s.w[i];
+    }
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) mldsa_final_kernel(const uint8_t *__restrict__ sig, const uint8_t *__restrict__ muw1_ws,
                                                           const uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ ok, size_t n) {
@@ -1084,6 +1127,38 @@ __global__ void __launch_bounds__(256) mldsa_keygen_finish_kernel(const uint8_t 
     KeccakState s;
     sponge17_words<G::PK / 8>(s, reinterpret_cast<const uint64_t *>(pk + idx * G::PK), kDsShake);
     store_words<0, DP<MODE>::TR / 8>(reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64), s);
+}
+// The same for small and medium batches (tr is 10 / 15 / 20 dependent permutations, the longest stage of a key generation):
+// form 1 = two keys per wavefront on the cooperative permutation, form 2 = a key per lane pair (keccak_f1600_split).
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_keygen_finish_small_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ sk, size_t n, int form) {
+    using G = DG<MODE>;
+    constexpr int TRW = DP<MODE>::TR / 8;
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x;
+    if (form == 1) {
+        const int half = lane >> 5, j = lane & 31;
+        size_t idx = 2 * (size_t)blockIdx.x + half;
+        const bool live = idx < n;
+        if (!live) idx = n - 1;
+        const CoopLane c = coop_lane(ws, lane);
+        const uint64_t *pkw = reinterpret_cast<const uint64_t *>(pk + idx * G::PK);
+        uint32_t vlo, vhi;
+        mlkem::coop_sponge17(vlo, vhi, [&](int k) { return pkw[k]; }, G::PK / 8, kDsShake, c, j);
+        if (live && j < TRW) reinterpret_cast<uint64_t *>(sk + idx * KG<MODE>::SK + 64)[j] = ((uint64_t)vhi << 32) | vlo;
+        return;
+    }
+    const int parity = lane & 1;
+    size_t idx = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    SplitState h;
+    mlkem::split_sponge17<G::PK / 8>(h, reinterpret_cast<const uint32_t *>(pk + idx * G::PK) + parity, kDsShake, parity != 0);
+    if (live) {
+        uint32_t *tr = reinterpret_cast<uint32_t *>(sk + idx * KG<MODE>::SK + 64) + parity;
+#pragma unroll
+        for (int i = 0; i < TRW; i++) tr[2 * i] = h.w[i];
+    }
 }
 
 // ---- signing (sign/mldsa/mldsa65/internal/dilithium.go:340-470 SignTo) ------

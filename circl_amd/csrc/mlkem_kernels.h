@@ -1565,5 +1565,41 @@ __global__ void __launch_bounds__(256) mlkem_keygen_finish_kernel(const uint8_t 
     }
 }
 
+// The same for small and medium batches, where the nine permutations of H(ek) on a lone lane are the longest stage of a key
+// generation: form 1 = two keys per wavefront on the cooperative permutation, form 2 = a key per lane pair (32 per wavefront).
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_keygen_finish_small_kernel(const uint8_t *__restrict__ seed64, const uint8_t *__restrict__ ek,
+                                                                       uint8_t *__restrict__ dk, size_t n, int form) {
+    using Gm = Geom<K>;
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x;
+    if (form == 1) {
+        const int half = lane >> 5, j = lane & 31;
+        size_t idx = 2 * (size_t)blockIdx.x + half;
+        const bool live = idx < n;
+        if (!live) idx = n - 1;
+        const CoopLane c = coop_lane(ws, lane);
+        const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ek + idx * Gm::EK);
+        uint32_t vlo, vhi;
+        coop_sponge17(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
+        uint64_t *tail = reinterpret_cast<uint64_t *>(dk + idx * Gm::DK + 768 * K + 32);
+        if (live && j < 4) tail[j] = ((uint64_t)vhi << 32) | vlo;
+        else if (live && j < 8) tail[j] = reinterpret_cast<const uint64_t *>(seed64 + idx * 64 + 32)[j - 4];
+        return;
+    }
+    const int parity = lane & 1;
+    size_t idx = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = idx < n;
+    if (!live) idx = n - 1;
+    SplitState h;
+    split_sponge17<Gm::EK / 8>(h, reinterpret_cast<const uint32_t *>(ek + idx * Gm::EK) + parity, kDsSha3, parity != 0);
+    if (live) {
+        uint32_t *tail = reinterpret_cast<uint32_t *>(dk + idx * Gm::DK + 768 * K + 32) + parity;
+        const uint32_t *zsrc = reinterpret_cast<const uint32_t *>(seed64 + idx * 64 + 32) + parity;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { tail[2 * i] = h.w[i]; tail[8 + 2 * i] = zsrc[2 * i]; }
+    }
+}
+
 }  // namespace mlkem
 }  // namespace circl

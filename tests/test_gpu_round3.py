@@ -122,6 +122,37 @@ def test_kem_batch_routes(env_extra, param):
     assert r.returncode == 0 and "kem routes ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
 
 
+# ---- ML-DSA: medium batches (hash chains on lane pairs) against the oracle ------------------------------------------------------
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+def test_mldsa_medium_batch_against_the_oracle(param):
+    # 1 024 < n <= 2^14: tr = H(pk) of key generation and of verification, and c' = H(mu || w1), run with an item per lane pair
+    # (keccak_f1600_split) instead of per lane; keys, signatures and verdicts must be the reference's
+    # (sign/mldsa/mldsa65/internal/dilithium.go:78-147 NewKeyFromSeed, :181-257 Verify)
+    import numpy as np
+    from circl_amd import hostapi
+    from oracle import orc
+    rng = np.random.default_rng(77 + param)
+    n = 1500 + 7
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = hostapi.mldsa_keygen(param, seeds)
+    pk0, sk0 = orc.mldsa_keygen(param, seeds)
+    assert (pk == pk0).all() and (sk == sk0).all()
+    r3 = param in (2, 3, 5)
+    msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 150, n)]
+    ctxs = None if r3 else [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 20, n)]
+    sig = hostapi.mldsa_sign(param, sk, msgs, ctxs=ctxs)
+    assert (sig[::50] == orc.mldsa_sign(param, sk0[::50], msgs[::50], ctxs=None if r3 else ctxs[::50])).all()
+    bad = sig.copy()
+    bad[3::7, 5] ^= 1          # c~ differs
+    bad[5::11, 200] ^= 0x10    # z differs
+    ok = hostapi.mldsa_verify(param, pk, bad, msgs, ctxs=ctxs)
+    want = np.ones(n, bool)
+    want[3::7] = False
+    want[5::11] = False
+    assert (ok.astype(bool) == want).all()
+    assert hostapi.mldsa_verify(param, pk, sig, msgs, ctxs=ctxs).all()
+
+
 # ---- long and ragged messages ---------------------------------------------------------------------------
 @pytest.mark.parametrize("param", [44, 65, 87, 3])
 def test_long_and_ragged_messages_against_the_oracle(param):
