@@ -316,7 +316,12 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, size_t nkeys, c
 // ---- ML-DSA sign ------------------------------------------------------------------------------
 constexpr int kSignBlocksPerCU = 8;
 
-constexpr size_t kSignBatchedMin = 16;  // below this the single persistent kernel has less launch overhead
+// below this many items the single persistent kernel signs the batch (CIRCL_HIP_SIGN_BATCHED_MIN; default 1 = never: measured, the
+// round structure with wide speculation is faster at every size -- n = 1 674 -> 499 us, n = 8 971 -> 386 us; the route stays for A/B runs)
+size_t sign_batched_min() {
+    static const size_t v = (size_t)env_int("CIRCL_HIP_SIGN_BATCHED_MIN", 1, 1, 1 << 20);
+    return v;
+}
 
 // CIRCL_HIP_SIGN_PAIR=1: the long rounds try two attempts per item with shared matrix reads (lazy pairs, sign_next_k in
 // mldsa_sign_batched.h).  Measured on MI355X (profiles/r03_sign_sweep.txt): the w kernel's HBM traffic per attempt falls by 35 %
@@ -348,7 +353,7 @@ template <int MODE> struct SignLayout {
         o_mr = take(128 * n);
         o_work = take(256);
         o_scratch = take(tail_units * S::SCRATCH_BYTES);
-        if (n >= kSignBatchedMin) {
+        if (n >= sign_batched_min()) {
             o_A = take(n * B::A_BYTES);
             o_sec = take(n * B::SEC_BYTES);
             o_y = take(E * B::Y_BYTES);
@@ -555,7 +560,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < mldsa_sign_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(rnd) || rnd == nullptr)
         return CIRCL_HIP_EWORKSPACE;
-    if (n >= kSignBatchedMin) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
+    if (n >= sign_batched_min()) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
     const SignLayout<MODE> lay(n);
     uint8_t *base = static_cast<uint8_t *>(ws);
     uint8_t *mr = base + lay.o_mr, *dead = base + lay.o_dead, *scratch = base + lay.o_scratch;

@@ -92,8 +92,8 @@ def test_randomised_soak_against_the_oracle():
 
 # ---- batch signing: every round mode against the oracle ---------------------------------------------------------------------
 @pytest.mark.parametrize("env_extra", [{"CIRCL_HIP_SIGN_SPEC": "1", "CIRCL_HIP_SIGN_PAIR": "1"}, {"CIRCL_HIP_SIGN_SPEC": "1"},
-                                       {"CIRCL_HIP_SIGN_SPEC": "4", "CIRCL_HIP_SIGN_PAIR": "1"}, {}],
-                         ids=["lazy-pairs", "single-attempts", "pairs-then-speculation", "default"])
+                                       {"CIRCL_HIP_SIGN_SPEC": "4", "CIRCL_HIP_SIGN_PAIR": "1"}, {}, {"CIRCL_HIP_SIGN_BATCHED_MIN": "100000"}],
+                         ids=["lazy-pairs", "single-attempts", "pairs-then-speculation", "default", "persistent-kernel"])
 @pytest.mark.parametrize("param,n,shared", [(65, 1500, ""), (44, 777, ""), (87, 600, ""), (3, 640, ""), (65, 900, "shared")])
 def test_sign_round_modes(env_extra, param, n, shared):
     # sign/mldsa/mldsa65/internal/dilithium.go:340-470: the signature is the one of the FIRST attempt that passes the norm tests,
