@@ -315,6 +315,7 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, size_t nkeys, c
 
 // ---- ML-DSA sign ------------------------------------------------------------------------------
 constexpr int kSignBlocksPerCU = 8;
+constexpr size_t kSignSplitLanes = size_t(1) << 16;  // streams of a round up to which its hash kernels run a stream per lane pair
 
 // below this many items the single persistent kernel signs the batch (CIRCL_HIP_SIGN_BATCHED_MIN; default 1 = never: measured, the
 // round structure with wide speculation is faster at every size -- n = 1 674 -> 499 us, n = 8 971 -> 386 us; the route stays for A/B runs)
@@ -346,7 +347,8 @@ template <int MODE> struct SignLayout {
     explicit SignLayout(size_t n_) : n(n_) {
         // entries: one per item (two with lazy pairs) in the long rounds; small batches get room for up to 64 attempts per item
         // and round, capped at kMinEntryCapacity entries
-        E = std::max((sign_pair_mode() ? 2 : 1) * n, std::min(circl::mldsa::kMinEntryCapacity, 64 * n));
+        static const size_t min_entries = (size_t)env_int("CIRCL_HIP_SIGN_MIN_ENTRIES", (int)circl::mldsa::kMinEntryCapacity, 64, 1 << 22);  // tuning aid
+        E = std::max((sign_pair_mode() ? 2 : 1) * n, std::min(min_entries, 64 * n));
         tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
         size_t o = 0;
         auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
@@ -426,13 +428,18 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const int x = e ? atoi(e) : -1;
         return (uint32_t)(x >= 0 && x <= 4096 ? x : 128);  // plateau 96 .. 256 at 2^16 items
     }();
+    // ... and small batches less widely than the chip could take: a round costs ~200 us plus ~13 us per 1 024 entries, so 8 192
+    // entries (or 8 attempts per item) in each of two rounds beat 32 k entries in one (measured 2^8 .. 2^12 items, tools/sign_spec_sweep.sh)
+    static const bool spec_env = getenv("CIRCL_HIP_SIGN_SPEC") != nullptr;
     S.spec_target = (uint32_t)std::min<size_t>((size_t)cus * spec_per_cu, lay.E);
+    if (!spec_env) S.spec_target = (uint32_t)std::min<size_t>(S.spec_target, std::max<size_t>(8192, 8 * n));
     S.pair = sign_pair_mode() ? 1u : 0u;
     const unsigned k0 = sign_next_k(n, S.spec_target, S.pair);
     constexpr int kMaxRounds = 400;
     size_t entries_upper[kMaxRounds];
     bool lazy[kMaxRounds];
-    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, S.pair, entries_upper, lazy, kMaxRounds);
+    static const double eps = __builtin_ldexp(1.0, -env_int("CIRCL_HIP_SIGN_EPS_LOG2", 20, 1, 60));  // expected unsigned items behind the schedule
+    const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, S.pair, entries_upper, lazy, kMaxRounds, eps);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -466,15 +473,19 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const unsigned gc = (unsigned)std::max<size_t>(1, std::min((upper + 255) / 256, lane_cap));
         auto g256 = [&](size_t work) { return (unsigned)std::max<size_t>(1, std::min((work + 255) / 256, lane_cap)); };
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        hipLaunchKernelGGL(sign_mask_kernel<MODE>, dim3(gm), dim3(256), 0, st, S, cur);
+        // hash chains of short rounds on lane pairs (sign_mask_kernel): while a lane per stream leaves the SIMDs at or below one wavefront each
+        const bool split_mask = upper * L <= kSignSplitLanes, split_ch = upper <= kSignSplitLanes;
+        if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
+        else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
         if (w_waves == 6) hipLaunchKernelGGL((sign_w_kernel<MODE, 6>), dim3(gw), dim3(64), 0, st, S, cur);
         else if (w_waves == 5) hipLaunchKernelGGL((sign_w_kernel<MODE, 5>), dim3(gw), dim3(64), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_w_kernel<MODE, 4>), dim3(gw), dim3(64), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
+        if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
+        else hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
         if (f_waves == 6) hipLaunchKernelGGL((sign_finish_kernel<MODE, 6>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
         else if (f_waves == 5) hipLaunchKernelGGL((sign_finish_kernel<MODE, 5>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
         else hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
-        hipLaunchKernelGGL(sign_challenge_kernel<MODE>, dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
+        hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
         hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
         hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(lazy[round] ? small : std::min<unsigned>((unsigned)std::max<size_t>(1, upper), (unsigned)cus * 32)),
                            dim3(64), 0, st, S, cur, sig);

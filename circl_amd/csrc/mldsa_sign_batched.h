@@ -202,39 +202,63 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
 // st.count[cur]; grids are fixed-size (the host does not know the count), work is distributed by grid-stride loops.
 
 // lane = (entry, l): y = ExpandMask(rho'', L * attempts + l)  (sample.go:178-196).  Also clears the next list's length.
-template <int MODE>
+template <int MODE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     using G = DG<MODE>;
     using B = SB<MODE>;
     constexpr int L = DP<MODE>::L;
+    // SPLIT: a stream per lane PAIR (keccak_f1600_split) for the rounds whose streams would leave the SIMDs at or below one
+    // wavefront each: 2/3 of the five-permutation chain.  The output is the raw stream, so each lane stores its own dwords.
+    constexpr int PER = SPLIT ? 128 : 256;
     const size_t total = (size_t)st.count[cur] * L;
     if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // filled by this round's compact kernel, several launches later
+    const int parity = threadIdx.x & 1;
 #pragma unroll 1
-    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {  // block-uniform
-        const size_t sidx = base + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * PER; base < total; base += (size_t)gridDim.x * PER) {  // block-uniform
+        const size_t sidx = base + (SPLIT ? threadIdx.x >> 1 : threadIdx.x);
         const bool on = sidx < total;
         const size_t slot = on ? sidx / L : 0;
         const uint32_t e = st.list[cur][slot];
         const size_t item = e & kEntryItemMask;
         const uint32_t off = e >> kEntryShift;
         const int l = on ? (int)(sidx % L) : 0;
-        KeccakState s;
-        keccak_zero(s);
-        xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
-        s.lo[8] = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
-        s.hi[16] = 0x80000000u;
+        const uint32_t nonce = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
         uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+        if constexpr (SPLIT) {
+            SplitState s;
+            const uint32_t *seed = reinterpret_cast<const uint32_t *>(st.mr + item * 128 + 64) + parity;
+#pragma unroll
+            for (int w = 0; w < 25; w++) s.w[w] = w < 8 ? seed[2 * w] : 0;
+            if (parity == 0) s.w[8] = nonce;
+            else s.w[16] = 0x80000000u;
 #pragma unroll 1
-        for (int blk = 0; blk < 5; blk++) {
-            keccak_f1600(s);
-            if (on) {
-                detail::static_for<0, 17>([&](auto ic) {
-                    constexpr int w = decltype(ic)::v;
-                    if (34 * blk + 2 * w < G::ZSZ / 4) {  // only the ZSZ payload bytes are kept
-                        yrow[34 * blk + 2 * w] = s.lo[w];
-                        yrow[34 * blk + 2 * w + 1] = s.hi[w];
-                    }
-                });
+            for (int blk = 0; blk < 5; blk++) {
+                keccak_f1600_split(s, parity != 0);
+                if (on) {
+                    detail::static_for<0, 17>([&](auto ic) {
+                        constexpr int w = decltype(ic)::v;
+                        if (34 * blk + 2 * w + parity < G::ZSZ / 4) yrow[34 * blk + 2 * w + parity] = s.w[w];  // only the ZSZ payload bytes are kept
+                    });
+                }
+            }
+        } else {
+            KeccakState s;
+            keccak_zero(s);
+            xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64));
+            s.lo[8] = nonce;
+            s.hi[16] = 0x80000000u;
+#pragma unroll 1
+            for (int blk = 0; blk < 5; blk++) {
+                keccak_f1600(s);
+                if (on) {
+                    detail::static_for<0, 17>([&](auto ic) {
+                        constexpr int w = decltype(ic)::v;
+                        if (34 * blk + 2 * w < G::ZSZ / 4) {  // only the ZSZ payload bytes are kept
+                            yrow[34 * blk + 2 * w] = s.lo[w];
+                            yrow[34 * blk + 2 * w + 1] = s.hi[w];
+                        }
+                    });
+                }
             }
         }
     }
@@ -436,28 +460,46 @@ struct PassMap {
 };
 
 // lane = entry: c~ = SHAKE256(mu || w1)[:CT] and the first SampleInBall block (dilithium.go:400-405)
-template <int MODE>
+template <int MODE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int cur, int pass) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
     const PassMap pm(st, cur, pass);
+    constexpr int PER = SPLIT ? 128 : 256;  // SPLIT: an entry per lane pair (see sign_mask_kernel)
+    const int parity = threadIdx.x & 1;
 #pragma unroll 1
-    for (size_t base = (size_t)blockIdx.x * 256; base < pm.nwork; base += (size_t)gridDim.x * 256) {
-        if (base + threadIdx.x >= pm.nwork) continue;
-        const size_t a = pm.slot(base + threadIdx.x);
+    for (size_t base = (size_t)blockIdx.x * PER; base < pm.nwork; base += (size_t)gridDim.x * PER) {
+        const size_t w = base + (SPLIT ? threadIdx.x >> 1 : threadIdx.x);
+        if (w >= pm.nwork) continue;  // (both lanes of a pair take the same branches)
+        const size_t a = pm.slot(w);
         const uint32_t e = st.list[cur][a];
         if (st.best[e & kEntryItemMask] < (e >> kEntryShift)) continue;  // a lower attempt of the item has already succeeded
-        KeccakState s;
-        sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
-        uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
-        store_words<0, P::CT / 8>(cb, s);
+        if constexpr (SPLIT) {
+            SplitState s;
+            mlkem::split_sponge17<G::MUW1 / 8>(s, reinterpret_cast<const uint32_t *>(st.muw1 + a * B::MUW1_BYTES) + parity, kDsShake, parity != 0);
+            uint32_t *cb = reinterpret_cast<uint32_t *>(st.cb + a * B::CB_BYTES) + parity;
 #pragma unroll
-        for (int i = P::CT / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }  // the SampleInBall sponge absorbs c~: same state
-        s.lo[P::CT / 8] ^= kDsShake;
-        s.hi[16] ^= 0x80000000u;
-        keccak_f1600(s);
-        store_words<0, 25>(cb + 15, s);  // ball state at byte 120
+            for (int i = 0; i < P::CT / 8; i++) cb[2 * i] = s.w[i];
+#pragma unroll
+            for (int i = P::CT / 8; i < 25; i++) s.w[i] = 0;  // the SampleInBall sponge absorbs c~: same state
+            if (parity == 0) s.w[P::CT / 8] ^= kDsShake;
+            else s.w[16] ^= 0x80000000u;
+            keccak_f1600_split(s, parity != 0);
+#pragma unroll
+            for (int i = 0; i < 25; i++) cb[30 + 2 * i] = s.w[i];  // ball state at byte 120
+        } else {
+            KeccakState s;
+            sponge17_words<G::MUW1 / 8>(s, reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES), kDsShake);
+            uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
+            store_words<0, P::CT / 8>(cb, s);
+#pragma unroll
+            for (int i = P::CT / 8; i < 25; i++) { s.lo[i] = 0; s.hi[i] = 0; }  // the SampleInBall sponge absorbs c~: same state
+            s.lo[P::CT / 8] ^= kDsShake;
+            s.hi[16] ^= 0x80000000u;
+            keccak_f1600(s);
+            store_words<0, 25>(cb + 15, s);  // ball state at byte 120
+        }
     }
 }
 
@@ -719,13 +761,14 @@ __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur
 // the EXPECTED survivor count (with a pessimistic p and a safety margin on the count that drives k) until it is below
 // 2^-40; the persistent tail kernel behind the schedule makes the result independent of that estimate.
 template <int MODE>
-inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target, unsigned pair, size_t *entries_upper, bool *lazy, int max_rounds) {
+inline int sign_round_schedule(size_t n, unsigned k0, unsigned spec_target, unsigned pair, size_t *entries_upper, bool *lazy, int max_rounds,
+                               double eps = 9.1e-13) {
     // expected attempts per signature 4.25 / 5.1 / 3.85 (FIPS 204 table 1): success probability per attempt, times 0.85
     const double p = 0.85 * (DP<MODE>::K == 4 ? 0.235 : DP<MODE>::K == 6 ? 0.196 : 0.26);
     double items = (double)n;
     unsigned k = k0;
     int rounds = 0;
-    while (items > 9.1e-13 && rounds < max_rounds) {
+    while (items > eps && rounds < max_rounds) {
         // an upper estimate of the round's entries sizes its grids (one workgroup per entry: the hardware then balances the
         // unevenly long attempts; workgroups beyond the real count leave at once, and the kernels' grid-stride loops keep a
         // too-small estimate correct)
