@@ -315,7 +315,11 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, size_t nkeys, c
 
 // ---- ML-DSA sign ------------------------------------------------------------------------------
 constexpr int kSignBlocksPerCU = 8;
-constexpr size_t kSignSplitLanes = size_t(1) << 16;  // streams of a round up to which its hash kernels run a stream per lane pair
+// streams of a round up to which its hash kernels run a stream per lane pair (CIRCL_HIP_SIGN_SPLIT_LOG2: tuning aid)
+size_t sign_split_lanes() {
+    static const size_t v = size_t(1) << env_int("CIRCL_HIP_SIGN_SPLIT_LOG2", 16, 0, 30);
+    return v;
+}
 
 // below this many items the single persistent kernel signs the batch (CIRCL_HIP_SIGN_BATCHED_MIN; default 1 = never: measured, the
 // round structure with wide speculation is faster at every size -- n = 1 674 -> 499 us, n = 8 971 -> 386 us; the route stays for A/B runs)
@@ -474,7 +478,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         auto g256 = [&](size_t work) { return (unsigned)std::max<size_t>(1, std::min((work + 255) / 256, lane_cap)); };
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         // hash chains of short rounds on lane pairs (sign_mask_kernel): while a lane per stream leaves the SIMDs at or below one wavefront each
-        const bool split_mask = upper * L <= kSignSplitLanes, split_ch = upper <= kSignSplitLanes;
+        const bool split_mask = upper * L <= sign_split_lanes(), split_ch = upper <= sign_split_lanes();
         if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
         if (w_waves == 6) hipLaunchKernelGGL((sign_w_kernel<MODE, 6>), dim3(gw), dim3(64), 0, st, S, cur);
