@@ -220,6 +220,59 @@ class DsaWork:
         return res
 
 
+def small_batches(dev):
+    """Cost per call of small / medium batches on resident arrays (stream-ordered, 20 calls per sample, best of 3): the routes of
+    DESIGN.md 4.4 / 4.5.  Every size is checked: all decapsulated secrets equal the encapsulated ones, a sample of each batch
+    against the oracle; ML-DSA signatures verify and a sample equals the oracle's."""
+    from circl_amd import device as cdev
+    from oracle import orc
+
+    def best(fn, reps=20):  # stream-ordered calls back to back, one synchronisation per `reps` (tests/gpu_microbench.py measures the same way)
+        fn()
+        torch.cuda.synchronize()
+        b = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            b = min(b, (time.perf_counter() - t) / reps)
+        return b * 1e6
+
+    out = {"unit": "us per call", "mlkem768": {}, "mldsa65": {}, "bit_exact_vs_oracle": True}
+    g = torch.Generator(device=dev).manual_seed(77)
+    for n in (1, 1 << 10, 1 << 12, 1 << 14):
+        eng = cdev.MLKEMDevice(768, n, dev)
+        ek, dk = eng.keygen(torch.randint(0, 256, (n, 64), dtype=torch.uint8, device=dev, generator=g))
+        m = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        ct = torch.empty((n, eng.CT), dtype=torch.uint8, device=dev)
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        ss2 = torch.empty_like(ss)
+        te = best(lambda: eng.encaps(ek, m, ct, ss))
+        td = best(lambda: eng.decaps(dk, ct, ss2))
+        t1 = best(lambda: eng.encaps_shared(ek[:1], m, ct, ss))
+        eng.encaps(ek, m, ct, ss)
+        torch.cuda.synchronize()
+        k = min(n, 64)
+        ct0, ss0, _ = orc.mlkem_encaps(768, ek[:k].cpu().numpy(), m[:k].cpu().numpy())
+        ok = bool((ss2 == ss).all().item()) and bool((ct[:k].cpu().numpy() == ct0).all()) and bool((ss[:k].cpu().numpy() == ss0).all())
+        out["bit_exact_vs_oracle"] &= ok
+        out["mlkem768"][str(n)] = {"encaps": te, "decaps": td, "encaps_one_key": t1, "encaps_per_s": n / te * 1e6}
+    for n in (1, 1 << 10):
+        eng = cdev.MLDSADevice(65, n, dev, sign=True)
+        pk, sk = eng.keygen(torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g))
+        msg = torch.randint(0, 256, (n * 32 + 16,), dtype=torch.uint8, device=dev, generator=g)
+        sig = eng.sign(sk, msg)
+        ts = best(lambda: eng.sign(sk, msg, sig), 10)
+        tv = best(lambda: eng.verify(pk, sig, msg))
+        k = min(n, 4)
+        msgs = [bytes(msg[32 * i:32 * i + 32].cpu().numpy()) for i in range(k)]
+        ok = bool(eng.verify(pk, sig, msg).all().item()) and bool((orc.mldsa_sign(65, sk[:k].cpu().numpy(), msgs) == sig[:k].cpu().numpy()).all())
+        out["bit_exact_vs_oracle"] &= ok
+        out["mldsa65"][str(n)] = {"sign": ts, "verify": tv}
+    return out
+
+
 def host_abi(work, dev_index, runs=3):
     """End to end through circl_hip_mlkem_encaps (host pointers): H2D + kernels + D2H, first with buffers from
     circl_hip_alloc_host (page-locked), then with ordinary pageable numpy memory, as a Go caller's []byte would be."""
@@ -798,6 +851,9 @@ def main():
 
     if args.mode == "host":
         headline = {"elapsed": B / host["pageable"]["value"] * args.steps, "value": host["pageable"]["whole_job_value"], "kern": {}}
+
+    if extras and rank == 0 and world == 1:
+        out_cfg["small_batches"] = small_batches(dev)
 
     # ---- PMC: traffic / VALU instructions of the dominant kernels ----
     traffic, valu, pmc_note = None, None, None
