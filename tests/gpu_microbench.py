@@ -176,7 +176,7 @@ def latency_curve(param=768):
 
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "latency":
-    latency_curve()
+    latency_curve(int(sys.argv[3]) if len(sys.argv) > 3 else 768)
     sys.exit(0)
 
 if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "host"):
