@@ -154,6 +154,22 @@ def test_mldsa_medium_batch_against_the_oracle(param):
     assert hostapi.mldsa_verify(param, pk, sig, msgs, ctxs=ctxs).all()
 
 
+@pytest.mark.parametrize("param", [768, 1024])
+def test_kem_route_boundaries(param):
+    # the batch sizes on both sides of every route switch (2^11, 2^14, 2^15, 2^17) give the same bytes through the latency-oriented
+    # routes and through the big-batch routes (which the oracle checks at its own sizes above)
+    digests = []
+    for env_extra in ({}, {"CIRCL_HIP_KEM_SMALL": "0", "CIRCL_HIP_KEM_SMALL_SHARED": "0", "CIRCL_HIP_KEM_SMALL_SHARED_DECAPS": "0"},
+                      {"CIRCL_HIP_KEM_COOP": "13", "CIRCL_HIP_KEM_SMALL": "17", "CIRCL_HIP_KEM_SMALL_SHARED_DECAPS": "17"}):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "kem_boundary_worker.py"), str(param)], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0 and "kem boundary digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+        digests.append(r.stdout.strip().split()[-1])
+    assert digests[0] == digests[1] == digests[2], digests
+
+
 # ---- long and ragged messages ---------------------------------------------------------------------------
 @pytest.mark.parametrize("param", [44, 65, 87, 3])
 def test_long_and_ragged_messages_against_the_oracle(param):
