@@ -170,6 +170,34 @@ def test_kem_route_boundaries(param):
     assert digests[0] == digests[1] == digests[2], digests
 
 
+@pytest.mark.parametrize("param", [44, 65])
+def test_mldsa_route_boundaries(param):
+    # batch sizes on both sides of the ML-DSA route switches (2^10: cooperative pre-pass / lane pairs, 2^14: lane pairs / a lane per
+    # item): key generation and verification of the SAME items through different routes give the same bytes and verdicts
+    import numpy as np
+    from circl_amd import hostapi
+    rng = np.random.default_rng(500 + param)
+    n = (1 << 14) + 1
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = hostapi.mldsa_keygen(param, seeds)
+    for k in (1023, 1024, 1025, 1 << 14):
+        pk_k, sk_k = hostapi.mldsa_keygen(param, seeds[:k])
+        assert (pk_k == pk[:k]).all() and (sk_k == sk[:k]).all(), k
+    msgs = [bytes(rng.integers(0, 256, 1 + (i % 50), dtype=np.uint8)) for i in range(n)]
+    sig = hostapi.mldsa_sign(param, sk, msgs)
+    for k in (1023, 1025):
+        assert (hostapi.mldsa_sign(param, sk[:k], msgs[:k]) == sig[:k]).all(), k
+    bad = sig.copy()
+    bad[3::7, 5] ^= 1
+    bad[5::11, 300] ^= 0x10
+    want = np.ones(n, bool)
+    want[3::7] = False
+    want[5::11] = False
+    for k in (1023, 1024, 1025, 1 << 14, n):
+        ok = hostapi.mldsa_verify(param, pk[:k], bad[:k], msgs[:k]).astype(bool)
+        assert (ok == want[:k]).all(), k
+
+
 # ---- long and ragged messages ---------------------------------------------------------------------------
 @pytest.mark.parametrize("param", [44, 65, 87, 3])
 def test_long_and_ragged_messages_against_the_oracle(param):
