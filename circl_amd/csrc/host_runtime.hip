@@ -533,6 +533,19 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
 
     hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
     if (int rc = pipeline_streams(dev, &h2d, &d2h, &st)) return rc;
+    {
+        // A call that is ONE small chunk gains nothing from separate copy streams and pays for them: two cross-stream event hops
+        // and two SDMA start-ups are ~20 us of a one-item call's 140 (measured through the Python binding: n = 1 139 -> 120 us, 64 items
+        // 166 -> 147, 1 024 items 316 -> 299).  Its copies go on the compute stream (the events below are then recorded and awaited on
+        // one stream, which costs nothing).  CIRCL_HIP_HOST_INLINE_BYTES: the largest such call (default 4 MB moved), 0 = never.
+        static const size_t inline_bytes = (size_t)env_int("CIRCL_HIP_HOST_INLINE_BYTES", 4 << 20, 0, 1 << 30);
+        size_t moved = 0;
+        for (auto &in : ins) moved += in.row * (in.per_call ? 1 : n);
+        for (auto &o : outs) moved += o.row * n;
+        for (auto &b : blobs)
+            if (b.blob) moved += (size_t)(b.off[n] - b.off[0]) + 8 * (n + 1);
+        if (n <= chunk && moved <= inline_bytes) h2d = d2h = st;
+    }
     std::deque<InFlight> inflight;
     // error paths must not recycle a slot (or return to the caller) with copies or kernels still in flight
     struct Drain {
