@@ -3,6 +3,7 @@
 // No CPU path: every compute entry point launches the HIP kernels of mldsa_kernels.h / mldsa_sign_batched.h or fails
 // with CIRCL_HIP_ENODEV.
 #include "host_common.h"
+#include "keytable.h"
 #include "mldsa_kernels.h"
 #include "mldsa_sign_batched.h"
 
@@ -124,12 +125,15 @@ template <int MODE> size_t mldsa_table_bytes(size_t nkeys) {
 template <int MODE, int KM>
 int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob,
                           const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n,
-                          void *ws, size_t ws_bytes, hipStream_t st) {
+                          void *ws, size_t ws_bytes, hipStream_t st, const circl_hip_keytable *cached = nullptr) {
+    // cached (KM_KEYED only): a key table that lives across calls (keytable.h) -- pk, the expanded rows and tr come from it, the
+    // workspace needs no table tail, and key_idx == nullptr means entry 0 for every item
     using G = circl::mldsa::DG<MODE>;
     using namespace circl::mldsa;
     if (n == 0) return CIRCL_HIP_OK;
     if (KM == KM_KEYED && nkeys == 0) return CIRCL_HIP_EPARAM;
-    const size_t need = mldsa_ws_bytes<MODE>(n) + (KM == KM_KEYED ? mldsa_table_bytes<MODE>(nkeys) : 0);
+    if (cached) pk = cached->d_keys;
+    const size_t need = mldsa_ws_bytes<MODE>(n) + (KM == KM_KEYED && !cached ? mldsa_table_bytes<MODE>(nkeys) : 0);
     if (ws_bytes < need || !aligned16(ws) || !aligned16(pk) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
     uint8_t *muw1 = static_cast<uint8_t *>(ws);
     uint8_t *ball = muw1 + up256(n * G::MUW1);
@@ -145,12 +149,14 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (KM == KM_KEYED) {
         const size_t padded = (nkeys + G::IT - 1) / G::IT * G::IT;
-        key_rows = reinterpret_cast<uint32_t *>(muw1 + mldsa_ws_bytes<MODE>(n));
+        key_rows = reinterpret_cast<uint32_t *>(cached ? cached->d_table : muw1 + mldsa_ws_bytes<MODE>(n));
         uint8_t *key_tr = reinterpret_cast<uint8_t *>(key_rows) + up256(padded * G::STREAMS * kPackedRowDwords * 4);
         tr_arg = key_tr;
-        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYTABLE, st);
-        hipLaunchKernelGGL(mldsa_tr_table_kernel<MODE>, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, pk, key_tr, nkeys);
-        hipLaunchKernelGGL(mldsa_expand_keys_kernel<MODE>, dim3((unsigned)(padded / G::IT)), dim3(64), G::LDS_FIFO, st, pk, key_rows, nkeys);
+        if (!cached) {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYTABLE, st);
+            hipLaunchKernelGGL(mldsa_tr_table_kernel<MODE>, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, pk, key_tr, nkeys);
+            hipLaunchKernelGGL(mldsa_expand_keys_kernel<MODE>, dim3((unsigned)(padded / G::IT)), dim3(64), G::LDS_FIFO, st, pk, key_rows, nkeys);
+        }
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
@@ -167,7 +173,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
             tr_arg = tr;
         }
         {
-            const int rc = tr_arg ? mldsa_long_mu<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+            const int rc = tr_arg ? mldsa_long_mu<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED && kidx ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
                                                                     internal_eff, muw1, G::MUW1, lctl, n, mu_st)
                                   : mldsa_long_mu<DP<MODE>::TR / 8>(nullptr, 0, nullptr, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
                                                                     muw1, G::MUW1, lctl, n, mu_st);
@@ -249,12 +255,24 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     case 5: return CALL(5);          \
     }
 
+template <int MODE> int mldsa_table_build(circl_hip_keytable *t, hipStream_t st) {
+    using G = circl::mldsa::DG<MODE>;
+    using namespace circl::mldsa;
+    const size_t padded = (t->nkeys + G::IT - 1) / G::IT * G::IT;
+    uint32_t *key_rows = reinterpret_cast<uint32_t *>(t->d_table);
+    uint8_t *key_tr = t->d_table + up256(padded * G::STREAMS * kPackedRowDwords * 4);
+    hipLaunchKernelGGL(mldsa_tr_table_kernel<MODE>, dim3((unsigned)((t->nkeys + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, key_tr, t->nkeys);
+    hipLaunchKernelGGL(mldsa_expand_keys_kernel<MODE>, dim3((unsigned)(padded / G::IT)), dim3(64), G::LDS_FIFO, st, (const uint8_t *)t->d_keys, key_rows, t->nkeys);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
 template <int KM>
 int mldsa_verify_dev_any(int param, const uint8_t *pk, size_t nkeys, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob,
                          const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n, void *ws,
-                         size_t wsb, hipStream_t st) {
+                         size_t wsb, hipStream_t st, const circl_hip_keytable *cached = nullptr) {
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
-#define CALL(M) mldsa_verify_dev_impl<M, KM>(pk, nkeys, key_idx, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st)
+#define CALL(M) mldsa_verify_dev_impl<M, KM>(pk, nkeys, key_idx, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, ws, wsb, st, cached)
     DSA_SWITCH(param, CALL)
 #undef CALL
     return CIRCL_HIP_EPARAM;
@@ -697,6 +715,69 @@ int circl_hip_mldsa_verify_keyed_dev(int param, const uint8_t *d_pk_table, size_
                                      uint8_t *d_ok, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
     return mldsa_verify_dev_any<KM_KEYED>(param, d_pk_table, nkeys, d_key_idx, d_sig, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, 0, d_ok, n, d_ws,
                                           ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+// ---- a public-key table that lives across calls (keytable.h): A and tr of every entry, once ---------------------------------------
+int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    const size_t PK = circl_hip_mldsa_pk_size(param);
+    if (!PK || !pks || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(physical_device(device)));
+    circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
+    if (!t) return CIRCL_HIP_ENOMEM;
+    t->magic = kKeytableMagic; t->family = 2; t->param = param; t->device = device; t->private_keys = 0; t->nkeys = nkeys; t->row = PK;
+    t->keys_bytes = up256(PK * nkeys + 16);
+    t->table_bytes = mldsa_table_any(param, nkeys);
+    hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
+    int rc = pipeline_streams(device, &h2d, &d2h, &st);
+    if (rc == CIRCL_HIP_OK && (hipMalloc(reinterpret_cast<void **>(&t->d_keys), t->keys_bytes) != hipSuccess ||
+                               hipMalloc(reinterpret_cast<void **>(&t->d_table), t->table_bytes) != hipSuccess)) {
+        (void)hipGetLastError();
+        rc = CIRCL_HIP_ENOMEM;
+    }
+    if (rc == CIRCL_HIP_OK && hipMemcpyAsync(t->d_keys, pks, PK * nkeys, hipMemcpyHostToDevice, st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc == CIRCL_HIP_OK) {
+#define CALL(M) mldsa_table_build<M>(t, st)
+        rc = [&]() -> int {
+            DSA_SWITCH(param, CALL)
+            return CIRCL_HIP_EPARAM;
+        }();
+#undef CALL
+    }
+    if (rc == CIRCL_HIP_OK && hipStreamSynchronize(st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc != CIRCL_HIP_OK) {
+        (void)hipGetLastError();
+        circl_hip_keytable_free(t);
+        return rc;
+    }
+    *out = t;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_sig, const uint8_t *d_msg_blob,
+                                     const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n, void *d_ws,
+                                     size_t ws_bytes, void *stream) {
+    if (!t || t->magic != kKeytableMagic || t->family != 2) return CIRCL_HIP_EPARAM;
+    return mldsa_verify_dev_any<KM_KEYED>(t->param, t->d_keys, t->nkeys, d_key_idx, d_sig, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, 0, d_ok, n, d_ws,
+                                          ws_bytes, static_cast<hipStream_t>(stream), t);
+}
+int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                 const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n) {
+    if (!t || t->magic != kKeytableMagic || t->family != 2) return CIRCL_HIP_EPARAM;
+    const int param = t->param;
+    const size_t SIG = circl_hip_mldsa_sig_size(param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        for (size_t i = 0; i < n; i++)
+            if (key_idx[i] >= t->nkeys) return CIRCL_HIP_EPARAM;
+    if (check_contexts(param, ctx_blob, ctx_off, n) == CTX_UNSUPPORTED) return CIRCL_HIP_EPARAM;
+    return run_pipeline(t->device, n, {{sig, SIG}, {reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}},
+                        {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{ok, 1}}, [&](size_t c) { return mldsa_ws_any(param, c); },
+                        dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
+                            return circl_hip_mldsa_verify_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.in[0], c.blob[0], c.off[0],
+                                                                    c.blob[1], c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                        });
 }
 
 int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,

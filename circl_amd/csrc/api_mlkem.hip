@@ -3,6 +3,7 @@
 // There is deliberately no CPU path in this file: every compute entry point launches the HIP kernels of
 // mlkem_kernels.h or fails with CIRCL_HIP_ENODEV.
 #include "host_common.h"
+#include "keytable.h"
 #include "mlkem_kernels.h"
 
 using namespace circl::host;
@@ -465,6 +466,106 @@ int check_key_idx(const uint32_t *key_idx, size_t n, size_t nkeys) {
     return CIRCL_HIP_OK;
 }
 
+// ---- key tables that live across calls (keytable.h) ------------------------------------------------------------------------------
+// The table memory has the layout of the per-call key tables' workspace tail (kem_table_bytes): A^T rows of whole groups, H(ek)
+// per entry, a status byte per entry.  key_idx == nullptr: every item uses entry 0 (the kernels see key stride 0).
+template <int K> int kem_table_build(circl_hip_keytable *t, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    int16_t *key_rows = reinterpret_cast<int16_t *>(t->d_table);
+    uint8_t *key_h = t->d_table + up256(padded * K * K * 512);
+    uint8_t *key_status = key_h + up256(t->nkeys * 32);
+    const size_t row = t->private_keys ? Gm::DK : Gm::EK;
+    hipLaunchKernelGGL(mlkem_hek_table_kernel<K>, dim3((unsigned)((t->nkeys + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, row,
+                       (size_t)(t->private_keys ? 384 * K : 0), key_h, key_status, t->private_keys ? 1 : 0, t->nkeys);
+    hipLaunchKernelGGL(mlkem_expand_keys_kernel<K>, dim3((unsigned)(padded / Gm::G)), dim3(64), Gm::LDS_FIFO, st, (const uint8_t *)t->d_keys, row,
+                       (size_t)(t->private_keys ? 768 * K : 384 * K), key_rows, t->nkeys);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+template <int K>
+int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                          void *ws, size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(m) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
+        return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *r_ws = w.slot0;
+    const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    const int16_t *key_rows = reinterpret_cast<const int16_t *>(t->d_table);
+    const uint8_t *key_h = t->d_table + up256(padded * K * K * 512);
+    const size_t stride = key_idx ? (size_t)Gm::EK : 0;
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key_h, m, ss, r_ws, n, key_idx);
+    }
+    {
+        auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
+        // small batches: as few items per workgroup as the idle SIMDs allow (kem_small_group), like the other latency-oriented routes
+        const size_t want = n <= kem_small_shared_batch(false) ? kem_small_group(n) : (size_t)Gm::GS;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, (const uint8_t *)t->d_keys, stride, m, (const uint8_t *)r_ws, ct, ss, status,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, key_idx, key_rows);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+template <int K>
+int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, void *ws,
+                          size_t ws_bytes, hipStream_t st) {
+    using Gm = circl::mlkem::Geom<K>;
+    using namespace circl::mlkem;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
+    KemWs w(ws, n);
+    uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
+    const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
+    const int16_t *key_rows = reinterpret_cast<const int16_t *>(t->d_table);
+    const uint8_t *key_status = t->d_table + up256(padded * K * K * 512) + up256(t->nkeys * 32);
+    const uint8_t *dk = t->d_keys;
+    const size_t stride = key_idx ? (size_t)Gm::DK : 0;
+    if (status == nullptr) status = w.status_slot;  // (the kernels want one; the caller may not)
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
+    const unsigned hb = (unsigned)((n + 255) / 256);
+    const bool small = key_idx == nullptr && n <= kem_small_shared_batch(true);
+    if (small) {
+        // ONE key, small batch: J(z || ct) on the cooperative permutation / lane pairs beside Decrypt + G (mlkem_small_decaps_pre_kernel
+        // without its hash-check and expansion workgroups: both are in the table)
+        const int coop = kem_hash_form(n, kem_coop_batch());
+        const unsigned nb_j = kem_hash_blocks(n, coop);
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_small_decaps_pre_kernel<K>, dim3(nb_j + (unsigned)n), dim3(64), Gm::LDS_FIFO, st, dk, (size_t)0, ct, mprime, kbar, r_ws, ssrej,
+                           status, (uint8_t *)nullptr, (int16_t *)nullptr, n, nb_j, 0u, coop);
+        hipLaunchKernelGGL(mlkem_fill_status_kernel, dim3(hb), dim3(256), 0, st, status, key_status, n);
+    } else {
+        {
+            ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+            hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, stride, ct, mprime, n, key_idx);
+        }
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
+        hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, stride, ct, (const uint8_t *)mprime, kbar, r_ws, ssrej, status, n,
+                           key_status, key_idx);
+    }
+    {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
+        const size_t want = n <= kem_small_shared_batch(true) ? kem_small_group(n) : (size_t)Gm::GS;
+        const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
+        hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, stride, (const uint8_t *)mprime, (const uint8_t *)r_ws,
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n, key_idx, key_rows);
+    }
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+bool kem_table_ok(const circl_hip_keytable *t, int want_private) {
+    return t && t->magic == kKeytableMagic && t->family == 1 && t->private_keys == want_private && kem_k(t->param) != 0;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -624,6 +725,91 @@ int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkey
                                                                         c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
+}
+
+// ---- key tables that live across calls ---------------------------------------------------------------------------------------
+int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                 circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    const int K = kem_k(param);
+    if (!K || !keys || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(physical_device(device)));
+    circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
+    if (!t) return CIRCL_HIP_ENOMEM;
+    t->magic = kKeytableMagic; t->family = 1; t->param = param; t->device = device; t->private_keys = private_keys ? 1 : 0; t->nkeys = nkeys;
+    t->row = private_keys ? circl_hip_mlkem_dk_size(param) : circl_hip_mlkem_ek_size(param);
+    t->keys_bytes = up256(t->row * nkeys + 16);
+    t->table_bytes = kem_table_bytes_any(param, nkeys);
+    hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
+    int rc = pipeline_streams(device, &h2d, &d2h, &st);
+    if (rc == CIRCL_HIP_OK && (hipMalloc(reinterpret_cast<void **>(&t->d_keys), t->keys_bytes) != hipSuccess ||
+                               hipMalloc(reinterpret_cast<void **>(&t->d_table), t->table_bytes) != hipSuccess)) {
+        (void)hipGetLastError();
+        rc = CIRCL_HIP_ENOMEM;
+    }
+    if (rc == CIRCL_HIP_OK && hipMemcpyAsync(t->d_keys, keys, t->row * nkeys, hipMemcpyHostToDevice, st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc == CIRCL_HIP_OK) rc = K == 2 ? kem_table_build<2>(t, st) : K == 3 ? kem_table_build<3>(t, st) : kem_table_build<4>(t, st);
+    if (rc == CIRCL_HIP_OK && key_status) {
+        const size_t G = K == 2 ? 16 : K == 3 ? 7 : 4, padded = (nkeys + G - 1) / G * G;  // (Geom<K>::G)
+        const uint8_t *ks = t->d_table + up256(padded * K * K * 512) + up256(nkeys * 32);
+        if (private_keys) {
+            if (hipMemcpyAsync(key_status, ks, nkeys, hipMemcpyDeviceToHost, st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+        } else {
+            memset(key_status, 0, nkeys);  // a public key's canonicity is reported per item by the encapsulation (status 1)
+        }
+    }
+    if (rc == CIRCL_HIP_OK && hipStreamSynchronize(st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc != CIRCL_HIP_OK) {
+        (void)hipGetLastError();
+        circl_hip_keytable_free(t);
+        return rc;
+    }
+    *out = t;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_mlkem_encaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
+                                     uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!kem_table_ok(t, 0)) return CIRCL_HIP_EPARAM;
+    const int param = t->param;
+    KEM_DISPATCH(encaps_table_dev_impl<2>(t, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_table_dev_impl<3>(t, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 encaps_table_dev_impl<4>(t, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+int circl_hip_mlkem_decaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status,
+                                     size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!kem_table_ok(t, 1)) return CIRCL_HIP_EPARAM;
+    const int param = t->param;
+    KEM_DISPATCH(decaps_table_dev_impl<2>(t, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_table_dev_impl<3>(t, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
+                 decaps_table_dev_impl<4>(t, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
+}
+// host buffers: only the per-item data travel; the keys and what was parsed out of them are already on the table's device
+int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                 size_t n) {
+    if (!kem_table_ok(t, 0)) return CIRCL_HIP_EPARAM;
+    const size_t CT = circl_hip_mlkem_ct_size(t->param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
+    return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {m, 32, true}}, {},
+                        {{ct, CT}, {ss, 32, true}, {status, 1}}, [&](size_t c) { return kem_ws_bytes(c); }, kem_opts(true), [&](Chunk &c) {
+                            return circl_hip_mlkem_encaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                    c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                        });
+}
+int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n) {
+    if (!kem_table_ok(t, 1)) return CIRCL_HIP_EPARAM;
+    const size_t CT = circl_hip_mlkem_ct_size(t->param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
+    return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {ct, CT}}, {},
+                        {{ss, 32, true}, {status, 1}}, [&](size_t c) { return kem_ws_bytes(c); }, kem_opts(false), [&](Chunk &c) {
+                            return circl_hip_mlkem_decaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                    c.cnt, c.ws, c.ws_bytes, c.st);
+                        });
 }
 
 // ---- round-3 Kyber (kem/kyber/kyber{512,768,1024}), SURVEY 8f row f3 ------------------------------------

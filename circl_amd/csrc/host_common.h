@@ -169,6 +169,7 @@ int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size
 
 // host_runtime.hip: two library-owned non-blocking streams of device `dev` for calls that fork internally
 int aux_streams(int dev, hipStream_t (&s)[2]);
+int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *compute);  // the device's shared copy / compute streams
 
 // api_x25519.hip: both X25519 ladders of a hybrid KEM operation (base point and peer point, same scalar) in one launch
 int x25519_pair_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out_base, uint8_t *d_out_shared, uint8_t *d_ok, size_t n,

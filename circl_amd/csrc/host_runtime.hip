@@ -2,6 +2,7 @@
 // (declared in host_common.h).  No compute happens on the CPU here: the threads only copy bytes between the caller's
 // memory and page-locked staging buffers.
 #include "host_common.h"
+#include "keytable.h"
 
 #include <immintrin.h>
 #include <pthread.h>
@@ -388,6 +389,7 @@ SlotPool *slot_pool_of(int dev) {
     if (!g_slot_pools[dev]) g_slot_pools[dev] = new SlotPool;
     return g_slot_pools[dev];
 }
+}  // namespace
 int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *compute) {
     SlotPool *p = slot_pool_of(dev);
     std::call_once(p->copy_once, [&] {
@@ -402,7 +404,6 @@ int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *c
     *compute = p->compute[p->next_compute.fetch_add(1) & 1];
     return CIRCL_HIP_OK;
 }
-}  // namespace
 // two more non-blocking streams per device for device-resident calls that fork internally (batch signing runs its two halves
 // side by side: their latency-bound late rounds fill each other's gaps)
 int aux_streams(int dev, hipStream_t (&s)[2]) {
@@ -817,6 +818,21 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
     g_prof_ms[kernel] = 0;
     g_prof_n[kernel] = 0;
     return CIRCL_HIP_OK;
+}
+
+// keytable.h: a table of private keys is wiped before its memory goes back (the expanded rows are public, the key rows are not)
+void circl_hip_keytable_free(circl_hip_keytable *t) {
+    if (!t || t->magic != kKeytableMagic) return;
+    t->magic = 0;
+    if (ndev() > 0 && t->device >= 0 && t->device < ndev() && hipSetDevice(circl::host::physical_device(t->device)) == hipSuccess) {
+        if (t->d_keys) {
+            if (t->private_keys) (void)hipMemset(t->d_keys, 0, t->keys_bytes);
+            (void)hipFree(t->d_keys);
+        }
+        if (t->d_table) (void)hipFree(t->d_table);
+    }
+    (void)hipGetLastError();
+    delete t;
 }
 
 void *circl_hip_alloc_host(size_t bytes) {

@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     for (int g = 0; g < G::IT; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;  // wave-uniform
-        const size_t kq = KEYED ? (size_t)key_idx[item] : item;  // wave-uniform
+        const size_t kq = KEYED ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item;  // wave-uniform; a table without an index vector: entry 0 for every item
         const uint32_t *irows = KEYED ? key_rows + kq * (size_t)(G::STREAMS * kPackedRowDwords) : rows;
         // ------------------------------ phase 1 ------------------------------
         uint32_t zhat[L][4], chat[4] = {0, 0, 0, 0};

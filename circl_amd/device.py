@@ -59,6 +59,24 @@ class MLKEMDevice:
         nat.check(rc, "mlkem_encaps_shared_dev")
         return ct, ss, status
 
+    def encaps_table(self, table, m, key_idx=None, ct=None, ss=None, status=None):
+        """through a resident key table (hostapi.KeyTable of kind "mlkem-public"); key_idx None: entry 0 for every item"""
+        ct = self.ct if ct is None else ct
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        rc = self.L.circl_hip_mlkem_encaps_table_dev(table.handle, None if key_idx is None else key_idx.data_ptr(), _chk(m, 32), _chk(ct, self.CT),
+                                                     _chk(ss, 32), _chk(status), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mlkem_encaps_table_dev")
+        return ct, ss, status
+
+    def decaps_table(self, table, ct, key_idx=None, ss=None, status=None):
+        ss = self.ss if ss is None else ss
+        status = self.status if status is None else status
+        rc = self.L.circl_hip_mlkem_decaps_table_dev(table.handle, None if key_idx is None else key_idx.data_ptr(), _chk(ct, self.CT), _chk(ss, 32),
+                                                     _chk(status), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mlkem_decaps_table_dev")
+        return ss, status
+
     def decaps(self, dk, ct, ss=None, status=None):
         ss = self.ss if ss is None else ss
         status = self.status if status is None else status
@@ -163,6 +181,14 @@ class MLDSADevice:
         rc = self.L.circl_hip_mldsa_verify_dev(self.param, _chk(pk, self.PK), _chk(sig, self.SIG), self._msg(msg), self.off.data_ptr(), None, None,
                                                _chk(ok), self.n, self.ws.data_ptr(), self.wsb, _stream())
         nat.check(rc, "mldsa_verify_dev")
+        return ok
+
+    def verify_table(self, table, sig, msg, key_idx=None, ok=None):
+        """through a resident key table (hostapi.KeyTable of kind "mldsa-public"); key_idx None: entry 0 for every item"""
+        ok = self.ok if ok is None else ok
+        rc = self.L.circl_hip_mldsa_verify_table_dev(table.handle, None if key_idx is None else key_idx.data_ptr(), _chk(sig, self.SIG), self._msg(msg),
+                                                     self.off.data_ptr(), None, None, _chk(ok), self.n, self.ws.data_ptr(), self.wsb, _stream())
+        nat.check(rc, "mldsa_verify_table_dev")
         return ok
 
     def verify_shared(self, pk1, sig, msg, ok=None):

@@ -267,6 +267,75 @@ def mldsa_verify_keyed(param, pk_table, key_idx, sig, msgs, ctxs=None, device=0)
     return ok
 
 
+class KeyTable:
+    """A parsed-key cache that lives across calls (circl_hip_*_keytable_new): the counterpart of CIRCL's key objects, which keep
+    A^T / H(ek) (ML-KEM) or A / tr (ML-DSA) after unmarshalling.  kind: "mlkem-public", "mlkem-private", "mldsa-public"."""
+
+    def __init__(self, kind, param, keys, device=0):
+        import ctypes as C
+        self.kind, self.param, self.device = kind, param, device
+        self.handle = C.c_void_p()
+        self.key_status = None
+        L = nat.lib()
+        if kind.startswith("mlkem"):
+            EK, DK, _ = KEM_SIZES[param]
+            priv = kind == "mlkem-private"
+            keys = _u8(keys, DK if priv else EK)
+            self.nkeys = len(keys)
+            self.key_status = np.zeros(self.nkeys, np.uint8)
+            nat.check(L.circl_hip_mlkem_keytable_new(param, 1 if priv else 0, _p(keys), self.nkeys, device, _p(self.key_status), C.byref(self.handle)),
+                      "mlkem_keytable_new")
+        else:
+            PK, _ = DSA_SIZES[param]
+            keys = _u8(keys, PK)
+            self.nkeys = len(keys)
+            nat.check(L.circl_hip_mldsa_keytable_new(param, _p(keys), self.nkeys, device, C.byref(self.handle)), "mldsa_keytable_new")
+
+    def close(self):
+        if self.handle:
+            nat.lib().circl_hip_keytable_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _kidx(self, key_idx, n):
+        return None if key_idx is None else _p(_idx(key_idx, n))
+
+    def encaps(self, m, key_idx=None):
+        """item i encapsulates to entry key_idx[i] (None: entry 0) -> ct, ss, status"""
+        _, _, CT = KEM_SIZES[self.param]
+        m = _u8(m, 32)
+        n = len(m)
+        ct, ss, st = np.empty((n, CT), np.uint8), np.empty((n, 32), np.uint8), np.empty(n, np.uint8)
+        nat.check(nat.lib().circl_hip_mlkem_encaps_table(self.handle, self._kidx(key_idx, n), _p(m), _p(ct), _p(ss), _p(st), n), "mlkem_encaps_table")
+        return ct, ss, st
+
+    def decaps(self, ct, key_idx=None):
+        _, _, CT = KEM_SIZES[self.param]
+        ct = _u8(ct, CT)
+        n = len(ct)
+        ss, st = np.empty((n, 32), np.uint8), np.empty(n, np.uint8)
+        nat.check(nat.lib().circl_hip_mlkem_decaps_table(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n), "mlkem_decaps_table")
+        return ss, st
+
+    def verify(self, sig, msgs, ctxs=None, key_idx=None):
+        _, SIG = DSA_SIZES[self.param]
+        sig = _u8(sig, SIG)
+        n = len(sig)
+        assert len(msgs) == n
+        mb, mo = _blob(msgs)
+        ok = np.empty(n, np.uint8)
+        cb, co = _blob(ctxs) if ctxs is not None else (None, None)
+        rc = nat.lib().circl_hip_mldsa_verify_table(self.handle, self._kidx(key_idx, n), _p(sig), _p(mb), _p(mo), _p(cb) if ctxs is not None else None,
+                                                    _p(co) if ctxs is not None else None, _p(ok), n)
+        nat.check(rc, "mldsa_verify_table")
+        return ok
+
+
 def keccak_f1600(states, rounds=24, device=0):
     a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 25).copy()
     nat.check(nat.lib().circl_hip_keccak_f1600(_p(a), len(a), rounds, device), "keccak_f1600")

@@ -154,6 +154,43 @@ int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_
                                      const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n,
                                      void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- key tables that LIVE ACROSS CALLS: the reference's parsed key objects ----------------------
+ * kem.Scheme.UnmarshalBinaryPublicKey / UnmarshalBinaryPrivateKey return objects that keep A^T and H(ek) (kem/mlkem/mlkem768/
+ * kyber.go:39-43, :247-263; the private key's hash check :219-228 happens there); sign.Scheme.UnmarshalBinaryPublicKey keeps A
+ * and tr (sign/mldsa/mldsa65/internal/dilithium.go:114-126).  A circl_hip_keytable is that cache for nkeys keys, built ONCE on
+ * one device: the key bytes, the expanded matrices and the hashes stay resident, and a call moves only its per-item data.
+ * Item i of a call uses entry key_idx[i]; key_idx == NULL: every item uses entry 0 (a table of one key = one key object).
+ * Results are identical to the per-call key-table entry points above.  A Go bridge keeps one table per key object (or per
+ * key set) and frees it from the object's finalizer; a table is immutable and may be used by concurrent calls.
+ *   circl_hip_mlkem_keytable_new : private_keys = 0: rows are encapsulation keys; 1: decapsulation keys, whose stored-hash
+ *       verdicts (0 | 2 = kem.ErrPrivKey) are written to key_status[nkeys] if it is not NULL.  A public key's canonicity is
+ *       reported per item by the encapsulation (status 1 = kem.ErrPubKey), as everywhere in this ABI.
+ *   _dev variants: pointers are device memory on the TABLE's device; workspace = circl_hip_mlkem_workspace_size(param, n) /
+ *       circl_hip_mldsa_workspace_size(param, n) bytes (no table tail: the table brings its own).
+ *   circl_hip_keytable_free wipes the key rows of a private table before releasing them. */
+typedef struct circl_hip_keytable circl_hip_keytable;
+int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device,
+                                 uint8_t *key_status, circl_hip_keytable **out);
+int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out);
+void circl_hip_keytable_free(circl_hip_keytable *table);
+int circl_hip_mlkem_encaps_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct,
+                                 uint8_t *ss, uint8_t *status, size_t n);
+int circl_hip_mlkem_decaps_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss,
+                                 uint8_t *status, size_t n);
+int circl_hip_mldsa_verify_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *sig,
+                                 const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                                 const uint64_t *ctx_off, uint8_t *ok, size_t n);
+int circl_hip_mlkem_encaps_table_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_m,
+                                     uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_workspace,
+                                     size_t workspace_bytes, void *stream);
+int circl_hip_mlkem_decaps_table_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_ct,
+                                     uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_workspace, size_t workspace_bytes,
+                                     void *stream);
+int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_sig,
+                                     const uint8_t *d_msg_blob, const uint64_t *d_msg_off, const uint8_t *d_ctx_blob,
+                                     const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n, void *d_workspace,
+                                     size_t workspace_bytes, void *stream);
+
 /* ---- round-3 Kyber ------------------------------------------------------
  * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in
  * kem/schemes).  param 512 | 768 | 1024; key and ciphertext sizes are those of ML-KEM.  Differences from

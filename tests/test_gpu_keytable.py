@@ -1,0 +1,94 @@
+"""Key tables that live across calls (circl_hip_*_keytable_new, include/circl_hip.h): the reference's parsed key objects.
+kem.Scheme.UnmarshalBinaryPublicKey / UnmarshalBinaryPrivateKey keep A^T and H(ek) in the object (kem/mlkem/mlkem768/kyber.go:39-43,
+:219-228, :247-263), sign.Scheme.UnmarshalBinaryPublicKey keeps A and tr (sign/mldsa/mldsa65/internal/dilithium.go:114-126); every
+later Encapsulate / Decapsulate / Verify on the object reuses them.  Here: a table built once, used by many calls, against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("param", [512, 768, 1024])
+def test_mlkem_tables_match_the_oracle_call_after_call(param):
+    from circl_amd import hostapi
+    rng = np.random.default_rng(param)
+    nkeys = 23
+    ek, dk = orc.mlkem_keygen(param, rng.integers(0, 256, (nkeys, 64), dtype=np.uint8))
+    dk_bad = dk.copy()
+    dk_bad[5, -40] ^= 1                                  # entry 5: stored H(ek) no longer matches (kem.ErrPrivKey)
+    pub = hostapi.KeyTable("mlkem-public", param, ek)
+    prv = hostapi.KeyTable("mlkem-private", param, dk_bad)
+    assert prv.key_status.tolist() == [2 if i == 5 else 0 for i in range(nkeys)]
+    for n in (1, 7, 300, 2500, 40000):                   # small routes, big routes, and a host call of more than one chunk
+        m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        idx = rng.integers(0, nkeys, n).astype(np.uint32)
+        idx[:2] = [nkeys - 1, 0][:min(n, 2)]
+        ct, ss, st = pub.encaps(m, idx)
+        ct0, ss0, _ = orc.mlkem_encaps(param, ek[idx], m)
+        assert (st == 0).all() and (ct == ct0).all() and (ss == ss0).all(), n
+        ct[::3, 11] ^= 8                                  # implicit rejection for every third item
+        got, st = prv.decaps(ct, idx)
+        want, _ = orc.mlkem_decaps(param, dk[idx], ct)
+        bad = idx == 5
+        assert (st[bad] == 2).all() and not got[bad].any() and (st[~bad] == 0).all() and (got[~bad] == want[~bad]).all(), n
+        # no index vector: every item uses entry 0 -- a table of one key object
+        ct1, ss1, st1 = pub.encaps(m)
+        ct10, ss10, _ = orc.mlkem_encaps(param, np.tile(ek[:1], (n, 1)), m)
+        assert (st1 == 0).all() and (ct1 == ct10).all() and (ss1 == ss10).all(), n
+        ct1[::3, 11] ^= 8
+        got, st = prv.decaps(ct1)
+        want, _ = orc.mlkem_decaps(param, np.tile(dk[:1], (n, 1)), ct1)
+        assert (st == 0).all() and (got == want).all(), n
+    # an index beyond the table, a table of the wrong kind
+    with pytest.raises(Exception):
+        pub.encaps(rng.integers(0, 256, (3, 32), dtype=np.uint8), np.array([0, nkeys, 1], np.uint32))
+    with pytest.raises(Exception):
+        prv.encaps(rng.integers(0, 256, (3, 32), dtype=np.uint8))
+    pub.close()
+    prv.close()
+    with pytest.raises(Exception):                       # a freed table is refused, not dereferenced
+        pub.encaps(rng.integers(0, 256, (3, 32), dtype=np.uint8))
+
+
+def test_mlkem_table_reports_a_non_canonical_public_key_per_item():
+    from circl_amd import hostapi
+    rng = np.random.default_rng(9)
+    ek, _ = orc.mlkem_keygen(768, rng.integers(0, 256, (3, 64), dtype=np.uint8))
+    ek[1, 0] = 0xff
+    ek[1, 1] |= 0x0f                                      # first coefficient of entry 1 = 0xfff >= q (cpapke.go:45-55)
+    t = hostapi.KeyTable("mlkem-public", 768, ek)
+    idx = np.array([0, 1, 2, 1, 0], np.uint32)
+    ct, ss, st = t.encaps(rng.integers(0, 256, (5, 32), dtype=np.uint8), idx)
+    assert st.tolist() == [0, 1, 0, 1, 0] and not ct[st == 1].any() and not ss[st == 1].any()
+
+
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+def test_mldsa_table_matches_the_oracle_call_after_call(param):
+    from circl_amd import hostapi
+    rng = np.random.default_rng(70 + param)
+    nkeys = 9
+    r3 = param in (2, 3, 5)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (nkeys, 32), dtype=np.uint8))
+    t = hostapi.KeyTable("mldsa-public", param, pk)
+    for n in (1, 40, 1500):                               # cooperative pre-pass, lane pairs
+        idx = rng.integers(0, nkeys, n).astype(np.uint32)
+        msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 300, n)]
+        if n > 20:
+            msgs[3] = bytes(rng.integers(0, 256, 5000, dtype=np.uint8))  # a long message goes through the pre-pass with the table's tr
+        ctxs = None if r3 else [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 30, n)]
+        sig = hostapi.mldsa_sign(param, sk[idx], msgs, ctxs=ctxs)
+        bad = sig.copy()
+        bad[1::5, 7] ^= 2
+        ok = t.verify(bad, msgs, ctxs=ctxs, key_idx=idx).astype(bool)
+        want = orc.mldsa_verify(param, pk[idx], bad, msgs, ctxs=ctxs).astype(bool)
+        assert (ok == want).all() and ok[0::5].all() and not ok[1::5].any(), n
+        # entry 0 for every item
+        sig0 = hostapi.mldsa_sign(param, np.tile(sk[:1], (n, 1)), msgs, ctxs=ctxs)
+        sig0[2::7, 40] ^= 1
+        ok = t.verify(sig0, msgs, ctxs=ctxs).astype(bool)
+        want = np.ones(n, bool)
+        want[2::7] = False
+        assert (ok == want).all(), n
+    t.close()
