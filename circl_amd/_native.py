@@ -15,7 +15,7 @@ SYMBOLS = [
     "circl_hip_mlkem_encaps_keyed_dev", "circl_hip_mlkem_decaps_keyed_dev",
     "circl_hip_mldsa_verify_keyed", "circl_hip_mldsa_keyed_workspace_size", "circl_hip_mldsa_verify_keyed_dev",
     "circl_hip_mlkem_keytable_new", "circl_hip_mldsa_keytable_new", "circl_hip_keytable_free", "circl_hip_mlkem_encaps_table", "circl_hip_mlkem_decaps_table",
-    "circl_hip_mldsa_verify_table", "circl_hip_mlkem_encaps_table_dev", "circl_hip_mlkem_decaps_table_dev", "circl_hip_mldsa_verify_table_dev",
+    "circl_hip_mldsa_verify_table", "circl_hip_mldsa_privkey_new", "circl_hip_mldsa_sign_table", "circl_hip_mldsa_sign_table_dev", "circl_hip_mlkem_encaps_table_dev", "circl_hip_mlkem_decaps_table_dev", "circl_hip_mldsa_verify_table_dev",
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
     "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
     "circl_hip_mldsa_keygen", "circl_hip_mldsa_keygen_dev",
@@ -119,6 +119,9 @@ def lib():
         L.circl_hip_mlkem_encaps_table_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mlkem_decaps_table_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_mldsa_verify_table_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_mldsa_privkey_new.argtypes = [i, vp, i, C.POINTER(vp)]
+        L.circl_hip_mldsa_sign_table.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz]
+        L.circl_hip_mldsa_sign_table_dev.argtypes = [vp, vp, vp, vp, vp, vp, i, vp, sz, vp, sz, vp]
         L.circl_hip_kyber_keygen.argtypes = [i, vp, vp, vp, sz, i]
         L.circl_hip_kyber_encaps.argtypes = [i, vp, vp, vp, vp, sz, i]
         L.circl_hip_kyber_decaps.argtypes = [i, vp, vp, vp, sz, i]

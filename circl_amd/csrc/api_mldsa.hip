@@ -413,6 +413,10 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
 
 // Phase-split signing: rounds over the list of unsigned items (mldsa_sign_batched.h), driven by the device: the host
 // enqueues a fixed schedule of rounds plus the persistent tail and reads nothing back, so the call is asynchronous.
+// A private key prepared once (circl_hip_mldsa_privkey_new): its entry point parks the table here for the length of its call, and the
+// round signer takes A and the transformed secrets from it instead of expanding them (thread-local: calls are per thread)
+thread_local const circl_hip_keytable *tl_sign_prepared = nullptr;
+
 template <int MODE>
 int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                             const uint64_t *ctx_off, const uint8_t *rnd, int internal, uint8_t *sig, size_t n, void *ws, hipStream_t st,
@@ -425,9 +429,15 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     uint8_t *base = static_cast<uint8_t *>(ws);
     SignState S;
     S.shared = shared ? 1u : 0u;
+    const circl_hip_keytable *prep = shared ? tl_sign_prepared : nullptr;
     S.mr = base + lay.o_mr;
     S.A = reinterpret_cast<uint32_t *>(base + lay.o_A);
     S.sec = reinterpret_cast<uint32_t *>(base + lay.o_sec);
+    if (prep) {
+        S.A = reinterpret_cast<uint32_t *>(prep->d_table);
+        S.sec = reinterpret_cast<uint32_t *>(prep->d_table + up256(SB<MODE>::A_BYTES));
+        S.shared = 2u;
+    }
     S.y = reinterpret_cast<uint32_t *>(base + lay.o_y);
     S.w0 = reinterpret_cast<uint32_t *>(base + lay.o_w0);
     S.muw1 = base + lay.o_muw1;
@@ -475,7 +485,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         const size_t nkeys = shared ? 1 : n;
-        hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
+        if (!prep) hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n, k0);
     }
     // grids: the kernels loop over the device-side count, so any grid is correct; the schedule's upper estimate of a
@@ -528,7 +538,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     // signatures: nothing key-equivalent stays behind in the caller's workspace (the matrix rows are public).
     HIP_TRY(hipMemsetAsync(S.mr, 0, up256(128 * n), st));
     HIP_TRY(hipMemsetAsync(tail_scratch, 0, lay.tail_units * SG<MODE>::SCRATCH_BYTES, st));
-    HIP_TRY(hipMemsetAsync(S.sec, 0, lay.o_secret_end - lay.o_sec, st));
+    HIP_TRY(hipMemsetAsync(base + lay.o_sec, 0, lay.o_secret_end - lay.o_sec, st));  // (the workspace's; a prepared key's table stays)
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -640,6 +650,31 @@ size_t mldsa_sign_ws_any(int param, size_t n) {
     DSA_SWITCH(param, CALL)
 #undef CALL
     return 0;
+}
+
+// the table of ONE prepared private key: [A: K L packed rows][s1-hat, s2-hat, t0-hat: L + 2 K packed rows][set-up scratch], made by the
+// round signer's own set-up kernels
+template <int MODE> int mldsa_privkey_build(circl_hip_keytable *t, const uint8_t *sk, hipStream_t st) {
+    using namespace circl::mldsa;
+    using B = SB<MODE>;
+    constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
+    t->table_bytes = up256(B::A_BYTES) + up256(B::SEC_BYTES) + 1024;
+    if (hipMalloc(reinterpret_cast<void **>(&t->d_keys), t->keys_bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&t->d_table), t->table_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return CIRCL_HIP_ENOMEM;
+    }
+    HIP_TRY(hipMemcpyAsync(t->d_keys, sk, KG<MODE>::SK, hipMemcpyHostToDevice, st));
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(t->d_table + up256(B::A_BYTES) + up256(B::SEC_BYTES));
+    SignState S{};
+    S.shared = 1u;
+    S.A = reinterpret_cast<uint32_t *>(t->d_table);
+    S.sec = reinterpret_cast<uint32_t *>(t->d_table + up256(B::A_BYTES));
+    S.attempts = scratch; S.best = scratch + 1; S.list[0] = scratch + 64; S.list[1] = scratch + 128; S.count = scratch + 8; S.kk = scratch + 10;
+    hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((K * L + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, S, (size_t)1);
+    hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3(1), dim3(64), 0, st, (const uint8_t *)t->d_keys, S, (size_t)1, 1u);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
 }
 
 int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
@@ -777,6 +812,65 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
                         dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
                             return circl_hip_mldsa_verify_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.in[0], c.blob[0], c.off[0],
                                                                     c.blob[1], c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                        });
+}
+
+// ---- ONE private key prepared once: A and the NTT-domain secrets of the reference's parsed PrivateKey (internal/dilithium.go:149-179) ----
+int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    const size_t SK = circl_hip_mldsa_sk_size(param);
+    if (!SK || !sk || !out) return CIRCL_HIP_EPARAM;
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
+    HIP_TRY(hipSetDevice(physical_device(device)));
+    circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
+    if (!t) return CIRCL_HIP_ENOMEM;
+    t->magic = kKeytableMagic; t->family = 2; t->param = param; t->device = device; t->private_keys = 1; t->nkeys = 1; t->row = SK;
+    t->keys_bytes = up256(SK + 16);
+    hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
+    int rc = pipeline_streams(device, &h2d, &d2h, &st);
+#define CALL(M) mldsa_privkey_build<M>(t, sk, st)
+    if (rc == CIRCL_HIP_OK)
+        rc = [&]() -> int {
+            DSA_SWITCH(param, CALL)
+            return CIRCL_HIP_EPARAM;
+        }();
+#undef CALL
+    if (rc == CIRCL_HIP_OK && hipStreamSynchronize(st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc != CIRCL_HIP_OK) {
+        (void)hipGetLastError();
+        circl_hip_keytable_free(t);
+        return rc;
+    }
+    *out = t;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_mldsa_sign_table_dev(const circl_hip_keytable *t, const uint8_t *d_msg_blob, const uint64_t *d_msg_off, const uint8_t *d_ctx_blob,
+                                   const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n, void *d_ws, size_t ws_bytes,
+                                   void *stream) {
+    if (!t || t->magic != kKeytableMagic || t->family != 2 || !t->private_keys) return CIRCL_HIP_EPARAM;
+    struct Park {  // (restored on every path)
+        explicit Park(const circl_hip_keytable *p) { tl_sign_prepared = p; }
+        ~Park() { tl_sign_prepared = nullptr; }
+    } park(t);
+    return mldsa_sign_dev_any(t->param, t->d_keys, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, d_rnd, internal, d_sig, n, d_ws, ws_bytes,
+                              static_cast<hipStream_t>(stream), true);
+}
+int circl_hip_mldsa_sign_table(const circl_hip_keytable *t, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
+                               const uint8_t *rnd, uint8_t *sig, size_t n) {
+    if (!t || t->magic != kKeytableMagic || t->family != 2 || !t->private_keys) return CIRCL_HIP_EPARAM;
+    const int param = t->param;
+    const size_t SIG = circl_hip_mldsa_sig_size(param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (check_contexts(param, ctx_blob, ctx_off, n) != CTX_OK) return CIRCL_HIP_EPARAM;  // sign.ErrContextTooLong / ErrContextNotSupported
+    const PipeOpts opts = dsa_opts(size_t(1) << 13, true, /*depth=*/3);
+    std::vector<uint8_t> zeros;
+    if (!rnd) zeros.assign(32 * std::min(n, opts.chunk_items), 0);  // deterministic signing: 32 zero bytes per item
+    std::vector<HIn> ins;
+    ins.push_back(rnd ? HIn{rnd, 32, true} : HIn{zeros.data(), zeros.size(), false, true});
+    return run_pipeline(t->device, n, ins, {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{sig, SIG}},
+                        [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
+                            return circl_hip_mldsa_sign_table_dev(t, c.blob[0], c.off[0], c.blob[1], c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
                         });
 }
 

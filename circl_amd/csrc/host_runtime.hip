@@ -829,7 +829,10 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
             if (t->private_keys) (void)hipMemset(t->d_keys, 0, t->keys_bytes);
             (void)hipFree(t->d_keys);
         }
-        if (t->d_table) (void)hipFree(t->d_table);
+        if (t->d_table) {
+            if (t->private_keys && t->family == 2) (void)hipMemset(t->d_table, 0, t->table_bytes);  // ML-DSA: the transformed secrets
+            (void)hipFree(t->d_table);
+        }
     }
     (void)hipGetLastError();
     delete t;

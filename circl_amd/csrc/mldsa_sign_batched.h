@@ -62,7 +62,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t *list[2];      // active lists of entries: item | off << kEntryShift; round r reads list[r & 1]
     uint32_t *count;        // [0], [1]: list lengths (round r reads count[r & 1], its commit kernel fills count[(r + 1) & 1])
     uint32_t *kk;           // [0], [1]: entries per item of the list with the same parity
-    uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once)
+    uint32_t shared;        // 1: every item signs with the ONE private key at sk (A and the NTT-domain secrets exist once); 2: ... and they are ready-made (key table)
     uint32_t spec_target;   // rounds speculate (k > 1) once at most this many entries would result
     uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
     uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
@@ -170,7 +170,9 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
             c[r] = v < 0 ? Q + v : (uint32_t)v;
         }
     };
-    const int npoly = (st.shared && item) ? 0 : L + 2 * K;  // shared key: workgroup 0 transforms the one key
+    // shared key: workgroup 0 transforms the one key; shared == 2: A and the transformed secrets come ready-made from a key table
+    // that lives across calls (keytable.h) -- nothing to transform, only the lists to set up
+    const int npoly = (st.shared == 2 || (st.shared && item)) ? 0 : L + 2 * K;
     Raw raw;
     if (npoly) fetch(raw, 0);
 #pragma unroll 1

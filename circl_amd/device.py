@@ -176,6 +176,16 @@ class MLDSADevice:
         nat.check(rc, "mldsa_sign_dev")
         return sig
 
+    def sign_table(self, table, msg, sig=None, rnd=None):
+        """with a private key prepared once (hostapi.KeyTable of kind "mldsa-private")"""
+        assert self.sws is not None, "construct with sign=True"
+        sig = torch.empty(self.n * self.SIG + 16, dtype=torch.uint8, device=msg.device)[:self.n * self.SIG].view(self.n, self.SIG) if sig is None else sig
+        rnd = self.rnd0 if rnd is None else rnd
+        rc = self.L.circl_hip_mldsa_sign_table_dev(table.handle, self._msg(msg), self.off.data_ptr(), None, None, _chk(rnd, 32), 0, _chk(sig, self.SIG), self.n,
+                                                   self.sws.data_ptr(), self.swsb, _stream())
+        nat.check(rc, "mldsa_sign_table_dev")
+        return sig
+
     def verify(self, pk, sig, msg, ok=None):
         ok = self.ok if ok is None else ok
         rc = self.L.circl_hip_mldsa_verify_dev(self.param, _chk(pk, self.PK), _chk(sig, self.SIG), self._msg(msg), self.off.data_ptr(), None, None,

@@ -269,7 +269,7 @@ def mldsa_verify_keyed(param, pk_table, key_idx, sig, msgs, ctxs=None, device=0)
 
 class KeyTable:
     """A parsed-key cache that lives across calls (circl_hip_*_keytable_new): the counterpart of CIRCL's key objects, which keep
-    A^T / H(ek) (ML-KEM) or A / tr (ML-DSA) after unmarshalling.  kind: "mlkem-public", "mlkem-private", "mldsa-public"."""
+    A^T / H(ek) (ML-KEM) or A / tr (ML-DSA) after unmarshalling.  kind: "mlkem-public", "mlkem-private", "mldsa-public", "mldsa-private" (one key)."""
 
     def __init__(self, kind, param, keys, device=0):
         import ctypes as C
@@ -285,6 +285,11 @@ class KeyTable:
             self.key_status = np.zeros(self.nkeys, np.uint8)
             nat.check(L.circl_hip_mlkem_keytable_new(param, 1 if priv else 0, _p(keys), self.nkeys, device, _p(self.key_status), C.byref(self.handle)),
                       "mlkem_keytable_new")
+        elif kind == "mldsa-private":
+            keys = _u8(keys, nat.lib().circl_hip_mldsa_sk_size(param))
+            assert len(keys) == 1, "one private key per table"
+            self.nkeys = 1
+            nat.check(L.circl_hip_mldsa_privkey_new(param, _p(keys), device, C.byref(self.handle)), "mldsa_privkey_new")
         else:
             PK, _ = DSA_SIZES[param]
             keys = _u8(keys, PK)
@@ -321,6 +326,19 @@ class KeyTable:
         ss, st = np.empty((n, 32), np.uint8), np.empty(n, np.uint8)
         nat.check(nat.lib().circl_hip_mlkem_decaps_table(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n), "mlkem_decaps_table")
         return ss, st
+
+    def sign(self, msgs, ctxs=None, rnd=None):
+        """scheme.Sign with the prepared private key -> (n, SIG)"""
+        _, SIG = DSA_SIZES[self.param]
+        n = len(msgs)
+        mb, mo = _blob(msgs)
+        sig = np.empty((n, SIG), np.uint8)
+        cb, co = _blob(ctxs) if ctxs is not None else (None, None)
+        r = None if rnd is None else _u8(rnd, 32)
+        rc = nat.lib().circl_hip_mldsa_sign_table(self.handle, _p(mb), _p(mo), _p(cb) if ctxs is not None else None, _p(co) if ctxs is not None else None,
+                                                  None if r is None else _p(r), _p(sig), n)
+        nat.check(rc, "mldsa_sign_table")
+        return sig
 
     def verify(self, sig, msgs, ctxs=None, key_idx=None):
         _, SIG = DSA_SIZES[self.param]

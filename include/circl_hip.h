@@ -172,6 +172,15 @@ typedef struct circl_hip_keytable circl_hip_keytable;
 int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device,
                                  uint8_t *key_status, circl_hip_keytable **out);
 int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out);
+/* ONE ML-DSA private key prepared once -- A and the NTT-domain s1, s2, t0 of the reference's parsed PrivateKey (sign/mldsa/mldsa65/
+ * internal/dilithium.go:149-179) -- then any number of scheme.Sign calls with it: circl_hip_mldsa_sign_table[_dev] = circl_hip_mldsa_
+ * sign_shared[_dev] without the per-call ExpandA and transforms (workspace: circl_hip_mldsa_sign_workspace_size(param, n)). */
+int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out);
+int circl_hip_mldsa_sign_table(const circl_hip_keytable *table, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
+                               const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n);
+int circl_hip_mldsa_sign_table_dev(const circl_hip_keytable *table, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                                   const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig,
+                                   size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 void circl_hip_keytable_free(circl_hip_keytable *table);
 int circl_hip_mlkem_encaps_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct,
                                  uint8_t *ss, uint8_t *status, size_t n);

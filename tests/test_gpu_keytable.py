@@ -92,3 +92,27 @@ def test_mldsa_table_matches_the_oracle_call_after_call(param):
         want[2::7] = False
         assert (ok == want).all(), n
     t.close()
+
+
+@pytest.mark.parametrize("param", [44, 65, 87, 3])
+def test_mldsa_prepared_private_key_signs_like_the_oracle(param):
+    # the parsed PrivateKey of the reference keeps A and the NTT-domain s1, s2, t0 (internal/dilithium.go:149-179): prepared once
+    # here, then every call signs with it -- deterministic and hedged, contexts, short and long messages, small and larger batches
+    from circl_amd import hostapi
+    rng = np.random.default_rng(900 + param)
+    r3 = param in (2, 3, 5)
+    pk, sk = orc.mldsa_keygen(param, rng.integers(0, 256, (1, 32), dtype=np.uint8))
+    t = hostapi.KeyTable("mldsa-private", param, sk)
+    for n in (1, 33, 700):
+        msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 200, n)]
+        if n > 20:
+            msgs[5] = bytes(rng.integers(0, 256, 4000, dtype=np.uint8))
+        ctxs = None if r3 else [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 40, n)]
+        rnd = None if r3 else rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        if rnd is not None:
+            rnd[::2] = 0
+        got = t.sign(msgs, ctxs=ctxs, rnd=rnd)
+        want = orc.mldsa_sign(param, np.tile(sk, (n, 1)), msgs, ctxs=ctxs, rnd=rnd)
+        assert (got == want).all(), n
+        assert hostapi.mldsa_verify_shared(param, pk, got, msgs, ctxs=ctxs).all()
+    t.close()

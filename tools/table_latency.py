@@ -32,6 +32,7 @@ prv = hostapi.KeyTable("mlkem-private", 768, dk1.cpu().numpy())
 dg = cdev.MLDSADevice(65, 1, "cuda", sign=True)
 pk1, sk1 = dg.keygen(torch.randint(0, 256, (1, 32), dtype=torch.uint8, device="cuda", generator=g))
 vt = hostapi.KeyTable("mldsa-public", 65, pk1.cpu().numpy())
+st_ = hostapi.KeyTable("mldsa-private", 65, sk1.cpu().numpy())
 for logn in (0, 6, 10, 12, 14, 16, 18):
     n = 1 << logn
     eng = cdev.MLKEMDevice(768, n)
@@ -52,4 +53,8 @@ for logn in (0, 6, 10, 12, 14, 16, 18):
         torch.cuda.synchronize()
         assert bool(ok.all())
         line += f" | ML-DSA-65 verify: {timed(lambda: d.verify_shared(pk1, sig, msg)):7.1f} -> {timed(lambda: d.verify_table(vt, sig, msg)):7.1f} us"
+        sig2 = d.sign_table(st_, msg)
+        torch.cuda.synchronize()
+        assert bool((sig2 == sig).all())
+        line += f" | sign: {timed(lambda: d.sign(sk1, msg, sig, shared=True), 10):7.1f} -> {timed(lambda: d.sign_table(st_, msg, sig), 10):7.1f} us"
     print(line)
