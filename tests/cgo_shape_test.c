@@ -56,6 +56,27 @@ static void kem_round_trip(int param, size_t n, int device) {
     CHECK(memcmp(ss2, ss3, 32 * n) == 0);
     uint32_t bad_idx[1] = {(uint32_t)nk};
     CHECK(circl_hip_mlkem_encaps_keyed(param, ek, nk, bad_idx, m, ct2, ss3, st, 1, device) == CIRCL_HIP_EPARAM);
+    /* go/kem/mlkem/hipbatch/keytable.go: the same table kept resident across calls (one device: logical device 0) */
+    circl_hip_keytable *pub = NULL, *prv = NULL;
+    uint8_t *kst = slice(nk, 3);
+    CHECK(circl_hip_mlkem_keytable_new(param, 0, ek, nk, 0, NULL, &pub) == 0 && pub != NULL);
+    CHECK(circl_hip_mlkem_keytable_new(param, 1, dk, nk, 0, kst, &prv) == 0 && prv != NULL);
+    for (size_t i = 0; i < nk; i++) CHECK(kst[i] == 0);
+    for (int rep = 0; rep < 2; rep++) { /* call after call on one table */
+        memset(ct3, 0, CT * n);
+        CHECK(circl_hip_mlkem_encaps_table(pub, idx, m, ct3, ss4, st, n) == 0);
+        CHECK(memcmp(ct2, ct3, CT * n) == 0 && memcmp(ss3, ss4, 32 * n) == 0);
+        CHECK(circl_hip_mlkem_decaps_table(prv, idx, ct3, ss2, NULL, n) == 0);
+        CHECK(memcmp(ss2, ss3, 32 * n) == 0);
+    }
+    CHECK(circl_hip_mlkem_encaps_table(pub, NULL /* nil index slice: entry 0 */, m, ct3, ss4, st, n) == 0);
+    CHECK(circl_hip_mlkem_decaps_table(prv, NULL, ct3, ss2, st, n) == 0);
+    CHECK(memcmp(ss2, ss4, 32 * n) == 0);
+    CHECK(circl_hip_mlkem_encaps_table(pub, bad_idx, m, ct2, ss3, st, 1) == CIRCL_HIP_EPARAM);
+    CHECK(circl_hip_mlkem_encaps_table(prv, NULL, m, ct2, ss3, st, 1) == CIRCL_HIP_EPARAM); /* a private table does not encapsulate */
+    circl_hip_keytable_free(pub);
+    circl_hip_keytable_free(prv);
+    circl_hip_keytable_free(NULL);
 }
 
 static void dsa_round_trip(int param, size_t n, int device) {
@@ -79,6 +100,22 @@ static void dsa_round_trip(int param, size_t n, int device) {
     for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i; /* the table is the whole key array here */
     CHECK(circl_hip_mldsa_verify_keyed(param, pk, n, idx, sig, mblob, moff, cblob, coff, ok, n, device) == 0);
     for (size_t i = 0; i < n; i++) CHECK(ok[i] == (i == n / 2 ? 0 : 1));
+    /* go/sign/mldsa/hipbatch/keytable.go: resident public keys, one prepared private key */
+    circl_hip_keytable *vt = NULL, *st1 = NULL;
+    CHECK(circl_hip_mldsa_keytable_new(param, pk, n, 0, &vt) == 0 && vt != NULL);
+    memset(ok, 7, n);
+    CHECK(circl_hip_mldsa_verify_table(vt, idx, sig, mblob, moff, cblob, coff, ok, n) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(ok[i] == (i == n / 2 ? 0 : 1));
+    CHECK(circl_hip_mldsa_privkey_new(param, sk, 0, &st1) == 0 && st1 != NULL);
+    uint8_t *sig1 = slice(SIG * n, 11), *sig2 = slice(SIG * n, 13);
+    CHECK(circl_hip_mldsa_sign_table(st1, mblob, moff, cblob, coff, NULL, sig1, n) == 0);
+    CHECK(circl_hip_mldsa_sign_shared(param, sk, mblob, moff, cblob, coff, NULL, sig2, n, 0) == 0);
+    CHECK(memcmp(sig1, sig2, SIG * n) == 0);
+    CHECK(circl_hip_mldsa_verify_table(vt, NULL /* entry 0 */, sig1, mblob, moff, cblob, coff, ok, n) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
+    CHECK(circl_hip_mldsa_sign_table(vt, mblob, moff, cblob, coff, NULL, sig1, n) == CIRCL_HIP_EPARAM); /* a public table does not sign */
+    circl_hip_keytable_free(vt);
+    circl_hip_keytable_free(st1);
 }
 
 /* go/kem/hybrid/hipbatch + go/dh/x25519/hipbatch: packed keys / ciphertexts as byte-aligned sub-slices, NULL status */
