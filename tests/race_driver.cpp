@@ -50,6 +50,27 @@ struct Kem {
         CHECK(circl_hip_mlkem_decaps(p, dk.data(), ct.data(), ssd.data(), st.data(), n, 0) == 0);
         CHECK(ss == ssd);
     }
+    // one resident table shared by every caller thread (tables are immutable: concurrent calls are allowed)
+    circl_hip_keytable *pub = nullptr, *prv = nullptr;
+    std::vector<uint32_t> idx;
+    std::vector<uint8_t> ct_t, ss_t;
+    void tables() {
+        const size_t nk = n < 9 ? n : 9;
+        CHECK(circl_hip_mlkem_keytable_new(param, 0, ek.data(), nk, 0, nullptr, &pub) == 0);
+        CHECK(circl_hip_mlkem_keytable_new(param, 1, dk.data(), nk, 0, nullptr, &prv) == 0);
+        idx.resize(n);
+        for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)((i * 7) % nk);
+        ct_t.resize(CT * n); ss_t.resize(32 * n);
+        std::vector<uint8_t> st_t(n);
+        CHECK(circl_hip_mlkem_encaps_table(pub, idx.data(), m.data(), ct_t.data(), ss_t.data(), st_t.data(), n) == 0);
+    }
+    void again_tables() const {
+        std::vector<uint8_t> ct2(CT * n), ss2(32 * n), ss3(32 * n), st2(n);
+        CHECK(circl_hip_mlkem_encaps_table(pub, idx.data(), m.data(), ct2.data(), ss2.data(), st2.data(), n) == 0);
+        CHECK(ct2 == ct_t && ss2 == ss_t);
+        CHECK(circl_hip_mlkem_decaps_table(prv, idx.data(), ct_t.data(), ss3.data(), nullptr, n) == 0);
+        CHECK(ss3 == ss_t);
+    }
     void again(int device) const {
         std::vector<uint8_t> ek2(EK * n), dk2(DK * n), ct2(CT * n), ss2(32 * n), ss3(32 * n), st2(n);
         CHECK(circl_hip_mlkem_keygen(param, seed.data(), ek2.data(), dk2.data(), n, device) == 0);
@@ -117,7 +138,8 @@ int main(int argc, char **argv) {
     const int nd = circl_hip_init();
     if (nd <= 0) { fprintf(stderr, "race_driver: no HIP device\n"); return 2; }
     printf("race_driver: %d (logical) devices, %d callers x %d rounds, %zu ML-KEM items, %zu ML-DSA items\n", nd, callers, rounds, n_kem, n_dsa);
-    const Kem kem768(768, n_kem), kem1024(1024, n_kem / 4 + 3);
+    Kem kem768(768, n_kem), kem1024(1024, n_kem / 4 + 3);
+    kem768.tables();
     const Dsa dsa65(65, n_dsa), dsa44(44, 9);  // 9 items: shards below the 16-item switch of the signer, and empty shards
     const Hyb xwing(1, n_kem / 8 + 5);
     circl_hip_profile_enable(1);  // the profiling records are shared state too
@@ -130,10 +152,10 @@ int main(int argc, char **argv) {
             for (int r = 0; r < rounds; r++) {
                 const int device = (c + r) % 3 == 2 ? nd - 1 : CIRCL_HIP_ALL_DEVICES;  // mostly all devices; now and then one device alone
                 switch ((c + r) % 4) {
-                case 0: kem768.again(device); break;
+                case 0: kem768.again(device); kem768.again_tables(); break;
                 case 1: dsa65.again(device); dsa44.again(CIRCL_HIP_ALL_DEVICES); break;
                 case 2: kem1024.again(device); xwing.again(device); break;
-                case 3: kem768.again(device); dsa44.again(device); break;
+                case 3: kem768.again(device); dsa44.again(device); kem768.again_tables(); break;
                 }
                 // an error path in the middle of everything: the Drain guard must give its slots back
                 uint8_t junk[64] = {0};
@@ -143,6 +165,8 @@ int main(int argc, char **argv) {
         });
     }
     for (auto &t : th) t.join();
+    circl_hip_keytable_free(kem768.pub);
+    circl_hip_keytable_free(kem768.prv);
     double ms = 0;
     uint64_t launches = 0;
     for (int k = 0; k < CIRCL_HIP_KERNEL_COUNT; k++) {
