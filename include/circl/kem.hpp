@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <random>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -51,10 +52,16 @@ struct ErrDevice : Error { explicit ErrDevice(const std::string &m) : Error("cir
 
 class Scheme;
 
+// A key object made by UnmarshalBinary* carries what the reference's parsed objects carry (A^T, H(ek), the hash-check verdict:
+// kem/mlkem/mlkem768/kyber.go:39-43, :219-228, :247-263) as a resident one-key table on the scheme's device
+// (circl_hip_mlkem_keytable_new); copies of the object share it, the last one frees it.  Objects made by DeriveKeyPair carry
+// none and go through the packed bytes, as before.
+using ResidentKey = std::shared_ptr<circl_hip_keytable>;
 class PublicKey {
   public:
     const Scheme *scheme = nullptr;
     Bytes packed;  // MarshalBinary form
+    ResidentKey resident;
     Bytes MarshalBinary() const { return packed; }
     bool Equal(const PublicKey &o) const { return scheme == o.scheme && packed == o.packed; }
 };
@@ -62,6 +69,7 @@ class PrivateKey {
   public:
     const Scheme *scheme = nullptr;
     Bytes packed;
+    ResidentKey resident;
     Bytes MarshalBinary() const { return packed; }
     bool Equal(const PrivateKey &o) const { return scheme == o.scheme && packed == o.packed; }
     PublicKey Public() const;
@@ -92,22 +100,23 @@ class Scheme {
 
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
         if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
-        if (r3_) return PublicKey{this, buf};  // kem/kyber/kyber768/kyber.go:248-262: non-canonical encodings are accepted
-        // canonical check == cpapke.go:45-55; done on the device by an encapsulation's status byte
+        if (r3_) return PublicKey{this, buf, nullptr};  // kem/kyber/kyber768/kyber.go:248-262: non-canonical encodings are accepted
+        // parse once: the key, A^T and H(ek) stay on the device with the object.  The canonical check == cpapke.go:45-55 is the
+        // status byte of an encapsulation to the resident key
+        PublicKey pk{this, buf, resident_key(buf, 0)};
         Bytes ct(CiphertextSize()), ss(32), m(32, 0);
         uint8_t st = 0;
-        check(circl_hip_mlkem_encaps(param_, buf.data(), m.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        check(circl_hip_mlkem_encaps_table(pk.resident.get(), nullptr, m.data(), ct.data(), ss.data(), &st, 1));
         if (st == CIRCL_HIP_ITEM_ERR_PUBKEY) throw ErrPubKey();
-        return PublicKey{this, buf};
+        return pk;
     }
     PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
         if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
-        if (r3_) return PrivateKey{this, buf};  // kyber.go:215-232: no hash check
-        Bytes ct(CiphertextSize(), 0), ss(32);
+        if (r3_) return PrivateKey{this, buf, nullptr};  // kyber.go:215-232: no hash check
         uint8_t st = 0;
-        check(circl_hip_mlkem_decaps(param_, buf.data(), ct.data(), ss.data(), &st, 1, dev1()));
+        PrivateKey sk{this, buf, resident_key(buf, 1, &st)};  // the stored-hash check (kyber.go:219-228) is the table's verdict
         if (st == CIRCL_HIP_ITEM_ERR_PRIVKEY) throw ErrPrivKey();
-        return PrivateKey{this, buf};
+        return sk;
     }
 
     std::pair<Bytes, Bytes> EncapsulateDeterministically(const PublicKey &pk, const Bytes &seed) const {
@@ -116,6 +125,7 @@ class Scheme {
         Bytes ct(CiphertextSize()), ss(32);
         uint8_t st = 0;
         if (r3_) check(circl_hip_kyber_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), 1, dev1()));
+        else if (pk.resident) check(circl_hip_mlkem_encaps_table(pk.resident.get(), nullptr, seed.data(), ct.data(), ss.data(), &st, 1));
         else check(circl_hip_mlkem_encaps(param_, pk.packed.data(), seed.data(), ct.data(), ss.data(), &st, 1, dev1()));
         if (st) throw ErrPubKey();
         return {ct, ss};
@@ -129,6 +139,7 @@ class Scheme {
         Bytes ss(32);
         uint8_t st = 0;
         if (r3_) check(circl_hip_kyber_decaps(param_, sk.packed.data(), ct.data(), ss.data(), 1, dev1()));
+        else if (sk.resident) check(circl_hip_mlkem_decaps_table(sk.resident.get(), nullptr, ct.data(), ss.data(), &st, 1));
         else check(circl_hip_mlkem_decaps(param_, sk.packed.data(), ct.data(), ss.data(), &st, 1, dev1()));
         if (st) throw ErrPrivKey();
         return ss;
@@ -153,12 +164,14 @@ class Scheme {
             EncapsulateBatch(eks.data(), seeds, cts, sss, status, n);
             return;
         }
-        check(circl_hip_mlkem_encaps_shared(param_, pk.packed.data(), seeds, cts, sss, status, n, device));
+        if (pk.resident) check(circl_hip_mlkem_encaps_table(pk.resident.get(), nullptr, seeds, cts, sss, status, n));  // (on the object's device)
+        else check(circl_hip_mlkem_encaps_shared(param_, pk.packed.data(), seeds, cts, sss, status, n, device));
     }
     // n ciphertexts for ONE private key (ML-KEM only)
     void DecapsulateSharedKeyBatch(const PrivateKey &sk, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
         if (sk.scheme != this || r3_) throw ErrTypeMismatch();
-        check(circl_hip_mlkem_decaps_shared(param_, sk.packed.data(), cts, sss, status, n, device));
+        if (sk.resident) check(circl_hip_mlkem_decaps_table(sk.resident.get(), nullptr, cts, sss, status, n));
+        else check(circl_hip_mlkem_decaps_shared(param_, sk.packed.data(), cts, sss, status, n, device));
     }
     void DecapsulateBatch(const uint8_t *dks, const uint8_t *cts, uint8_t *sss, uint8_t *status, size_t n) const {
         if (r3_) {
@@ -177,6 +190,11 @@ class Scheme {
     const char *name_;
     bool r3_;
     int dev1() const { return device < 0 ? 0 : device; }
+    ResidentKey resident_key(const Bytes &buf, int private_key, uint8_t *verdict = nullptr) const {
+        circl_hip_keytable *t = nullptr;
+        check(circl_hip_mlkem_keytable_new(param_, private_key, buf.data(), 1, dev1(), verdict, &t));
+        return ResidentKey(t, circl_hip_keytable_free);
+    }
     static void check(int rc) {
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("error ") + std::to_string(rc) + " " + circl_hip_last_error());
     }
@@ -190,7 +208,7 @@ class Scheme {
 
 inline PublicKey PrivateKey::Public() const {
     const int k = (scheme->PublicKeySize() - 32) / 384;
-    return PublicKey{scheme, Bytes(packed.begin() + 384 * k, packed.begin() + 384 * k + scheme->PublicKeySize())};
+    return PublicKey{scheme, Bytes(packed.begin() + 384 * k, packed.begin() + 384 * k + scheme->PublicKeySize()), nullptr};
 }
 
 // kem/schemes/schemes.go:35-75

@@ -16,6 +16,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -38,14 +39,20 @@ struct SignatureOpts {
 };
 
 class Scheme;
+// A key object made by UnmarshalBinary* carries what the reference's parsed objects carry -- A and tr for a public key, A and the
+// NTT-domain s1, s2, t0 for a private key (sign/mldsa/mldsa65/internal/dilithium.go:114-126, :149-179) -- as a resident table on the
+// scheme's device (circl_hip_mldsa_keytable_new / circl_hip_mldsa_privkey_new); copies share it, the last one frees (and wipes) it.
+using ResidentKey = std::shared_ptr<circl_hip_keytable>;
 struct PublicKey {
     const Scheme *scheme = nullptr;
     Bytes packed;
+    ResidentKey resident;
     Bytes MarshalBinary() const { return packed; }
 };
 struct PrivateKey {
     const Scheme *scheme = nullptr;
     Bytes packed;
+    ResidentKey resident;
     Bytes MarshalBinary() const { return packed; }
 };
 
@@ -63,11 +70,15 @@ class Scheme {
 
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
         if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
-        return PublicKey{this, buf};
+        circl_hip_keytable *t = nullptr;  // parse once: A and tr stay on the device with the object
+        check(circl_hip_mldsa_keytable_new(param_, buf.data(), 1, dev1(), &t));
+        return PublicKey{this, buf, ResidentKey(t, circl_hip_keytable_free)};
     }
     PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
         if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
-        return PrivateKey{this, buf};
+        circl_hip_keytable *t = nullptr;  // ... and A with the NTT-domain secrets
+        check(circl_hip_mldsa_privkey_new(param_, buf.data(), dev1(), &t));
+        return PrivateKey{this, buf, ResidentKey(t, circl_hip_keytable_free)};
     }
     std::pair<PublicKey, PrivateKey> DeriveKey(const Bytes &seed) const {
         if ((int)seed.size() != SeedSize()) throw std::invalid_argument("seed must be of length SeedSize");
@@ -84,8 +95,9 @@ class Scheme {
         const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
         const uint8_t pad = 0;
         Bytes sig(SignatureSize());
-        check(circl_hip_mldsa_sign(param_, sk.packed.data(), msg.empty() ? &pad : msg.data(), moff,
-                                   ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data()), coff, nullptr, sig.data(), 1, dev1()));
+        const uint8_t *cp = ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data());
+        if (sk.resident) check(circl_hip_mldsa_sign_table(sk.resident.get(), msg.empty() ? &pad : msg.data(), moff, cp, coff, nullptr, sig.data(), 1));
+        else check(circl_hip_mldsa_sign(param_, sk.packed.data(), msg.empty() ? &pad : msg.data(), moff, cp, coff, nullptr, sig.data(), 1, dev1()));
         return sig;
     }
     bool Verify(const PublicKey &pk, const Bytes &msg, const Bytes &sig, const SignatureOpts *opts = nullptr) const {
@@ -97,9 +109,10 @@ class Scheme {
         const uint64_t moff[2] = {0, msg.size()}, coff[2] = {0, ctx.size()};
         const uint8_t pad = 0;
         uint8_t ok = 0;
-        const int rc = circl_hip_mldsa_verify(param_, pk.packed.data(), sig.data(), msg.empty() ? &pad : msg.data(), moff,
-                                              ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data()), coff, &ok, 1,
-                                              device < 0 ? 0 : device);
+        const uint8_t *cp = ctx.empty() ? &pad : reinterpret_cast<const uint8_t *>(ctx.data());
+        const int rc = pk.resident ? circl_hip_mldsa_verify_table(pk.resident.get(), nullptr, sig.data(), msg.empty() ? &pad : msg.data(), moff, cp, coff, &ok, 1)
+                                   : circl_hip_mldsa_verify(param_, pk.packed.data(), sig.data(), msg.empty() ? &pad : msg.data(), moff, cp, coff, &ok, 1,
+                                                            device < 0 ? 0 : device);
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
         return ok != 0;
     }
@@ -115,7 +128,8 @@ class Scheme {
     void SignSharedKeyBatch(const PrivateKey &sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                             const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, size_t n) const {
         if (sk.scheme != this) throw ErrTypeMismatch();
-        const int rc = circl_hip_mldsa_sign_shared(param_, sk.packed.data(), msg_blob, msg_off, ctx_blob, ctx_off, rnd, sigs, n, device);
+        const int rc = sk.resident ? circl_hip_mldsa_sign_table(sk.resident.get(), msg_blob, msg_off, ctx_blob, ctx_off, rnd, sigs, n)
+                                   : circl_hip_mldsa_sign_shared(param_, sk.packed.data(), msg_blob, msg_off, ctx_blob, ctx_off, rnd, sigs, n, device);
         if (rc == CIRCL_HIP_EPARAM) throw ErrContextTooLong();
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
     }
@@ -123,7 +137,8 @@ class Scheme {
     void VerifySharedKeyBatch(const PublicKey &pk, const uint8_t *sigs, const uint8_t *msg_blob, const uint64_t *msg_off,
                               const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n) const {
         if (pk.scheme != this) throw ErrTypeMismatch();
-        const int rc = circl_hip_mldsa_verify_shared(param_, pk.packed.data(), sigs, msg_blob, msg_off, ctx_blob, ctx_off, ok, n, device);
+        const int rc = pk.resident ? circl_hip_mldsa_verify_table(pk.resident.get(), nullptr, sigs, msg_blob, msg_off, ctx_blob, ctx_off, ok, n)
+                                   : circl_hip_mldsa_verify_shared(param_, pk.packed.data(), sigs, msg_blob, msg_off, ctx_blob, ctx_off, ok, n, device);
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
     }
     void SignBatch(const uint8_t *sks, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,

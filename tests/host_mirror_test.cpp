@@ -76,6 +76,16 @@ int main() {
         s->EncapsulateBatch(eks1.data(), ms.data(), cts1.data(), sss1.data(), st.data(), n);
         s->EncapsulateSharedKeyBatch(pk, ms.data(), cts2.data(), sss3.data(), st.data(), n);
         REQUIRE(cts1 == cts2 && sss1 == sss3);
+        if (!r3) {  // the same through PARSED key objects: their A^T / H(ek) live on the device with the object (and with its copies)
+            REQUIRE(pk3.resident && sk3.resident && !pk.resident);
+            kem::PublicKey pk4 = pk3;  // a copy shares the resident key
+            std::fill(cts2.begin(), cts2.end(), 0);
+            s->EncapsulateSharedKeyBatch(pk4, ms.data(), cts2.data(), sss3.data(), st.data(), n);
+            REQUIRE(cts1 == cts2 && sss1 == sss3);
+            s->DecapsulateSharedKeyBatch(sk3, cts2.data(), sss2.data(), st.data(), n);
+            REQUIRE(sss2 == sss3);
+            for (auto x : st) REQUIRE(x == 0);
+        }
     }
     REQUIRE(kem::ByName("FrodoKEM-640-SHAKE") == nullptr);
     for (const char *name : {"ML-DSA-44", "ML-DSA-65", "ML-DSA-87"}) {
@@ -123,6 +133,18 @@ int main() {
             sigs[3 * s->SignatureSize() + 100] ^= 1;
             s->VerifySharedKeyBatch(gpk, sigs.data(), blob.data(), off.data(), nullptr, nullptr, ok.data(), nb);
             for (size_t i = 0; i < nb; i++) REQUIRE(ok[i] == (i == 3 ? 0 : 1));
+            // the same through PARSED key objects (A, tr / the NTT-domain secrets resident with the object)
+            const sign::PrivateKey psk = s->UnmarshalBinaryPrivateKey(gsk.MarshalBinary());
+            const sign::PublicKey ppk = s->UnmarshalBinaryPublicKey(gpk.MarshalBinary());
+            REQUIRE(psk.resident && ppk.resident && !gsk.resident);
+            std::vector<uint8_t> sigs2(sigs.size());
+            s->SignSharedKeyBatch(psk, blob.data(), off.data(), nullptr, nullptr, nullptr, sigs2.data(), nb);
+            sigs[3 * s->SignatureSize() + 100] ^= 1;
+            REQUIRE(sigs2 == sigs);
+            sigs2[5 * s->SignatureSize() + 9] ^= 2;
+            s->VerifySharedKeyBatch(ppk, sigs2.data(), blob.data(), off.data(), nullptr, nullptr, ok.data(), nb);
+            for (size_t i = 0; i < nb; i++) REQUIRE(ok[i] == (i == 5 ? 0 : 1));
+            REQUIRE(s->Verify(ppk, msg, s->Sign(psk, msg, &ctx), &ctx));
         }
         REQUIRE(throws<std::invalid_argument>([&] { s->DeriveKey(shortsig); }));
     }
