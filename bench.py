@@ -224,7 +224,7 @@ def small_batches(dev):
     """Cost per call of small / medium batches on resident arrays (stream-ordered, 20 calls per sample, best of 3): the routes of
     DESIGN.md 4.4 / 4.5.  Every size is checked: all decapsulated secrets equal the encapsulated ones, a sample of each batch
     against the oracle; ML-DSA signatures verify and a sample equals the oracle's."""
-    from circl_amd import device as cdev
+    from circl_amd import device as cdev, hostapi
     from oracle import orc
 
     def best(fn, reps=20):  # stream-ordered calls back to back, one synchronisation per `reps` (tests/gpu_microbench.py measures the same way)
@@ -251,13 +251,21 @@ def small_batches(dev):
         te = best(lambda: eng.encaps(ek, m, ct, ss))
         td = best(lambda: eng.decaps(dk, ct, ss2))
         t1 = best(lambda: eng.encaps_shared(ek[:1], m, ct, ss))
+        tab = hostapi.KeyTable("mlkem-public", 768, ek[:1].cpu().numpy())   # the key parsed ONCE and resident (circl_hip_mlkem_keytable_new)
+        tt = best(lambda: eng.encaps_table(tab, m, ct=ct, ss=ss))
+        ct_t = ct.clone()
+        eng.encaps_shared(ek[:1], m, ct, ss)
+        torch.cuda.synchronize()
+        out["bit_exact_vs_oracle"] &= bool((ct_t == ct).all().item())
+        tab.close()
         eng.encaps(ek, m, ct, ss)
         torch.cuda.synchronize()
         k = min(n, 64)
         ct0, ss0, _ = orc.mlkem_encaps(768, ek[:k].cpu().numpy(), m[:k].cpu().numpy())
         ok = bool((ss2 == ss).all().item()) and bool((ct[:k].cpu().numpy() == ct0).all()) and bool((ss[:k].cpu().numpy() == ss0).all())
         out["bit_exact_vs_oracle"] &= ok
-        out["mlkem768"][str(n)] = {"encaps": te, "decaps": td, "encaps_one_key": t1, "encaps_per_s": n / te * 1e6}
+        out["mlkem768"][str(n)] = {"encaps": te, "decaps": td, "encaps_one_key": t1, "encaps_resident_key": tt, "encaps_per_s": n / te * 1e6,
+                                   "encaps_resident_key_per_s": n / tt * 1e6}
     for n in (1, 1 << 10):
         eng = cdev.MLDSADevice(65, n, dev, sign=True)
         pk, sk = eng.keygen(torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g))
@@ -265,11 +273,20 @@ def small_batches(dev):
         sig = eng.sign(sk, msg)
         ts = best(lambda: eng.sign(sk, msg, sig), 10)
         tv = best(lambda: eng.verify(pk, sig, msg))
+        vtab = hostapi.KeyTable("mldsa-public", 65, pk[:1].cpu().numpy())
+        stab = hostapi.KeyTable("mldsa-private", 65, sk[:1].cpu().numpy())
+        sig1 = eng.sign_table(stab, msg)
+        ok1 = bool(eng.verify_table(vtab, sig1, msg).all().item())
+        tsr = best(lambda: eng.sign_table(stab, msg, sig1), 10)
+        tvr = best(lambda: eng.verify_table(vtab, sig1, msg))
+        out["bit_exact_vs_oracle"] &= ok1 and bool((orc.mldsa_sign(65, sk[:1].cpu().numpy(), [bytes(msg[:32].cpu().numpy())]) == sig1[:1].cpu().numpy()).all())
+        vtab.close()
+        stab.close()
         k = min(n, 4)
         msgs = [bytes(msg[32 * i:32 * i + 32].cpu().numpy()) for i in range(k)]
         ok = bool(eng.verify(pk, sig, msg).all().item()) and bool((orc.mldsa_sign(65, sk[:k].cpu().numpy(), msgs) == sig[:k].cpu().numpy()).all())
         out["bit_exact_vs_oracle"] &= ok
-        out["mldsa65"][str(n)] = {"sign": ts, "verify": tv}
+        out["mldsa65"][str(n)] = {"sign": ts, "verify": tv, "sign_resident_key": tsr, "verify_resident_key": tvr}
     return out
 
 
