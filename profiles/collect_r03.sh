@@ -36,6 +36,8 @@ CIRCL_LATENCY_ALL=1 python tests/gpu_microbench.py 0 latency 2>&1 | grep -v amdg
 python tools/hbm_probe.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_hbm_probe.txt"
 bash tools/kem_params_check.sh 2>&1 | grep -v amdgpu.ids > "$OUT/r03_latency_params.txt"
 python tools/hybrid_latency.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_hybrid_latency.txt"
+python tools/table_latency.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_table_latency.txt"
+python tools/host_small.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_host_small.txt"
 { python tools/host_path.py 20; CIRCL_HIP_HOST_AHEAD=0 python tools/host_path.py 20; CIRCL_HIP_HOST_CHUNK=14 python tools/host_path.py 20; CIRCL_HIP_HOST_CHUNK=16 python tools/host_path.py 20; CIRCL_HIP_HOST_THREADS=8 python tools/host_path.py 20; } 2>&1 | grep -v amdgpu.ids > "$OUT/r03_host_path.txt"
 tools/bin/pcie_probe > "$OUT/r03_pcie_probe.txt" 2>&1
 tools/sign_trace.sh 65 18 > "$OUT/r03_sign_trace.txt" 2>&1
