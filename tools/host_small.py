@@ -20,5 +20,13 @@ for n in (1, 16, 64, 256, 1024):
         t = time.perf_counter(); hostapi.mlkem_encaps(768, ek, m); ts.append(time.perf_counter() - t)
         t = time.perf_counter(); hostapi.mlkem_decaps(768, dk, ct); td.append(time.perf_counter() - t)
     ts.sort(); td.sort()
-    out.append(f"n={n}: encaps {ts[25] * 1e6:.0f} decaps {td[25] * 1e6:.0f}")
+    pub, prv = hostapi.KeyTable("mlkem-public", 768, ek[:1]), hostapi.KeyTable("mlkem-private", 768, dk[:1])  # ONE resident key
+    ct1, _, _ = pub.encaps(m)
+    tt, tu = [], []
+    for _ in range(50):
+        t = time.perf_counter(); pub.encaps(m); tt.append(time.perf_counter() - t)
+        t = time.perf_counter(); prv.decaps(ct1); tu.append(time.perf_counter() - t)
+    tt.sort(); tu.sort()
+    pub.close(); prv.close()
+    out.append(f"n={n}: encaps {ts[25] * 1e6:.0f} decaps {td[25] * 1e6:.0f}, resident key {tt[25] * 1e6:.0f} / {tu[25] * 1e6:.0f}")
 print("ML-KEM-768 through host buffers, median us:", " | ".join(out), {k: v for k, v in os.environ.items() if k.startswith("CIRCL_HIP_HOST")})
