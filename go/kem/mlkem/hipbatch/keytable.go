@@ -15,21 +15,21 @@ import (
 	"github.com/cloudflare/circl/kem"
 )
 
-// KeyTable is the GPU-side counterpart of parsed key objects: what kem.Scheme.UnmarshalBinaryPublicKey /
+// ResidentTable is the GPU-side counterpart of parsed key objects: what kem.Scheme.UnmarshalBinaryPublicKey /
 // UnmarshalBinaryPrivateKey compute once and keep in the object (A^T, H(ek), the private key's hash check:
 // kem/mlkem/mlkem768/kyber.go:39-43, :219-228, :247-263) is computed once on one device and stays there; an
 // Encapsulate / Decapsulate call then moves only seeds, ciphertexts and shared secrets.  A table is immutable and may be
 // used from several goroutines; it is released by Close or by the finalizer (private tables are wiped first).
 //
 // NOT COMPILED IN THIS REPOSITORY'S CI (no Go toolchain); tests/test_gpu_keytable.py drives the same symbols.
-type KeyTable struct {
+type ResidentTable struct {
 	s       kem.Scheme
 	t       *C.circl_hip_keytable
 	private bool
 	n       int
 }
 
-func newKeyTable(s kem.Scheme, rows []byte, rowSize int, private bool, device int) (*KeyTable, []error, error) {
+func newResidentTable(s kem.Scheme, rows []byte, rowSize int, private bool, device int) (*ResidentTable, []error, error) {
 	p, ok := params[s.Name()]
 	if !ok {
 		return nil, nil, kem.ErrTypeMismatch
@@ -42,7 +42,7 @@ func newKeyTable(s kem.Scheme, rows []byte, rowSize int, private bool, device in
 	}
 	n := len(rows) / rowSize
 	st := make([]byte, n)
-	kt := &KeyTable{s: s, private: private, n: n}
+	kt := &ResidentTable{s: s, private: private, n: n}
 	priv := C.int(0)
 	if private {
 		priv = 1
@@ -50,7 +50,7 @@ func newKeyTable(s kem.Scheme, rows []byte, rowSize int, private bool, device in
 	if err := status(C.circl_hip_mlkem_keytable_new(p, priv, ptr(rows), C.size_t(n), C.int(device), ptr(st), &kt.t), "mlkem_keytable_new"); err != nil {
 		return nil, nil, err
 	}
-	runtime.SetFinalizer(kt, func(k *KeyTable) { k.Close() })
+	runtime.SetFinalizer(kt, func(k *ResidentTable) { k.Close() })
 	errs := make([]error, n)
 	for i := range st {
 		errs[i] = itemErr(st[i])
@@ -58,19 +58,19 @@ func newKeyTable(s kem.Scheme, rows []byte, rowSize int, private bool, device in
 	return kt, errs, nil
 }
 
-// NewPublicKeyTable parses n packed public keys ([n][PublicKeySize]) on `device`.
-func NewPublicKeyTable(s kem.Scheme, eks []byte, device int) (*KeyTable, error) {
-	kt, _, err := newKeyTable(s, eks, s.PublicKeySize(), false, device)
+// NewResidentPublicKeys parses n packed public keys ([n][PublicKeySize]) on `device`.
+func NewResidentPublicKeys(s kem.Scheme, eks []byte, device int) (*ResidentTable, error) {
+	kt, _, err := newResidentTable(s, eks, s.PublicKeySize(), false, device)
 	return kt, err
 }
 
-// NewPrivateKeyTable parses n packed private keys; errs[i] is kem.ErrPrivKey for a key whose stored hash does not match.
-func NewPrivateKeyTable(s kem.Scheme, dks []byte, device int) (*KeyTable, []error, error) {
-	return newKeyTable(s, dks, s.PrivateKeySize(), true, device)
+// NewPrivateResidentTable parses n packed private keys; errs[i] is kem.ErrPrivKey for a key whose stored hash does not match.
+func NewPrivateResidentTable(s kem.Scheme, dks []byte, device int) (*ResidentTable, []error, error) {
+	return newResidentTable(s, dks, s.PrivateKeySize(), true, device)
 }
 
 // Close releases the device memory (idempotent).
-func (k *KeyTable) Close() {
+func (k *ResidentTable) Close() {
 	if k.t != nil {
 		C.circl_hip_keytable_free(k.t)
 		k.t = nil
@@ -79,7 +79,7 @@ func (k *KeyTable) Close() {
 
 // Encapsulate is len(seeds)/EncapsulationSeedSize times EncapsulateDeterministically on table entry idx[i]
 // (idx == nil: every item uses entry 0 -- a table of one key object).
-func (k *KeyTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte, errs []error, err error) {
+func (k *ResidentTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte, errs []error, err error) {
 	if k.t == nil || k.private {
 		return nil, nil, nil, kem.ErrTypeMismatch
 	}
@@ -105,7 +105,7 @@ func (k *KeyTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte, err
 }
 
 // Decapsulate is len(cts)/CiphertextSize times Decapsulate with table entry idx[i] (idx == nil: entry 0).
-func (k *KeyTable) Decapsulate(idx []uint32, cts []byte) (sss []byte, errs []error, err error) {
+func (k *ResidentTable) Decapsulate(idx []uint32, cts []byte) (sss []byte, errs []error, err error) {
 	if k.t == nil || !k.private {
 		return nil, nil, kem.ErrTypeMismatch
 	}

@@ -185,11 +185,11 @@ func rows(flat []byte, size int) [][]byte {
 //	cts, sss, _ := rpk.EncapsulateBatch(seeds)    // len(seeds) / 32 encapsulations to that key, ≈30 µs per call up to 1 024
 type ResidentPublicKey struct {
 	kem.PublicKey
-	table *KeyTable
+	table *ResidentTable
 }
 type ResidentPrivateKey struct {
 	kem.PrivateKey
-	table *KeyTable
+	table *ResidentTable
 }
 
 // ResidentPublicKey parses pk on `device` (ML-KEM only: round-3 Kyber has no table route).
@@ -198,7 +198,7 @@ func (s *Scheme) ResidentPublicKey(pk kem.PublicKey, device int) (*ResidentPubli
 	if err != nil {
 		return nil, err
 	}
-	t, err := NewPublicKeyTable(s.Scheme, b, device)
+	t, err := NewResidentPublicKeys(s.Scheme, b, device)
 	if err != nil {
 		return nil, err
 	}
@@ -212,7 +212,7 @@ func (s *Scheme) ResidentPrivateKey(sk kem.PrivateKey, device int) (*ResidentPri
 		return nil, err
 	}
 	defer clear(b) // the marshalled copy of the private key does not outlive the call
-	t, errs, err := NewPrivateKeyTable(s.Scheme, b, device)
+	t, errs, err := NewResidentPrivateKeys(s.Scheme, b, device)
 	if err != nil {
 		return nil, err
 	}
