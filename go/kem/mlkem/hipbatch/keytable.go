@@ -64,8 +64,8 @@ func NewResidentPublicKeys(s kem.Scheme, eks []byte, device int) (*ResidentTable
 	return kt, err
 }
 
-// NewPrivateResidentTable parses n packed private keys; errs[i] is kem.ErrPrivKey for a key whose stored hash does not match.
-func NewPrivateResidentTable(s kem.Scheme, dks []byte, device int) (*ResidentTable, []error, error) {
+// NewResidentPrivateKeys parses n packed private keys; errs[i] is kem.ErrPrivKey for a key whose stored hash does not match.
+func NewResidentPrivateKeys(s kem.Scheme, dks []byte, device int) (*ResidentTable, []error, error) {
 	return newResidentTable(s, dks, s.PrivateKeySize(), true, device)
 }
 
