@@ -470,7 +470,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     constexpr int kMaxRounds = 400;
     size_t entries_upper[kMaxRounds];
     bool lazy[kMaxRounds];
-    static const double eps = __builtin_ldexp(1.0, -env_int("CIRCL_HIP_SIGN_EPS_LOG2", 20, 1, 60));  // expected unsigned items behind the schedule
+    static const double eps = __builtin_ldexp(1.0, -env_int("CIRCL_HIP_SIGN_EPS_LOG2", 16, 1, 60));  // expected unsigned items behind the schedule
     const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, S.pair, entries_upper, lazy, kMaxRounds, eps);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     {
