@@ -55,3 +55,13 @@ def test_no_gpu_means_loud_failure(L):
         hostapi.mlkem_encaps(768, np.zeros((1, 1184), np.uint8), np.zeros((1, 32), np.uint8))
     with pytest.raises(nat.CirclHipError):
         hostapi.keccak_f1600(np.zeros((1, 25), np.uint64))
+    # key tables that live across calls: no device, no table (and nothing to free); a NULL table is refused, not dereferenced
+    for kind, param, row in (("mlkem-public", 768, 1184), ("mlkem-private", 768, 2400), ("mldsa-public", 65, 1952), ("mldsa-private", 65, 4032)):
+        with pytest.raises(nat.CirclHipError) as e:
+            hostapi.KeyTable(kind, param, np.zeros((1, row), np.uint8))
+        assert e.value.code == nat.ENODEV
+    out = np.zeros(4000, np.uint8)
+    import ctypes as C
+    assert L.circl_hip_mlkem_encaps_table(None, None, out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p), 1) == nat.EPARAM
+    L.circl_hip_keytable_free(None)
