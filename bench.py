@@ -121,13 +121,15 @@ def roofline(kernel_name, ops_per_step, bytes_per_op, kernel_ms_per_step, note=N
 class KemWork:
     """ML-KEM encaps / decaps over B resident items (distinct keys: pool of min(2^16, B) GPU-generated keys, tiled)."""
 
-    def __init__(self, param, B, rank, dev, shake_inputs=True):
+    def __init__(self, param, B, rank, dev, shake_inputs=True, window=None):
+        """window = (lo, total): this rank's B = hi - lo items are items [lo, hi) of ONE batch of `total` items (strong scaling:
+        the batch is the one rank 0 of a weak run owns -- item i has key pool[i mod pool] and message SHAKE256(label || LE64(i)))."""
         from circl_amd import device as cdev
         self.param, self.B, self.dev = param, B, dev
-        pool = min(POOL, B)
+        pool = min(POOL, B if window is None else window[1])
         if shake_inputs:
-            seeds = torch.from_numpy(shake_seeds("circl-hip/keygen", pool, 64, start=rank * POOL)).to(dev)
-            self.m = torch.from_numpy(shake_seeds("circl-hip/m", B, 32, start=rank * B)).to(dev)
+            seeds = torch.from_numpy(shake_seeds("circl-hip/keygen", pool, 64, start=(rank * POOL if window is None else 0))).to(dev)
+            self.m = torch.from_numpy(shake_seeds("circl-hip/m", B, 32, start=(rank * B if window is None else window[0]))).to(dev)
         else:
             g = torch.Generator(device=dev).manual_seed(1000 + rank)
             seeds = torch.randint(0, 256, (pool, 64), dtype=torch.uint8, device=dev, generator=g)
@@ -135,11 +137,12 @@ class KemWork:
         kg = cdev.MLKEMDevice(param, pool, dev)
         ek_pool, dk_pool = kg.keygen(seeds)   # GPU keygen is itself parity-pinned (tests/test_gpu_mlkem.py: ACVP keyGen, KAT hashes)
         torch.cuda.synchronize()
-        reps = (B + pool - 1) // pool
+        first = 0 if window is None else window[0] % pool
+        reps = (first + B + pool - 1) // pool
         self.pool = pool
         self.seeds = seeds
-        self.ek = ek_pool.repeat(reps, 1)[:B].contiguous()
-        self.dk = dk_pool.repeat(reps, 1)[:B].contiguous()
+        self.ek = ek_pool.repeat(reps, 1)[first:first + B].contiguous()
+        self.dk = dk_pool.repeat(reps, 1)[first:first + B].contiguous()
         self.eng = cdev.MLKEMDevice(param, B, dev)
         self.ss_dec = torch.empty((B, 32), dtype=torch.uint8, device=dev)
         self.st_dec = torch.empty(B, dtype=torch.uint8, device=dev)
@@ -619,6 +622,22 @@ def valu_issue(insts, launch_ms):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 and a free port, exactly as the driver does for N > 1; returns its exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes: the host driver only has dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -632,11 +651,25 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    share = bool(os.environ.get("CIRCL_BENCH_SHARE_GPU"))  # test aid: several ranks on one device (then with CIRCL_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(3)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: launched with WORLD_SIZE=%s but --gpus %d: the line would report the wrong n_gpus; refusing" %
+              (os.environ["WORLD_SIZE"], args.gpus), file=sys.stderr)
+        sys.exit(3)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (circl_amd has no CPU path)", file=sys.stderr)
         sys.exit(2)
+    if not share and torch.cuda.device_count() < args.gpus:
+        print("bench.py: --gpus %d but this process sees %d GPU(s): refusing to time fewer devices than asked for" %
+              (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        sys.exit(launch_ranks(args.gpus))      # one rank per GPU, this very command line in every rank
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("CIRCL_BENCH_SHARE_GPU"):  # test aid: several ranks on one device (then with CIRCL_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
+    if share:
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -714,6 +747,27 @@ def main():
     parity_fail = ranks.sum(0 if parity_enc["bit_exact_vs_oracle"] else 1)
     parity_enc["ranks_failing"] = int(parity_fail)
     per_rank = {"encaps_per_s": ranks.gather(B * args.steps / headline["elapsed"]) if args.mode == "encaps" else None}
+
+    # ---- strong scaling: the metric read literally -- ONE batch of B items, n/G contiguous items per rank ----
+    strong = None
+    if args.mode == "encaps":
+        lo, hi = parallel.shard_bounds(B, world, rank)
+        if world == 1:
+            strong = {"value": headline["value"], "ms_per_step": headline["elapsed"] / args.steps * 1e3, "items_per_rank": [B],
+                      "note": "one rank: the strong and the weak figure are the same measurement"}
+        else:
+            ks = KemWork(768, hi - lo, rank, dev, window=(lo, B))
+            el_s, _ = Timer(ranks, []).run(ks.encaps, args.steps, args.warmup)
+            v_s, el_s = parallel.whole_job_rate(ranks, (hi - lo) * args.steps, el_s)
+            ps = ks.parity_encaps(1 << 12)
+            strong = {"value": v_s, "ms_per_step": el_s / args.steps * 1e3, "items_per_rank": [int(x) for x in ranks.gather(hi - lo)],
+                      "per_rank_encaps_per_s": ranks.gather((hi - lo) * args.steps / el_s),
+                      "parity": dict(ps, ranks_failing=int(ranks.sum(0 if ps["bit_exact_vs_oracle"] else 1)))}
+            del ks
+            torch.cuda.empty_cache()
+        strong.update({"unit": "encaps/s", "scaling": "strong", "batch_total": B, "steps": args.steps, "warmup": args.warmup,
+                       "workload": "ONE batch of %d ML-KEM-768 encapsulations (distinct-key), contiguous split n/G per rank, same barrier / "
+                                   "max-over-ranks protocol as `value`" % B})
 
     # ---- decaps + config 3 (second half of Encaps + Decaps on the same items) ----
     if extras or args.mode == "config3":
@@ -927,6 +981,12 @@ def main():
                                     "config5": "ML-KEM-1024 Encapsulate + ML-DSA-87 Verify on two streams, %d + %d per GPU, inputs resident in HBM" % (max(B // 16, 64), max(B // 16, 64)),
                                     "host": "ML-KEM-768 Encapsulate through circl_hip_mlkem_encaps (host pointers, pageable), batch=%d per GPU" % B}[args.mode],
                        "key_pool": min(POOL, B), "parallelism": "batch split per device, no collectives", "mode": args.mode},
+            "value_is": "weak: every rank times its own batch of %d (per-GPU work fixed as N grows); `strong` = one batch of %d split over the ranks; "
+                        "`value_host_abi` = the same metric through the host-pointer C ABI (PCIe-inclusive, pageable caller memory)" % (B, B),
+            "strong": strong,
+            "value_host_abi": ({"value": host["pageable"]["whole_job_value"], "pinned": host["pinned"]["whole_job_value"], "unit": "encaps/s",
+                                "what": "circl_hip_mlkem_encaps with host pointers (SURVEY 8d scope ii): H2D + kernels + D2H, pageable / page-locked caller buffers"}
+                               if host else None),
             "sustained": sustained,
             "parity": parity_enc,
             "per_rank": per_rank,

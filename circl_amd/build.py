@@ -7,6 +7,7 @@ into one shared object.  The .so is git-ignored but travels to the GPU box with 
 the gfx950 assembly of every kernel) go to build/ (also git-ignored).
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -16,16 +17,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcirclhip.so")
-COMMON = ["host_common.h", "keccak_dev.h"]
-# translation unit -> the headers it includes (besides COMMON and include/circl_hip.h)
-UNITS = {
-    "host_runtime.hip": [],
-    "api_mlkem.hip": ["kyber_dev.h", "mlkem_kernels.h"],
-    "api_mldsa.hip": ["kyber_dev.h", "dilithium_dev.h", "mlkem_kernels.h", "mldsa_kernels.h", "mldsa_sign_batched.h"],
-    "api_prims.hip": ["kyber_dev.h", "dilithium_dev.h", "prim_kernels.h", "sampler_prims.h", "mlkem_kernels.h", "mldsa_kernels.h"],
-    "api_x25519.hip": ["x25519_dev.h", "x25519_base_table.h", "x25519_kernels.h"],
-    "api_hybrid.hip": ["hybrid_kernels.h"],
-}
+UNITS = ["host_runtime.hip", "api_mlkem.hip", "api_mldsa.hip", "api_prims.hip", "api_x25519.hip", "api_hybrid.hip"]
+_INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+
+
+def deps(unit):
+    """Every file `unit` depends on: the transitive closure of its #include "..." graph over csrc/ and include/ (read from the
+    sources at every call, so a new header can never be forgotten in a table)."""
+    seen, todo = set(), [os.path.join(CSRC, unit)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        with open(f, errors="replace") as fh:
+            for inc in _INCLUDE.findall(fh.read()):
+                for base in (os.path.dirname(f), CSRC, os.path.join(ROOT, "include")):
+                    cand = os.path.normpath(os.path.join(base, inc))
+                    if os.path.exists(cand):
+                        todo.append(cand)
+                        break
+    return sorted(seen)
+
+
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
@@ -45,8 +59,7 @@ def _stale(unit):
     if not os.path.exists(o):
         return True
     t = os.path.getmtime(o)
-    deps = [os.path.join(CSRC, unit)] + [os.path.join(CSRC, h) for h in COMMON + UNITS[unit]] + [os.path.join(ROOT, "include", "circl_hip.h")]
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in deps(unit))
 
 
 def needs_build():

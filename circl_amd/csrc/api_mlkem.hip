@@ -47,9 +47,17 @@ size_t kem_small_shared_batch(bool decaps) {
     static const size_t dec = size_t(1) << env_int("CIRCL_HIP_KEM_SMALL_SHARED_DECAPS", 15, 0, 24);
     return decaps ? dec : enc;  // (log2 0 = batches of one only)
 }
-size_t kem_small_table_bytes(size_t n) { return up256(((n && n <= kem_small_batch() ? n : 1) + 15) / 16 * 16 * size_t(16 * 512)); }
-size_t kem_small_table_ofs(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
-size_t kem_ws_bytes(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes() + kem_small_table_bytes(n); }
+// The row cache behind the scratch slices holds min(n, kem_small_batch()) entries (at least one: the one-key routes), so the
+// workspace size is MONOTONE in n: a workspace sized once for the largest batch serves every smaller one.
+size_t kem_cache_bytes(size_t entries) { return up256((std::max<size_t>(entries, 1) + 15) / 16 * 16 * size_t(16 * 512)); }
+size_t kem_small_table_bytes(size_t n) { return kem_cache_bytes(std::min(n, kem_small_batch())); }
+size_t kem_ws_base(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
+size_t kem_small_table_ofs(size_t n) { return kem_ws_base(n); }
+size_t kem_ws_bytes(size_t n) { return kem_ws_base(n) + kem_small_table_bytes(n); }
+// What a call on n items cannot do without (the big-batch routes and the one-entry cache); with at least kem_ws_base(n) +
+// kem_cache_bytes(n) bytes a batch of n <= kem_small_batch() takes the small-batch routes, with less the scratch routes.
+size_t kem_ws_min(size_t n) { return kem_ws_base(n) + kem_cache_bytes(1); }
+bool kem_small_route(size_t n, size_t ws_bytes) { return n <= kem_small_batch() && ws_bytes >= kem_ws_base(n) + kem_cache_bytes(n); }
 
 // Items per ring-phase workgroup of a small batch: about two groups per SIMD -- one item per workgroup up to 2 x 4 x CUs items,
 // then as few per group as that allows (measured 2^11 .. 2^15: 8 groups per CU up to 2^14 items, 16 beyond)
@@ -100,12 +108,12 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *m_ws = w.slot1;
     const unsigned hb = (unsigned)((n + 255) / 256);
-    if (!R3 && n <= kem_small_batch()) {
+    if (!R3 && kem_small_route(n, ws_bytes)) {
         // small batch: [H(ek), G] and [A^T] side by side in one launch, then PRF + ring phase with the rows from the cache
         int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
         // up to kem_coop_batch() items the hashes run two items per wavefront (25 lanes per state): shorter chains while the chip
@@ -158,7 +166,7 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(ek) || !aligned16(m) || !aligned16(ct) || !aligned16(ss))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *h_ws = w.slot1;
@@ -247,7 +255,7 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
@@ -355,13 +363,13 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(dk) || !aligned16(ct) || !aligned16(ss)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     if (R3) status = w.status_slot;
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
-    if (!R3 && n <= kem_small_batch()) {
+    if (!R3 && kem_small_route(n, ws_bytes)) {
         // small batch: J(z || ct), the key's hash check, Decrypt + G and A^T side by side in one launch, then the key-table form
         // of the re-encryption (mlkem_small_decaps_pre_kernel)
         int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
@@ -416,7 +424,7 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *rs = w.slot0;
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
@@ -454,8 +462,10 @@ PipeOpts kem_opts(bool encaps_only) {
     if (encaps_only) o.ws_secret_bytes = [](size_t cnt) { return up256(kKemWsPerItem * cnt); };
     return o;
 }
+// (a host-buffer chunk beyond 2^13 items is PCIe-bound whichever route it takes: it gets the workspace of the scratch routes, so
+// a staging slot carries at most 64 MB of row cache instead of 256 MB)
 std::function<size_t(size_t)> kem_ws_fn() {
-    return [](size_t cnt) { return kem_ws_bytes(cnt); };
+    return [](size_t cnt) { return cnt <= (size_t(1) << 13) ? kem_ws_bytes(cnt) : kem_ws_min(cnt); };
 }
 
 // host-side check of a key-index vector (the device path trusts its caller: an out-of-range index would read past the table)
@@ -490,7 +500,7 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(m) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(m) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0;
@@ -521,7 +531,7 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     using Gm = circl::mlkem::Geom<K>;
     using namespace circl::mlkem;
     if (n == 0) return CIRCL_HIP_OK;
-    if (ws_bytes < kem_ws_bytes(n) || !aligned16(ws) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
@@ -794,7 +804,7 @@ int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *ke
     if (key_idx)
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {m, 32, true}}, {},
-                        {{ct, CT}, {ss, 32, true}, {status, 1}}, [&](size_t c) { return kem_ws_bytes(c); }, kem_opts(true), [&](Chunk &c) {
+                        {{ct, CT}, {ss, 32, true}, {status, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
                             return circl_hip_mlkem_encaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                     c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                         });
@@ -806,7 +816,7 @@ int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *ke
     if (key_idx)
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {ct, CT}}, {},
-                        {{ss, 32, true}, {status, 1}}, [&](size_t c) { return kem_ws_bytes(c); }, kem_opts(false), [&](Chunk &c) {
+                        {{ss, 32, true}, {status, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
                             return circl_hip_mlkem_decaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                     c.cnt, c.ws, c.ws_bytes, c.st);
                         });

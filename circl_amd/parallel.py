@@ -22,7 +22,8 @@ class Ranks:
         self.device = device
         self.dist = None
         self.backend = None
-        if self.world > 1:
+        # CIRCL_DIST_FORCE_PG: create the process group even for one rank (tests/test_gpu_round4.py runs the RCCL branch that way)
+        if self.world > 1 or os.environ.get("CIRCL_DIST_FORCE_PG"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")

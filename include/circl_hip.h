@@ -105,6 +105,10 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
  * `workspace` must hold circl_hip_mlkem_workspace_size(param, n) bytes.  status may NOT be NULL.
  * After a call the workspace still holds per-item intermediates that are as secret as the call's secret inputs (the
  * encryption coins r, the decrypted m'): a caller that hands the memory on should zero it (the host-buffer forms do).
+ * circl_hip_mlkem_workspace_size is MONOTONE in n: 129 B per item + 32 KB of matrix scratch per resident workgroup (about
+ * 134 MB) + a row cache of 8 KB per item for the first 2^15 items (the small-batch routes; at most 256 MB).  A workspace
+ * sized once for the largest batch serves every smaller batch.  A call whose workspace lacks the row cache for its n (but
+ * has the first two parts and 128 KB) still succeeds, through the big-batch routes; results are identical either way.
  */
 size_t circl_hip_mlkem_workspace_size(int param, size_t n);
 int circl_hip_mlkem_encaps_dev(int param, const uint8_t *d_ek, const uint8_t *d_m, uint8_t *d_ct,

@@ -65,3 +65,28 @@ def test_no_gpu_means_loud_failure(L):
     assert L.circl_hip_mlkem_encaps_table(None, None, out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                                           out.ctypes.data_as(C.c_void_p), 1) == nat.EPARAM
     L.circl_hip_keytable_free(None)
+
+
+def test_build_dependencies_follow_the_include_graph(tmp_path):
+    # circl_amd/build.py must rebuild after an edit to ANY header a unit includes (a stale .so would travel to the GPU box):
+    # the dependency set is the #include closure, so keytable.h / lane_ops.h are in it, and a newer header makes the unit stale
+    import os
+    import time
+    from circl_amd import build
+    names = {u: {os.path.basename(d) for d in build.deps(u)} for u in build.UNITS}
+    assert {"keytable.h", "host_common.h", "circl_hip.h"} <= names["host_runtime.hip"]
+    assert "keytable.h" in names["api_mlkem.hip"] and "keytable.h" in names["api_mldsa.hip"]
+    assert {"lane_ops.h", "prim_kernels.h", "sampler_prims.h"} <= names["api_prims.hip"]
+    assert {"mldsa_sign_batched.h", "dilithium_dev.h", "keccak_dev.h"} <= names["api_mldsa.hip"]
+    every = set().union(*names.values())
+    assert {f for f in os.listdir(build.CSRC) if f.endswith(".h")} <= every    # no header outside the graph
+    kt = os.path.join(build.CSRC, "keytable.h")
+    obj = build._obj("host_runtime.hip")
+    if os.path.exists(obj):
+        st = os.stat(kt)
+        try:
+            os.utime(kt, (time.time() + 5, time.time() + 5))
+            assert build._stale("host_runtime.hip") and build.needs_build()
+            assert not build._stale("api_x25519.hip") or not os.path.exists(build._obj("api_x25519.hip"))
+        finally:
+            os.utime(kt, (st.st_atime, st.st_mtime))

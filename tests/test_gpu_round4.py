@@ -1,0 +1,80 @@
+"""Round-4 GPU tests: bench.py launches and verifies its own ranks, the RCCL process-group branch executes on a GPU.
+
+SURVEY.md 8(e): n/G items per device, no data-path collective; the shape of the work is the reference's
+kem/schemes/schemes_test.go:28-51 (Encapsulate over a scheme)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_py_launches_its_own_eight_ranks():
+    # `python bench.py --gpus 8` WITHOUT a launcher: it must start 8 ranks itself and report n_gpus 8, with the strong-scaling
+    # block (one batch of --batch items split n/G) beside the weak figure (ranks share this box's GPU, process group on gloo)
+    env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", str(1 << 12),
+                        "--mode", "encaps", "--no-extras", "--no-pmc"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["parity"]["ranks_failing"] == 0
+    st = out["strong"]
+    assert st["scaling"] == "strong" and st["batch_total"] == 1 << 12 and st["items_per_rank"] == [512] * 8
+    assert st["parity"]["ranks_failing"] == 0 and st["value"] > 0 and len(st["per_rank_encaps_per_s"]) == 8
+
+
+def test_bench_py_refuses_a_rank_count_it_was_not_asked_for():
+    # under a launcher: WORLD_SIZE != --gpus must fail (a SCALE run would otherwise report the wrong n_gpus)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--batch", "256",
+                        "--no-extras", "--no-pmc"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    # without the share-GPU aid: more GPUs asked for than the box has
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("CIRCL_BENCH_SHARE_GPU", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--no-extras", "--no-pmc"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and "refusing" in r.stderr
+
+
+def test_rccl_process_group_branch_runs_on_the_gpu():
+    # circl_amd/parallel.py with backend nccl (= RCCL on ROCm): one rank, device-bound process group; barrier, all_reduce (max, sum)
+    # and all_gather on GPU tensors -- the only collectives bench.py ever issues (timing barrier and reductions of timings)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    prog = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %r)
+        import torch
+        from circl_amd import parallel
+        torch.cuda.set_device(0)
+        r = parallel.Ranks("nccl", torch.device("cuda", 0))
+        assert r.dist is not None and r.backend == "nccl" and r.dist.get_backend() == "nccl"
+        t = r._tensor(3.5)
+        assert t.is_cuda
+        r.barrier()
+        v, worst = parallel.whole_job_rate(r, 1000, 2.0)
+        g = r.gather(7.25)
+        r.barrier()
+        print(json.dumps({"value": v, "worst": worst, "gather": g, "max": r.max(4.0), "sum": r.sum(5.0)}))
+        r.close()
+    """ % ROOT)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CIRCL_DIST_FORCE_PG="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CIRCL_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-5000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res == {"value": 500.0, "worst": 2.0, "gather": [7.25], "max": 4.0, "sum": 5.0}

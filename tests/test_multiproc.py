@@ -47,3 +47,10 @@ def test_two_rank_gloo_aggregation():
     import json
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["world"] == 2 and res["worst"] == 2.0 and abs(res["value"] - 1001 / 2.0) < 1e-9
+
+
+def test_bench_py_refuses_world_size_mismatch():
+    # bench.py under a launcher whose WORLD_SIZE differs from --gpus must fail before anything is timed (rc 3), GPU or not
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-extras", "--no-pmc"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
