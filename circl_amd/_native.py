@@ -33,6 +33,11 @@ SYMBOLS = [
     "circl_hip_hybrid_ss_size", "circl_hip_hybrid_workspace_size", "circl_hip_hybrid_keygen", "circl_hip_hybrid_encaps", "circl_hip_hybrid_decaps",
     "circl_hip_hybrid_keygen_dev", "circl_hip_hybrid_encaps_dev", "circl_hip_hybrid_decaps_dev", "circl_hip_alloc_host", "circl_hip_free_host",
     "circl_hip_profile_enable", "circl_hip_profile_read",
+    "circl_hip_keytable_device", "circl_hip_keytable_nkeys", "circl_hip_keytable_on_device",
+    "circl_hip_mldsa_privkeys_new", "circl_hip_mldsa_sign_table_keyed", "circl_hip_mldsa_sign_table_keyed_dev",
+    "circl_hip_mlkem_public_from_private", "circl_hip_mldsa_public_from_private", "circl_hip_mldsa_public_from_private_dev",
+    "circl_hip_hybrid_keytable_new", "circl_hip_hybrid_encaps_table", "circl_hip_hybrid_decaps_table",
+    "circl_hip_hybrid_encaps_table_dev", "circl_hip_hybrid_decaps_table_dev",
 ]
 
 OK, EPARAM, ENODEV, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
@@ -167,6 +172,22 @@ def lib():
         L.circl_hip_hybrid_keygen_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_hybrid_encaps_dev.argtypes = [i, vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_hybrid_decaps_dev.argtypes = [i, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_keytable_device.argtypes = [vp]
+        L.circl_hip_keytable_nkeys.argtypes = [vp]
+        L.circl_hip_keytable_nkeys.restype = sz
+        L.circl_hip_keytable_on_device.argtypes = [vp, i]
+        L.circl_hip_keytable_on_device.restype = vp
+        L.circl_hip_mldsa_privkeys_new.argtypes = [i, vp, sz, i, C.POINTER(vp)]
+        L.circl_hip_mldsa_sign_table_keyed.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz]
+        L.circl_hip_mldsa_sign_table_keyed_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, sz, vp, sz, vp]
+        L.circl_hip_mlkem_public_from_private.argtypes = [i, vp, vp, sz]
+        L.circl_hip_mldsa_public_from_private.argtypes = [i, vp, vp, sz, i]
+        L.circl_hip_mldsa_public_from_private_dev.argtypes = [i, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_hybrid_keytable_new.argtypes = [i, i, vp, sz, i, vp, C.POINTER(vp)]
+        L.circl_hip_hybrid_encaps_table.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+        L.circl_hip_hybrid_decaps_table.argtypes = [vp, vp, vp, vp, vp, sz]
+        L.circl_hip_hybrid_encaps_table_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.circl_hip_hybrid_decaps_table_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, vp]
         L.circl_hip_profile_enable.argtypes = [i]
         L.circl_hip_profile_read.argtypes = [i, vp, vp]
         _lib = L

@@ -55,15 +55,22 @@ def _obj(unit):
 
 
 def _stale(unit):
+    """True when `unit` must be recompiled.  The object's time stamp decides; where build/ did not travel with the tree (a GPU box
+    gets the sources and the built .so, not the objects) the library's own time stamp stands in for it, so an up-to-date
+    library is never rebuilt -- and never replaced under a process that has it loaded."""
     o = _obj(unit)
-    if not os.path.exists(o):
+    if os.path.exists(o):
+        t = os.path.getmtime(o)
+    elif os.path.exists(LIB):
+        t = os.path.getmtime(LIB)
+    else:
         return True
-    t = os.path.getmtime(o)
     return any(os.path.getmtime(p) > t for p in deps(unit))
 
 
 def needs_build():
-    return not os.path.exists(LIB) or any(_stale(u) for u in UNITS) or any(os.path.getmtime(_obj(u)) > os.path.getmtime(LIB) for u in UNITS)
+    return (not os.path.exists(LIB) or any(_stale(u) for u in UNITS) or
+            any(os.path.exists(_obj(u)) and os.path.getmtime(_obj(u)) > os.path.getmtime(LIB) for u in UNITS))
 
 
 def _compile(unit, verbose):
@@ -77,7 +84,7 @@ def _compile(unit, verbose):
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    todo = [u for u in UNITS if force or _stale(u)]
+    todo = [u for u in UNITS if force or _stale(u) or not os.path.exists(_obj(u))]
     with ThreadPoolExecutor(max_workers=max(1, len(todo))) as ex:
         list(ex.map(lambda u: _compile(u, verbose), todo))
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -86,7 +93,11 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=_bdir())
-    shutil.copy2(out, LIB)
+    # a NEW file renamed over the old one: a process that has the old library mapped keeps its (unlinked) file -- writing into
+    # the mapped file in place would change the code under it
+    tmp = LIB + ".new.%d" % os.getpid()
+    shutil.copy2(out, tmp)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -8,6 +8,7 @@
 // combiner, strided joins.  Nothing is computed on the host.
 #include "host_common.h"
 #include "hybrid_kernels.h"
+#include "keytable.h"
 
 using namespace circl::host;
 namespace hk = circl::hybridk;
@@ -288,6 +289,180 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
     return wipe.finish();
 }
 
+// ---- hybrid key tables that live across calls (keytable.h) ------------------------------------------------------------------
+// kem/xwing's PrivateKey keeps the expanded ML-KEM-768 key, the X25519 scalar and its public point next to the 32-byte seed
+// (xwing.go:20-25), its PublicKey the parsed ML-KEM key (:28-31); kem/hybrid's keys hold the component schemes' parsed keys
+// (hybrid.go:101-114).  A hybrid table is that: an ML-KEM key table (A^T, H(ek), the private key's hash verdict) of the lattice
+// halves plus the X25519 rows, built once; a call then moves only seeds / ciphertexts and runs the shared-key ML-KEM work.
+static int gather_rows(hipStream_t st, uint8_t *dst, const uint8_t *table, const uint32_t *key_idx, size_t n) {
+    hipLaunchKernelGGL(hk::rows_gather_kernel, g256(n * 8), dim3(256), 0, st, w(dst), w(table), key_idx, 8u, n);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+static bool hybrid_table_ok(const circl_hip_keytable *t, int want_private) {
+    return t && t->magic == kKeytableMagic && t->family == 3 && t->private_keys == want_private && t->inner && t->d_x;
+}
+static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                   circl_hip_keytable **out) {
+    HIP_TRY(hipSetDevice(physical_device(device)));
+    hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
+    TRY(pipeline_streams(device, &h2d, &d2h, &st));
+    circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
+    if (!t) return CIRCL_HIP_ENOMEM;
+    t->magic = kKeytableMagic; t->family = 3; t->param = d.param; t->device = device; t->private_keys = private_keys ? 1 : 0; t->nkeys = nkeys;
+    t->scheme = scheme;
+    t->row = private_keys ? d.sk : d.pk;
+    t->x_bytes = up256(nkeys * 64);
+    struct Tmp {  // scratch of the build, freed (private material wiped) on every path
+        uint8_t *p = nullptr; size_t bytes = 0;
+        ~Tmp() { if (p) { (void)hipMemset(p, 0, bytes); (void)hipFree(p); } }
+    } tmp;
+    // the lattice halves, contiguous on the host, for the inner ML-KEM table
+    const size_t KROW = private_keys ? d.DK : d.EK;
+    std::vector<uint8_t> krows, xrows(nkeys * 32);
+    int rc = CIRCL_HIP_OK;
+    if (hipMalloc(reinterpret_cast<void **>(&t->d_x), t->x_bytes) != hipSuccess) { (void)hipGetLastError(); rc = CIRCL_HIP_ENOMEM; }
+    if (rc == CIRCL_HIP_OK && private_keys && d.xwing) {
+        // the packed private key is the 32-byte seed: expand it on the device as every X-Wing decapsulation would (xwing.go:98-144)
+        const size_t ws_bytes = circl_hip_mlkem_workspace_size(d.param, nkeys);
+        auto r = [](size_t b) { return (b + 255) & ~size_t(255); };
+        tmp.bytes = r(nkeys * 32) + r(nkeys * 64) + r(nkeys * d.EK) + r(nkeys * d.DK) + ws_bytes;
+        if (hipMalloc(reinterpret_cast<void **>(&tmp.p), tmp.bytes) != hipSuccess) { (void)hipGetLastError(); rc = CIRCL_HIP_ENOMEM; }
+        if (rc == CIRCL_HIP_OK) {
+            Carve c{tmp.p};
+            uint8_t *seed = c.take(nkeys * 32), *seedm = c.take(nkeys * 64), *ek = c.take(nkeys * d.EK), *dk = c.take(nkeys * d.DK), *kws = c.p;
+            uint8_t *skx = t->d_x, *pkx = t->d_x + nkeys * 32;
+            krows.resize(nkeys * d.DK);
+            auto build = [&]() -> int {
+                HIP_TRY(hipMemcpyAsync(seed, keys, nkeys * 32, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(nkeys), dim3(256), 0, st, w(seed), w(seedm), w(skx), nkeys);
+                HIP_TRY(hipGetLastError());
+                TRY(kem_keygen(d, seedm, ek, dk, nkeys, kws, ws_bytes, st));
+                TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, nkeys, st));
+                HIP_TRY(hipMemcpyAsync(krows.data(), dk, nkeys * d.DK, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                return CIRCL_HIP_OK;
+            };
+            rc = build();
+        }
+    } else if (rc == CIRCL_HIP_OK) {
+        krows.resize(nkeys * KROW);
+        for (size_t i = 0; i < nkeys; i++) {
+            const uint8_t *row = keys + i * t->row;
+            memcpy(krows.data() + i * KROW, row + d.kem_off(32), KROW);
+            memcpy(xrows.data() + i * 32, row + d.x_off(KROW), 32);
+        }
+        // public: pk_X rows; private (kem/hybrid): sk_X rows (the decapsulation never needs pk_X there)
+        if (hipMemcpyAsync(t->d_x, xrows.data(), nkeys * 32, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = CIRCL_HIP_EHIP;
+        }
+    }
+    if (rc == CIRCL_HIP_OK) rc = circl_hip_mlkem_keytable_new(d.param, private_keys ? 1 : 0, krows.data(), nkeys, device, key_status, &t->inner);
+    if (private_keys) {  // the host copies of the private rows do not outlive the build
+        volatile uint8_t *z = krows.data();
+        for (size_t i = 0; i < krows.size(); i++) z[i] = 0;
+        volatile uint8_t *x = xrows.data();
+        for (size_t i = 0; i < xrows.size(); i++) x[i] = 0;
+    }
+    if (rc != CIRCL_HIP_OK) { circl_hip_keytable_free(t); return rc; }
+    *out = t;
+    return CIRCL_HIP_OK;
+}
+
+int circl_hip_hybrid_keytable_new(int scheme, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                  circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    Desc d;
+    if (!desc_of(scheme, d) || d.r3 || !keys || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;  // (round-3 Kyber has no key tables)
+    return keytable_replicate(device, [&](int dev, circl_hip_keytable **one) {
+        return hybrid_keytable_new_one(scheme, d, private_keys, keys, nkeys, dev, dev == 0 || device >= 0 ? key_status : nullptr, one);
+    }, out);
+}
+
+// workspace of the table forms: the per-call temporaries + the ML-KEM workspace (as circl_hip_hybrid_workspace_size)
+int circl_hip_hybrid_encaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_eseed, uint8_t *d_ct, uint8_t *d_ss,
+                                      uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    t = keytable_here(t);
+    if (!hybrid_table_ok(t, 0)) return CIRCL_HIP_EPARAM;
+    Desc d;
+    if (!desc_of(t->scheme, d)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!d_status || !d_eseed || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(t->scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (!args_ok(d_eseed, d_ct, d_ss, nullptr, d_ws) || (reinterpret_cast<uintptr_t>(d_key_idx) & 3)) return misaligned();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carve c{static_cast<uint8_t *>(d_ws)};
+    uint8_t *pkx = c.take(n * 32), *m = c.take(n * 32), *ekx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ssm = c.take(n * 32), *ctx = c.take(n * 32),
+            *ssx = c.take(n * 32), *okx = c.take(n);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    SecretWipe wipe{st};
+    wipe.add(m, n * 32); wipe.add(ekx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32);
+    TRY(gather_rows(st, pkx, t->d_x, d_key_idx, n));
+    if (d.xwing) {
+        TRY(copy_rows(st, m, 32, d_eseed, 64, 32, n));
+        TRY(copy_rows(st, ekx, 32, d_eseed + 32, 64, 32, n));
+    } else {
+        hipLaunchKernelGGL((hk::hybrid_expand_kernel<4, 4, false>), g256(n), dim3(256), 0, st, w(d_eseed), w(m), w(ekx), n);
+        HIP_TRY(hipGetLastError());
+    }
+    TRY(circl_hip_mlkem_encaps_table_dev(t->inner, d_key_idx, m, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    TRY(x25519_pair_dev(ekx, pkx, ctx, ssx, okx, n, st));
+    TRY(copy_rows(st, d_ct + d.kem_off(32), d.ct, ctm, d.CTM, d.CTM, n));
+    TRY(copy_rows(st, d_ct + d.x_off(d.CTM), d.ct, ctx, 32, 32, n));
+    if (d.xwing) {
+        hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), d_status, w(d_ss), n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
+        HIP_TRY(hipGetLastError());
+        TRY(copy_rows(st, d_ss + d.kem_off(32), 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.x_off(32), 64, ssx, 32, 32, n));
+        TRY(zero_failed(st, d_ss, 64, d_status, n));
+    }
+    TRY(zero_failed(st, d_ct, d.ct, d_status, n));
+    return wipe.finish();
+}
+
+int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status,
+                                      size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    t = keytable_here(t);
+    if (!hybrid_table_ok(t, 1)) return CIRCL_HIP_EPARAM;
+    Desc d;
+    if (!desc_of(t->scheme, d)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!d_status || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
+    if (ws_bytes < circl_hip_hybrid_workspace_size(t->scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (!args_ok(d_ct, d_ss, nullptr, nullptr, d_ws) || (reinterpret_cast<uintptr_t>(d_key_idx) & 3)) return misaligned();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carve c{static_cast<uint8_t *>(d_ws)};
+    uint8_t *skx = c.take(n * 32), *pkx = c.take(n * 32), *ctm = c.take(n * d.CTM), *ctx = c.take(n * 32), *ssm = c.take(n * 32), *ssx = c.take(n * 32),
+            *okx = c.take(n);
+    uint8_t *kws = static_cast<uint8_t *>(d_ws) + tmp_bytes(d, n);
+    const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
+    SecretWipe wipe{st};
+    wipe.add(skx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32);
+    TRY(copy_rows(st, ctm, d.CTM, d_ct + d.kem_off(32), d.ct, d.CTM, n));
+    TRY(copy_rows(st, ctx, 32, d_ct + d.x_off(d.CTM), d.ct, 32, n));
+    TRY(gather_rows(st, skx, t->d_x, d_key_idx, n));
+    if (d.xwing) TRY(gather_rows(st, pkx, t->d_x + t->nkeys * 32, d_key_idx, n));  // sk.xpk, computed when the table was built
+    TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
+    TRY(circl_hip_mlkem_decaps_table_dev(t->inner, d_key_idx, ctm, ssm, d_status, n, kws, kws_bytes, st));
+    if (d.xwing) {
+        hipLaunchKernelGGL(hk::xwing_combine_kernel, g256(n), dim3(256), 0, st, w(ssm), w(ssx), w(ctx), w(pkx), static_cast<const uint8_t *>(nullptr),
+                           w(d_ss), n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(hk::hybrid_status_kernel, g256(n), dim3(256), 0, st, d_status, okx, n);
+        HIP_TRY(hipGetLastError());
+        TRY(copy_rows(st, d_ss + d.kem_off(32), 64, ssm, 32, 32, n));
+        TRY(copy_rows(st, d_ss + d.x_off(32), 64, ssx, 32, 32, n));
+        TRY(zero_failed(st, d_ss, 64, d_status, n));
+    }
+    return wipe.finish();
+}
+
 // ---- host-buffer forms on the staging pipeline ----
 static PipeOpts hybrid_opts() {
     PipeOpts o;
@@ -330,6 +505,50 @@ int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, ui
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
                             [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
                                 return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+
+static int check_idx(const uint32_t *key_idx, size_t n, size_t nkeys) {
+    if (key_idx)
+        for (size_t i = 0; i < n; i++)
+            if (key_idx[i] >= nkeys) return CIRCL_HIP_EPARAM;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_hybrid_encaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                  size_t n) {
+    if (!t || t->magic != kKeytableMagic || t->family != 3 || t->private_keys) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(t->scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!eseed || !ct || !ss) return CIRCL_HIP_EPARAM;
+    TRY(check_idx(key_idx, n, t->nkeys));
+    const int scheme = t->scheme;
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {eseed + lo * s.eseed, s.eseed, true}}, {},
+                            {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                                return circl_hip_hybrid_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                         c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n) {
+    if (!t || t->magic != kKeytableMagic || t->family != 3 || !t->private_keys) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(t->scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!ct || !ss) return CIRCL_HIP_EPARAM;
+    TRY(check_idx(key_idx, n, t->nkeys));
+    const int scheme = t->scheme;
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * s.ct, s.ct}}, {},
+                            {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
+                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                                return circl_hip_hybrid_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                         c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
 }

@@ -245,6 +245,24 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     return CIRCL_HIP_OK;
 }
 
+// PrivateKey.Public() over a batch (sign/mldsa/mldsa65/internal/dilithium.go:473-484): t1 recomputed from the packed private keys
+template <int MODE>
+int mldsa_public_dev_impl(const uint8_t *sk, uint8_t *pk, size_t n, void *ws, size_t ws_bytes, hipStream_t st) {
+    using Kg = circl::mldsa::KG<MODE>;
+    using namespace circl::mldsa;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (ws_bytes < mldsa_ws_bytes<MODE>(n) || !aligned16(ws) || !aligned16(sk) || !aligned16(pk)) return CIRCL_HIP_EWORKSPACE;
+    unsigned *work = reinterpret_cast<unsigned *>(static_cast<uint8_t *>(ws) + mldsa_item_ws_bytes<MODE>(n));
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
+    HIP_TRY(hipMemsetAsync(work, 0, 256, st));
+    ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYGEN, st);
+    auto kern = mldsa_keygen_kernel<MODE, true>;
+    const unsigned kb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, Kg::LDS_TOTAL));
+    hipLaunchKernelGGL(kern, dim3(kb), dim3(64), Kg::LDS_TOTAL, st, sk, pk, (uint8_t *)nullptr, scratch, work, n);
+    HIP_TRY(hipGetLastError());
+    return CIRCL_HIP_OK;
+}
+
 #define DSA_SWITCH(param, CALL)      \
     switch (param) {                 \
     case 44: return CALL(44);        \
@@ -416,6 +434,8 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
 // A private key prepared once (circl_hip_mldsa_privkey_new): its entry point parks the table here for the length of its call, and the
 // round signer takes A and the transformed secrets from it instead of expanding them (thread-local: calls are per thread)
 thread_local const circl_hip_keytable *tl_sign_prepared = nullptr;
+// ... and, for a table of SEVERAL prepared keys, the device array that names every item's entry (nullptr: entry 0)
+thread_local const uint32_t *tl_sign_key_idx = nullptr;
 
 template <int MODE>
 int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
@@ -430,13 +450,16 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     SignState S;
     S.shared = shared ? 1u : 0u;
     const circl_hip_keytable *prep = shared ? tl_sign_prepared : nullptr;
+    const uint32_t *key_idx = prep ? tl_sign_key_idx : nullptr;
+    S.key_idx = nullptr;
     S.mr = base + lay.o_mr;
     S.A = reinterpret_cast<uint32_t *>(base + lay.o_A);
     S.sec = reinterpret_cast<uint32_t *>(base + lay.o_sec);
     if (prep) {
         S.A = reinterpret_cast<uint32_t *>(prep->d_table);
-        S.sec = reinterpret_cast<uint32_t *>(prep->d_table + up256(SB<MODE>::A_BYTES));
+        S.sec = reinterpret_cast<uint32_t *>(prep->d_table + up256(prep->nkeys * SB<MODE>::A_BYTES));
         S.shared = 2u;
+        S.key_idx = key_idx;
     }
     S.y = reinterpret_cast<uint32_t *>(base + lay.o_y);
     S.w0 = reinterpret_cast<uint32_t *>(base + lay.o_w0);
@@ -476,11 +499,11 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
-        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, shared ? 0 : KG<MODE>::SK, nullptr, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
-                                                          DP<MODE>::NIST ? internal : 1, S.mr, 128, lctl, n, st))
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
+                                                          ctx_off, DP<MODE>::NIST ? internal : 1, S.mr, 128, lctl, n, st))
             return rc;
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                           S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl);
+                           S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
@@ -491,8 +514,6 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     // grids: the kernels loop over the device-side count, so any grid is correct; the schedule's upper estimate of a
     // round's entries gives (nearly) one workgroup per entry while the lists are long, and small launches for the late and
     // the empty rounds
-    static const int w_waves = [] { const char *e = getenv("CIRCL_HIP_SIGN_W_WAVES"); return e ? atoi(e) : 4; }();  // tuning aids
-    static const int f_waves = [] { const char *e = getenv("CIRCL_HIP_SIGN_F_WAVES"); return e ? atoi(e) : 4; }();
     const size_t lane_cap = (size_t)cus * 10;
     const unsigned small = (unsigned)cus * 4;  // grid of the kernels that usually have nothing to do (grid-stride loops: any grid is correct)
     for (int round = 0; round < rounds; round++) {
@@ -509,14 +530,10 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const bool split_mask = upper * L <= sign_split_lanes(), split_ch = upper <= sign_split_lanes();
         if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
-        if (w_waves == 6) hipLaunchKernelGGL((sign_w_kernel<MODE, 6>), dim3(gw), dim3(64), 0, st, S, cur);
-        else if (w_waves == 5) hipLaunchKernelGGL((sign_w_kernel<MODE, 5>), dim3(gw), dim3(64), 0, st, S, cur);
-        else hipLaunchKernelGGL((sign_w_kernel<MODE, 4>), dim3(gw), dim3(64), 0, st, S, cur);
+        hipLaunchKernelGGL((sign_w_kernel<MODE, 4>), dim3(gw), dim3(64), 0, st, S, cur);
         if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
         else hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
-        if (f_waves == 6) hipLaunchKernelGGL((sign_finish_kernel<MODE, 6>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
-        else if (f_waves == 5) hipLaunchKernelGGL((sign_finish_kernel<MODE, 5>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
-        else hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
+        hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
         hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
         hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
         hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(lazy[round] ? small : std::min<unsigned>((unsigned)std::max<size_t>(1, upper), (unsigned)cus * 32)),
@@ -531,7 +548,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const int fin = rounds & 1;
         hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>(lay.tail_units, 512)), dim3(64), SG<MODE>::LDS_TOTAL, st, sk,
                            (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[fin], (const uint32_t *)S.attempts, (size_t)0, 1u,
-                           (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin));
+                           (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin), key_idx);
         hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }
     // The workspace held rho'', the NTT-domain secrets, the accepted attempts' y next to c~ (z - y = c s1) and parked
@@ -581,8 +598,11 @@ int mldsa_sign_batched(const uint8_t *sk, const uint8_t *msg_blob, const uint64_
     };
     for (int p = 0; p < 2; p++) {
         if (note(hipStreamWaitEvent(aux[p], fork, 0), "fork")) {
+            const uint32_t *kidx = tl_sign_key_idx;  // (a table of several prepared keys: this half's slice of the index array)
+            tl_sign_key_idx = kidx ? kidx + lo[p] : nullptr;
             const int r = mldsa_sign_batched_part<MODE>(shared ? sk : sk + lo[p] * SK, msg_blob, msg_off + lo[p], ctx_blob, ctx_off ? ctx_off + lo[p] : nullptr,
                                                         rnd + lo[p] * 32, internal, sig + lo[p] * SIG, cnt[p], wsp[p], aux[p], shared);
+            tl_sign_key_idx = kidx;
             if (r != CIRCL_HIP_OK && rc == CIRCL_HIP_OK) rc = r;
         }
         // join on EVERY path: whatever was enqueued on the library's streams is ordered before the caller's later work (the
@@ -605,6 +625,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         return CIRCL_HIP_EWORKSPACE;
     if (n >= sign_batched_min()) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
     const SignLayout<MODE> lay(n);
+    const uint32_t *key_idx = (shared && tl_sign_prepared) ? tl_sign_key_idx : nullptr;
     uint8_t *base = static_cast<uint8_t *>(ws);
     uint8_t *mr = base + lay.o_mr, *dead = base + lay.o_dead, *scratch = base + lay.o_scratch;
     unsigned *work = reinterpret_cast<unsigned *>(base + lay.o_work);
@@ -612,11 +633,11 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
-        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, shared ? 0 : KG<MODE>::SK, nullptr, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
-                                                          DP<MODE>::NIST ? internal : 1, mr, 128, lctl, n, st))
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
+                                                          ctx_off, DP<MODE>::NIST ? internal : 1, mr, 128, lctl, n, st))
             return rc;
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sk, msg_blob,
-                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl);
+                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
     }
     {
         auto kern = mldsa_sign_kernel<MODE>;
@@ -626,7 +647,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0,
-                           (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, key_idx);
         hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }
     HIP_TRY(hipMemsetAsync(mr, 0, up256(128 * n), st));  // rho'' and the NTT-domain secrets do not stay behind
@@ -652,27 +673,29 @@ size_t mldsa_sign_ws_any(int param, size_t n) {
     return 0;
 }
 
-// the table of ONE prepared private key: [A: K L packed rows][s1-hat, s2-hat, t0-hat: L + 2 K packed rows][set-up scratch], made by the
-// round signer's own set-up kernels
+// the table of nkeys prepared private keys: [A: nkeys x K L packed rows][s1-hat, s2-hat, t0-hat: nkeys x (L + 2 K) packed rows][set-up
+// scratch], made by the round signer's own set-up kernels (every key is an "item" of an unshared batch of nkeys)
 template <int MODE> int mldsa_privkey_build(circl_hip_keytable *t, const uint8_t *sk, hipStream_t st) {
     using namespace circl::mldsa;
     using B = SB<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
-    t->table_bytes = up256(B::A_BYTES) + up256(B::SEC_BYTES) + 1024;
+    const size_t nk = t->nkeys;
+    const size_t o_sec = up256(nk * B::A_BYTES), o_scr = o_sec + up256(nk * B::SEC_BYTES);
+    t->table_bytes = o_scr + up256(12 * nk) + 1024;
     if (hipMalloc(reinterpret_cast<void **>(&t->d_keys), t->keys_bytes) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&t->d_table), t->table_bytes) != hipSuccess) {
         (void)hipGetLastError();
         return CIRCL_HIP_ENOMEM;
     }
-    HIP_TRY(hipMemcpyAsync(t->d_keys, sk, KG<MODE>::SK, hipMemcpyHostToDevice, st));
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(t->d_table + up256(B::A_BYTES) + up256(B::SEC_BYTES));
+    HIP_TRY(hipMemcpyAsync(t->d_keys, sk, KG<MODE>::SK * nk, hipMemcpyHostToDevice, st));
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(t->d_table + o_scr);
     SignState S{};
-    S.shared = 1u;
+    S.shared = 0u;
     S.A = reinterpret_cast<uint32_t *>(t->d_table);
-    S.sec = reinterpret_cast<uint32_t *>(t->d_table + up256(B::A_BYTES));
-    S.attempts = scratch; S.best = scratch + 1; S.list[0] = scratch + 64; S.list[1] = scratch + 128; S.count = scratch + 8; S.kk = scratch + 10;
-    hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((K * L + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, S, (size_t)1);
-    hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3(1), dim3(64), 0, st, (const uint8_t *)t->d_keys, S, (size_t)1, 1u);
+    S.sec = reinterpret_cast<uint32_t *>(t->d_table + o_sec);
+    S.count = scratch; S.kk = scratch + 2; S.attempts = scratch + 64; S.best = scratch + 64 + nk; S.list[0] = scratch + 64 + 2 * nk; S.list[1] = S.list[0];
+    hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nk * K * L + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, S, nk);
+    hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)nk), dim3(64), 0, st, (const uint8_t *)t->d_keys, S, nk, 1u);
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -753,12 +776,8 @@ int circl_hip_mldsa_verify_keyed_dev(int param, const uint8_t *d_pk_table, size_
 }
 
 // ---- a public-key table that lives across calls (keytable.h): A and tr of every entry, once ---------------------------------------
-int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out) {
-    if (out) *out = nullptr;
+static int mldsa_keytable_new_one(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out) {
     const size_t PK = circl_hip_mldsa_pk_size(param);
-    if (!PK || !pks || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
-    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
-    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
     HIP_TRY(hipSetDevice(physical_device(device)));
     circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
     if (!t) return CIRCL_HIP_ENOMEM;
@@ -790,16 +809,22 @@ int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, in
     *out = t;
     return CIRCL_HIP_OK;
 }
+int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    if (!circl_hip_mldsa_pk_size(param) || !pks || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
+    return keytable_replicate(device, [&](int dev, circl_hip_keytable **one) { return mldsa_keytable_new_one(param, pks, nkeys, dev, one); }, out);
+}
 int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_sig, const uint8_t *d_msg_blob,
                                      const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n, void *d_ws,
                                      size_t ws_bytes, void *stream) {
-    if (!t || t->magic != kKeytableMagic || t->family != 2) return CIRCL_HIP_EPARAM;
+    t = keytable_here(t);
+    if (!t || t->family != 2 || t->private_keys) return CIRCL_HIP_EPARAM;
     return mldsa_verify_dev_any<KM_KEYED>(t->param, t->d_keys, t->nkeys, d_key_idx, d_sig, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, 0, d_ok, n, d_ws,
                                           ws_bytes, static_cast<hipStream_t>(stream), t);
 }
 int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
                                  const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n) {
-    if (!t || t->magic != kKeytableMagic || t->family != 2) return CIRCL_HIP_EPARAM;
+    if (!t || t->magic != kKeytableMagic || t->family != 2 || t->private_keys) return CIRCL_HIP_EPARAM;
     const int param = t->param;
     const size_t SIG = circl_hip_mldsa_sig_size(param);
     if (n == 0) return CIRCL_HIP_OK;
@@ -807,29 +832,28 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
         for (size_t i = 0; i < n; i++)
             if (key_idx[i] >= t->nkeys) return CIRCL_HIP_EPARAM;
     if (check_contexts(param, ctx_blob, ctx_off, n) == CTX_UNSUPPORTED) return CIRCL_HIP_EPARAM;
-    return run_pipeline(t->device, n, {{sig, SIG}, {reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}},
-                        {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{ok, 1}}, [&](size_t c) { return mldsa_ws_any(param, c); },
-                        dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
-                            return circl_hip_mldsa_verify_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.in[0], c.blob[0], c.off[0],
-                                                                    c.blob[1], c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
-                        });
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        return run_pipeline(r->device, cnt, {{sig + lo * SIG, SIG}, {reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}},
+                            {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}}, [&](size_t c) { return mldsa_ws_any(param, c); },
+                            dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
+                                return circl_hip_mldsa_verify_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.in[0], c.blob[0], c.off[0],
+                                                                        c.blob[1], c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
 }
 
-// ---- ONE private key prepared once: A and the NTT-domain secrets of the reference's parsed PrivateKey (internal/dilithium.go:149-179) ----
-int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out) {
-    if (out) *out = nullptr;
+// ---- private keys prepared once: A and the NTT-domain secrets of the reference's parsed PrivateKey (internal/dilithium.go:149-179) ----
+static int mldsa_privkeys_new_one(int param, const uint8_t *sks, size_t nkeys, int device, circl_hip_keytable **out) {
     const size_t SK = circl_hip_mldsa_sk_size(param);
-    if (!SK || !sk || !out) return CIRCL_HIP_EPARAM;
-    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
-    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
     HIP_TRY(hipSetDevice(physical_device(device)));
     circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
     if (!t) return CIRCL_HIP_ENOMEM;
-    t->magic = kKeytableMagic; t->family = 2; t->param = param; t->device = device; t->private_keys = 1; t->nkeys = 1; t->row = SK;
-    t->keys_bytes = up256(SK + 16);
+    t->magic = kKeytableMagic; t->family = 2; t->param = param; t->device = device; t->private_keys = 1; t->nkeys = nkeys; t->row = SK;
+    t->keys_bytes = up256(SK * nkeys + 16);
     hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
     int rc = pipeline_streams(device, &h2d, &d2h, &st);
-#define CALL(M) mldsa_privkey_build<M>(t, sk, st)
+#define CALL(M) mldsa_privkey_build<M>(t, sks, st)
     if (rc == CIRCL_HIP_OK)
         rc = [&]() -> int {
             DSA_SWITCH(param, CALL)
@@ -845,33 +869,59 @@ int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_
     *out = t;
     return CIRCL_HIP_OK;
 }
-int circl_hip_mldsa_sign_table_dev(const circl_hip_keytable *t, const uint8_t *d_msg_blob, const uint64_t *d_msg_off, const uint8_t *d_ctx_blob,
-                                   const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n, void *d_ws, size_t ws_bytes,
-                                   void *stream) {
-    if (!t || t->magic != kKeytableMagic || t->family != 2 || !t->private_keys) return CIRCL_HIP_EPARAM;
+int circl_hip_mldsa_privkeys_new(int param, const uint8_t *sks, size_t nkeys, int device, circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    if (!circl_hip_mldsa_sk_size(param) || !sks || !out || nkeys == 0 || nkeys >= (size_t(1) << 26)) return CIRCL_HIP_EPARAM;
+    return keytable_replicate(device, [&](int dev, circl_hip_keytable **one) { return mldsa_privkeys_new_one(param, sks, nkeys, dev, one); }, out);
+}
+int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out) {
+    return circl_hip_mldsa_privkeys_new(param, sk, 1, device, out);
+}
+int circl_hip_mldsa_sign_table_keyed_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
+                                         const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n,
+                                         void *d_ws, size_t ws_bytes, void *stream) {
+    t = keytable_here(t);
+    if (!t || t->family != 2 || !t->private_keys || (reinterpret_cast<uintptr_t>(d_key_idx) & 3)) return CIRCL_HIP_EPARAM;
     struct Park {  // (restored on every path)
-        explicit Park(const circl_hip_keytable *p) { tl_sign_prepared = p; }
-        ~Park() { tl_sign_prepared = nullptr; }
-    } park(t);
+        Park(const circl_hip_keytable *p, const uint32_t *k) { tl_sign_prepared = p; tl_sign_key_idx = k; }
+        ~Park() { tl_sign_prepared = nullptr; tl_sign_key_idx = nullptr; }
+    } park(t, d_key_idx);
     return mldsa_sign_dev_any(t->param, t->d_keys, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, d_rnd, internal, d_sig, n, d_ws, ws_bytes,
                               static_cast<hipStream_t>(stream), true);
 }
-int circl_hip_mldsa_sign_table(const circl_hip_keytable *t, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
-                               const uint8_t *rnd, uint8_t *sig, size_t n) {
+int circl_hip_mldsa_sign_table_dev(const circl_hip_keytable *t, const uint8_t *d_msg_blob, const uint64_t *d_msg_off, const uint8_t *d_ctx_blob,
+                                   const uint64_t *d_ctx_off, const uint8_t *d_rnd, int internal, uint8_t *d_sig, size_t n, void *d_ws, size_t ws_bytes,
+                                   void *stream) {
+    return circl_hip_mldsa_sign_table_keyed_dev(t, nullptr, d_msg_blob, d_msg_off, d_ctx_blob, d_ctx_off, d_rnd, internal, d_sig, n, d_ws, ws_bytes, stream);
+}
+int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                     const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n) {
     if (!t || t->magic != kKeytableMagic || t->family != 2 || !t->private_keys) return CIRCL_HIP_EPARAM;
     const int param = t->param;
     const size_t SIG = circl_hip_mldsa_sig_size(param);
     if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        for (size_t i = 0; i < n; i++)
+            if (key_idx[i] >= t->nkeys) return CIRCL_HIP_EPARAM;
     if (check_contexts(param, ctx_blob, ctx_off, n) != CTX_OK) return CIRCL_HIP_EPARAM;  // sign.ErrContextTooLong / ErrContextNotSupported
     const PipeOpts opts = dsa_opts(size_t(1) << 13, true, /*depth=*/3);
     std::vector<uint8_t> zeros;
     if (!rnd) zeros.assign(32 * std::min(n, opts.chunk_items), 0);  // deterministic signing: 32 zero bytes per item
-    std::vector<HIn> ins;
-    ins.push_back(rnd ? HIn{rnd, 32, true} : HIn{zeros.data(), zeros.size(), false, true});
-    return run_pipeline(t->device, n, ins, {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{sig, SIG}},
-                        [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
-                            return circl_hip_mldsa_sign_table_dev(t, c.blob[0], c.off[0], c.blob[1], c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
-                        });
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        std::vector<HIn> ins;
+        ins.push_back(rnd ? HIn{rnd + lo * 32, 32, true} : HIn{zeros.data(), zeros.size(), false, true});
+        ins.push_back(HIn{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)});
+        return run_pipeline(r->device, cnt, ins, {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{sig + lo * SIG, SIG}},
+                            [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
+                                return circl_hip_mldsa_sign_table_keyed_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.blob[0], c.off[0], c.blob[1],
+                                                                            c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+int circl_hip_mldsa_sign_table(const circl_hip_keytable *t, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
+                               const uint8_t *rnd, uint8_t *sig, size_t n) {
+    return circl_hip_mldsa_sign_table_keyed(t, nullptr, msg_blob, msg_off, ctx_blob, ctx_off, rnd, sig, n);
 }
 
 int circl_hip_mldsa_verify(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
@@ -943,6 +993,23 @@ int circl_hip_mldsa_keygen_dev(int param, const uint8_t *d_seed32, uint8_t *d_pk
     return CIRCL_HIP_EPARAM;
 }
 
+int circl_hip_mldsa_public_from_private_dev(int param, const uint8_t *d_sk, uint8_t *d_pk, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define CALL(M) mldsa_public_dev_impl<M>(d_sk, d_pk, n, d_ws, ws_bytes, st)
+    DSA_SWITCH(param, CALL)
+#undef CALL
+    return CIRCL_HIP_EPARAM;
+}
+int circl_hip_mldsa_public_from_private(int param, const uint8_t *sk, uint8_t *pk, size_t n, int device) {
+    const size_t PK = circl_hip_mldsa_pk_size(param), SK = circl_hip_mldsa_sk_size(param);
+    if (!PK || (n && (!sk || !pk))) return CIRCL_HIP_EPARAM;
+    return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
+        return run_pipeline(dev, cnt, {{sk + lo * SK, SK, true}}, {}, {{pk + lo * PK, PK}}, [&](size_t c) { return mldsa_ws_any(param, c); },
+                            dsa_opts(size_t(1) << 13, true),
+                            [&](Chunk &c) { return circl_hip_mldsa_public_from_private_dev(param, c.in[0], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st); });
+    });
+}
 int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_t n, int device) {
     const size_t PK = circl_hip_mldsa_pk_size(param), SK = circl_hip_mldsa_sk_size(param);
     if (!PK) return CIRCL_HIP_EPARAM;

@@ -738,13 +738,9 @@ int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkey
 }
 
 // ---- key tables that live across calls ---------------------------------------------------------------------------------------
-int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
-                                 circl_hip_keytable **out) {
-    if (out) *out = nullptr;
+static int kem_keytable_new_one(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                circl_hip_keytable **out) {
     const int K = kem_k(param);
-    if (!K || !keys || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
-    if (ndev() <= 0) return CIRCL_HIP_ENODEV;
-    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
     HIP_TRY(hipSetDevice(physical_device(device)));
     circl_hip_keytable *t = new (std::nothrow) circl_hip_keytable();
     if (!t) return CIRCL_HIP_ENOMEM;
@@ -779,8 +775,18 @@ int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *key
     *out = t;
     return CIRCL_HIP_OK;
 }
+int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                 circl_hip_keytable **out) {
+    if (out) *out = nullptr;
+    if (!kem_k(param) || !keys || !out || nkeys == 0 || nkeys > 0xffffffffull) return CIRCL_HIP_EPARAM;
+    // device = CIRCL_HIP_ALL_DEVICES: the same table on every device (the verdicts are the same everywhere: replica 0 reports them)
+    return keytable_replicate(device, [&](int dev, circl_hip_keytable **one) {
+        return kem_keytable_new_one(param, private_keys, keys, nkeys, dev, dev == 0 || device >= 0 ? key_status : nullptr, one);
+    }, out);
+}
 int circl_hip_mlkem_encaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_m, uint8_t *d_ct, uint8_t *d_ss,
                                      uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    t = keytable_here(t);
     if (!kem_table_ok(t, 0)) return CIRCL_HIP_EPARAM;
     const int param = t->param;
     KEM_DISPATCH(encaps_table_dev_impl<2>(t, d_key_idx, d_m, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
@@ -789,6 +795,7 @@ int circl_hip_mlkem_encaps_table_dev(const circl_hip_keytable *t, const uint32_t
 }
 int circl_hip_mlkem_decaps_table_dev(const circl_hip_keytable *t, const uint32_t *d_key_idx, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status,
                                      size_t n, void *d_ws, size_t ws_bytes, void *stream) {
+    t = keytable_here(t);
     if (!kem_table_ok(t, 1)) return CIRCL_HIP_EPARAM;
     const int param = t->param;
     KEM_DISPATCH(decaps_table_dev_impl<2>(t, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st),
@@ -803,11 +810,14 @@ int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *ke
     if (n == 0) return CIRCL_HIP_OK;
     if (key_idx)
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
-    return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {m, 32, true}}, {},
-                        {{ct, CT}, {ss, 32, true}, {status, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
-                            return circl_hip_mlkem_encaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
-                                                                    c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
-                        });
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {m + lo * 32, 32, true}}, {},
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
+                                return circl_hip_mlkem_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                        c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
 }
 int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n) {
     if (!kem_table_ok(t, 1)) return CIRCL_HIP_EPARAM;
@@ -815,11 +825,23 @@ int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *ke
     if (n == 0) return CIRCL_HIP_OK;
     if (key_idx)
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
-    return run_pipeline(t->device, n, {{reinterpret_cast<const uint8_t *>(key_idx), key_idx ? size_t(4) : size_t(0)}, {ct, CT}}, {},
-                        {{ss, 32, true}, {status, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
-                            return circl_hip_mlkem_decaps_table_dev(t, key_idx ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
-                                                                    c.cnt, c.ws, c.ws_bytes, c.st);
-                        });
+    return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
+        const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * CT, CT}}, {},
+                            {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
+                                return circl_hip_mlkem_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
+                                                                        c.cnt, c.ws, c.ws_bytes, c.st);
+                            });
+    });
+}
+/* PrivateKey.Public() over a batch (kem/mlkem/mlkem768/kyber.go:323-328): the encapsulation key stored inside each decapsulation
+ * key (dk = s || ek || H(ek) || z, :189-201).  No device work: a strided copy. */
+int circl_hip_mlkem_public_from_private(int param, const uint8_t *dk, uint8_t *ek, size_t n) {
+    const int K = kem_k(param);
+    if (!K || (n && (!dk || !ek))) return CIRCL_HIP_EPARAM;
+    const size_t DK = circl_hip_mlkem_dk_size(param), EK = circl_hip_mlkem_ek_size(param);
+    for (size_t i = 0; i < n; i++) memcpy(ek + i * EK, dk + i * DK + 384 * (size_t)K, EK);
+    return CIRCL_HIP_OK;
 }
 
 // ---- round-3 Kyber (kem/kyber/kyber{512,768,1024}), SURVEY 8f row f3 ------------------------------------

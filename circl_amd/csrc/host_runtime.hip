@@ -744,6 +744,40 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     return CIRCL_HIP_OK;
 }
 
+// ---- key tables on several devices (keytable.h) ---------------------------------------------------
+const circl_hip_keytable *keytable_here(const circl_hip_keytable *t) {
+    if (!t || t->magic != kKeytableMagic) return nullptr;
+    if (t->device >= 0) return t;
+    int phys = 0;
+    if (hipGetDevice(&phys) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    for (int d = 0; d < t->nreplica; d++)
+        if (physical_device(d) == phys) return t->replica[d];
+    return nullptr;
+}
+int keytable_replicate(int device, const std::function<int(int dev, circl_hip_keytable **one)> &make, circl_hip_keytable **out) {
+    *out = nullptr;
+    const int nd = ndev();
+    if (nd <= 0) return CIRCL_HIP_ENODEV;
+    if (device >= 0) return device < nd ? make(device, out) : CIRCL_HIP_ENODEV;
+    if (device != CIRCL_HIP_ALL_DEVICES) return CIRCL_HIP_EPARAM;
+    circl_hip_keytable *top = new (std::nothrow) circl_hip_keytable();
+    if (!top) return CIRCL_HIP_ENOMEM;
+    top->magic = kKeytableMagic;
+    top->device = CIRCL_HIP_ALL_DEVICES;
+    top->replica = new (std::nothrow) circl_hip_keytable *[nd]();
+    if (!top->replica) { delete top; return CIRCL_HIP_ENOMEM; }
+    for (int d = 0; d < nd; d++) {
+        const int rc = make(d, &top->replica[d]);
+        if (rc != CIRCL_HIP_OK) { circl_hip_keytable_free(top); return rc; }
+        top->nreplica = d + 1;
+    }
+    const circl_hip_keytable *r0 = top->replica[0];
+    top->family = r0->family; top->param = r0->param; top->private_keys = r0->private_keys; top->nkeys = r0->nkeys; top->row = r0->row;
+    top->scheme = r0->scheme;
+    *out = top;
+    return CIRCL_HIP_OK;
+}
+
 // ---- shard ----------------------------------------------------------------------------------------
 int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn) {
     const int nd = ndev();
@@ -824,6 +858,9 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
 void circl_hip_keytable_free(circl_hip_keytable *t) {
     if (!t || t->magic != kKeytableMagic) return;
     t->magic = 0;
+    for (int d = 0; d < t->nreplica; d++) circl_hip_keytable_free(t->replica[d]);
+    delete[] t->replica;
+    if (t->inner) circl_hip_keytable_free(t->inner);
     if (ndev() > 0 && t->device >= 0 && t->device < ndev() && hipSetDevice(circl::host::physical_device(t->device)) == hipSuccess) {
         if (t->d_keys) {
             if (t->private_keys) (void)hipMemset(t->d_keys, 0, t->keys_bytes);
@@ -833,10 +870,17 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
             if (t->private_keys && t->family == 2) (void)hipMemset(t->d_table, 0, t->table_bytes);  // ML-DSA: the transformed secrets
             (void)hipFree(t->d_table);
         }
+        if (t->d_x) {
+            if (t->private_keys) (void)hipMemset(t->d_x, 0, t->x_bytes);
+            (void)hipFree(t->d_x);
+        }
     }
     (void)hipGetLastError();
     delete t;
 }
+int circl_hip_keytable_device(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->device : CIRCL_HIP_EPARAM - 1; }
+size_t circl_hip_keytable_nkeys(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->nkeys : 0; }
+const circl_hip_keytable *circl_hip_keytable_on_device(const circl_hip_keytable *t, int device) { return circl::host::keytable_on(t, device); }
 
 void *circl_hip_alloc_host(size_t bytes) {
     void *p = nullptr;

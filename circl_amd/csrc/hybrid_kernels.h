@@ -42,6 +42,14 @@ static __global__ __launch_bounds__(256) void rows_copy_kernel(uint32_t *__restr
     const unsigned c = (unsigned)(t - r * width);
     if (r < n) dst[r * dst_stride + c] = src[r * src_stride + c];
 }
+// dst[r] = table[key_idx ? key_idx[r] : 0]: rows of `width` dwords gathered from a key table (a resident hybrid key table's X25519 rows)
+static __global__ __launch_bounds__(256) void rows_gather_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ table,
+                                                                 const uint32_t *__restrict__ key_idx, unsigned width, size_t n) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t r = t / width;
+    const unsigned c = (unsigned)(t - r * width);
+    if (r < n) dst[r * width + c] = table[(key_idx ? (size_t)key_idx[r] : size_t(0)) * width + c];
+}
 // rows whose status byte is non-zero are zero-filled (the reference returns nil, nil, err: hybrid.go:283-300)
 static __global__ __launch_bounds__(256) void rows_zero_failed_kernel(uint32_t *__restrict__ dst, size_t dst_stride, unsigned width,
                                                                       const uint8_t *__restrict__ status, size_t n) {

@@ -996,7 +996,11 @@ __global__ void __launch_bounds__(256) mldsa_keygen_seed_kernel(const uint8_t *_
 // (sample.go:125-175, SHAKE256(rho' || LE16(nonce)), nibble rejection) into LDS as small integers.
 // Then per item, in registers: s1-hat = NTT(s1) per polynomial, eta-packing of s1, s2 into sk;
 // t-hat[i] = sum_j A[i][j] o s1-hat[j]; t = InvNTT(t-hat) + s2, Power2Round (field.go:35-52), t1 -> pk, t0 -> sk.
-template <int MODE>
+// FROM_SK: PrivateKey.Public() (dilithium.go:473-484 -> computeT0andT1 :149-179): `es_ws` is then the array of packed PRIVATE keys
+// (rho at the head of each row, stride Kg::SK), the secrets are decoded from them instead of sampled, and only pk = rho || t1 is
+// written (sk is not touched).
+template <int D> __device__ __forceinline__ uint32_t gbits(const uint32_t *p, int n, int ndwords);
+template <int MODE, bool FROM_SK = false>
 __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     mldsa_keygen_kernel(const uint8_t *__restrict__ es_ws, uint8_t *__restrict__ pk, uint8_t *__restrict__ sk,
                         uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n) {
@@ -1004,6 +1008,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     using P = DP<MODE>;
     using Kg = KG<MODE>;
     constexpr int K = P::K, L = P::L, NS = Kg::NS;
+    constexpr size_t ES = FROM_SK ? (size_t)Kg::SK : size_t(128);  // stride of the rows that start with rho
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int8_t *sec = reinterpret_cast<int8_t *>(smem);  // aliases the FIFOs of phase A
     uint32_t *xch = reinterpret_cast<uint32_t *>(smem + Kg::LDS_SEC);
@@ -1017,11 +1022,21 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     const size_t item0 = grp * G::IT;
     // ---- phase A: the matrix ----
     __syncthreads();
-    expand_a_scratch<MODE>(smem, rows, es_ws, 128, item0, n, lane);
+    expand_a_scratch<MODE>(smem, rows, es_ws, ES, item0, n, lane);
     rows_acquire();
 
     // ---- phase 1a: sample the secrets, one stream per lane ----
-    {
+    if constexpr (FROM_SK) {  // ... or decode them from the packed private key (pack.go:9-37: field = eta - coefficient)
+#pragma unroll 1
+        for (int gk = 0; gk < G::IT * NS; gk++) {
+            size_t item = item0 + gk / NS;
+            if (item >= n) item = n - 1;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(es_ws + item * ES + Kg::SKHDR + Kg::ETASZ * (gk % NS));
+            int8_t *row = sec + gk * Kg::S_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 4; r++) row[lane + 64 * r] = (int8_t)(P::ETA - (int)gbits<Kg::ETABITS>(p, lane + 64 * r, Kg::ETASZ / 4));
+        }
+    } else {
         const bool on = lane < G::IT * NS;
         const int g = on ? lane / NS : 0, nonce = on ? lane % NS : 0;
         size_t item = item0 + g;
@@ -1063,7 +1078,7 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     for (int g = 0; g < G::IT; g++) {
         const size_t item = item0 + g;
         if (item >= n) break;
-        uint8_t *pkp = pk + item * G::PK, *skp = sk + item * Kg::SK;
+        uint8_t *pkp = pk + item * G::PK, *skp = FROM_SK ? nullptr : sk + item * Kg::SK;
         // ---- phase 1b: NTT(s1), pack s1 and s2 ----
         uint32_t shat[L][4];
 #pragma unroll
@@ -1077,8 +1092,10 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                 fld[r] = (unsigned)(P::ETA - v);              // pack.go:9-37: field = q + eta - coefficient
                 c[r] = v < 0 ? Q + v : (uint32_t)v;
             }
-            mlkem::stage_bits_l1<Kg::ETABITS>(xch, fld, lane);
-            mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * k), xch, lane, false);
+            if constexpr (!FROM_SK) {
+                mlkem::stage_bits_l1<Kg::ETABITS>(xch, fld, lane);
+                mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * k), xch, lane, false);
+            }
             if (k < L) {
                 dilithium::ntt(c, z, xch, lane);
 #pragma unroll
@@ -1105,14 +1122,18 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             }
             mlkem::stage_bits_l1<10>(xch, t1, lane);
             mlkem::store_staged<10>(reinterpret_cast<uint32_t *>(pkp + 32 + 320 * i), xch, lane, false);
-            mlkem::stage_bits_l1<13>(xch, t0, lane);
-            mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * NS + 416 * i), xch, lane, false);
+            if constexpr (!FROM_SK) {
+                mlkem::stage_bits_l1<13>(xch, t0, lane);
+                mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * NS + 416 * i), xch, lane, false);
+            }
         }
         if (lane < 8) {
-            const uint32_t r = reinterpret_cast<const uint32_t *>(es_ws + item * 128)[lane];
+            const uint32_t r = reinterpret_cast<const uint32_t *>(es_ws + item * ES)[lane];
             reinterpret_cast<uint32_t *>(pkp)[lane] = r;                                                     // rho
-            reinterpret_cast<uint32_t *>(skp)[lane] = r;
-            reinterpret_cast<uint32_t *>(skp + 32)[lane] = reinterpret_cast<const uint32_t *>(es_ws + item * 128 + 96)[lane];  // key
+            if constexpr (!FROM_SK) {
+                reinterpret_cast<uint32_t *>(skp)[lane] = r;
+                reinterpret_cast<uint32_t *>(skp + 32)[lane] = reinterpret_cast<const uint32_t *>(es_ws + item * 128 + 96)[lane];  // key
+            }
         }
     }
   }
@@ -1197,7 +1218,8 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob,
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
                                                               int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key,
-                                                              uint8_t *__restrict__ dead_ws, const LongCtl *__restrict__ long_ctl) {
+                                                              uint8_t *__restrict__ dead_ws, const LongCtl *__restrict__ long_ctl,
+                                                              const uint32_t *__restrict__ key_idx) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
     __shared__ uint32_t stage_lds[256 * kStageStride];
@@ -1212,7 +1234,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
         dead_ws[idx] = (cl > 255 || (!P::NIST && cl > 0)) ? 1 : 0;
     }
     if (!P::NIST) internal = 1;  // round 3: mu = CRH(tr || msg)
-    const uint8_t *skp = sk + (shared_key ? 0 : idx) * Kg::SK;
+    const uint8_t *skp = sk + (key_idx ? (size_t)key_idx[idx] : shared_key ? size_t(0) : idx) * Kg::SK;  // key_idx: a table of private keys
     KeccakState h;
     keccak_zero(h);
     xor_words<0, P::TR / 8>(h, reinterpret_cast<const uint64_t *>(skp + 64));  // tr
@@ -1265,7 +1287,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                                                        unsigned *__restrict__ work, const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ attempts, size_t n, unsigned spec_w,
                                                        uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig, int shared_key,
-                                                       const uint32_t *__restrict__ count_ptr) {
+                                                       const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ key_idx) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;
@@ -1298,7 +1320,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
         const size_t t = u / spec_w;
         const unsigned spec_class = (unsigned)(u % spec_w);
         const size_t item = list ? (list[t] & 0x03ffffffu) : t;  // (entries carry an attempt offset above bit 26; the tail's are 0)
-        const uint8_t *skp = sk + (shared_key ? 0 : item) * Kg::SK;
+        const uint8_t *skp = sk + (key_idx ? (size_t)key_idx[item] : shared_key ? size_t(0) : item) * Kg::SK;
         const uint32_t *sk32 = reinterpret_cast<const uint32_t *>(skp);
         __syncthreads();
         // ---- setup 1: ExpandA(rho) into the scratch, lane = (i, j) ----

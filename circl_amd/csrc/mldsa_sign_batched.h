@@ -66,6 +66,9 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t spec_target;   // rounds speculate (k > 1) once at most this many entries would result
     uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
     uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
+    const uint32_t *key_idx; // shared == 2 with a table of SEVERAL prepared keys: item i signs with entry key_idx[i] (nullptr: entry 0)
+    // which entry of A / sec an item uses
+    __device__ __forceinline__ size_t key_of(size_t item) const { return shared ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item; }
 };
 
 constexpr uint32_t kNoSuccess = 0xffffffffu;
@@ -303,7 +306,7 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
             }
             dilithium::ntt(yh[l], z, xch0, lane);  // plain y-hat, < 17q
         }
-        const uint32_t *arows1 = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+        const uint32_t *arows1 = st.A + st.key_of(item) * K * L * kPackedRowDwords;
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             uint64_t acc[4] = {0, 0, 0, 0};  // lazy 64-bit dot product, one reduction per coefficient
@@ -372,7 +375,7 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
             park(ya, L - 1);
         }
     }
-    const uint32_t *arows = st.A + (st.shared ? 0 : item) * K * L * kPackedRowDwords;
+    const uint32_t *arows = st.A + st.key_of(item) * K * L * kPackedRowDwords;
     // Decompose, the low part to w0, the high part packed behind mu (PackW1, pack.go:256-270: the challenge hash absorbs it from
     // there and the hint computation of the finish kernel reads its fields back)
     auto emit = [&](uint32_t (&w)[4], size_t sl, int i, uint32_t *stage) {
@@ -524,7 +527,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     const uint8_t *cb = st.cb + slot * B::CB_BYTES;
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
-    const uint32_t *sec = st.sec + (st.shared ? 0 : item) * (L + 2 * K) * kPackedRowDwords;
+    const uint32_t *sec = st.sec + st.key_of(item) * (L + 2 * K) * kPackedRowDwords;
     uint32_t *w0 = st.w0 + slot * K * 256;
     uint32_t *best = st.best;
     // Every loop below is software-pipelined by hand: the packed row of polynomial i + 1 (and its w0 / w1 words) is requested

@@ -19,7 +19,7 @@
 #include <stdint.h>
 
 #ifndef CIRCL_HD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CIRCL_HD __host__ __device__ __forceinline__
 #else
 #define CIRCL_HD inline

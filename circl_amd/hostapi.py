@@ -269,7 +269,8 @@ def mldsa_verify_keyed(param, pk_table, key_idx, sig, msgs, ctxs=None, device=0)
 
 class KeyTable:
     """A parsed-key cache that lives across calls (circl_hip_*_keytable_new): the counterpart of CIRCL's key objects, which keep
-    A^T / H(ek) (ML-KEM) or A / tr (ML-DSA) after unmarshalling.  kind: "mlkem-public", "mlkem-private", "mldsa-public", "mldsa-private" (one key)."""
+    A^T / H(ek) (ML-KEM) or A / tr (ML-DSA) after unmarshalling.  kind: "mlkem-public", "mlkem-private", "mldsa-public", "mldsa-private",
+    "hybrid-public", "hybrid-private" (param = the hybrid scheme id).  device = -1: replicated on every device, calls shard the batch."""
 
     def __init__(self, kind, param, keys, device=0):
         import ctypes as C
@@ -287,9 +288,15 @@ class KeyTable:
                       "mlkem_keytable_new")
         elif kind == "mldsa-private":
             keys = _u8(keys, nat.lib().circl_hip_mldsa_sk_size(param))
-            assert len(keys) == 1, "one private key per table"
-            self.nkeys = 1
-            nat.check(L.circl_hip_mldsa_privkey_new(param, _p(keys), device, C.byref(self.handle)), "mldsa_privkey_new")
+            self.nkeys = len(keys)
+            nat.check(L.circl_hip_mldsa_privkeys_new(param, _p(keys), self.nkeys, device, C.byref(self.handle)), "mldsa_privkeys_new")
+        elif kind.startswith("hybrid"):  # param = the hybrid scheme id (XWING, X25519MLKEM768)
+            priv = kind == "hybrid-private"
+            keys = _u8(keys, HYBRID_SIZES[param]["sk" if priv else "pk"])
+            self.nkeys = len(keys)
+            self.key_status = np.zeros(self.nkeys, np.uint8)
+            nat.check(L.circl_hip_hybrid_keytable_new(param, 1 if priv else 0, _p(keys), self.nkeys, device, _p(self.key_status), C.byref(self.handle)),
+                      "hybrid_keytable_new")
         else:
             PK, _ = DSA_SIZES[param]
             keys = _u8(keys, PK)
@@ -327,18 +334,38 @@ class KeyTable:
         nat.check(nat.lib().circl_hip_mlkem_decaps_table(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n), "mlkem_decaps_table")
         return ss, st
 
-    def sign(self, msgs, ctxs=None, rnd=None):
-        """scheme.Sign with the prepared private key -> (n, SIG)"""
+    def sign(self, msgs, ctxs=None, rnd=None, key_idx=None):
+        """scheme.Sign with the prepared private key(s): message i with entry key_idx[i] (None: entry 0) -> (n, SIG)"""
         _, SIG = DSA_SIZES[self.param]
         n = len(msgs)
         mb, mo = _blob(msgs)
         sig = np.empty((n, SIG), np.uint8)
         cb, co = _blob(ctxs) if ctxs is not None else (None, None)
         r = None if rnd is None else _u8(rnd, 32)
-        rc = nat.lib().circl_hip_mldsa_sign_table(self.handle, _p(mb), _p(mo), _p(cb) if ctxs is not None else None, _p(co) if ctxs is not None else None,
-                                                  None if r is None else _p(r), _p(sig), n)
+        if key_idx is None:
+            rc = nat.lib().circl_hip_mldsa_sign_table(self.handle, _p(mb), _p(mo), _p(cb) if ctxs is not None else None, _p(co) if ctxs is not None else None,
+                                                      None if r is None else _p(r), _p(sig), n)
+        else:
+            rc = nat.lib().circl_hip_mldsa_sign_table_keyed(self.handle, self._kidx(key_idx, n), _p(mb), _p(mo), _p(cb) if ctxs is not None else None,
+                                                            _p(co) if ctxs is not None else None, None if r is None else _p(r), _p(sig), n)
         nat.check(rc, "mldsa_sign_table")
         return sig
+
+    def hybrid_encaps(self, eseeds, key_idx=None):
+        S = HYBRID_SIZES[self.param]
+        es = _u8(eseeds, S["eseed"])
+        n = len(es)
+        ct, ss, st = np.empty((n, S["ct"]), np.uint8), np.empty((n, S["ss"]), np.uint8), np.empty(n, np.uint8)
+        nat.check(nat.lib().circl_hip_hybrid_encaps_table(self.handle, self._kidx(key_idx, n), _p(es), _p(ct), _p(ss), _p(st), n), "hybrid_encaps_table")
+        return ct, ss, st
+
+    def hybrid_decaps(self, ct, key_idx=None):
+        S = HYBRID_SIZES[self.param]
+        ct = _u8(ct, S["ct"])
+        n = len(ct)
+        ss, st = np.empty((n, S["ss"]), np.uint8), np.empty(n, np.uint8)
+        nat.check(nat.lib().circl_hip_hybrid_decaps_table(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n), "hybrid_decaps_table")
+        return ss, st
 
     def verify(self, sig, msgs, ctxs=None, key_idx=None):
         _, SIG = DSA_SIZES[self.param]
@@ -352,6 +379,23 @@ class KeyTable:
                                                     _p(co) if ctxs is not None else None, _p(ok), n)
         nat.check(rc, "mldsa_verify_table")
         return ok
+
+
+def mlkem_public_from_private(param, dk):
+    """PrivateKey.Public() over a batch (kem/mlkem/mlkem768/kyber.go:323-328)"""
+    EK, DK, _ = KEM_SIZES[param]
+    dk = _u8(dk, DK)
+    ek = np.empty((len(dk), EK), np.uint8)
+    nat.check(nat.lib().circl_hip_mlkem_public_from_private(param, _p(dk), _p(ek), len(dk)), "mlkem_public_from_private")
+    return ek
+
+
+def mldsa_public_from_private(param, sk, device=0):
+    """PrivateKey.Public() over a batch (sign/mldsa/mldsa65/internal/dilithium.go:473-484)"""
+    sk = _u8(sk, nat.lib().circl_hip_mldsa_sk_size(param))
+    pk = np.empty((len(sk), nat.lib().circl_hip_mldsa_pk_size(param)), np.uint8)
+    nat.check(nat.lib().circl_hip_mldsa_public_from_private(param, _p(sk), _p(pk), len(sk), device), "mldsa_public_from_private")
+    return pk
 
 
 def keccak_f1600(states, rounds=24, device=0):

@@ -164,7 +164,8 @@ class Scheme {
             EncapsulateBatch(eks.data(), seeds, cts, sss, status, n);
             return;
         }
-        if (pk.resident) check(circl_hip_mlkem_encaps_table(pk.resident.get(), nullptr, seeds, cts, sss, status, n));  // (on the object's device)
+        // (the object's table lives where the scheme's `device` says: one device, or -- CIRCL_HIP_ALL_DEVICES -- replicated, the batch sharded)
+        if (pk.resident) check(circl_hip_mlkem_encaps_table(pk.resident.get(), nullptr, seeds, cts, sss, status, n));
         else check(circl_hip_mlkem_encaps_shared(param_, pk.packed.data(), seeds, cts, sss, status, n, device));
     }
     // n ciphertexts for ONE private key (ML-KEM only)
@@ -185,6 +186,9 @@ class Scheme {
         check(r3_ ? circl_hip_kyber_keygen(param_, seeds64, eks, dks, n, device) : circl_hip_mlkem_keygen(param_, seeds64, eks, dks, n, device));
     }
 
+    // PrivateKey.Public() over a batch of packed decapsulation keys (kem/mlkem/mlkem768/kyber.go:323-328; the same layout for round 3)
+    void PublicBatch(const uint8_t *dks, uint8_t *eks, size_t n) const { check(circl_hip_mlkem_public_from_private(param_, dks, eks, n)); }
+
   private:
     int param_;
     const char *name_;
@@ -192,7 +196,7 @@ class Scheme {
     int dev1() const { return device < 0 ? 0 : device; }
     ResidentKey resident_key(const Bytes &buf, int private_key, uint8_t *verdict = nullptr) const {
         circl_hip_keytable *t = nullptr;
-        check(circl_hip_mlkem_keytable_new(param_, private_key, buf.data(), 1, dev1(), verdict, &t));
+        check(circl_hip_mlkem_keytable_new(param_, private_key, buf.data(), 1, device, verdict, &t));
         return ResidentKey(t, circl_hip_keytable_free);
     }
     static void check(int rc) {

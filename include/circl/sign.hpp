@@ -54,6 +54,7 @@ struct PrivateKey {
     Bytes packed;
     ResidentKey resident;
     Bytes MarshalBinary() const { return packed; }
+    PublicKey Public() const;  // sign/mldsa/mldsa65/internal/dilithium.go:473-484: t1 recomputed from s1, s2 (on the device)
 };
 
 class Scheme {
@@ -71,13 +72,13 @@ class Scheme {
     PublicKey UnmarshalBinaryPublicKey(const Bytes &buf) const {
         if ((int)buf.size() != PublicKeySize()) throw ErrPubKeySize();
         circl_hip_keytable *t = nullptr;  // parse once: A and tr stay on the device with the object
-        check(circl_hip_mldsa_keytable_new(param_, buf.data(), 1, dev1(), &t));
+        check(circl_hip_mldsa_keytable_new(param_, buf.data(), 1, device, &t));
         return PublicKey{this, buf, ResidentKey(t, circl_hip_keytable_free)};
     }
     PrivateKey UnmarshalBinaryPrivateKey(const Bytes &buf) const {
         if ((int)buf.size() != PrivateKeySize()) throw ErrPrivKeySize();
         circl_hip_keytable *t = nullptr;  // ... and A with the NTT-domain secrets
-        check(circl_hip_mldsa_privkey_new(param_, buf.data(), dev1(), &t));
+        check(circl_hip_mldsa_privkey_new(param_, buf.data(), device, &t));
         return PrivateKey{this, buf, ResidentKey(t, circl_hip_keytable_free)};
     }
     std::pair<PublicKey, PrivateKey> DeriveKey(const Bytes &seed) const {
@@ -149,6 +150,9 @@ class Scheme {
         check(circl_hip_mldsa_keygen(param_, seeds32, pks, sks, n, device));
     }
 
+    // PrivateKey.Public() over a batch of packed private keys -> packed public keys (dilithium.go:473-484)
+    void PublicBatch(const uint8_t *sks, uint8_t *pks, size_t n) const { check(circl_hip_mldsa_public_from_private(param_, sks, pks, n, device)); }
+
   private:
     int param_;
     const char *name_;
@@ -158,6 +162,12 @@ class Scheme {
         if (rc != CIRCL_HIP_OK) throw ErrDevice(std::string("circl-hip: error ") + std::to_string(rc) + " " + circl_hip_last_error());
     }
 };
+
+inline PublicKey PrivateKey::Public() const {
+    Bytes pk((size_t)scheme->PublicKeySize());
+    scheme->PublicBatch(packed.data(), pk.data(), 1);
+    return scheme->UnmarshalBinaryPublicKey(pk);
+}
 
 // sign/schemes/schemes.go:31-74
 inline const Scheme *ByName(const std::string &name) {

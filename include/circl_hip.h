@@ -171,8 +171,16 @@ int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_
  *       reported per item by the encapsulation (status 1 = kem.ErrPubKey), as everywhere in this ABI.
  *   _dev variants: pointers are device memory on the TABLE's device; workspace = circl_hip_mlkem_workspace_size(param, n) /
  *       circl_hip_mldsa_workspace_size(param, n) bytes (no table tail: the table brings its own).
- *   circl_hip_keytable_free wipes the key rows of a private table before releasing them. */
+ *   circl_hip_keytable_free wipes the key rows of a private table before releasing them.
+ *   device = CIRCL_HIP_ALL_DEVICES in any *_new below REPLICATES the table: it is built once on every device, and the host-buffer
+ *       *_table calls then split a batch into contiguous shards, one per device, like every other entry point (a table made for
+ *       one device runs its calls there).  The _dev variants use the replica on the calling thread's current device;
+ *       circl_hip_keytable_on_device returns that replica (or the table itself if it lives on `device`, else NULL) and
+ *       circl_hip_keytable_device the table's device (CIRCL_HIP_ALL_DEVICES for a replicated one). */
 typedef struct circl_hip_keytable circl_hip_keytable;
+int circl_hip_keytable_device(const circl_hip_keytable *table);
+size_t circl_hip_keytable_nkeys(const circl_hip_keytable *table);
+const circl_hip_keytable *circl_hip_keytable_on_device(const circl_hip_keytable *table, int device);
 int circl_hip_mlkem_keytable_new(int param, int private_keys, const uint8_t *keys, size_t nkeys, int device,
                                  uint8_t *key_status, circl_hip_keytable **out);
 int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, int device, circl_hip_keytable **out);
@@ -180,6 +188,15 @@ int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, in
  * internal/dilithium.go:149-179) -- then any number of scheme.Sign calls with it: circl_hip_mldsa_sign_table[_dev] = circl_hip_mldsa_
  * sign_shared[_dev] without the per-call ExpandA and transforms (workspace: circl_hip_mldsa_sign_workspace_size(param, n)). */
 int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out);
+/* ... and a table of nkeys prepared private keys (a signer that holds several identities): message i is signed with entry
+ * key_idx[i]; key_idx == NULL: entry 0.  Same signatures as circl_hip_mldsa_sign on the gathered rows sks[key_idx[i]].  The host
+ * form returns CIRCL_HIP_EPARAM for an index >= nkeys; the _dev form trusts d_key_idx (4-byte aligned). */
+int circl_hip_mldsa_privkeys_new(int param, const uint8_t *sks, size_t nkeys, int device, circl_hip_keytable **out);
+int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                     const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n);
+int circl_hip_mldsa_sign_table_keyed_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_msg_blob,
+                                         const uint64_t *d_msg_off, const uint8_t *d_ctx_blob, const uint64_t *d_ctx_off, const uint8_t *d_rnd,
+                                         int internal, uint8_t *d_sig, size_t n, void *d_workspace, size_t workspace_bytes, void *stream);
 int circl_hip_mldsa_sign_table(const circl_hip_keytable *table, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
                                const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n);
 int circl_hip_mldsa_sign_table_dev(const circl_hip_keytable *table, const uint8_t *d_msg_blob, const uint64_t *d_msg_off,
@@ -203,6 +220,17 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
                                      const uint8_t *d_msg_blob, const uint64_t *d_msg_off, const uint8_t *d_ctx_blob,
                                      const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n, void *d_workspace,
                                      size_t workspace_bytes, void *stream);
+
+/* ---- PrivateKey.Public() over a batch -----------------------------------------------------------
+ * circl_hip_mlkem_public_from_private: kem/mlkem/mlkem768/kyber.go:323-328 -- the encapsulation key stored inside each
+ *   decapsulation key (a strided copy on the host, no device work).
+ * circl_hip_mldsa_public_from_private: sign/mldsa/mldsa65/internal/dilithium.go:473-484 -- t = A s1 + s2 recomputed from the
+ *   packed private key (ExpandA, NTT, Power2Round), pk = rho || PackT1(t1).  The _dev form needs
+ *   circl_hip_mldsa_workspace_size(param, n) bytes. */
+int circl_hip_mlkem_public_from_private(int param, const uint8_t *dk, uint8_t *ek, size_t n);
+int circl_hip_mldsa_public_from_private(int param, const uint8_t *sk, uint8_t *pk, size_t n, int device);
+int circl_hip_mldsa_public_from_private_dev(int param, const uint8_t *d_sk, uint8_t *d_pk, size_t n, void *d_workspace, size_t workspace_bytes,
+                                            void *stream);
 
 /* ---- round-3 Kyber ------------------------------------------------------
  * kem/kyber/kyber{512,768,1024}: the pre-standard KEM the reference still ships ("Kyber512/768/1024" in
@@ -453,6 +481,24 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
                                 void *d_ws, size_t ws_bytes, void *stream);
 int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *d_ct, uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws,
                                 size_t ws_bytes, void *stream);
+
+/* Hybrid key tables that live across calls (scheme = CIRCL_HIP_HYBRID_XWING or _X25519MLKEM768): kem/xwing's PrivateKey keeps the
+ * expanded ML-KEM-768 key, the X25519 scalar and its public point next to the 32-byte seed (xwing.go:20-25), its PublicKey the
+ * parsed ML-KEM key; kem/hybrid's keys hold the component schemes' parsed keys (hybrid.go:101-114).  keys = nkeys packed public
+ * (private_keys = 0) or private (1) keys of the scheme; an X-Wing private key (the seed) is expanded ONCE, on the device.  The table
+ * holds an ML-KEM key table of the lattice halves (A^T, H(ek), hash verdicts -> key_status[nkeys] if not NULL) and the X25519
+ * rows.  Item i uses entry key_idx[i] (NULL: entry 0).  Results are those of circl_hip_hybrid_encaps / _decaps on the gathered
+ * keys.  The _dev forms need circl_hip_hybrid_workspace_size(scheme, n) bytes. */
+int circl_hip_hybrid_keytable_new(int scheme, int private_keys, const uint8_t *keys, size_t nkeys, int device, uint8_t *key_status,
+                                  circl_hip_keytable **out);
+int circl_hip_hybrid_encaps_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *eseed, uint8_t *ct, uint8_t *ss,
+                                  uint8_t *status, size_t n);
+int circl_hip_hybrid_decaps_table(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                  size_t n);
+int circl_hip_hybrid_encaps_table_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_eseed, uint8_t *d_ct,
+                                      uint8_t *d_ss, uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream);
+int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *table, const uint32_t *d_key_idx, const uint8_t *d_ct, uint8_t *d_ss,
+                                      uint8_t *d_status, size_t n, void *d_ws, size_t ws_bytes, void *stream);
 
 /* ---- kernel-level profiling (used by bench.py for the roofline figures) --------------------
  * While enabled, every *_dev call brackets each kernel it enqueues with HIP events recorded on

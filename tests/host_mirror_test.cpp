@@ -163,6 +163,34 @@ int main() {
         sign::SignatureOpts ctx{"x"};
         REQUIRE(throws<sign::ErrContextNotSupported>([&] { s->Sign(sk, msg, &ctx); }));
         REQUIRE(throws<sign::ErrContextNotSupported>([&] { s->Verify(pk, msg, sg, &ctx); }));
+        REQUIRE(sk.Public().MarshalBinary() == pk.MarshalBinary());  // PrivateKey.Public(): dilithium.go:473-484
+    }
+    {
+        // a scheme that targets EVERY device (device = -1): parsed key objects are replicated tables, shared-key batches shard over
+        // the devices and give the bytes of the one-device scheme (sign/mldsa/mldsa65/dilithium.go:283-327, kem/mlkem/mlkem768/kyber.go:347-386)
+        kem::Scheme all(768, "ML-KEM-768"), one(768, "ML-KEM-768");
+        all.device = CIRCL_HIP_ALL_DEVICES;
+        kem::Bytes seed(64, 3);
+        auto kp = one.DeriveKeyPair(seed);
+        const kem::PublicKey pa = all.UnmarshalBinaryPublicKey(kp.first.MarshalBinary()), po = one.UnmarshalBinaryPublicKey(kp.first.MarshalBinary());
+        const kem::PrivateKey sa = all.UnmarshalBinaryPrivateKey(kp.second.MarshalBinary());
+        REQUIRE(circl_hip_keytable_device(pa.resident.get()) == CIRCL_HIP_ALL_DEVICES && circl_hip_keytable_device(po.resident.get()) == 0);
+        const size_t n = 777;
+        std::vector<uint8_t> ms(32 * n), c1(n * 1088), s1(32 * n), c2(n * 1088), s2(32 * n), s3(32 * n), st(n);
+        for (size_t i = 0; i < ms.size(); i++) ms[i] = (uint8_t)(i * 13 + 5);
+        all.EncapsulateSharedKeyBatch(pa, ms.data(), c1.data(), s1.data(), st.data(), n);
+        one.EncapsulateSharedKeyBatch(po, ms.data(), c2.data(), s2.data(), st.data(), n);
+        REQUIRE(c1 == c2 && s1 == s2);
+        all.DecapsulateSharedKeyBatch(sa, c1.data(), s3.data(), st.data(), n);
+        REQUIRE(s3 == s1);
+        sign::Scheme dall(65, "ML-DSA-65");
+        dall.device = CIRCL_HIP_ALL_DEVICES;
+        const sign::Scheme *d1 = sign::ByName("ML-DSA-65");
+        auto dk = d1->DeriveKey(sign::Bytes(32, 7));
+        const sign::PrivateKey dsa = dall.UnmarshalBinaryPrivateKey(dk.second.MarshalBinary());
+        const sign::PublicKey dpa = dall.UnmarshalBinaryPublicKey(dk.first.MarshalBinary());
+        sign::Bytes msg{9, 8, 7};
+        REQUIRE(dall.Sign(dsa, msg) == d1->Sign(dk.second, msg) && dall.Verify(dpa, msg, dall.Sign(dsa, msg)));
     }
     std::printf("OK\n");
     return 0;

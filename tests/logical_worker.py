@@ -138,6 +138,43 @@ def parity():
         assert (ct[:k] == ct0).all() and (ss[:k] == ss0).all()
     sc = rng.integers(0, 256, (999, 32), dtype=np.uint8)
     both(hostapi.x25519, sc)
+    # ---- key tables that live across calls: on device 0, on the last device, REPLICATED over all (device = -1: every call shards) ----
+    def tables(kind, param, keys, call):
+        res = []
+        for dev in (0, nd - 1, ALL):
+            t = hostapi.KeyTable(kind, param, keys, device=dev)
+            assert L.circl_hip_keytable_device(t.handle) == dev and L.circl_hip_keytable_nkeys(t.handle) == len(keys)
+            for d in range(nd):  # circl_hip_keytable_on_device: the replica / the table itself / NULL
+                assert bool(L.circl_hip_keytable_on_device(t.handle, d)) == (dev == ALL or d == dev)
+            res.append(call(t))
+            t.close()
+        assert eq(res[0], res[1]) and eq(res[0], res[2]), kind
+        report["checks"] += 2
+        return res[0]
+    L = nat.lib()
+    for n in (5, 4099):
+        nk = 13
+        ek, dk = hostapi.mlkem_keygen(768, rng.integers(0, 256, (nk, 64), dtype=np.uint8))
+        idx = rng.integers(0, nk, n).astype(np.uint32)
+        m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        ct, ss, st = tables("mlkem-public", 768, ek, lambda t: t.encaps(m, idx))
+        assert eq((ct, ss, st), hostapi.mlkem_encaps(768, ek[idx], m))
+        assert eq(tables("mlkem-private", 768, dk, lambda t: t.decaps(ct, idx)), hostapi.mlkem_decaps(768, dk[idx], ct))
+        pk, sk = hostapi.mldsa_keygen(65, rng.integers(0, 256, (nk, 32), dtype=np.uint8))
+        msgs = ragged(rng, n, 0, 120)
+        sig = tables("mldsa-private", 65, sk, lambda t: t.sign(msgs, key_idx=idx))
+        k = min(n, 40)
+        assert (sig[:k] == orc.mldsa_sign(65, sk[idx[:k]], msgs[:k])).all()
+        assert tables("mldsa-public", 65, pk, lambda t: t.verify(sig, msgs, key_idx=idx)).all()
+        for scheme in (hostapi.XWING, hostapi.X25519MLKEM768):
+            S = hostapi.HYBRID_SIZES[scheme]
+            hpk, hsk = hostapi.hybrid_keygen(scheme, rng.integers(0, 256, (nk, S["seed"]), dtype=np.uint8))
+            es = rng.integers(0, 256, (n, S["eseed"]), dtype=np.uint8)
+            hct, hss, hst = tables("hybrid-public", scheme, hpk, lambda t: t.hybrid_encaps(es, idx))
+            assert eq((hct, hss, hst), hostapi.hybrid_encaps(scheme, hpk[idx], es))
+            got = tables("hybrid-private", scheme, hsk, lambda t: t.hybrid_decaps(hct, idx))
+            assert (got[0] == hss).all() and not got[1].any()
+    assert eq(both(hostapi.mldsa_public_from_private, 65, sk), pk)
     # ---- primitives and the sponge service ----
     both(hostapi.keccak_f1600, rng.integers(0, 1 << 63, (777, 25), dtype=np.uint64))
     both(hostapi.kyber_ntt, rng.integers(0, 3329, (515, 256)).astype(np.int16))
