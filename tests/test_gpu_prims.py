@@ -147,7 +147,17 @@ def test_abi_error_codes():
     call = lambda param, ekp, wsp, wsbytes: L.circl_hip_mlkem_encaps_dev(param, ekp, m.data_ptr(), ct.data_ptr(), ss.data_ptr(), st.data_ptr(), n, wsp, wsbytes, stream)
     assert call(768, ek.data_ptr(), ws.data_ptr(), wsb) == nat.OK
     assert call(769, ek.data_ptr(), ws.data_ptr(), wsb) == nat.EPARAM                 # unknown parameter set
-    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb - 1) == nat.EWORKSPACE          # workspace too small
+    # the workspace size is MONOTONE in n and a call only needs the part its own n needs (include/circl_hip.h): without room for the row
+    # cache of the small-batch routes the call takes the big-batch routes -- same bytes; below per-item slots + scratch + 128 KB it fails
+    torch.cuda.synchronize()
+    ct_small = ct.clone()
+    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb - 1) == nat.OK
+    torch.cuda.synchronize()
+    assert (ct == ct_small).all().item()
+    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb - 48 * 8192) == nat.OK          # exactly the minimum for 64 items (a 16-entry cache)
+    assert call(768, ek.data_ptr(), ws.data_ptr(), wsb - 48 * 8192 - 1) == nat.EWORKSPACE  # workspace too small
+    sizes = [L.circl_hip_mlkem_workspace_size(768, k) for k in (1, 2, 17, 1000, 20000, 32768, 32769, 65536, 1 << 20)]
+    assert sizes == sorted(sizes)
     assert call(768, ek.data_ptr() + 1, ws.data_ptr(), wsb) == nat.EWORKSPACE          # misaligned input
     assert call(768, ek.data_ptr(), ws.data_ptr() + 8, wsb) == nat.EWORKSPACE          # misaligned workspace
     assert L.circl_hip_mlkem_workspace_size(100, n) == 0 and L.circl_hip_mldsa_workspace_size(1, n) == 0
