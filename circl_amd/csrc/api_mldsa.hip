@@ -530,12 +530,12 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const bool split_mask = upper * L <= sign_split_lanes(), split_ch = upper <= sign_split_lanes();
         if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL((sign_w_kernel<MODE, 4>), dim3(gw), dim3(64), 0, st, S, cur);
+        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur);
         if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
         else hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
-        hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
+        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
         hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
-        hipLaunchKernelGGL((sign_finish_kernel<MODE, 4>), dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
+        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
         hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(lazy[round] ? small : std::min<unsigned>((unsigned)std::max<size_t>(1, upper), (unsigned)cus * 32)),
                            dim3(64), 0, st, S, cur, sig);
         hipLaunchKernelGGL(sign_compact_kernel, dim3(gc), dim3(256), 0, st, S, cur, round == rounds - 1 ? 1 : 0);

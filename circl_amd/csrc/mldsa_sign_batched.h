@@ -42,7 +42,10 @@ template <int MODE> struct SB {
     static constexpr size_t SEC_BYTES = (size_t)(L + 2 * K) * kPackedRowDwords * 4;
     static constexpr size_t Y_BYTES = (size_t)L * (G::ZSZ + 64);   // ZSZ payload + slack, per polynomial
     static constexpr int YROW_DW = (G::ZSZ + 64) / 4;
-    static constexpr size_t W0_BYTES = (size_t)K * 1024;
+    // low parts a0 + q < 2^24 (later r0 < q), four per lane in three dwords (pack24): an internal array, so no coefficient order --
+    // 768 B per polynomial instead of 1 KB as uint32 (measured on one box, profiles/r04_sign_ab.txt: +2.1 % signatures/s)
+    static constexpr size_t W0_BYTES = (size_t)K * kPackedRowDwords * 4;
+    static constexpr int W0_SLOT_DW = K * kPackedRowDwords;
     static constexpr size_t MUW1_BYTES = ((G::MUW1 + 63) / 64) * 64;
     static constexpr size_t CB_BYTES = 320;                          // c~ (<= 64 B), 56 B pad, ball state (200 B)
     static constexpr size_t PER_ITEM = A_BYTES + SEC_BYTES + 128 /* mu, rho'' */;                   // per item (key material)
@@ -54,7 +57,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t *A;            // n x K L x 256
     uint32_t *sec;          // n x (L + 2K) x 256
     uint32_t *y;            // n x L x YROW_DW
-    uint32_t *w0;           // n x K x 256
+    uint32_t *w0;           // entries x K x kPackedRowDwords (pack24)
     uint8_t *muw1;          // n x MUW1_BYTES
     uint8_t *cb;            // n x 320
     uint32_t *attempts;     // n: attempts already spent on the item
@@ -285,6 +288,10 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
+    // the exchange buffers belong to this wavefront alone: its LDS instructions execute in order, so the reads of an exchange need
+    // no s_waitcnt behind the writes (dilithium_dev.h xch_sync; +1 % signatures/s measured)
+    constexpr bool NW = true;
+    auto put_w0 = [&](size_t sl, int i, const uint32_t (&a0v)[4]) { store_poly24(st.w0 + sl * B::W0_SLOT_DW + i * kPackedRowDwords, a0v, lane); };
     static_assert(K % 2 == 0, "output polynomials are processed in pairs");
 #pragma unroll
     for (int t = 0; t < T; t++)
@@ -304,7 +311,7 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
                 x += (uint32_t)((int32_t)x >> 31) & Q;
                 yh[l][r] = x;
             }
-            dilithium::ntt(yh[l], z, xch0, lane);  // plain y-hat, < 17q
+            dilithium::ntt<NW>(yh[l], z, xch0, lane);  // plain y-hat, < 17q
         }
         const uint32_t *arows1 = st.A + st.key_of(item) * K * L * kPackedRowDwords;
 #pragma unroll 1
@@ -320,15 +327,16 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
             uint32_t w[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
-            dilithium::invntt<dilithium::INV256_RR>(w, z, xch0, lane);
+            dilithium::invntt<dilithium::INV256_RR, NW>(w, z, xch0, lane);
             unsigned w1v[4];
+            uint32_t a0v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                uint32_t a0, a1;
-                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
-                st.w0[(slot * K + i) * 256 + kyber::idx_l1(lane, r)] = a0;
+                uint32_t a1;
+                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0v[r], a1);
                 w1v[r] = a1;
             }
+            put_w0(slot, i, a0v);
             mlkem::stage_bits_l1<G::W1BITS>(xch0, w1v, lane);
             mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch0, lane, false);
         }
@@ -354,7 +362,7 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
             uint32_t ya[4], yb[4];
             load_y(ya, slot, l);
             load_y(yb, slot + 1, l);
-            dilithium::ntt2(ya, yb, z, xch0, xch1, lane);
+            dilithium::ntt2<NW>(ya, yb, z, xch0, xch1, lane);
             park(ya, l);
             park(yb, L + l);
         }
@@ -364,14 +372,14 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
             uint32_t ya[4], yb[4];
             load_y(ya, slot, l);
             load_y(yb, slot, l + 1);
-            dilithium::ntt2(ya, yb, z, xch0, xch1, lane);
+            dilithium::ntt2<NW>(ya, yb, z, xch0, xch1, lane);
             park(ya, l);
             park(yb, l + 1);
         }
         if constexpr (L % 2 == 1) {
             uint32_t ya[4];
             load_y(ya, slot, L - 1);
-            dilithium::ntt(ya, z, xch0, lane);
+            dilithium::ntt<NW>(ya, z, xch0, lane);
             park(ya, L - 1);
         }
     }
@@ -380,13 +388,14 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
     // there and the hint computation of the finish kernel reads its fields back)
     auto emit = [&](uint32_t (&w)[4], size_t sl, int i, uint32_t *stage) {
         unsigned w1v[4];
+        uint32_t a0v[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            uint32_t a0, a1;
-            dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0, a1);
-            st.w0[(sl * K + i) * 256 + kyber::idx_l1(lane, r)] = a0;
+            uint32_t a1;
+            dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0v[r], a1);
             w1v[r] = a1;
         }
+        put_w0(sl, i, a0v);
         mlkem::stage_bits_l1<G::W1BITS>(stage, w1v, lane);
         mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + sl * B::MUW1_BYTES + 64 + G::W1SZ * i), stage, lane, false);
     };
@@ -418,15 +427,15 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
         uint32_t wa[4], wb[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { wa[r] = dilithium::mont64(acc0[r]); wb[r] = dilithium::mont64(acc1[r]); }
-        dilithium::invntt2<dilithium::INV256_RR>(wa, wb, z, xch0, xch1, lane);
+        dilithium::invntt2<dilithium::INV256_RR, NW>(wa, wb, z, xch0, xch1, lane);
         emit(wa, slot, i, xch0);
         if constexpr (T == 2) emit(wb, slot + 1, i, xch1);
         else emit(wb, slot, i + 1, xch1);
     }
     __syncthreads();  // the exchange buffers are reused by the next entry
 }
-template <int MODE, int WAVES = 4>
-__global__ void __launch_bounds__(64, WAVES) sign_w_kernel(SignState st, int cur) {
+template <int MODE>
+__global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
     constexpr int L = DP<MODE>::L;
     __shared__ __attribute__((aligned(16))) uint32_t xch0[dilithium::kXchWords];
     __shared__ __attribute__((aligned(16))) uint32_t xch1[dilithium::kXchWords];
@@ -528,7 +537,8 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     uint32_t chat[4];
     sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
     const uint32_t *sec = st.sec + st.key_of(item) * (L + 2 * K) * kPackedRowDwords;
-    uint32_t *w0 = st.w0 + slot * K * 256;
+    constexpr bool NW = true;  // (wave-private exchange buffer: see sign_w_entries)
+    uint32_t *w0 = st.w0 + slot * B::W0_SLOT_DW;
     uint32_t *best = st.best;
     // Every loop below is software-pipelined by hand: the packed row of polynomial i + 1 (and its w0 / w1 words) is requested
     // before the inverse transform of polynomial i, so the wave has loads in flight while it computes (the attempts are
@@ -541,41 +551,45 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         const uint32_t sv[4] = {raw[0] & 0xffffffu, (raw[0] >> 24) | ((raw[1] & 0xffffu) << 8), (raw[1] >> 16) | ((raw[2] & 0xffu) << 16), raw[2] >> 8};
 #pragma unroll
         for (int r = 0; r < 4; r++) t[r] = dilithium::fold(dilithium::mont32(sv[r], chat[r]));
-        dilithium::invntt(t, z, xch, lane);
+        dilithium::invntt<dilithium::INV256_R, NW>(t, z, xch, lane);
     };
     bool bad = false;
     // The three norm tests decide together and their order is free; the reference's (r0, z, hints: dilithium.go:409-450) is also
     // the cheap one: for ML-DSA-65 the r0 test rejects 68 % of the attempts (1536 coefficients against gamma2 - beta), the z
     // test 38 % (1280 against gamma1 - beta), so r0 first costs ~6.4 inverse transforms per attempt, z first ~7.8 (measured:
     // 14.7 vs 16.3 ms of finish kernels per 2^18 signatures).
-    // w0 - c s2
+    // r0 = w0 - c s2.  The differences are parked in LDS (the area that will hold the packed z: not live yet) and go back to the
+    // slot's w0 area only when ALL of them are in range -- a third of the attempts; the hint computation reads them there.
     {
-        uint32_t raw[3], wv[4];
+        uint32_t *r0l = reinterpret_cast<uint32_t *>(zpk);
+        uint32_t raw[3], wraw[3];
         load_row(raw, sec + L * kPackedRowDwords);
-#pragma unroll
-        for (int r = 0; r < 4; r++) wv[r] = w0[kyber::idx_l1(lane, r)];
+        load_row(wraw, w0);
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
-            uint32_t raw_n[3] = {0, 0, 0}, wv_n[4] = {0, 0, 0, 0};
+            uint32_t raw_n[3] = {0, 0, 0}, wraw_n[3] = {0, 0, 0};
             if (i + 1 < K) {
                 load_row(raw_n, sec + (L + i + 1) * kPackedRowDwords);
-#pragma unroll
-                for (int r = 0; r < 4; r++) wv_n[r] = w0[(i + 1) * 256 + kyber::idx_l1(lane, r)];
+                load_row(wraw_n, w0 + (i + 1) * kPackedRowDwords);
             }
             uint32_t t[4];
             mul_c(t, raw);
+            const uint32_t wv[4] = {wraw[0] & 0xffffffu, (wraw[0] >> 24) | ((wraw[1] & 0xffffu) << 8), (wraw[1] >> 16) | ((wraw[2] & 0xffu) << 16), wraw[2] >> 8};
+            uint32_t v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t v = dilithium::normalize(wv[r] + (2 * Q - t[r]));
-                bad |= dilithium::exceeds(v, P::GAMMA2 - G::BETA);
-                w0[i * 256 + kyber::idx_l1(lane, r)] = v;
+                v[r] = dilithium::normalize(wv[r] + (2 * Q - t[r]));
+                bad |= dilithium::exceeds(v[r], P::GAMMA2 - G::BETA);
             }
             if (__any(bad)) break;  // one polynomial out of range decides the attempt: the remaining inverse transforms are moot
+            store_poly24(r0l + i * kPackedRowDwords, v, lane);
 #pragma unroll
-            for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
-#pragma unroll
-            for (int r = 0; r < 4; r++) wv[r] = wv_n[r];
+            for (int r = 0; r < 3; r++) { raw[r] = raw_n[r]; wraw[r] = wraw_n[r]; }
         }
+        if (__any(bad)) return;
+        __syncthreads();
+        for (int d = lane; d < K * kPackedRowDwords; d += 64) w0[d] = r0l[d];
+        __syncthreads();  // ... before z is packed into the same area
     }
     if (__any(bad)) return;
     // z = y + c s1
@@ -634,9 +648,9 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         for (int i = 0; i < K; i++) {
             uint32_t raw_n[3] = {0, 0, 0}, wv[4], r1v[4];
             if (i + 1 < K) load_row(raw_n, sec + (L + K + i + 1) * kPackedRowDwords);
+            load_poly24(wv, w0 + i * kPackedRowDwords, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                wv[r] = w0[i * 256 + kyber::idx_l1(lane, r)];
                 r1v[r] = get_bits32<G::W1BITS>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i, kyber::idx_l1(lane, r));  // w1 as packed by the w kernel
             }
             uint32_t t[4];
@@ -682,15 +696,15 @@ __device__ __noinline__ void sign_finish_entry(const SignState &st, int cur, uin
                                                uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
     sign_finish_body<MODE>(st, cur, sig, slot, direct, xch, zpk, hbytes, blk);
 }
-template <int MODE, int WAVES = 4>
-__global__ void __launch_bounds__(64, WAVES) sign_finish_kernel(SignState st, int cur, int pass, uint8_t *__restrict__ sig) {
+template <int MODE>
+__global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cur, int pass, uint8_t *__restrict__ sig) {
     using G = DG<MODE>;
     constexpr int K = DP<MODE>::K, L = DP<MODE>::L;
     __shared__ __attribute__((aligned(16))) uint32_t xch[dilithium::kXchWords];
-    __shared__ __attribute__((aligned(16))) uint8_t zpk[L * G::ZSZ];
+    __shared__ __attribute__((aligned(16))) uint8_t zpk[K * kPackedRowDwords * 4 > L * G::ZSZ ? K * kPackedRowDwords * 4 : L * G::ZSZ];  // packed z; before that, r0
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
     __shared__ __attribute__((aligned(16))) uint8_t blk[144];
-    static_assert((size_t)K * 1024 >= (size_t)G::SIG, "a slot's w0 area can park its signature");
+    static_assert(SB<MODE>::W0_BYTES >= (size_t)G::SIG, "a slot's w0 area can park its signature");
     const PassMap pm(st, cur, pass);
     const bool direct = pm.lazy || st.kk[cur] == 1;
     if (blockIdx.x >= pm.nwork) return;
@@ -718,7 +732,7 @@ __global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, 
         const uint32_t e = st.list[cur][slot];
         const uint32_t item = e & kEntryItemMask;
         if (st.best[item] != (e >> kEntryShift)) continue;
-        const uint32_t *src = st.w0 + slot * K * 256;
+        const uint32_t *src = st.w0 + slot * SB<MODE>::W0_SLOT_DW;
         uint8_t *dst = sig + (size_t)item * G::SIG;   // SIG is not a multiple of 4 for every parameter set: dwords, then the tail bytes
         for (int d = threadIdx.x; d < G::SIG / 4; d += 64) {
             const uint32_t w = src[d];

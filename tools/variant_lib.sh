@@ -10,4 +10,5 @@ for u in host_runtime api_mlkem api_mldsa api_prims api_x25519 api_hybrid; do
   if [ "$u.hip" = "$unit" ]; then objs="$objs $ROOT/build/variant_$name/$u.o"; else objs="$objs $ROOT/build/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libcirclhip_$name.so $objs -lpthread
+mkdir -p $ROOT/tools/bin; cp $ROOT/build/libcirclhip_$name.so $ROOT/tools/bin/  # (build/ does not travel to the GPU box, tools/bin does)
 echo built build/libcirclhip_$name.so
