@@ -50,6 +50,11 @@ size_t kem_small_shared_batch(bool decaps) {
 // The row cache behind the scratch slices holds min(n, kem_small_batch()) entries (at least one: the one-key routes), so the
 // workspace size is MONOTONE in n: a workspace sized once for the largest batch serves every smaller one.
 size_t kem_cache_bytes(size_t entries) { return up256((std::max<size_t>(entries, 1) + 15) / 16 * 16 * size_t(16 * 512)); }
+// Resident private keys: batches up to 2^CIRCL_HIP_KEM_CHAIN items (0 = never) decapsulate in one launch (mlkem_decaps_chain_kernel)
+size_t kem_chain_batch() {
+    static const int lg = env_int("CIRCL_HIP_KEM_CHAIN", 10, 0, 20);
+    return lg <= 0 ? size_t(0) : size_t(1) << lg;
+}
 size_t kem_small_table_bytes(size_t n) { return kem_cache_bytes(std::min(n, kem_small_batch())); }
 size_t kem_ws_base(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
 size_t kem_small_table_ofs(size_t n) { return kem_ws_base(n); }
@@ -540,8 +545,16 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     const uint8_t *dk = t->d_keys;
     const size_t stride = key_idx ? (size_t)Gm::DK : 0;
     if (status == nullptr) status = w.status_slot;  // (the kernels want one; the caller may not)
-    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
+    // up to kem_chain_batch() items: the whole decapsulation of an item in ONE launch, a two-wavefront workgroup per item
+    // (mlkem_decaps_chain_kernel: J beside Decrypt -> G -> PRF -> re-encryption, one barrier, then the select)
+    if (n <= kem_chain_batch()) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL(mlkem_decaps_chain_kernel<K>, dim3((unsigned)n), dim3(128), 0, st, dk, (size_t)Gm::DK, key_idx, key_rows, key_status, ct, ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
+    HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const bool small = key_idx == nullptr && n <= kem_small_shared_batch(true);
     if (small) {
         // ONE key, small batch: J(z || ct) on the cooperative permutation / lane pairs beside Decrypt + G (mlkem_small_decaps_pre_kernel

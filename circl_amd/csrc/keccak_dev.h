@@ -260,14 +260,20 @@ __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     c.unrot = rho == 0;
     return c;
 }
-__device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi, const CoopLane &c) {
+// NW: see kyber_dev.h wave_sync -- the exchange area belongs to this wavefront alone (a workgroup of several wavefronts gives each
+// its own), and its LDS instructions execute in order
+template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi, const CoopLane &c) {
+    auto sync = [] {
+        if constexpr (NW) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     auto ld = [](const uint64_t *p, uint32_t &lo, uint32_t &hi) { const uint64_t w = *p; lo = (uint32_t)w; hi = (uint32_t)(w >> 32); };
 #pragma unroll 1
     for (int r = 0; r < 24; r++) {
         const RcPair rc = rc_pair(r);
-        __syncthreads();  // chi's reads of the previous round are done
+        sync();  // chi's reads of the previous round are done
         if (c.on) *c.a_self = ((uint64_t)vhi << 32) | vlo;
-        __syncthreads();
+        sync();
         uint32_t ml[5], mh[5], pl[5], ph[5];
 #pragma unroll
         for (int y = 0; y < 5; y++) { ld(c.a_cm + 5 * y, ml[y], mh[y]); ld(c.a_cp + 5 * y, pl[y], ph[y]); }
@@ -281,7 +287,7 @@ __device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi,
         tl = c.unrot ? tl : rl;
         th = c.unrot ? th : rh;
         if (c.on) *c.b_dst = ((uint64_t)th << 32) | tl;  // pi
-        __syncthreads();
+        sync();
         uint32_t b0l, b0h, b1l, b1h, b2l, b2h;
         ld(c.b0, b0l, b0h); ld(c.b1, b1l, b1h); ld(c.b2, b2l, b2h);
         vlo = bitop3_chi(b0l, b1l, b2l);

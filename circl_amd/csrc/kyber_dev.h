@@ -164,36 +164,42 @@ template <int BOUND> CIRCL_HD void gs(int &a, int &b, uint32_t c) {
 
 // All kernels that use these run ONE wavefront per workgroup, so a workgroup barrier is a
 // wave-local ordering point for LDS.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// NW ("no wait"): the buffer belongs to ONE wavefront, whose LDS instructions execute in order, so the reads behind the writes of
+// an exchange need neither a barrier nor an s_waitcnt -- only the compiler must keep their order.  This is the form for
+// workgroups of SEVERAL wavefronts that each work on their own buffers (mlkem_decaps_chain_kernel): no s_barrier is issued.
+template <bool NW = false> __device__ __forceinline__ void wave_sync() {
+    if constexpr (NW) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
 
 // Re-distribute a polynomial between register layouts through `xch` (256 elements of T in LDS: 512 bytes for
 // uint16_t, 1 KB for uint32_t -- values must fit T).
-template <int FROM, int TO, class T> __device__ __forceinline__ void relayout(int (&c)[4], void *xch_raw, int lane) {
+template <int FROM, int TO, class T, bool NW = false> __device__ __forceinline__ void relayout(int (&c)[4], void *xch_raw, int lane) {
     T *xch = reinterpret_cast<T *>(xch_raw);
     auto idx = [&](int which, int r) {
         return which == 1 ? idx_l1(lane, r) : which == 2 ? idx_l2(lane, r) : which == 3 ? idx_l3(lane, r) : idx_l4(lane, r);
     };
-    wave_sync();  // earlier readers of xch are done
+    wave_sync<NW>();  // earlier readers of xch are done
 #pragma unroll
     for (int r = 0; r < 4; r++) xch[idx(FROM, r)] = (T)c[r];
-    wave_sync();
+    wave_sync<NW>();
 #pragma unroll
     for (int r = 0; r < 4; r++) c[r] = (int)xch[idx(TO, r)];
 }
 
 // Poly.NTT (ntt.go:60-135).  In: layout L1, 0 <= c < IN_BOUND (any bound up to 2^16 - 7q).  Out: layout L4,
 // 0 <= c < IN_BOUND + 7q, congruent to the reference's transform.
-__device__ __forceinline__ void ntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
+template <bool NW = false> __device__ __forceinline__ void ntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
     const uint32_t z1 = zeta_c(1), z2 = zeta_c(2), z3 = zeta_c(3);
     ct(c[0], c[2], z1); ct(c[1], c[3], z1);
     ct(c[0], c[1], z2); ct(c[2], c[3], z3);
-    relayout<1, 2, uint16_t>(c, xch, lane);
+    relayout<1, 2, uint16_t, NW>(c, xch, lane);
     ct(c[0], c[2], z.f2); ct(c[1], c[3], z.f2);
     ct(c[0], c[1], z.f3a); ct(c[2], c[3], z.f3b);
-    relayout<2, 3, uint16_t>(c, xch, lane);
+    relayout<2, 3, uint16_t, NW>(c, xch, lane);
     ct(c[0], c[2], z.f4); ct(c[1], c[3], z.f4);
     ct(c[0], c[1], z.f5a); ct(c[2], c[3], z.f5b);
-    relayout<3, 4, uint16_t>(c, xch, lane);
+    relayout<3, 4, uint16_t, NW>(c, xch, lane);
     ct(c[0], c[2], z.f6); ct(c[1], c[3], z.f6);
 }
 
@@ -202,16 +208,16 @@ __device__ __forceinline__ void ntt(int (&c)[4], const LaneZetas &z, void *xch, 
 // 128^-1 R^2 after Montgomery products that each carried R^-1.)  In: layout L4, 0 <= c < q.  Out: layout L1, 0 <= c < q.
 // The sums double per layer (below 2^k q after k layers) and are never reduced on the way: 128 q is far below
 // MULC_LIMIT.  The first two exchanges fit 16-bit elements (< 8q), the third (< 32q) uses 32-bit ones.
-template <uint32_t SCALE> __device__ __forceinline__ void invntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
+template <uint32_t SCALE, bool NW = false> __device__ __forceinline__ void invntt(int (&c)[4], const LaneZetas &z, void *xch, int lane) {
     static_assert(128u * Q < MULC_LIMIT, "lazy sums stay inside the mulc domain");
     gs<Q>(c[0], c[2], z.i6); gs<Q>(c[1], c[3], z.i6);
-    relayout<4, 3, uint16_t>(c, xch, lane);
+    relayout<4, 3, uint16_t, NW>(c, xch, lane);
     gs<2 * Q>(c[0], c[1], z.i5a); gs<2 * Q>(c[2], c[3], z.i5b);
     gs<4 * Q>(c[0], c[2], z.i4); gs<4 * Q>(c[1], c[3], z.i4);
-    relayout<3, 2, uint16_t>(c, xch, lane);
+    relayout<3, 2, uint16_t, NW>(c, xch, lane);
     gs<8 * Q>(c[0], c[1], z.i3a); gs<8 * Q>(c[2], c[3], z.i3b);
     gs<16 * Q>(c[0], c[2], z.i2); gs<16 * Q>(c[1], c[3], z.i2);
-    relayout<2, 1, uint32_t>(c, xch, lane);
+    relayout<2, 1, uint32_t, NW>(c, xch, lane);
     const uint32_t z1 = zeta_c(1), z2 = zeta_c(2), z3 = zeta_c(3);
     gs<32 * Q>(c[0], c[1], z3); gs<32 * Q>(c[2], c[3], z2);
     gs<64 * Q>(c[0], c[2], z1); gs<64 * Q>(c[1], c[3], z1);

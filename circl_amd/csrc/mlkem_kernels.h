@@ -182,7 +182,7 @@ template <int FIRST, int COUNT> __device__ __forceinline__ void store_words(uint
 
 // A cooperative SHA3-256 / SHAKE256 sponge (rate 17 words) over `nwords` 64-bit words delivered by `src(k)`; returns with the
 // squeezed state in the lanes (word j in lane j of the half).
-template <class Src>
+template <bool NW = false, class Src>
 __device__ __forceinline__ void coop_sponge17(uint32_t &vlo, uint32_t &vhi, Src &&src, int nwords, uint32_t ds, const CoopLane &c, int j) {
     const int full = nwords / 17, rem = nwords % 17;
     vlo = vhi = 0;
@@ -192,13 +192,13 @@ __device__ __forceinline__ void coop_sponge17(uint32_t &vlo, uint32_t &vhi, Src 
         vlo ^= (uint32_t)next;
         vhi ^= (uint32_t)(next >> 32);
         next = (j < 17 && 17 * (b + 1) + j < nwords) ? src(17 * (b + 1) + j) : 0;
-        keccak_f1600_coop2(vlo, vhi, c);
+        keccak_f1600_coop2<NW>(vlo, vhi, c);
     }
     vlo ^= (uint32_t)next;
     vhi ^= (uint32_t)(next >> 32);
     if (j == rem) vlo ^= ds;
     if (j == 16) vhi ^= 0x80000000u;
-    keccak_f1600_coop2(vlo, vhi, c);
+    keccak_f1600_coop2<NW>(vlo, vhi, c);
 }
 
 // ---- kernel 1: H(ek), G(m || H(ek)) -----------------------------------------------------------
@@ -768,18 +768,18 @@ template <int D> __device__ __forceinline__ bool pack_bits_differs(const uint32_
 // starts at bit D*n = D*l + 64*D*r, so all four fields of a lane share the shift (D*l) mod 32 and
 // sit 2*D dwords apart: each is OR-ed into a zeroed LDS staging area with at most two 32-bit
 // atomics, then the 8*D dwords of the polynomial are streamed out (or compared) coalesced.
-template <int D> __device__ __forceinline__ void stage_bits_l1(uint32_t *stage, const unsigned (&v)[4], int lane) {
+template <int D, bool NW = false> __device__ __forceinline__ void stage_bits_l1(uint32_t *stage, const unsigned (&v)[4], int lane) {
     constexpr int WORDS = 8 * D;
-    __syncthreads();  // previous users of the staging area are done
+    kyber::wave_sync<NW>();  // previous users of the staging area are done
     for (int w = lane; w < WORDS; w += 64) stage[w] = 0;
-    __syncthreads();
+    kyber::wave_sync<NW>();
     const int bit = D * lane, w0 = bit >> 5, sh = bit & 31;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         atomicOr(&stage[w0 + 2 * D * r], v[r] << sh);
         if (sh + D > 32) atomicOr(&stage[w0 + 2 * D * r + 1], v[r] >> (32 - sh));
     }
-    __syncthreads();
+    kyber::wave_sync<NW>();
 }
 template <int D> __device__ __forceinline__ void store_staged(uint32_t *dst, const uint32_t *stage, int lane, bool zero) {
     constexpr int WORDS = 8 * D;
@@ -1204,8 +1204,8 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_shared
 // ---- decapsulation ---------------------------------------------------------------------------
 
 // K-PKE.Decrypt (cpapke.go:113-130) of one item by one wavefront: m' -> 32 bytes at `mprime`.
-template <int K>
-__device__ __forceinline__ void mlkem_decrypt_item(const uint8_t *__restrict__ dkp, const uint8_t *__restrict__ ctp, uint8_t *__restrict__ mprime,
+template <int K, bool NW = false>
+__device__ __forceinline__ void mlkem_decrypt_item(const uint8_t *__restrict__ dkp, const uint8_t *__restrict__ ctp, uint8_t *mprime,
                                                    uint32_t *xch, int lane) {
     using P = Params<K>;
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
@@ -1219,11 +1219,11 @@ __device__ __forceinline__ void mlkem_decrypt_item(const uint8_t *__restrict__ d
             sh[r] = kyber::csubq(sh[r]);  // PrivateKey.Unpack normalises (cpapke.go:33-36)
             u[r] = kyber::decompress_coeff<P::DU>(get_bits<P::DU>(ctp + 32 * P::DU * j, kyber::idx_l1(lane, r)));
         }
-        kyber::ntt(u, z, xch, lane);  // < 8q, left lazy
+        kyber::ntt<NW>(u, z, xch, lane);  // < 8q, left lazy
         kyber::mulhat_acc_packed(acc, kyber::pack16(sh[0], sh[1]), kyber::pack16(sh[2], sh[3]), kyber::hat_prepare(u, z.f6, z.f6n));
     }
     kyber::mulhat_finish(acc);
-    kyber::invntt<kyber::NEG_R32>(acc, z, xch, lane);  // <s-hat, u-hat> as plain coefficients in [0, q)
+    kyber::invntt<kyber::NEG_R32, NW>(acc, z, xch, lane);  // <s-hat, u-hat> as plain coefficients in [0, q)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int nidx = kyber::idx_l1(lane, r);
@@ -1425,6 +1425,167 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
     const size_t e0 = (size_t)b * Gm::G;
     sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), dk + 768 * K, dk_stride, e0, n, lane);
 }
+// ---- resident keys, small batches: the whole decapsulation of an item as ONE workgroup of two wavefronts -------------------------
+// With the key parsed beforehand (a key table: A^T rows, the verdict of the stored-hash check) a decapsulation is two independent
+// chains that meet at the final select (kyber.go:144-184):
+//   wave 0   m' = K-PKE.Decrypt(dk, ct) -> (K', r') = G(m' || h) [one cooperative permutation] -> the 2K+1 PRF streams [a stream per
+//            lane pair, keccak_f1600_split: one permutation] -> ct' = K-PKE.Encrypt(ek, m', r') compared with ct on the fly
+//   wave 1   J(z || ct): 9 sequential permutations (ML-KEM-768) on the cooperative form
+// and ONE workgroup barrier later wave 0 stores (ct == ct') ? K' : J.  No flags between workgroups, no second and third launch:
+// the small-batch route before it ran J / Decrypt+G / re-encryption as three dependent launches (profiles/r04_table_latency.txt).
+// Every LDS buffer belongs to one wavefront and every wave-level ordering point inside is the no-wait form (kyber::wave_sync<true>),
+// so the two wavefronts never meet at a barrier except the one at the end.  Grid = n workgroups.
+template <int K>
+__global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint32_t *__restrict__ key_idx,
+                                                                 const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_status,
+                                                                 const uint8_t *__restrict__ ct, uint8_t *__restrict__ ss, uint8_t *__restrict__ status,
+                                                                 size_t n) {
+    using Gm = Geom<K>;
+    using P = Params<K>;
+    __shared__ __attribute__((aligned(16))) uint64_t coopw[2][100];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t noise[Gm::NOISE * Gm::NOISE_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint64_t mprime[4];
+    __shared__ __attribute__((aligned(16))) uint64_t kr[8];      // K' (words 0..3), r' (4..7)
+    __shared__ __attribute__((aligned(16))) uint64_t ssrej[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;  // (block-uniform)
+    const size_t kq = key_idx ? (size_t)key_idx[item] : size_t(0);
+    const uint8_t *dkp = dk + kq * dk_stride;
+    const uint8_t *ctp = ct + item * Gm::CT;
+    constexpr int CTW = Gm::CT / 8;
+    auto handoff = [] {  // what the lanes wrote to LDS (by whatever instruction) is visible to the wavefront's later reads
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    };
+    bool differs = false;
+    if (wave == 1) {
+        const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
+        const uint64_t *cw = reinterpret_cast<const uint64_t *>(ctp);
+        const CoopLane c = coop_lane(coopw[1], lane);
+        uint32_t vlo, vhi;
+        coop_sponge17<true>(vlo, vhi, [&](int k) { return k < 4 ? zw[k] : cw[k - 4]; }, 4 + CTW, kDsShake, c, j);
+        if (half == 0 && j < 4) ssrej[j] = ((uint64_t)vhi << 32) | vlo;
+    } else {
+        mlkem_decrypt_item<K, true>(dkp, ctp, reinterpret_cast<uint8_t *>(mprime), xch, lane);
+        handoff();
+        {   // (K', r') = G(m' || h) with the STORED hash (kyber.go:158-162)
+            const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
+            const CoopLane c = coop_lane(coopw[0], lane);
+            uint64_t g = 0;
+            if (j < 4) g = mprime[j];
+            else if (j < 8) g = stored[j - 4];
+            else if (j == 8) g = 0x8000000000000000ull | kDsSha3;
+            uint32_t vlo = (uint32_t)g, vhi = (uint32_t)(g >> 32);
+            keccak_f1600_coop2<true>(vlo, vhi, c);
+            if (half == 0 && j < 8) kr[j] = ((uint64_t)vhi << 32) | vlo;
+        }
+        handoff();
+        {   // PRF(r', nonce) for the 2K+1 streams, a stream per lane pair (cpapke.go:139-147, sample.go:17-95)
+            const int sidx = lane >> 1, parity = lane & 1;
+            const bool on = sidx < Gm::NOISE;
+            const uint32_t *seed = reinterpret_cast<const uint32_t *>(kr + 4) + parity;
+            SplitState s;
+#pragma unroll
+            for (int w = 0; w < 25; w++) s.w[w] = w < 4 ? seed[2 * w] : 0u;
+            if (parity == 0) s.w[4] = (uint32_t)(on ? sidx : 0) | (kDsShake << 8);
+            else s.w[16] = 0x80000000u;
+            keccak_f1600_split(s, parity != 0);
+            uint32_t *out = reinterpret_cast<uint32_t *>(noise + (on ? sidx : 0) * Gm::NOISE_STRIDE) + parity;
+            const bool eta2 = P::ETA1 == 2 || sidx >= K;
+            if (on) {
+                detail::static_for<0, 16>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;
+                    out[2 * w] = eta2 ? kyber::cbd2_bias8_word(s.w[w]) : s.w[w];
+                });
+            }
+            if constexpr (P::ETA1 == 3) {  // 192 bytes for the eta1 = 3 streams: word 16 of this block, then 7 more of the next
+                if (on && sidx < K) out[32] = s.w[16];
+                keccak_f1600_split(s, parity != 0);
+                if (on && sidx < K) {
+                    detail::static_for<0, 7>([&](auto ic) {
+                        constexpr int w = decltype(ic)::v;
+                        out[34 + 2 * w] = s.w[w];
+                    });
+                }
+            }
+        }
+        handoff();
+        // ct' = K-PKE.Encrypt(ek, m', r') against ct (the REENCRYPT / KM_KEYED ring phase of mlkem_encrypt_kernel, one item)
+        const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+        const uint8_t *ekp = dkp + 384 * K;
+        const int16_t *krows = key_rows + kq * (size_t)(K * K * 256);
+        int th[K][4];
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            unpack12_l4(th[jj], ekp + 384 * jj, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) th[jj][r] = kyber::csubq(th[jj][r]);
+        }
+        kyber::HatOperand rop[K];
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            int rh[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) rh[r] = cbd_coeff<P::ETA1>(noise + jj * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+            kyber::ntt<true>(rh, z, xch, lane);
+            rop[jj] = kyber::hat_prepare(rh, z.f6, z.f6n);
+        }
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            RefWords<P::DU> ref;
+            ref.load(reinterpret_cast<const uint32_t *>(ctp + 32 * P::DU * i), lane);
+            int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int jj = 0; jj < K; jj++) {
+                uint32_t a01, a23;
+                AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+                kyber::mulhat_acc_packed(acc, a01, a23, rop[jj]);
+            }
+            kyber::mulhat_finish(acc);
+            kyber::invntt<kyber::NEG_R32, true>(acc, z, xch, lane);
+            const uint8_t *e1 = noise + (K + i) * Gm::NOISE_STRIDE;
+            unsigned cv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) cv[r] = kyber::compress_coeff<P::DU>(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r)));
+            stage_bits_l1<P::DU, true>(xch, cv, lane);
+            differs |= ref.differs(xch, lane);
+        }
+        {
+            RefWords<P::DV> ref;
+            ref.load(reinterpret_cast<const uint32_t *>(ctp + 32 * P::DU * K), lane);
+            int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int jj = 0; jj < K; jj++) kyber::mulhat_acc_packed(acc, kyber::pack16(th[jj][0], th[jj][1]), kyber::pack16(th[jj][2], th[jj][3]), rop[jj]);
+            kyber::mulhat_finish(acc);
+            kyber::invntt<kyber::NEG_R32, true>(acc, z, xch, lane);
+            const uint8_t *e2 = noise + 2 * K * Gm::NOISE_STRIDE;
+            const uint8_t *mp = reinterpret_cast<const uint8_t *>(mprime);
+            unsigned cv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                const int mbit = (mp[nidx >> 3] >> (nidx & 7)) & 1;
+                cv[r] = kyber::compress_coeff<P::DV>(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2)));
+            }
+            stage_bits_l1<P::DV, true>(xch, cv, lane);
+            differs |= ref.differs(xch, lane);
+        }
+    }
+    __syncthreads();  // the one meeting point of the two chains
+    if (wave == 0) {
+        // subtle.ConstantTimeCopy(ConstantTimeCompare(ct, ct'), ss2, K') (kyber.go:176-181); a key that failed its hash check: zeros, status 2
+        const bool mismatch = __any(differs);
+        const uint8_t verdict = key_status[kq];
+        if (lane < 8) {
+            const uint32_t kb = reinterpret_cast<const uint32_t *>(kr)[lane], rj = reinterpret_cast<const uint32_t *>(ssrej)[lane];
+            reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = verdict ? 0u : (mismatch ? rj : kb);
+        }
+        if (lane == 0) status[item] = verdict;
+    }
+}
+
 // one key for the batch: every item's status byte is the key's verdict
 static __global__ void __launch_bounds__(256) mlkem_fill_status_kernel(uint8_t *__restrict__ status, const uint8_t *__restrict__ key_status, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

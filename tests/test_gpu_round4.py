@@ -78,3 +78,48 @@ def test_rccl_process_group_branch_runs_on_the_gpu():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-5000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res == {"value": 500.0, "worst": 2.0, "gather": [7.25], "max": 4.0, "sum": 5.0}
+
+
+def test_resident_decapsulation_chain_route_boundaries():
+    # kem/mlkem/mlkem768/kyber.go:144-184 DecapsulateTo on parsed keys: up to 2^CIRCL_HIP_KEM_CHAIN items a resident-key decapsulation is
+    # ONE launch (a two-wavefront workgroup per item: J beside Decrypt -> G -> PRF -> re-encryption); beyond it the three-launch routes.
+    # The same bytes on both sides of the switch and with the route disabled / widened -- implicit rejection (every third ciphertext
+    # tampered with), a key whose stored hash is wrong (kem.ErrPrivKey: zeros, status 2), an index vector and none -- and the oracle's.
+    prog = textwrap.dedent("""
+        import sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        from circl_amd import hostapi
+        from oracle import orc
+        h = hashlib.sha256()
+        for param in (512, 768, 1024):
+            rng = np.random.default_rng(param)
+            nk = 5
+            ek, dk = orc.mlkem_keygen(param, rng.integers(0, 256, (nk, 64), dtype=np.uint8))
+            dk_bad = dk.copy()
+            dk_bad[3, -40] ^= 1
+            pub, prv = hostapi.KeyTable("mlkem-public", param, ek), hostapi.KeyTable("mlkem-private", param, dk_bad)
+            for n in (1, 2, 63, 1023, 1024, 1025, 3000):
+                m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                idx = rng.integers(0, nk, n).astype(np.uint32)
+                ct, ss, _ = pub.encaps(m, idx)
+                ct[::3, 9] ^= 0x20
+                got, st = prv.decaps(ct, idx)
+                want, _ = orc.mlkem_decaps(param, dk[idx], ct)
+                bad = idx == 3
+                assert (st[bad] == 2).all() and not got[bad].any() and not st[~bad].any() and (got[~bad] == want[~bad]).all(), (param, n)
+                ok_items = ~bad & (np.arange(n) %% 3 != 0)              # untouched ciphertexts of good keys decapsulate to the encapsulated secret
+                assert (got[ok_items] == ss[ok_items]).all(), (param, n)
+                got0, st0 = prv.decaps(ct)                      # no index vector: entry 0
+                want0, _ = orc.mlkem_decaps(param, np.tile(dk[:1], (n, 1)), ct)
+                assert not st0.any() and (got0 == want0).all(), (param, n)
+                h.update(got.tobytes() + st.tobytes() + got0.tobytes())
+        print("chain digest", h.hexdigest())
+    """ % ROOT)
+    digests = []
+    for chain in ("10", "0", "12", "1"):
+        env = dict(os.environ, CIRCL_HIP_KEM_CHAIN=chain)
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "chain digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+        digests.append(r.stdout.strip().split()[-1])
+    assert len(set(digests)) == 1, digests
