@@ -51,8 +51,10 @@ size_t kem_small_shared_batch(bool decaps) {
 // workspace size is MONOTONE in n: a workspace sized once for the largest batch serves every smaller one.
 size_t kem_cache_bytes(size_t entries) { return up256((std::max<size_t>(entries, 1) + 15) / 16 * 16 * size_t(16 * 512)); }
 // Resident private keys: batches up to 2^CIRCL_HIP_KEM_CHAIN items (0 = never) decapsulate in one launch (mlkem_decaps_chain_kernel)
-size_t kem_chain_batch() {
-    static const int lg = env_int("CIRCL_HIP_KEM_CHAIN", 10, 0, 20);
+// ... and encapsulate in one launch up to 2^CIRCL_HIP_KEM_CHAIN_ENCAPS items (mlkem_encaps_chain_kernel)
+size_t kem_chain_batch(bool decaps = true) {
+    static const int lg_d = env_int("CIRCL_HIP_KEM_CHAIN", 10, 0, 20), lg_e = env_int("CIRCL_HIP_KEM_CHAIN_ENCAPS", 10, 0, 20);
+    const int lg = decaps ? lg_d : lg_e;
     return lg <= 0 ? size_t(0) : size_t(1) << lg;
 }
 size_t kem_small_table_bytes(size_t n) { return kem_cache_bytes(std::min(n, kem_small_batch())); }
@@ -513,6 +515,13 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     const int16_t *key_rows = reinterpret_cast<const int16_t *>(t->d_table);
     const uint8_t *key_h = t->d_table + up256(padded * K * K * 512);
     const size_t stride = key_idx ? (size_t)Gm::EK : 0;
+    if (n <= kem_chain_batch(false)) {  // one launch, a wavefront per item: G -> PRF -> K-PKE.Encrypt (mlkem_encaps_chain_kernel)
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL(mlkem_encaps_chain_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, (const uint8_t *)t->d_keys, (size_t)Gm::EK, key_idx, key_rows, key_h, m, ct,
+                           ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);

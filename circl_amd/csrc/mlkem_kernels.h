@@ -1586,6 +1586,132 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
     }
 }
 
+// The encapsulation to a resident key, small batches, in ONE launch: a wavefront per item runs (K, r) = G(m || H(ek)) on the
+// cooperative permutation, the 2K+1 PRF streams a stream per lane pair, and K-PKE.Encrypt with the table's A^T rows
+// (kyber.go:103-137 EncapsulateTo on a parsed key) -- the route before it ran G for all items in one launch (a lane per item)
+// and the PRF + ring phase in a second one.  key_h: H(ek) per table entry.  Grid = n single-wave workgroups.
+template <int K>
+__global__ void __launch_bounds__(64) mlkem_encaps_chain_kernel(const uint8_t *__restrict__ ek, size_t ek_stride, const uint32_t *__restrict__ key_idx,
+                                                                const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_h,
+                                                                const uint8_t *__restrict__ m, uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
+                                                                uint8_t *__restrict__ status, size_t n) {
+    using Gm = Geom<K>;
+    using P = Params<K>;
+    __shared__ __attribute__((aligned(16))) uint64_t coopw[100];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t noise[Gm::NOISE * Gm::NOISE_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint64_t kr[8];      // K (words 0..3), r (4..7)
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;
+    const size_t kq = key_idx ? (size_t)key_idx[item] : size_t(0);
+    const uint8_t *ekp = ek + kq * ek_stride;
+    const uint8_t *mp = m + item * 32;
+    auto handoff = [] {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    };
+    {
+        const CoopLane c = coop_lane(coopw, lane);
+        uint64_t g = 0;
+        if (j < 4) g = reinterpret_cast<const uint64_t *>(mp)[j];
+        else if (j < 8) g = reinterpret_cast<const uint64_t *>(key_h + kq * 32)[j - 4];
+        else if (j == 8) g = 0x8000000000000000ull | kDsSha3;
+        uint32_t vlo = (uint32_t)g, vhi = (uint32_t)(g >> 32);
+        keccak_f1600_coop2<true>(vlo, vhi, c);
+        if (half == 0 && j < 8) kr[j] = ((uint64_t)vhi << 32) | vlo;
+    }
+    handoff();
+    {
+        const int sidx = lane >> 1, parity = lane & 1;
+        const bool on = sidx < Gm::NOISE;
+        const uint32_t *seed = reinterpret_cast<const uint32_t *>(kr + 4) + parity;
+        SplitState s;
+#pragma unroll
+        for (int w = 0; w < 25; w++) s.w[w] = w < 4 ? seed[2 * w] : 0u;
+        if (parity == 0) s.w[4] = (uint32_t)(on ? sidx : 0) | (kDsShake << 8);
+        else s.w[16] = 0x80000000u;
+        keccak_f1600_split(s, parity != 0);
+        uint32_t *out = reinterpret_cast<uint32_t *>(noise + (on ? sidx : 0) * Gm::NOISE_STRIDE) + parity;
+        const bool eta2 = P::ETA1 == 2 || sidx >= K;
+        if (on) {
+            detail::static_for<0, 16>([&](auto ic) {
+                constexpr int w = decltype(ic)::v;
+                out[2 * w] = eta2 ? kyber::cbd2_bias8_word(s.w[w]) : s.w[w];
+            });
+        }
+        if constexpr (P::ETA1 == 3) {
+            if (on && sidx < K) out[32] = s.w[16];
+            keccak_f1600_split(s, parity != 0);
+            if (on && sidx < K) {
+                detail::static_for<0, 7>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;
+                    out[34 + 2 * w] = s.w[w];
+                });
+            }
+        }
+    }
+    handoff();
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    const int16_t *krows = key_rows + kq * (size_t)(K * K * 256);
+    int th[K][4];
+    bool bad = false;
+#pragma unroll
+    for (int jj = 0; jj < K; jj++) {
+        unpack12_l4(th[jj], ekp + 384 * jj, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) bad |= th[jj][r] >= Q;  // UnpackMLKEM's range check (cpapke.go:45-55): kem.ErrPubKey
+    }
+    const bool reject = __any(bad);
+    kyber::HatOperand rop[K];
+#pragma unroll
+    for (int jj = 0; jj < K; jj++) {
+        int rh[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) rh[r] = cbd_coeff<P::ETA1>(noise + jj * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+        kyber::ntt<true>(rh, z, xch, lane);
+        rop[jj] = kyber::hat_prepare(rh, z.f6, z.f6n);
+    }
+    uint8_t *ctp = ct + item * Gm::CT;
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            uint32_t a01, a23;
+            AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+            kyber::mulhat_acc_packed(acc, a01, a23, rop[jj]);
+        }
+        kyber::mulhat_finish(acc);
+        kyber::invntt<kyber::NEG_R32, true>(acc, z, xch, lane);
+        const uint8_t *e1 = noise + (K + i) * Gm::NOISE_STRIDE;
+        unsigned cv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) cv[r] = kyber::compress_coeff<P::DU>(acc[r] + cbd_coeff<2>(e1, kyber::idx_l1(lane, r)));
+        stage_bits_l1<P::DU, true>(xch, cv, lane);
+        store_staged<P::DU>(reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * i), xch, lane, reject);
+    }
+    {
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) kyber::mulhat_acc_packed(acc, kyber::pack16(th[jj][0], th[jj][1]), kyber::pack16(th[jj][2], th[jj][3]), rop[jj]);
+        kyber::mulhat_finish(acc);
+        kyber::invntt<kyber::NEG_R32, true>(acc, z, xch, lane);
+        const uint8_t *e2 = noise + 2 * K * Gm::NOISE_STRIDE;
+        unsigned cv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            const int mbit = (mp[nidx >> 3] >> (nidx & 7)) & 1;
+            cv[r] = kyber::compress_coeff<P::DV>(acc[r] + cbd_coeff<2>(e2, nidx) + (-mbit & ((Q + 1) / 2)));
+        }
+        stage_bits_l1<P::DV, true>(xch, cv, lane);
+        store_staged<P::DV>(reinterpret_cast<uint32_t *>(ctp + 32 * P::DU * K), xch, lane, reject);
+    }
+    if (lane == 0) status[item] = reject ? 1 : 0;
+    if (lane < 8) reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = reject ? 0u : reinterpret_cast<const uint32_t *>(kr)[lane];
+}
+
 // one key for the batch: every item's status byte is the key's verdict
 static __global__ void __launch_bounds__(256) mlkem_fill_status_kernel(uint8_t *__restrict__ status, const uint8_t *__restrict__ key_status, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

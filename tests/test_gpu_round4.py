@@ -81,7 +81,8 @@ def test_rccl_process_group_branch_runs_on_the_gpu():
 
 
 def test_resident_decapsulation_chain_route_boundaries():
-    # kem/mlkem/mlkem768/kyber.go:144-184 DecapsulateTo on parsed keys: up to 2^CIRCL_HIP_KEM_CHAIN items a resident-key decapsulation is
+    # kem/mlkem/mlkem768/kyber.go:103-137 EncapsulateTo / :144-184 DecapsulateTo on parsed keys (encapsulation: one launch, a wavefront per
+    # item, up to 2^CIRCL_HIP_KEM_CHAIN_ENCAPS items): up to 2^CIRCL_HIP_KEM_CHAIN items a resident-key decapsulation is
     # ONE launch (a two-wavefront workgroup per item: J beside Decrypt -> G -> PRF -> re-encryption); beyond it the three-launch routes.
     # The same bytes on both sides of the switch and with the route disabled / widened -- implicit rejection (every third ciphertext
     # tampered with), a key whose stored hash is wrong (kem.ErrPrivKey: zeros, status 2), an index vector and none -- and the oracle's.
@@ -98,11 +99,21 @@ def test_resident_decapsulation_chain_route_boundaries():
             ek, dk = orc.mlkem_keygen(param, rng.integers(0, 256, (nk, 64), dtype=np.uint8))
             dk_bad = dk.copy()
             dk_bad[3, -40] ^= 1
-            pub, prv = hostapi.KeyTable("mlkem-public", param, ek), hostapi.KeyTable("mlkem-private", param, dk_bad)
+            ek_nc = ek.copy()
+            ek_nc[4, 0] = 0xff
+            ek_nc[4, 1] |= 0x0f                                    # first coefficient of entry 4 = 0xfff >= q (cpapke.go:45-55)
+            pub, prv = hostapi.KeyTable("mlkem-public", param, ek_nc), hostapi.KeyTable("mlkem-private", param, dk_bad)
             for n in (1, 2, 63, 1023, 1024, 1025, 3000):
                 m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
                 idx = rng.integers(0, nk, n).astype(np.uint32)
-                ct, ss, _ = pub.encaps(m, idx)
+                ct, ss, ste = pub.encaps(m, idx)
+                ct_o, ss_o, st_o = orc.mlkem_encaps(param, ek_nc[idx], m)   # (entry 4 is not canonical: kem.ErrPubKey, zeros)
+                assert (ste == st_o).all() and (ct == ct_o).all() and (ss == ss_o).all() and (ste == (idx == 4)).all(), (param, n)
+                ct1, ss1, st1 = pub.encaps(m)                                # no index vector: entry 0
+                ct1_o, ss1_o, _ = orc.mlkem_encaps(param, np.tile(ek[:1], (n, 1)), m)
+                assert not st1.any() and (ct1 == ct1_o).all() and (ss1 == ss1_o).all(), (param, n)
+                h.update(ct.tobytes() + ss.tobytes() + ste.tobytes() + ct1.tobytes())
+                ct, ss, _ = orc.mlkem_encaps(param, ek[idx], m)
                 ct[::3, 9] ^= 0x20
                 got, st = prv.decaps(ct, idx)
                 want, _ = orc.mlkem_decaps(param, dk[idx], ct)
@@ -118,7 +129,7 @@ def test_resident_decapsulation_chain_route_boundaries():
     """ % ROOT)
     digests = []
     for chain in ("10", "0", "12", "1"):
-        env = dict(os.environ, CIRCL_HIP_KEM_CHAIN=chain)
+        env = dict(os.environ, CIRCL_HIP_KEM_CHAIN=chain, CIRCL_HIP_KEM_CHAIN_ENCAPS=chain)
         r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "chain digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
         digests.append(r.stdout.strip().split()[-1])
