@@ -613,12 +613,17 @@ def valu_issue(insts, launch_ms):
         return None
     simds, nominal_hz = 1024, 2.4e9
     per_s = insts / (launch_ms * 1e-3)
+    cyc = simds * nominal_hz / per_s
     return {"wave_insts_per_launch": insts, "achieved_Ginst_per_s": per_s / 1e9,
             "peak_Ginst_per_s": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "frac": per_s / VALU_PEAK_WAVE_INSTS_PER_S,
             "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
-            "cycles_per_inst_per_simd_at_2.4GHz": simds * nominal_hz / per_s,
+            "cycles_per_inst_per_simd_at_2.4GHz": cyc,
             "keccak_probe_cycles_per_inst": {"4_waves_per_simd": 4.12, "8_waves_per_simd": 3.43},
-            "resident_waves_per_simd": 4}
+            "resident_waves_per_simd": 4,
+            # the wall these kernels really face: the issue rate a PURE Keccak-f[1600] instruction mix (V_BITOP3 / V_ALIGNBIT chains) reaches
+            # on this chip at the kernel's residency (profiles/r01_valu_mix_probe.txt, r03_ablation.txt), not the nominal 2 cycles
+            "frac_of_mix_ceiling": {"at_4_waves_per_simd": 4.12 / cyc, "at_8_waves_per_simd": 3.43 / cyc,
+                                    "definition": "(cycles per instruction of the pure-Keccak probe) / (this kernel's cycles per VALU instruction per SIMD)"}}
 
 
 # ------------------------------------------------------------------------------------------------------------------
