@@ -11,6 +11,7 @@ import "C"
 
 import (
 	"runtime"
+	"sync"
 
 	"github.com/cloudflare/circl/kem"
 )
@@ -23,6 +24,7 @@ import (
 //
 // NOT COMPILED IN THIS REPOSITORY'S CI (no Go toolchain); tests/test_gpu_keytable.py drives the same symbols.
 type ResidentTable struct {
+	mu      sync.RWMutex // calls hold the read lock, Close the write lock: a Close cannot free the table under a call
 	s       kem.Scheme
 	t       *C.circl_hip_keytable
 	private bool
@@ -58,7 +60,31 @@ func newResidentTable(s kem.Scheme, rows []byte, rowSize int, private bool, devi
 	return kt, errs, nil
 }
 
-// NewResidentPublicKeys parses n packed public keys ([n][PublicKeySize]) on `device`.
+// (AllDevices as the `device` of a constructor below replicates the table on every GPU; calls then split their batch into
+// contiguous shards, one per device: CIRCL_HIP_ALL_DEVICES, include/circl_hip.h.)
+
+// PublicKeys is PrivateKey.Public() over a batch of packed private keys (kem/mlkem/mlkem768/kyber.go:323-328): the encapsulation
+// key stored inside each decapsulation key.
+func PublicKeys(s kem.Scheme, dks []byte) ([]byte, error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		return nil, kem.ErrTypeMismatch
+	}
+	if len(dks)%s.PrivateKeySize() != 0 {
+		return nil, kem.ErrPrivKeySize
+	}
+	n := len(dks) / s.PrivateKeySize()
+	if n == 0 {
+		return []byte{}, nil
+	}
+	eks := make([]byte, n*s.PublicKeySize())
+	if err := status(C.circl_hip_mlkem_public_from_private(p, ptr(dks), ptr(eks), C.size_t(n)), "mlkem_public_from_private"); err != nil {
+		return nil, err
+	}
+	return eks, nil
+}
+
+// NewResidentPublicKeys parses n packed public keys ([n][PublicKeySize]) on `device` (AllDevices: on every device).
 func NewResidentPublicKeys(s kem.Scheme, eks []byte, device int) (*ResidentTable, error) {
 	kt, _, err := newResidentTable(s, eks, s.PublicKeySize(), false, device)
 	return kt, err
@@ -71,6 +97,8 @@ func NewResidentPrivateKeys(s kem.Scheme, dks []byte, device int) (*ResidentTabl
 
 // Close releases the device memory (idempotent).
 func (k *ResidentTable) Close() {
+	k.mu.Lock()
+	defer k.mu.Unlock()
 	if k.t != nil {
 		C.circl_hip_keytable_free(k.t)
 		k.t = nil
@@ -80,6 +108,8 @@ func (k *ResidentTable) Close() {
 // Encapsulate is len(seeds)/EncapsulationSeedSize times EncapsulateDeterministically on table entry idx[i]
 // (idx == nil: every item uses entry 0 -- a table of one key object).
 func (k *ResidentTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte, errs []error, err error) {
+	k.mu.RLock()
+	defer k.mu.RUnlock()
 	if k.t == nil || k.private {
 		return nil, nil, nil, kem.ErrTypeMismatch
 	}
@@ -89,6 +119,9 @@ func (k *ResidentTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte
 	n := len(seeds) / k.s.EncapsulationSeedSize()
 	if idx != nil && len(idx) != n {
 		return nil, nil, nil, kem.ErrTypeMismatch
+	}
+	if n == 0 {
+		return []byte{}, []byte{}, []error{}, nil
 	}
 	cts = make([]byte, n*k.s.CiphertextSize())
 	sss = make([]byte, n*k.s.SharedKeySize())
@@ -106,6 +139,8 @@ func (k *ResidentTable) Encapsulate(idx []uint32, seeds []byte) (cts, sss []byte
 
 // Decapsulate is len(cts)/CiphertextSize times Decapsulate with table entry idx[i] (idx == nil: entry 0).
 func (k *ResidentTable) Decapsulate(idx []uint32, cts []byte) (sss []byte, errs []error, err error) {
+	k.mu.RLock()
+	defer k.mu.RUnlock()
 	if k.t == nil || !k.private {
 		return nil, nil, kem.ErrTypeMismatch
 	}
@@ -115,6 +150,9 @@ func (k *ResidentTable) Decapsulate(idx []uint32, cts []byte) (sss []byte, errs 
 	n := len(cts) / k.s.CiphertextSize()
 	if idx != nil && len(idx) != n {
 		return nil, nil, kem.ErrTypeMismatch
+	}
+	if n == 0 {
+		return []byte{}, []error{}, nil
 	}
 	sss = make([]byte, n*k.s.SharedKeySize())
 	st := make([]byte, n)

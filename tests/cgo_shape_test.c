@@ -77,6 +77,15 @@ static void kem_round_trip(int param, size_t n, int device) {
     circl_hip_keytable_free(pub);
     circl_hip_keytable_free(prv);
     circl_hip_keytable_free(NULL);
+    /* round 4: a table replicated on every device (calls shard the batch) and PrivateKey.Public() over the batch */
+    CHECK(circl_hip_mlkem_keytable_new(param, 0, ek, nk, CIRCL_HIP_ALL_DEVICES, NULL, &pub) == 0 && circl_hip_keytable_device(pub) == CIRCL_HIP_ALL_DEVICES);
+    CHECK(circl_hip_mlkem_encaps_table(pub, idx, m, ct2, ss3, st, n) == 0);
+    CHECK(circl_hip_mlkem_encaps_keyed(param, ek, nk, idx, m, ct3, ss4, st, n, device) == 0);
+    CHECK(memcmp(ct2, ct3, CT * n) == 0 && memcmp(ss3, ss4, 32 * n) == 0);
+    circl_hip_keytable_free(pub);
+    uint8_t *ek2 = slice(circl_hip_mlkem_ek_size(param) * n, 9);
+    CHECK(circl_hip_mlkem_public_from_private(param, dk, ek2, n) == 0);
+    CHECK(memcmp(ek, ek2, circl_hip_mlkem_ek_size(param) * n) == 0);
 }
 
 static void dsa_round_trip(int param, size_t n, int device) {
@@ -114,6 +123,20 @@ static void dsa_round_trip(int param, size_t n, int device) {
     CHECK(circl_hip_mldsa_verify_table(vt, NULL /* entry 0 */, sig1, mblob, moff, cblob, coff, ok, n) == 0);
     for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
     CHECK(circl_hip_mldsa_sign_table(vt, mblob, moff, cblob, coff, NULL, sig1, n) == CIRCL_HIP_EPARAM); /* a public table does not sign */
+    /* round 4: a table of SEVERAL prepared private keys with an index slice, replicated on every device (device = -1), and
+     * PrivateKey.Public() over the batch (go/sign/mldsa/hipbatch/keytable.go: NewResidentPrivateKeys, Sign(idx, ...), PublicKeys) */
+    circl_hip_keytable *stn = NULL;
+    CHECK(circl_hip_mldsa_privkeys_new(param, sk, n, CIRCL_HIP_ALL_DEVICES, &stn) == 0 && stn != NULL);
+    CHECK(circl_hip_keytable_device(stn) == CIRCL_HIP_ALL_DEVICES && circl_hip_keytable_nkeys(stn) == n && circl_hip_keytable_on_device(stn, 0) != NULL);
+    CHECK(circl_hip_mldsa_sign_table_keyed(stn, idx, mblob, moff, cblob, coff, NULL, sig1, n) == 0);
+    CHECK(circl_hip_mldsa_sign(param, sk, mblob, moff, cblob, coff, NULL, sig2, n, device) == 0);
+    CHECK(memcmp(sig1, sig2, SIG * n) == 0);
+    uint32_t bad_idx[1] = {(uint32_t)n};
+    CHECK(circl_hip_mldsa_sign_table_keyed(stn, bad_idx, mblob, moff, cblob, coff, NULL, sig1, 1) == CIRCL_HIP_EPARAM);
+    uint8_t *pk2 = slice(PK * n, 15);
+    CHECK(circl_hip_mldsa_public_from_private(param, sk, pk2, n, device) == 0);
+    CHECK(memcmp(pk, pk2, PK * n) == 0);
+    circl_hip_keytable_free(stn);
     circl_hip_keytable_free(vt);
     circl_hip_keytable_free(st1);
 }
@@ -132,6 +155,24 @@ static void hybrid_round_trip(int scheme, size_t n, int device) {
     CHECK(circl_hip_hybrid_decaps(scheme, sk, ct, ss2, NULL, n, device) == 0);
     for (size_t i = 0; i < n; i++) CHECK(st[i] == 0);
     CHECK(memcmp(ss, ss2, SS * n) == 0);
+    if (scheme == CIRCL_HIP_HYBRID_XWING || scheme == CIRCL_HIP_HYBRID_X25519MLKEM768) {
+        /* go/kem/hybrid/hipbatch/keytable.go: the same keys parsed once (an X-Wing seed is expanded when the table is built), index slice */
+        const size_t nk = n < 9 ? n : 9;
+        circl_hip_keytable *hp = NULL, *hs = NULL;
+        uint8_t *kst = slice(nk, 1), *ct2 = slice(CT * n, 3), *ss3 = slice(SS * n, 5), *ss4 = slice(SS * n, 7);
+        uint32_t *idx = (uint32_t *)slice(4 * n + 8, 4);
+        for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)(i % nk);
+        CHECK(circl_hip_hybrid_keytable_new(scheme, 0, pk, nk, device, NULL, &hp) == 0 && hp != NULL);
+        CHECK(circl_hip_hybrid_keytable_new(scheme, 1, sk, nk, device, kst, &hs) == 0 && hs != NULL);
+        for (size_t i = 0; i < nk; i++) CHECK(kst[i] == 0);
+        CHECK(circl_hip_hybrid_encaps_table(hp, idx, es, ct2, ss3, st, n) == 0);
+        CHECK(circl_hip_hybrid_decaps_table(hs, idx, ct2, ss4, NULL, n) == 0);
+        CHECK(memcmp(ss3, ss4, SS * n) == 0);
+        if (nk == n) CHECK(memcmp(ct, ct2, CT * n) == 0 && memcmp(ss, ss3, SS * n) == 0); /* identity index: the per-item entry point's bytes */
+        CHECK(circl_hip_hybrid_encaps_table(hs, NULL, es, ct2, ss3, st, 1) == CIRCL_HIP_EPARAM); /* a private table does not encapsulate */
+        circl_hip_keytable_free(hp);
+        circl_hip_keytable_free(hs);
+    }
     /* the X25519 half alone: ct_X = KeyGen(ephemeral), and Shared agrees from both sides */
     uint8_t *a = slice(32 * n, 1), *b = slice(32 * n, 2), *pa = slice(32 * n, 3), *pb = slice(32 * n, 5), *s1 = slice(32 * n, 7), *s2 = slice(32 * n, 9), *ok = slice(n, 1);
     fill(a, 32 * n, 60);
@@ -196,6 +237,8 @@ int main(void) {
     CHECK(circl_hip_x25519(NULL, NULL, NULL, NULL, 0, 0) == 0);
     CHECK(circl_hip_hybrid_keygen(7, NULL, NULL, NULL, 0, 0) == CIRCL_HIP_EPARAM);
     hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 1, 0);
+    hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 7, 0);
+    hybrid_round_trip(CIRCL_HIP_HYBRID_X25519MLKEM768, 5, CIRCL_HIP_ALL_DEVICES);
     hybrid_round_trip(CIRCL_HIP_HYBRID_XWING, 2051, CIRCL_HIP_ALL_DEVICES);
     hybrid_round_trip(CIRCL_HIP_HYBRID_X25519MLKEM768, 777, 0);
     CHECK(circl_hip_xof(168, 0x1f, 24, NULL, NULL, NULL, 32, 0, 0) == 0);
