@@ -21,14 +21,7 @@ bool is_r3(int param) { return param == 2 || param == 3 || param == 5; }
 
 // ML-DSA verify / keygen workspace: per-item intermediates, the ticket counter, and one 48 KB scratch slice
 // (the sampled matrix rows) per resident workgroup of the persistent kernel.
-int dsa_blocks_per_cu() {
-    static const int v = [] {
-        const char *e = getenv("CIRCL_HIP_DSA_BLOCKS_PER_CU");  // tuning aid
-        const int x = e ? atoi(e) : 0;
-        return x >= 1 && x <= kMaxBlocksPerCU ? x : kMaxBlocksPerCU;
-    }();
-    return v;
-}
+int dsa_blocks_per_cu() { return kMaxBlocksPerCU; }
 template <int MODE> size_t mldsa_groups(size_t n) { return (n + circl::mldsa::DG<MODE>::IT - 1) / circl::mldsa::DG<MODE>::IT; }
 // scratch slices the workspace provides: enough for any visible device
 template <int MODE> size_t mldsa_scratch_blocks(size_t n) {
@@ -165,9 +158,8 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         if (int rc = mldsa_long_scan(msg_off, ctx_blob, ctx_off, internal_eff, lctl, n, st)) return rc;
         // small batches: every mu comes from the cooperative pre-pass (kSmallMu), and nothing before the final hash reads it --
         // so tr and mu run on a side stream next to SampleInBall's sponge and the verify kernel (n=1: ~75 us off the chain)
-        static const bool no_side = getenv("CIRCL_HIP_DSA_NOSIDE") != nullptr;  // tuning aid
         hipStream_t mu_st = st;
-        if (n <= kSmallMu && !no_side && side.begin(st)) mu_st = side.side;
+        if (n <= kSmallMu && side.begin(st)) mu_st = side.side;
         if (KM == KM_SHARED) {
             hipLaunchKernelGGL(mldsa_tr_kernel<MODE>, dim3(1), dim3(64), 0, mu_st, pk, tr);
             tr_arg = tr;
@@ -387,7 +379,7 @@ template <int MODE> struct SignLayout {
     explicit SignLayout(size_t n_) : n(n_) {
         // entries: one per item (two with lazy pairs) in the long rounds; small batches get room for up to 64 attempts per item
         // and round, capped at kMinEntryCapacity entries
-        static const size_t min_entries = (size_t)env_int("CIRCL_HIP_SIGN_MIN_ENTRIES", (int)circl::mldsa::kMinEntryCapacity, 64, 1 << 22);  // tuning aid
+        constexpr size_t min_entries = circl::mldsa::kMinEntryCapacity;
         E = std::max((sign_pair_mode() ? 2 : 1) * n, std::min(min_entries, 64 * n));
         tail_units = (size_t)max_cu_count() * kSignBlocksPerCU;
         size_t o = 0;

@@ -302,7 +302,7 @@ __attribute__((target("avx2"))) void copy_stream_avx2(uint8_t *dst, const uint8_
     if (i < n) memcpy(dst + i, src + i, n - i);
 }
 void copy_bytes(void *dst, const void *src, size_t n) {
-    static const bool nt = env_int("CIRCL_HIP_HOST_NT", 1, 0, 1) != 0 && __builtin_cpu_supports("avx2");
+    static const bool nt = __builtin_cpu_supports("avx2");  // non-temporal copies for the staging areas
     if (nt && n >= 4096) copy_stream_avx2(static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src), n);
     else memcpy(dst, src, n);
 }
@@ -525,8 +525,7 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         if (b.blob && !b.off) { g_err = "a blob without offsets"; return CIRCL_HIP_EPARAM; }
     HIP_TRY(hipSetDevice(physical_device(dev)));
     const size_t chunk = std::max<size_t>(1, std::min(n, opts.chunk_items));
-    static const int depth_env = env_int("CIRCL_HIP_HOST_DEPTH", 0, 1, 32);  // tuning aid: chunks in flight per call
-    const size_t depth = (size_t)std::max(1, (depth_env && opts.depth > 1) ? depth_env : opts.depth);
+    const size_t depth = (size_t)std::max(1, opts.depth);  // chunks in flight per call
     std::vector<char> in_pinned(ins.size()), out_pinned(outs.size()), blob_pinned(blobs.size());
     for (size_t k = 0; k < ins.size(); k++) in_pinned[k] = is_pinned_host(ins[k].p);
     for (size_t k = 0; k < outs.size(); k++) out_pinned[k] = outs[k].p && is_pinned_host(outs[k].p);
@@ -538,8 +537,8 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         // A call that is ONE small chunk gains nothing from separate copy streams and pays for them: two cross-stream event hops
         // and two SDMA start-ups are ~20 us of a one-item call's 140 (measured through the Python binding: n = 1 139 -> 120 us, 64 items
         // 166 -> 147, 1 024 items 316 -> 299).  Its copies go on the compute stream (the events below are then recorded and awaited on
-        // one stream, which costs nothing).  CIRCL_HIP_HOST_INLINE_BYTES: the largest such call (default 4 MB moved), 0 = never.
-        static const size_t inline_bytes = (size_t)env_int("CIRCL_HIP_HOST_INLINE_BYTES", 4 << 20, 0, 1 << 30);
+        // one stream, which costs nothing).  The largest such call moves 4 MB.
+        constexpr size_t inline_bytes = size_t(4) << 20;
         size_t moved = 0;
         for (auto &in : ins) moved += in.row * (in.per_call ? 1 : n);
         for (auto &o : outs) moved += o.row * n;
@@ -596,8 +595,8 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     // ever queued on the H2D stream, however many slots the call holds.  Measured (tools/host_path.py, 2^20 ML-KEM-768
     // encapsulations): without the bound the rate falls with every extra chunk in flight (4.0e7/s at depth 3, 2.6e7 at 4,
     // 2.0e7 at 6, page-locked caller buffers); with AHEAD = 1 it is 4.0e7/s (48.6 + 44.8 GB/s, the bidirectional PCIe
-    // ceiling of this box) at any depth.  0 = no bound (tuning aid).
-    static const int ahead = env_int("CIRCL_HIP_HOST_AHEAD", 1, 0, 32);
+    // ceiling of this box) at any depth.
+    constexpr int ahead = 1;
 
     for (size_t lo = 0; lo < n; lo += chunk) {
         const size_t cnt = std::min(chunk, n - lo);
