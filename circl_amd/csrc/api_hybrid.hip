@@ -334,7 +334,7 @@ static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, 
             uint8_t *skx = t->d_x, *pkx = t->d_x + nkeys * 32;
             krows.resize(nkeys * d.DK);
             auto build = [&]() -> int {
-                HIP_TRY(hipMemcpyAsync(seed, keys, nkeys * 32, hipMemcpyHostToDevice, st));
+                TRY(upload_secret(seed, keys, nkeys * 32, st));  // (the seeds ARE the private keys)
                 hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(nkeys), dim3(256), 0, st, w(seed), w(seedm), w(skx), nkeys);
                 HIP_TRY(hipGetLastError());
                 TRY(kem_keygen(d, seedm, ek, dk, nkeys, kws, ws_bytes, st));
@@ -353,7 +353,8 @@ static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, 
             memcpy(xrows.data() + i * 32, row + d.x_off(KROW), 32);
         }
         // public: pk_X rows; private (kem/hybrid): sk_X rows (the decapsulation never needs pk_X there)
-        if (hipMemcpyAsync(t->d_x, xrows.data(), nkeys * 32, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (private_keys) rc = upload_secret(t->d_x, xrows.data(), nkeys * 32, st);
+        else if (hipMemcpyAsync(t->d_x, xrows.data(), nkeys * 32, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             (void)hipGetLastError();
             rc = CIRCL_HIP_EHIP;
         }

@@ -679,7 +679,7 @@ template <int MODE> int mldsa_privkey_build(circl_hip_keytable *t, const uint8_t
         (void)hipGetLastError();
         return CIRCL_HIP_ENOMEM;
     }
-    HIP_TRY(hipMemcpyAsync(t->d_keys, sk, KG<MODE>::SK * nk, hipMemcpyHostToDevice, st));
+    if (int rc = upload_secret(t->d_keys, sk, KG<MODE>::SK * nk, st)) return rc;  // (through wiped page-locked staging)
     uint32_t *scratch = reinterpret_cast<uint32_t *>(t->d_table + o_scr);
     SignState S{};
     S.shared = 0u;

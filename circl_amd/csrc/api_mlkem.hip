@@ -57,6 +57,12 @@ size_t kem_chain_batch(bool decaps = true) {
     const int lg = decaps ? lg_d : lg_e;
     return lg <= 0 ? size_t(0) : size_t(1) << lg;
 }
+// Keys that are NOT resident: batches up to 2^CIRCL_HIP_KEM_CHAIN_ITEM items run the same one-launch form with the key work inside
+// (mlkem_*_chain_kernel<K, false>: two / four wavefronts per item)
+size_t kem_chain_item_batch() {
+    static const int lg = env_int("CIRCL_HIP_KEM_CHAIN_ITEM", 9, 0, 20);
+    return lg <= 0 ? size_t(0) : size_t(1) << lg;
+}
 size_t kem_small_table_bytes(size_t n) { return kem_cache_bytes(std::min(n, kem_small_batch())); }
 size_t kem_ws_base(size_t n) { return up256(kKemWsPerItem * n) + kem_scratch_bytes(); }
 size_t kem_small_table_ofs(size_t n) { return kem_ws_base(n); }
@@ -120,6 +126,13 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *m_ws = w.slot1;
     const unsigned hb = (unsigned)((n + 255) / 256);
+    if (!R3 && n <= kem_chain_item_batch()) {  // one launch: H(ek) -> G -> PRF beside A^T, then K-PKE.Encrypt, two wavefronts per item
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)Gm::EK, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr, (const uint8_t *)nullptr, m, ct, ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     if (!R3 && kem_small_route(n, ws_bytes)) {
         // small batch: [H(ek), G] and [A^T] side by side in one launch, then PRF + ring phase with the rows from the cache
         int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
@@ -374,6 +387,13 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     KemWs w(ws, n);
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     if (R3) status = w.status_slot;
+    if (!R3 && n <= kem_chain_item_batch()) {  // one launch, four wavefronts per item: [Decrypt -> G -> PRF] J, H(ek) check, A^T, then the re-encryption
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)Gm::DK, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr, (const uint8_t *)nullptr, ct, ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (!R3 && kem_small_route(n, ws_bytes)) {
@@ -458,15 +478,15 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     return CIRCL_HIP_OK;
 }
 
-// Every ML-KEM host-buffer call wipes what is secret in a chunk's device staging once its results are out.  encaps_only: the
-// secrets are m, ss and the per-item workspace slots (the coins r, G's output) -- the keys, the ciphertexts and the matrix
-// scratch are public -- so only those segments are zeroed; decapsulation and key generation (private keys in the staging)
-// zero the whole slot.
-PipeOpts kem_opts(bool encaps_only) {
+// Every ML-KEM host-buffer call wipes what is secret in a chunk's device staging once its results are out: the secret inputs and
+// outputs (seeds, m, private keys, shared secrets: flagged per array) and the per-item workspace slots (the coins r, G's output, m',
+// sigma).  The public keys, the ciphertexts, the matrix scratch and the row cache behind the slots are public and are NOT zeroed
+// (a whole-slot memset was ~390 MB per 2^15-item chunk).
+PipeOpts kem_opts(bool) {
     PipeOpts o;
     o.chunk_items = host_chunk_items(size_t(1) << 15);
     o.wipe_device = true;
-    if (encaps_only) o.ws_secret_bytes = [](size_t cnt) { return up256(kKemWsPerItem * cnt); };
+    o.ws_secret_bytes = [](size_t cnt) { return up256(kKemWsPerItem * cnt); };
     return o;
 }
 // (a host-buffer chunk beyond 2^13 items is PCIe-bound whichever route it takes: it gets the workspace of the scratch routes, so
@@ -777,7 +797,10 @@ static int kem_keytable_new_one(int param, int private_keys, const uint8_t *keys
         (void)hipGetLastError();
         rc = CIRCL_HIP_ENOMEM;
     }
-    if (rc == CIRCL_HIP_OK && hipMemcpyAsync(t->d_keys, keys, t->row * nkeys, hipMemcpyHostToDevice, st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    if (rc == CIRCL_HIP_OK) {  // (private rows: through wiped page-locked staging)
+        if (private_keys) rc = upload_secret(t->d_keys, keys, t->row * nkeys, st);
+        else if (hipMemcpyAsync(t->d_keys, keys, t->row * nkeys, hipMemcpyHostToDevice, st) != hipSuccess) rc = CIRCL_HIP_EHIP;
+    }
     if (rc == CIRCL_HIP_OK) rc = K == 2 ? kem_table_build<2>(t, st) : K == 3 ? kem_table_build<3>(t, st) : kem_table_build<4>(t, st);
     if (rc == CIRCL_HIP_OK && key_status) {
         const size_t G = K == 2 ? 16 : K == 3 ? 7 : 4, padded = (nkeys + G - 1) / G * G;  // (Geom<K>::G)

@@ -121,6 +121,10 @@ struct Slot {
 Slot *slot_acquire(int dev, bool block = true);
 void slot_release(Slot *s);
 bool is_pinned_host(const void *p);  // page-locked (hipHostMalloc / hipHostRegister) memory: DMA-able as is
+// Host -> device copy of SECRET bytes (private keys of a key table): through a page-locked buffer of the library's own that is
+// zeroed afterwards -- a hipMemcpyAsync straight from pageable memory bounces through the runtime's staging, which nobody wipes.
+// Synchronises `st`.
+int upload_secret(void *d_dst, const void *h_src, size_t bytes, hipStream_t st);
 
 // ---- the pipeline -------------------------------------------------------------------------------
 struct HIn {                 // fixed-size rows: item i is row i

@@ -743,6 +743,26 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     return CIRCL_HIP_OK;
 }
 
+int upload_secret(void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return CIRCL_HIP_OK;
+    if (is_pinned_host(h_src)) {  // the caller's own page-locked memory: DMA-ed as is, the caller's to clear
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return CIRCL_HIP_OK;
+    }
+    void *pin = nullptr;
+    HIP_TRY(hipHostMalloc(&pin, bytes, hipHostMallocDefault));
+    memcpy(pin, h_src, bytes);
+    const hipError_t e1 = hipMemcpyAsync(d_dst, pin, bytes, hipMemcpyHostToDevice, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    volatile uint8_t *z = static_cast<volatile uint8_t *>(pin);
+    for (size_t i = 0; i < bytes; i++) z[i] = 0;
+    (void)hipHostFree(pin);
+    HIP_TRY(e1);
+    HIP_TRY(e2);
+    return CIRCL_HIP_OK;
+}
+
 // ---- key tables on several devices (keytable.h) ---------------------------------------------------
 const circl_hip_keytable *keytable_here(const circl_hip_keytable *t) {
     if (!t || t->magic != kKeytableMagic) return nullptr;

@@ -1435,14 +1435,21 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
 // the small-batch route before it ran J / Decrypt+G / re-encryption as three dependent launches (profiles/r04_table_latency.txt).
 // Every LDS buffer belongs to one wavefront and every wave-level ordering point inside is the no-wait form (kyber::wave_sync<true>),
 // so the two wavefronts never meet at a barrier except the one at the end.  Grid = n workgroups.
-template <int K>
-__global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint32_t *__restrict__ key_idx,
+// RESIDENT = false: the same for keys that are NOT parsed beforehand (circl_hip_mlkem_decaps on a small batch): item t has its own
+// private key at dk + t dk_stride, and two more wavefronts do per item what a key table did once -- wave 2 the stored-hash check
+// H(ek) == h (9 permutations, kyber.go:219-228), wave 3 the matrix A^T into LDS (cpapke.go:19-25) -- with one more barrier in front
+// of the re-encryption.  Four wavefronts, 256 threads.
+template <int K, bool RESIDENT = true>
+__global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kernel(const uint8_t *__restrict__ dk, size_t dk_stride,
+                                                                 const uint32_t *__restrict__ key_idx,
                                                                  const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_status,
                                                                  const uint8_t *__restrict__ ct, uint8_t *__restrict__ ss, uint8_t *__restrict__ status,
                                                                  size_t n) {
     using Gm = Geom<K>;
     using P = Params<K>;
-    __shared__ __attribute__((aligned(16))) uint64_t coopw[2][100];
+    __shared__ __attribute__((aligned(16))) uint64_t coopw[RESIDENT ? 2 : 3][100];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_a[RESIDENT ? 16 : Gm::PAIRS * Gm::A_STRIDE];
+    __shared__ uint32_t verdict_lds;
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     __shared__ __attribute__((aligned(16))) uint8_t noise[Gm::NOISE * Gm::NOISE_STRIDE];
     __shared__ __attribute__((aligned(16))) uint64_t mprime[4];
@@ -1451,7 +1458,7 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
     const size_t item = blockIdx.x;
     if (item >= n) return;  // (block-uniform)
-    const size_t kq = key_idx ? (size_t)key_idx[item] : size_t(0);
+    const size_t kq = RESIDENT ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item;
     const uint8_t *dkp = dk + kq * dk_stride;
     const uint8_t *ctp = ct + item * Gm::CT;
     constexpr int CTW = Gm::CT / 8;
@@ -1460,7 +1467,31 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
         __builtin_amdgcn_wave_barrier();
     };
     bool differs = false;
-    if (wave == 1) {
+    if (!RESIDENT && wave == 2) {  // the key's hash check: H(ek) against the stored hash
+        const uint64_t *ekw = reinterpret_cast<const uint64_t *>(dkp + 384 * K);
+        const uint64_t *stored = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 32);
+        const CoopLane c = coop_lane(coopw[RESIDENT ? 0 : 2], lane);
+        uint32_t vlo, vhi;
+        coop_sponge17<true>(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
+        const bool mine = j >= 4 || ((((uint64_t)vhi << 32) | vlo) == stored[j & 3]);
+        const unsigned long long bad = __ballot(!mine);
+        if (lane == 0) verdict_lds = (bad & 0xfull) ? 2u : 0u;
+    } else if (!RESIDENT && wave == 3) {  // A^T of the item's key, a stream per lane (sample_matrix for one item)
+        const bool on = lane < Gm::PAIRS;
+        const int pi = on ? lane / K : 0, pj = on ? lane % K : 0;
+        KeccakState sa;
+        keccak_zero(sa);
+        xor_words<0, 4>(sa, reinterpret_cast<const uint64_t *>(dkp + 768 * K));  // rho behind t-hat in the embedded ek
+        sa.lo[4] = (uint32_t)pi | ((uint32_t)pj << 8) | (kDsShake << 16);
+        sa.hi[20] = 0x80000000u;
+        int16_t *poly = reinterpret_cast<int16_t *>(lds_a + (on ? lane : 0) * Gm::A_STRIDE);
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        for (int blk = 0; blk < 3 || __any(cnt < 256); blk++) {
+            keccak_f1600(sa);
+            if (on) parse_shake128_block(sa, poly, cnt);
+        }
+    } else if (wave == 1) {
         const uint64_t *zw = reinterpret_cast<const uint64_t *>(dkp + 768 * K + 64);
         const uint64_t *cw = reinterpret_cast<const uint64_t *>(ctp);
         const CoopLane c = coop_lane(coopw[1], lane);
@@ -1512,10 +1543,13 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
             }
         }
         handoff();
+    }
+    if constexpr (!RESIDENT) __syncthreads();  // A^T is in LDS (and, as it happens, J and the hash check are done)
+    if (wave == 0) {
         // ct' = K-PKE.Encrypt(ek, m', r') against ct (the REENCRYPT / KM_KEYED ring phase of mlkem_encrypt_kernel, one item)
         const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
         const uint8_t *ekp = dkp + 384 * K;
-        const int16_t *krows = key_rows + kq * (size_t)(K * K * 256);
+        const int16_t *krows = RESIDENT ? key_rows + kq * (size_t)(K * K * 256) : nullptr;
         int th[K][4];
 #pragma unroll
         for (int jj = 0; jj < K; jj++) {
@@ -1540,7 +1574,8 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
 #pragma unroll
             for (int jj = 0; jj < K; jj++) {
                 uint32_t a01, a23;
-                AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+                if constexpr (RESIDENT) AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+                else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, i * K + jj, lane);
                 kyber::mulhat_acc_packed(acc, a01, a23, rop[jj]);
             }
             kyber::mulhat_finish(acc);
@@ -1577,7 +1612,7 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
     if (wave == 0) {
         // subtle.ConstantTimeCopy(ConstantTimeCompare(ct, ct'), ss2, K') (kyber.go:176-181); a key that failed its hash check: zeros, status 2
         const bool mismatch = __any(differs);
-        const uint8_t verdict = key_status[kq];
+        const uint8_t verdict = RESIDENT ? key_status[kq] : (uint8_t)verdict_lds;
         if (lane < 8) {
             const uint32_t kb = reinterpret_cast<const uint32_t *>(kr)[lane], rj = reinterpret_cast<const uint32_t *>(ssrej)[lane];
             reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = verdict ? 0u : (mismatch ? rj : kb);
@@ -1590,8 +1625,12 @@ __global__ void __launch_bounds__(128) mlkem_decaps_chain_kernel(const uint8_t *
 // cooperative permutation, the 2K+1 PRF streams a stream per lane pair, and K-PKE.Encrypt with the table's A^T rows
 // (kyber.go:103-137 EncapsulateTo on a parsed key) -- the route before it ran G for all items in one launch (a lane per item)
 // and the PRF + ring phase in a second one.  key_h: H(ek) per table entry.  Grid = n single-wave workgroups.
-template <int K>
-__global__ void __launch_bounds__(64) mlkem_encaps_chain_kernel(const uint8_t *__restrict__ ek, size_t ek_stride, const uint32_t *__restrict__ key_idx,
+// RESIDENT = false: keys that are not parsed beforehand (circl_hip_mlkem_encaps on a small batch: item t has its own key at ek + t
+// ek_stride): wave 0 first hashes the key (H(ek), 9 permutations on the cooperative form), a second wavefront expands A^T into
+// LDS meanwhile, and one barrier sits in front of the ring phase.  128 threads.
+template <int K, bool RESIDENT = true>
+__global__ void __launch_bounds__(RESIDENT ? 64 : 128) mlkem_encaps_chain_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
+                                                                const uint32_t *__restrict__ key_idx,
                                                                 const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_h,
                                                                 const uint8_t *__restrict__ m, uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                                 uint8_t *__restrict__ status, size_t n) {
@@ -1601,28 +1640,52 @@ __global__ void __launch_bounds__(64) mlkem_encaps_chain_kernel(const uint8_t *_
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     __shared__ __attribute__((aligned(16))) uint8_t noise[Gm::NOISE * Gm::NOISE_STRIDE];
     __shared__ __attribute__((aligned(16))) uint64_t kr[8];      // K (words 0..3), r (4..7)
-    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    __shared__ __attribute__((aligned(16))) uint64_t hk[4];      // H(ek) (RESIDENT = false)
+    __shared__ __attribute__((aligned(16))) uint8_t lds_a[RESIDENT ? 16 : Gm::PAIRS * Gm::A_STRIDE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
     const size_t item = blockIdx.x;
     if (item >= n) return;
-    const size_t kq = key_idx ? (size_t)key_idx[item] : size_t(0);
+    const size_t kq = RESIDENT ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item;
     const uint8_t *ekp = ek + kq * ek_stride;
     const uint8_t *mp = m + item * 32;
     auto handoff = [] {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
     };
-    {
+    if (!RESIDENT && wave == 1) {  // A^T of the item's key, a stream per lane (sample_matrix for one item)
+        const bool on = lane < Gm::PAIRS;
+        const int pi = on ? lane / K : 0, pj = on ? lane % K : 0;
+        KeccakState sa;
+        keccak_zero(sa);
+        xor_words<0, 4>(sa, reinterpret_cast<const uint64_t *>(ekp + 384 * K));
+        sa.lo[4] = (uint32_t)pi | ((uint32_t)pj << 8) | (kDsShake << 16);
+        sa.hi[20] = 0x80000000u;
+        int16_t *poly = reinterpret_cast<int16_t *>(lds_a + (on ? lane : 0) * Gm::A_STRIDE);
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        for (int blk = 0; blk < 3 || __any(cnt < 256); blk++) {
+            keccak_f1600(sa);
+            if (on) parse_shake128_block(sa, poly, cnt);
+        }
+    }
+    if (wave == 0) {
+        if constexpr (!RESIDENT) {  // H(ek) (kyber.go:247-263 caches it in the parsed key)
+            const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ekp);
+            const CoopLane c = coop_lane(coopw, lane);
+            uint32_t vlo, vhi;
+            coop_sponge17<true>(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
+            if (half == 0 && j < 4) hk[j] = ((uint64_t)vhi << 32) | vlo;
+            handoff();
+        }
         const CoopLane c = coop_lane(coopw, lane);
         uint64_t g = 0;
         if (j < 4) g = reinterpret_cast<const uint64_t *>(mp)[j];
-        else if (j < 8) g = reinterpret_cast<const uint64_t *>(key_h + kq * 32)[j - 4];
+        else if (j < 8) g = RESIDENT ? reinterpret_cast<const uint64_t *>(key_h + kq * 32)[j - 4] : hk[j - 4];
         else if (j == 8) g = 0x8000000000000000ull | kDsSha3;
         uint32_t vlo = (uint32_t)g, vhi = (uint32_t)(g >> 32);
         keccak_f1600_coop2<true>(vlo, vhi, c);
         if (half == 0 && j < 8) kr[j] = ((uint64_t)vhi << 32) | vlo;
-    }
-    handoff();
-    {
+        handoff();
         const int sidx = lane >> 1, parity = lane & 1;
         const bool on = sidx < Gm::NOISE;
         const uint32_t *seed = reinterpret_cast<const uint32_t *>(kr + 4) + parity;
@@ -1650,10 +1713,14 @@ __global__ void __launch_bounds__(64) mlkem_encaps_chain_kernel(const uint8_t *_
                 });
             }
         }
+        handoff();
     }
-    handoff();
+    if constexpr (!RESIDENT) {
+        __syncthreads();  // A^T is in LDS
+        if (wave != 0) return;
+    }
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
-    const int16_t *krows = key_rows + kq * (size_t)(K * K * 256);
+    const int16_t *krows = RESIDENT ? key_rows + kq * (size_t)(K * K * 256) : nullptr;
     int th[K][4];
     bool bad = false;
 #pragma unroll
@@ -1679,7 +1746,8 @@ __global__ void __launch_bounds__(64) mlkem_encaps_chain_kernel(const uint8_t *_
 #pragma unroll
         for (int jj = 0; jj < K; jj++) {
             uint32_t a01, a23;
-            AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+            if constexpr (RESIDENT) AFromCache{krows}.load(a01, a23, i * K + jj, lane);
+            else AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, i * K + jj, lane);
             kyber::mulhat_acc_packed(acc, a01, a23, rop[jj]);
         }
         kyber::mulhat_finish(acc);

@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_round3.py::test_kem_batch_routes: ML-KEM encapsulation / decapsulation (per-item keys and one key)
 against the oracle in its own process, so that the environment can force each batch route at small sizes: the hashing
 wavefronts two sponges per wavefront (CIRCL_HIP_KEM_COOP), a sponge per lane pair (CIRCL_HIP_KEM_SPLIT), a sponge per lane;
-the small-batch routes on or off (CIRCL_HIP_KEM_SMALL, CIRCL_HIP_KEM_SMALL_SHARED, CIRCL_HIP_KEM_SMALL_SHARED_DECAPS).
+the small-batch routes on or off (CIRCL_HIP_KEM_SMALL, CIRCL_HIP_KEM_SMALL_SHARED, CIRCL_HIP_KEM_SMALL_SHARED_DECAPS); the one-launch
+form for up to 2^CIRCL_HIP_KEM_CHAIN_ITEM items (mlkem_*_chain_kernel<K, false>: two / four wavefronts per item; 512 by default).
     python tests/kem_routes_worker.py <param>"""
 import os
 import sys
@@ -14,13 +15,20 @@ from circl_amd import hostapi  # noqa: E402
 from oracle import orc  # noqa: E402
 
 p = int(sys.argv[1])
-for n in (1, 2, 31, 33, 64, 65, 700, 2049, 2500):  # lane pairs: 32 items per wavefront; cooperative: 2; groups of G = 16 / 7 / 4 items
+for n in (1, 2, 31, 33, 64, 65, 511, 512, 513, 700, 2049, 2500):  # lane pairs: 32 items per wavefront; cooperative: 2; groups of G = 16 / 7 / 4 items
     rng = np.random.default_rng(p * 131 + n)
     ek, dk = orc.mlkem_keygen(p, rng.integers(0, 256, (n, 64), dtype=np.uint8))
     m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     ct0, ss0, _ = orc.mlkem_encaps(p, ek, m)
     ct, ss, st = hostapi.mlkem_encaps(p, ek, m)
     assert (st == 0).all() and (ct == ct0).all() and (ss == ss0).all(), ("encaps", p, n)
+    if n >= 31:  # a key with a coefficient >= q among them: kem.ErrPubKey for that item only (cpapke.go:45-55)
+        ek_nc = ek.copy()
+        ek_nc[n // 2, 0] = 0xff
+        ek_nc[n // 2, 1] |= 0x0f
+        ctn, ssn, stn = hostapi.mlkem_encaps(p, ek_nc, m)
+        keep = np.arange(n) != n // 2
+        assert stn[n // 2] == 1 and not ctn[n // 2].any() and not ssn[n // 2].any() and not stn[keep].any() and (ctn[keep] == ct0[keep]).all(), ("encaps, bad key", p, n)
     bad_ct = ct.copy()
     bad_ct[::3, 9] ^= 2  # implicit rejection for every third item
     bad_dk = dk.copy()

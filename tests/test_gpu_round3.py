@@ -108,10 +108,12 @@ def test_sign_round_modes(env_extra, param, n, shared):
 
 
 # ---- ML-KEM: every batch route against the oracle ----------------------------------------------------------------------------
-@pytest.mark.parametrize("env_extra", [{}, {"CIRCL_HIP_KEM_COOP": "0"}, {"CIRCL_HIP_KEM_COOP": "15"}, {"CIRCL_HIP_KEM_COOP": "0", "CIRCL_HIP_KEM_SPLIT": "0"},
-                                       {"CIRCL_HIP_KEM_SMALL": "0", "CIRCL_HIP_KEM_SMALL_SHARED": "0", "CIRCL_HIP_KEM_SMALL_SHARED_DECAPS": "0"},
-                                       {"CIRCL_HIP_KEM_SMALL_WGS": "1"}],
-                         ids=["default", "lane-pairs", "two-per-wavefront", "lane-per-sponge", "big-batch-routes", "many-items-per-group"])
+@pytest.mark.parametrize("env_extra", [{}, {"CIRCL_HIP_KEM_COOP": "0", "CIRCL_HIP_KEM_CHAIN_ITEM": "0"}, {"CIRCL_HIP_KEM_COOP": "15", "CIRCL_HIP_KEM_CHAIN_ITEM": "0"},
+                                       {"CIRCL_HIP_KEM_COOP": "0", "CIRCL_HIP_KEM_SPLIT": "0", "CIRCL_HIP_KEM_CHAIN_ITEM": "0"},
+                                       {"CIRCL_HIP_KEM_SMALL": "0", "CIRCL_HIP_KEM_SMALL_SHARED": "0", "CIRCL_HIP_KEM_SMALL_SHARED_DECAPS": "0", "CIRCL_HIP_KEM_CHAIN_ITEM": "0"},
+                                       {"CIRCL_HIP_KEM_SMALL_WGS": "1", "CIRCL_HIP_KEM_CHAIN_ITEM": "0"}, {"CIRCL_HIP_KEM_CHAIN_ITEM": "0"}, {"CIRCL_HIP_KEM_CHAIN_ITEM": "12"}],
+                         ids=["default", "lane-pairs", "two-per-wavefront", "lane-per-sponge", "big-batch-routes", "many-items-per-group", "no-chain",
+                              "chain-everywhere"])
 @pytest.mark.parametrize("param", [512, 768, 1024])
 def test_kem_batch_routes(env_extra, param):
     # kem/mlkem/mlkem768/kyber.go:150-232 EncapsulateTo / DecapsulateTo: the same bytes whichever way a batch is laid over the
