@@ -190,6 +190,13 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *r_ws = w.slot0, *h_ws = w.slot1;
+    if (n <= kem_chain_item_batch()) {  // one launch, the key work inside every item's workgroup (key stride 0: the one key)
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)0, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr, (const uint8_t *)nullptr, m, ct, ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     if (n <= kem_small_shared_batch(false)) {
         // small batch: [A^T of the key] and [H(ek), G] side by side in one launch, then PRF + ring phase with the rows from the cache
@@ -279,6 +286,13 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
     KemWs w(ws, n);
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
+    if (n <= kem_chain_item_batch()) {  // one launch, four wavefronts per item, key stride 0: every workgroup checks and expands the one key
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
+        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)0, (const uint32_t *)nullptr,
+                           (const int16_t *)nullptr, (const uint8_t *)nullptr, ct, ss, status, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (n <= kem_small_shared_batch(true)) {
