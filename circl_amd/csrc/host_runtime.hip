@@ -546,6 +546,15 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             if (b.blob) moved += (size_t)(b.off[n] - b.off[0]) + 8 * (n + 1);
         if (n <= chunk && moved <= inline_bytes) h2d = d2h = st;
     }
+    // ... and such a call moves all its staged inputs with ONE copy and all its outputs with ONE copy: the page-locked staging areas
+    // then mirror the device staging's layout (same offsets, padding included), and the cross-stream events are not needed.  A one-item
+    // call spends most of its time in HIP API calls (~3 us each): 2 + 3 copies, 4 event calls and 3-4 memsets become 2 copies and
+    // 3 memsets (profiles/r04_host_small.txt).
+    const bool one_stream = h2d == st && d2h == st;
+    bool merge_in = one_stream, merge_out = one_stream;
+    for (size_t k = 0; k < ins.size(); k++) merge_in = merge_in && !in_pinned[k];
+    for (size_t k = 0; k < blobs.size(); k++) merge_in = merge_in && (!blobs[k].blob || !blob_pinned[k]);
+    for (size_t k = 0; k < outs.size(); k++) merge_out = merge_out && (!outs[k].p || !out_pinned[k]);
     std::deque<InFlight> inflight;
     // error paths must not recycle a slot (or return to the caller) with copies or kernels still in flight
     struct Drain {
@@ -614,26 +623,32 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             s.bytes = ins[k].row * (ins[k].per_call ? 1 : cnt);
             s.dofs = take_d(s.bytes);
             s.staged = !in_pinned[k];
-            if (s.staged) s.hofs = take_hin(s.bytes);
+            if (merge_in) { s.hofs = s.dofs; hin_ofs = dofs; }
+            else if (s.staged) s.hofs = take_hin(s.bytes);
         }
         for (size_t k = 0; k < blobs.size(); k++) {
             if (!blobs[k].blob) continue;
             sblob[k].bytes = (size_t)(blobs[k].off[lo + cnt] - blobs[k].off[lo]);
             sblob[k].dofs = take_d(sblob[k].bytes);
             sblob[k].staged = !blob_pinned[k];
-            if (sblob[k].staged) sblob[k].hofs = take_hin(sblob[k].bytes);
+            if (merge_in) { sblob[k].hofs = sblob[k].dofs; hin_ofs = dofs; }
+            else if (sblob[k].staged) sblob[k].hofs = take_hin(sblob[k].bytes);
             soff[k].bytes = (cnt + 1) * 8;
             soff[k].dofs = take_d(soff[k].bytes);
             soff[k].staged = true;
-            soff[k].hofs = take_hin(soff[k].bytes);
+            if (merge_in) { soff[k].hofs = soff[k].dofs; hin_ofs = dofs; }
+            else soff[k].hofs = take_hin(soff[k].bytes);
         }
+        const size_t in_end = dofs, out_begin = dofs;
         for (size_t k = 0; k < outs.size(); k++) {
             Seg &s = f.out[k];
             s.bytes = outs[k].row * cnt;
             s.dofs = take_d(s.bytes);
             s.staged = outs[k].p && !out_pinned[k];
-            if (s.staged) s.hofs = take_hout(s.bytes);
+            if (merge_out) { s.hofs = s.dofs - out_begin; hout_ofs = dofs - out_begin; }
+            else if (s.staged) s.hofs = take_hout(s.bytes);
         }
+        const size_t out_end = dofs;
         const size_t wsb = ws_bytes(cnt);
         const size_t ws_ofs = dofs;
         dofs += up256(wsb);
@@ -693,30 +708,34 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         for (size_t k = 0; k < ins.size(); k++) {
             uint8_t *dp = slot->d + sin[k].dofs;
             c.in.push_back(dp);
-            if (!sin[k].bytes) continue;
+            if (!sin[k].bytes || merge_in) continue;
             const void *src = sin[k].staged ? (const void *)(slot->hin + sin[k].hofs) : (const void *)(ins[k].p + (ins[k].per_call ? 0 : lo * ins[k].row));
             HIP_TRY(hipMemcpyAsync(dp, src, sin[k].bytes, hipMemcpyHostToDevice, h2d));
         }
+        if (merge_in && in_end) HIP_TRY(hipMemcpyAsync(slot->d, slot->hin, in_end, hipMemcpyHostToDevice, h2d));  // every input, blob and offset array at once
         for (size_t k = 0; k < blobs.size(); k++) {
             if (!blobs[k].blob) { c.blob.push_back(nullptr); c.off.push_back(nullptr); continue; }
             uint8_t *dp = slot->d + sblob[k].dofs;
-            if (sblob[k].bytes) {
+            if (sblob[k].bytes && !merge_in) {
                 const void *src = sblob[k].staged ? (const void *)(slot->hin + sblob[k].hofs) : (const void *)(blobs[k].blob + blobs[k].off[lo]);
                 HIP_TRY(hipMemcpyAsync(dp, src, sblob[k].bytes, hipMemcpyHostToDevice, h2d));
             }
-            HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, h2d));
+            if (!merge_in) HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, h2d));
             c.blob.push_back(dp - blobs[k].off[lo]);  // the kernels index it with the caller's absolute offsets
             c.off.push_back(reinterpret_cast<const uint64_t *>(slot->d + soff[k].dofs));
         }
         for (size_t k = 0; k < outs.size(); k++) c.out.push_back(slot->d + cur.out[k].dofs);
-        HIP_TRY(hipEventRecord(slot->ev_in, h2d));
-        HIP_TRY(hipStreamWaitEvent(st, slot->ev_in, 0));
+        HIP_TRY(hipEventRecord(slot->ev_in, h2d));  // (the look-ahead bound of the next chunk waits on it)
+        if (h2d != st) HIP_TRY(hipStreamWaitEvent(st, slot->ev_in, 0));
         rc = launch(c);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(slot->ev_k, st));
-        HIP_TRY(hipStreamWaitEvent(d2h, slot->ev_k, 0));
+        if (d2h != st) {
+            HIP_TRY(hipEventRecord(slot->ev_k, st));
+            HIP_TRY(hipStreamWaitEvent(d2h, slot->ev_k, 0));
+        }
+        if (merge_out && out_end > out_begin) HIP_TRY(hipMemcpyAsync(slot->hout, slot->d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, d2h));
         for (size_t k = 0; k < outs.size(); k++) {
-            if (!outs[k].p || !cur.out[k].bytes) continue;
+            if (!outs[k].p || !cur.out[k].bytes || merge_out) continue;
             void *dst = cur.out[k].staged ? (void *)(slot->hout + cur.out[k].hofs) : (void *)(outs[k].p + lo * outs[k].row);
             HIP_TRY(hipMemcpyAsync(dst, slot->d + cur.out[k].dofs, cur.out[k].bytes, hipMemcpyDeviceToHost, d2h));
         }
