@@ -592,8 +592,8 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         __syncthreads();  // ... before z is packed into the same area
     }
     if (__any(bad)) return;
-    // z = y + c s1
-    unsigned zfld[L][4];
+    // z = y + c s1.  A polynomial that passes its norm test is bit-packed at once as it will appear in the signature (pack.go:202-254)
+    // into the LDS area the parked r0 has just left: nothing of z stays in registers, and the loop stays rolled.
     {
         auto load_y = [&](uint32_t (&yv)[4], int l) {
             const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
@@ -603,7 +603,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         uint32_t raw[3], yv[4];
         load_row(raw, sec);
         load_y(yv, 0);
-#pragma unroll
+#pragma unroll 1
         for (int l = 0; l < L; l++) {
             uint32_t raw_n[3] = {0, 0, 0}, yv_n[4] = {0, 0, 0, 0};
             if (l + 1 < L) {
@@ -612,17 +612,20 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
             }
             uint32_t t[4];
             mul_c(t, raw);
+            unsigned f[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 uint32_t y = G::GAMMA1 - yv[r];
                 y += (uint32_t)((int32_t)y >> 31) & Q;
                 const uint32_t zz = dilithium::normalize(t[r] + y);
                 bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
-                uint32_t f = G::GAMMA1 - zz;
-                f += (uint32_t)((int32_t)f >> 31) & Q;
-                zfld[l][r] = f;
+                uint32_t fr = G::GAMMA1 - zz;
+                fr += (uint32_t)((int32_t)fr >> 31) & Q;
+                f[r] = fr;
             }
             if (__any(bad)) break;
+            mlkem::stage_bits_l1<G::ZBITS>(xch, f, lane);
+            for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
 #pragma unroll
             for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
 #pragma unroll
@@ -630,12 +633,6 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         }
     }
     if (__any(bad)) return;
-    // z passed: bit-pack it as it will appear in the signature (pack.go:202-254) -- only now: most attempts never get here
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        mlkem::stage_bits_l1<G::ZBITS>(xch, zfld[l], lane);
-        for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
-    }
     // c t0, hints
     unsigned pop = 0;
     __syncthreads();
