@@ -344,6 +344,11 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, size_t nkeys, c
 // ---- ML-DSA sign ------------------------------------------------------------------------------
 constexpr int kSignBlocksPerCU = 8;
 // streams of a round up to which its hash kernels run a stream per lane pair (CIRCL_HIP_SIGN_SPLIT_LOG2: tuning aid)
+// ... and up to which they run two streams per wavefront on the cooperative permutation (CIRCL_HIP_SIGN_COOP_LOG2, 0 = never)
+size_t sign_coop_streams() {
+    static const int lg = env_int("CIRCL_HIP_SIGN_COOP_LOG2", 11, 0, 20);
+    return lg <= 0 ? size_t(0) : size_t(1) << lg;
+}
 size_t sign_split_lanes() {
     static const size_t v = size_t(1) << env_int("CIRCL_HIP_SIGN_SPLIT_LOG2", 16, 0, 30);
     return v;
@@ -520,14 +525,19 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         // hash chains of short rounds on lane pairs (sign_mask_kernel): while a lane per stream leaves the SIMDs at or below one wavefront each
         const bool split_mask = upper * L <= sign_split_lanes(), split_ch = upper <= sign_split_lanes();
-        if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
+        const bool coop_mask = upper * L <= sign_coop_streams(), coop_ch = upper <= sign_coop_streams();
+        if (coop_mask) hipLaunchKernelGGL(sign_mask_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (upper * L + 1) / 2)), dim3(64), 0, st, S, cur);
+        else if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
         hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur);
-        if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
+        if (coop_ch) hipLaunchKernelGGL(sign_challenge_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (pass0 + 1) / 2)), dim3(64), 0, st, S, cur, 0);
+        else if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
         else hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
         hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, pass0)), dim3(64), 0, st, S, cur, 0, sig);
-        hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
-        hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
+        if (S.pair) {  // second passes exist only in lazy rounds, and a round can only be lazy with pairs on (sign_next_k): otherwise two launches less
+            hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(pass1 ? g256(pass1) : 1u), dim3(256), 0, st, S, cur, 1);
+            hipLaunchKernelGGL(sign_finish_kernel<MODE>, dim3(pass1 ? (unsigned)pass1 : small), dim3(64), 0, st, S, cur, 1, sig);
+        }
         hipLaunchKernelGGL(sign_commit_kernel<MODE>, dim3(lazy[round] ? small : std::min<unsigned>((unsigned)std::max<size_t>(1, upper), (unsigned)cus * 32)),
                            dim3(64), 0, st, S, cur, sig);
         hipLaunchKernelGGL(sign_compact_kernel, dim3(gc), dim3(256), 0, st, S, cur, round == rounds - 1 ? 1 : 0);

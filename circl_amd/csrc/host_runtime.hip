@@ -916,7 +916,7 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
     (void)hipGetLastError();
     delete t;
 }
-int circl_hip_keytable_device(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->device : CIRCL_HIP_EPARAM - 1; }
+int circl_hip_keytable_device(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->device : CIRCL_HIP_ENODEV; }
 size_t circl_hip_keytable_nkeys(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->nkeys : 0; }
 const circl_hip_keytable *circl_hip_keytable_on_device(const circl_hip_keytable *t, int device) { return circl::host::keytable_on(t, device); }
 

@@ -272,6 +272,45 @@ __global__ void __launch_bounds__(256) sign_mask_kernel(SignState st, int cur) {
     }
 }
 
+// The same for the shortest rounds (a few thousand streams at most: a small batch, or the tail of a large one): TWO streams per
+// wavefront on the cooperative permutation (keccak_f1600_coop2, 25 lanes per state) -- the five-permutation chain of a stream is
+// the round's first latency, and the cooperative form is the shortest chain there is (~3.5 us per permutation against ~6.5 on a lane pair).
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_mask_coop_kernel(SignState st, int cur) {
+    using G = DG<MODE>;
+    using B = SB<MODE>;
+    constexpr int L = DP<MODE>::L;
+    __shared__ __attribute__((aligned(16))) uint64_t ws[100];
+    const size_t total = (size_t)st.count[cur] * L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // (as sign_mask_kernel)
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+#pragma unroll 1
+    for (size_t base = (size_t)blockIdx.x * 2; base < total; base += (size_t)gridDim.x * 2) {  // block-uniform
+        const size_t sidx = base + half;
+        const bool on = sidx < total;
+        const size_t slot = on ? sidx / L : 0;
+        const uint32_t e = st.list[cur][slot];
+        const size_t item = e & kEntryItemMask;
+        const uint32_t off = e >> kEntryShift;
+        const int l = on ? (int)(sidx % L) : 0;
+        const uint32_t nonce = (((st.attempts[item] + off) * L + l) & 0xffff) | (kDsShake << 16);
+        const uint64_t *seed = reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64);
+        const uint64_t w0 = j < 8 ? seed[j] : j == 8 ? (uint64_t)nonce : j == 16 ? 0x8000000000000000ull : 0ull;
+        uint32_t vlo = (uint32_t)w0, vhi = (uint32_t)(w0 >> 32);
+        uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+#pragma unroll 1
+        for (int blk = 0; blk < 5; blk++) {
+            keccak_f1600_coop2<true>(vlo, vhi, c);
+            const int d = 34 * blk + 2 * j;
+            if (on && j < 17) {  // only the ZSZ payload bytes are kept
+                if (d < G::ZSZ / 4) yrow[d] = vlo;
+                if (d + 1 < G::ZSZ / 4) yrow[d + 1] = vhi;
+            }
+        }
+    }
+}
+
 // wave = one or two entries: y-hat, w = InvNTT(A y-hat), Decompose, w1 (dilithium.go:376-398).
 // Two consecutive list entries that belong to the SAME item (attempts a, a + 1 of a lazy pair, or neighbours of a speculative
 // round) are processed by one wavefront and every matrix row read (K L rows of 768 bytes, 23 KB for ML-DSA-65) serves both.
@@ -514,6 +553,38 @@ __global__ void __launch_bounds__(256) sign_challenge_kernel(SignState st, int c
             keccak_f1600(s);
             store_words<0, 25>(cb + 15, s);  // ball state at byte 120
         }
+    }
+}
+
+// ... and two entries per wavefront on the cooperative permutation for the shortest rounds (see sign_mask_coop_kernel): the 7-9
+// permutations of c~ = H(mu || w1) and the SampleInBall block are the round's longest chain.
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_challenge_coop_kernel(SignState st, int cur, int pass) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    static_assert(G::MUW1 % 8 == 0, "mu || w1 is absorbed as 64-bit words");
+    __shared__ __attribute__((aligned(16))) uint64_t ws[100];
+    const PassMap pm(st, cur, pass);
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+#pragma unroll 1
+    for (size_t base = (size_t)blockIdx.x * 2; base < pm.nwork; base += (size_t)gridDim.x * 2) {  // block-uniform
+        const size_t w = base + half;
+        const bool on = w < pm.nwork;
+        const size_t a = pm.slot(on ? w : base);
+        const uint32_t e = st.list[cur][a];
+        const bool live = on && !(st.best[e & kEntryItemMask] < (e >> kEntryShift));  // a lower attempt of the item has already succeeded
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(st.muw1 + a * B::MUW1_BYTES);
+        uint32_t vlo, vhi;
+        mlkem::coop_sponge17<true>(vlo, vhi, [&](int k) { return src[k]; }, G::MUW1 / 8, kDsShake, c, j);
+        uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + a * B::CB_BYTES);
+        if (live && j < P::CT / 8) cb[j] = ((uint64_t)vhi << 32) | vlo;
+        if (j >= P::CT / 8) { vlo = 0; vhi = 0; }  // the SampleInBall sponge absorbs c~: same state
+        if (j == P::CT / 8) vlo ^= kDsShake;
+        if (j == 16) vhi ^= 0x80000000u;
+        keccak_f1600_coop2<true>(vlo, vhi, c);
+        if (live && j < 25) cb[15 + j] = ((uint64_t)vhi << 32) | vlo;  // ball state at byte 120
     }
 }
 

@@ -176,7 +176,8 @@ int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_
  *       *_table calls then split a batch into contiguous shards, one per device, like every other entry point (a table made for
  *       one device runs its calls there).  The _dev variants use the replica on the calling thread's current device;
  *       circl_hip_keytable_on_device returns that replica (or the table itself if it lives on `device`, else NULL) and
- *       circl_hip_keytable_device the table's device (CIRCL_HIP_ALL_DEVICES for a replicated one). */
+ *       circl_hip_keytable_device the table's device (CIRCL_HIP_ALL_DEVICES for a replicated one; CIRCL_HIP_ENODEV for NULL or a
+ *       freed table), circl_hip_keytable_nkeys its number of entries (0 likewise). */
 typedef struct circl_hip_keytable circl_hip_keytable;
 int circl_hip_keytable_device(const circl_hip_keytable *table);
 size_t circl_hip_keytable_nkeys(const circl_hip_keytable *table);
