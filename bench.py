@@ -20,10 +20,14 @@ The same JSON line carries, under "configs", a measured figure (own HIP-event ke
     shared_key / keyed   one key for the batch / a table of 1000 keys (the reference's parsed-key cache)
     hybrid               X-Wing and X25519MLKEM768 on resident arrays, 2^18 per GPU
 
---mode config3 | config4 | config5 | host makes that workload the headline (metric / value / ms_per_step) instead; for
-N > 1 launch with torch.distributed.run (one rank per GPU): every rank owns its own batch (weak scaling), there is no
-data-path collective (the only collectives are the timing barrier and the reductions of timings), rank 0 prints ONE JSON
-line with whole-job aggregates and per-rank rates.
+--mode config3 | config4 | config5 | host makes that workload the headline (metric / value / ms_per_step) instead.
+
+N > 1: one rank per GPU.  `python bench.py --gpus N` without a launcher re-executes itself as N ranks under torch.distributed.run
+(127.0.0.1, a free port); under a launcher it refuses to run (exit code 3) unless WORLD_SIZE == N and the box has N GPUs.  Every rank
+owns its own batch of --batch items (`value`: weak scaling, per-GPU work fixed as N grows); `strong` in the same line is ONE batch of
+--batch items split n/G per rank (the metric read literally: SURVEY.md 8e); `value_host_abi` is the same metric through the
+host-pointer C ABI (PCIe-inclusive).  There is no data-path collective (the only collectives are the timing barrier and the
+reductions of timings: RCCL); rank 0 prints ONE JSON line with whole-job aggregates and per-rank rates.
 """
 import argparse
 import ctypes as C
