@@ -468,6 +468,12 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
     if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(seed64) || !aligned16(ek) || !aligned16(dk)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
     uint8_t *rs = w.slot0;
+    if (n <= kem_chain_item_batch()) {  // one launch, two wavefronts per key: G -> [PRF, NTT(s)] beside A, then t-hat, packing, H(ek) || z
+        ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_KEYGEN, st);
+        hipLaunchKernelGGL((mlkem_keygen_chain_kernel<K, R3>), dim3((unsigned)n), dim3(128), 0, st, seed64, ek, dk, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {

@@ -1956,5 +1956,138 @@ __global__ void __launch_bounds__(64) mlkem_keygen_finish_small_kernel(const uin
     }
 }
 
+// Key generation of a small batch in ONE launch (kem/mlkem/mlkem768/kyber.go:57-78 NewKeyFromSeed -> cpapke.go:66-110), two wavefronts
+// per key: wave 0 runs (rho, sigma) = G(d || K) on the cooperative permutation, then -- while wave 1 expands A into LDS -- the 2K PRF
+// streams a stream per lane pair and the transforms of s; one barrier later t-hat = A s-hat + e-hat, the 12-bit packing (ek is also
+// kept in LDS: the sponge of H(ek) absorbs it from there), and H(ek) || z behind it.  The three-launch form before it ran G for all
+// keys, then K-PKE.KeyGen, then H(ek) (profiles/r04_latency.txt).  Grid = n workgroups of 128 threads.
+template <int K, bool R3 = false>
+__global__ void __launch_bounds__(128) mlkem_keygen_chain_kernel(const uint8_t *__restrict__ seed64, uint8_t *__restrict__ ek, uint8_t *__restrict__ dk,
+                                                                 size_t n) {
+    using Gm = Geom<K>;
+    using P = Params<K>;
+    __shared__ __attribute__((aligned(16))) uint64_t coopw[100];
+    __shared__ __attribute__((aligned(16))) uint32_t xch[256];
+    __shared__ __attribute__((aligned(16))) uint8_t noise[2 * K * Gm::NOISE_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint64_t rs[8];  // rho (words 0..3), sigma (4..7)
+    __shared__ __attribute__((aligned(16))) uint8_t lds_a[Gm::PAIRS * Gm::A_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t ekl[Gm::EK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;  // (block-uniform)
+    const uint8_t *sd = seed64 + item * 64;
+    uint8_t *ekp = ek + item * Gm::EK, *dkp = dk + item * Gm::DK;
+    auto handoff = [] {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (wave == 0) {  // (rho, sigma) = G(d || K) (cpapke.go:72-79 with the FIPS 203 domain byte; round 3: G(d))
+        const CoopLane c = coop_lane(coopw, lane);
+        uint64_t g = 0;
+        if (j < 4) g = reinterpret_cast<const uint64_t *>(sd)[j];
+        else if (j == 4) g = R3 ? (uint64_t)kDsSha3 : ((uint64_t)K | ((uint64_t)kDsSha3 << 8));
+        else if (j == 8) g = 0x8000000000000000ull;
+        uint32_t vlo = (uint32_t)g, vhi = (uint32_t)(g >> 32);
+        keccak_f1600_coop2<true>(vlo, vhi, c);
+        if (half == 0 && j < 8) rs[j] = ((uint64_t)vhi << 32) | vlo;
+    }
+    __syncthreads();  // rho and sigma are in LDS
+    kyber::HatOperand sop[K];
+    const kyber::LaneZetas z = kyber::load_lane_zetas(lane);
+    if (wave == 1) {  // A (not transposed: stream (i, j) from x = j, y = i, mat.go:13-74), a stream per lane
+        const bool on = lane < Gm::PAIRS;
+        const int pi = on ? lane / K : 0, pj = on ? lane % K : 0;
+        KeccakState sa;
+        keccak_zero(sa);
+        xor_words<0, 4>(sa, rs);
+        sa.lo[4] = (uint32_t)pj | ((uint32_t)pi << 8) | (kDsShake << 16);
+        sa.hi[20] = 0x80000000u;
+        int16_t *poly = reinterpret_cast<int16_t *>(lds_a + (on ? lane : 0) * Gm::A_STRIDE);
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        for (int blk = 0; blk < 3 || __any(cnt < 256); blk++) {
+            keccak_f1600(sa);
+            if (on) parse_shake128_block(sa, poly, cnt);
+        }
+    } else {
+        {   // PRF(sigma, nonce) for the 2K eta1 streams of s and e, a stream per lane pair
+            const int sidx = lane >> 1, parity = lane & 1;
+            const bool on = sidx < 2 * K;
+            const uint32_t *seed = reinterpret_cast<const uint32_t *>(rs + 4) + parity;
+            SplitState s;
+#pragma unroll
+            for (int w = 0; w < 25; w++) s.w[w] = w < 4 ? seed[2 * w] : 0u;
+            if (parity == 0) s.w[4] = (uint32_t)(on ? sidx : 0) | (kDsShake << 8);
+            else s.w[16] = 0x80000000u;
+            keccak_f1600_split(s, parity != 0);
+            uint32_t *out = reinterpret_cast<uint32_t *>(noise + (on ? sidx : 0) * Gm::NOISE_STRIDE) + parity;
+            if (on) {
+                detail::static_for<0, 16>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;
+                    out[2 * w] = P::ETA1 == 2 ? kyber::cbd2_bias8_word(s.w[w]) : s.w[w];
+                });
+            }
+            if constexpr (P::ETA1 == 3) {
+                if (on) out[32] = s.w[16];
+                keccak_f1600_split(s, parity != 0);
+                if (on) {
+                    detail::static_for<0, 7>([&](auto ic) {
+                        constexpr int w = decltype(ic)::v;
+                        out[34 + 2 * w] = s.w[w];
+                    });
+                }
+            }
+        }
+        handoff();
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            int sh[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) sh[r] = cbd_coeff<P::ETA1>(noise + jj * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+            kyber::ntt<true>(sh, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) sh[r] = kyber::normalize(sh[r]);
+            pack12_l4(dkp + 384 * jj, sh, lane);
+            sop[jj] = kyber::hat_prepare(sh, z.f6, z.f6n);
+        }
+    }
+    __syncthreads();  // A is in LDS
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+        int eh[4], acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) eh[r] = cbd_coeff<P::ETA1>(noise + (K + i) * Gm::NOISE_STRIDE, kyber::idx_l1(lane, r));
+        kyber::ntt<true>(eh, z, xch, lane);
+#pragma unroll
+        for (int jj = 0; jj < K; jj++) {
+            uint32_t a01, a23;
+            AFromLds{lds_a, Gm::A_STRIDE}.load(a01, a23, i * K + jj, lane);
+            kyber::mulhat_acc_packed(acc, a01, a23, sop[jj]);
+        }
+        kyber::mulhat_finish(acc);
+        int t[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = kyber::normalize((int)kyber::mulc((uint32_t)acc[r], kyber::mulc_const(kyber::NEG_R32)) + eh[r]);
+        pack12_l4(ekl + 384 * i, t, lane);
+    }
+    if (lane < 8) reinterpret_cast<uint32_t *>(ekl + 384 * K)[lane] = reinterpret_cast<const uint32_t *>(rs)[lane];  // rho
+    handoff();
+    for (int d = lane; d < Gm::EK / 4; d += 64) {  // ek, and its copy inside dk
+        const uint32_t w = reinterpret_cast<const uint32_t *>(ekl)[d];
+        reinterpret_cast<uint32_t *>(ekp)[d] = w;
+        reinterpret_cast<uint32_t *>(dkp + 384 * K)[d] = w;
+    }
+    {   // dk tail = H(ek) || z (kyber.go:69-75, :189-201)
+        const CoopLane c = coop_lane(coopw, lane);
+        const uint64_t *ekw = reinterpret_cast<const uint64_t *>(ekl);
+        uint32_t vlo, vhi;
+        coop_sponge17<true>(vlo, vhi, [&](int k) { return ekw[k]; }, Gm::EK / 8, kDsSha3, c, j);
+        uint64_t *tail = reinterpret_cast<uint64_t *>(dkp + 768 * K + 32);
+        if (half == 0 && j < 4) tail[j] = ((uint64_t)vhi << 32) | vlo;
+        else if (half == 0 && j < 8) tail[j] = reinterpret_cast<const uint64_t *>(sd + 32)[j - 4];
+    }
+}
+
 }  // namespace mlkem
 }  // namespace circl

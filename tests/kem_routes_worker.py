@@ -17,7 +17,10 @@ from oracle import orc  # noqa: E402
 p = int(sys.argv[1])
 for n in (1, 2, 31, 33, 64, 65, 511, 512, 513, 700, 2049, 2500):  # lane pairs: 32 items per wavefront; cooperative: 2; groups of G = 16 / 7 / 4 items
     rng = np.random.default_rng(p * 131 + n)
-    ek, dk = orc.mlkem_keygen(p, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    seeds = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ek, dk = orc.mlkem_keygen(p, seeds)
+    ek_g, dk_g = hostapi.mlkem_keygen(p, seeds)   # (one launch with two wavefronts per key up to 2^CIRCL_HIP_KEM_CHAIN_ITEM keys, three launches beyond)
+    assert (ek_g == ek).all() and (dk_g == dk).all(), ("keygen", p, n)
     m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     ct0, ss0, _ = orc.mlkem_encaps(p, ek, m)
     ct, ss, st = hostapi.mlkem_encaps(p, ek, m)
