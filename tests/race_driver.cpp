@@ -56,8 +56,10 @@ struct Kem {
     std::vector<uint8_t> ct_t, ss_t;
     void tables() {
         const size_t nk = n < 9 ? n : 9;
-        CHECK(circl_hip_mlkem_keytable_new(param, 0, ek.data(), nk, 0, nullptr, &pub) == 0);
-        CHECK(circl_hip_mlkem_keytable_new(param, 1, dk.data(), nk, 0, nullptr, &prv) == 0);
+        // the public table REPLICATED on every (logical) device -- its calls shard their batch over the replicas from every caller
+        // thread at once -- the private one on the last device alone
+        CHECK(circl_hip_mlkem_keytable_new(param, 0, ek.data(), nk, CIRCL_HIP_ALL_DEVICES, nullptr, &pub) == 0);
+        CHECK(circl_hip_mlkem_keytable_new(param, 1, dk.data(), nk, circl_hip_device_count() - 1, nullptr, &prv) == 0);
         idx.resize(n);
         for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)((i * 7) % nk);
         ct_t.resize(CT * n); ss_t.resize(32 * n);
@@ -98,6 +100,27 @@ struct Dsa {
         mblob = bytes(mt, 4); cblob = bytes(ctot, 5);
         CHECK(circl_hip_mldsa_keygen(p, seed.data(), pk.data(), sk.data(), n, 0) == 0);
         CHECK(circl_hip_mldsa_sign(p, sk.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig.data(), n, 0) == 0);
+    }
+    // several prepared private keys (replicated) and their public keys, shared by every caller thread: message i is signed with
+    // entry i mod nk (the signer's per-call key index travels in a thread-local of the library: concurrent calls must not mix theirs)
+    circl_hip_keytable *signer = nullptr, *verifier = nullptr;
+    std::vector<uint32_t> kidx;
+    std::vector<uint8_t> sig_t;
+    void tables() {
+        const size_t nk = n < 5 ? n : 5;
+        CHECK(circl_hip_mldsa_privkeys_new(param, sk.data(), nk, CIRCL_HIP_ALL_DEVICES, &signer) == 0);
+        CHECK(circl_hip_mldsa_keytable_new(param, pk.data(), nk, CIRCL_HIP_ALL_DEVICES, &verifier) == 0);
+        kidx.resize(n);
+        for (size_t i = 0; i < n; i++) kidx[i] = (uint32_t)((i * 3) % nk);
+        sig_t.resize(SIG * n + 4);
+        CHECK(circl_hip_mldsa_sign_table_keyed(signer, kidx.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig_t.data(), n) == 0);
+    }
+    void again_tables() const {
+        std::vector<uint8_t> sig2(SIG * n + 4), ok(n);
+        CHECK(circl_hip_mldsa_sign_table_keyed(signer, kidx.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig2.data(), n) == 0);
+        CHECK(memcmp(sig2.data(), sig_t.data(), SIG * n) == 0);
+        CHECK(circl_hip_mldsa_verify_table(verifier, kidx.data(), sig2.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), ok.data(), n) == 0);
+        for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
     }
     void again(int device) const {
         std::vector<uint8_t> sig2(SIG * n + 4), ok(n);
@@ -140,7 +163,8 @@ int main(int argc, char **argv) {
     printf("race_driver: %d (logical) devices, %d callers x %d rounds, %zu ML-KEM items, %zu ML-DSA items\n", nd, callers, rounds, n_kem, n_dsa);
     Kem kem768(768, n_kem), kem1024(1024, n_kem / 4 + 3);
     kem768.tables();
-    const Dsa dsa65(65, n_dsa), dsa44(44, 9);  // 9 items: shards below the 16-item switch of the signer, and empty shards
+    Dsa dsa65(65, n_dsa), dsa44(44, 9);  // 9 items: shards below the 16-item switch of the signer, and empty shards
+    dsa65.tables();
     const Hyb xwing(1, n_kem / 8 + 5);
     circl_hip_profile_enable(1);  // the profiling records are shared state too
     std::atomic<int> started{0};
@@ -153,7 +177,7 @@ int main(int argc, char **argv) {
                 const int device = (c + r) % 3 == 2 ? nd - 1 : CIRCL_HIP_ALL_DEVICES;  // mostly all devices; now and then one device alone
                 switch ((c + r) % 4) {
                 case 0: kem768.again(device); kem768.again_tables(); break;
-                case 1: dsa65.again(device); dsa44.again(CIRCL_HIP_ALL_DEVICES); break;
+                case 1: dsa65.again(device); dsa44.again(CIRCL_HIP_ALL_DEVICES); dsa65.again_tables(); break;
                 case 2: kem1024.again(device); xwing.again(device); break;
                 case 3: kem768.again(device); dsa44.again(device); kem768.again_tables(); break;
                 }
@@ -167,6 +191,8 @@ int main(int argc, char **argv) {
     for (auto &t : th) t.join();
     circl_hip_keytable_free(kem768.pub);
     circl_hip_keytable_free(kem768.prv);
+    circl_hip_keytable_free(dsa65.signer);
+    circl_hip_keytable_free(dsa65.verifier);
     double ms = 0;
     uint64_t launches = 0;
     for (int k = 0; k < CIRCL_HIP_KERNEL_COUNT; k++) {

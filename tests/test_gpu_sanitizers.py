@@ -15,10 +15,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAN = os.path.join(ROOT, "tests", "_san")
 
 
+def sources_hash():
+    """What the instrumented binaries are built from: a prebuilt pair in tests/_san (git-ignored, but it travels to the GPU box) is only
+    trusted while its stamp carries this hash -- a stale instrumented library would test last week's runtime."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "circl_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "circl_hip.h"),
+                                                                                 os.path.join(ROOT, "tests", "race_driver.cpp"),
+                                                                                 os.path.join(ROOT, "tests", "san_shims.c"), os.path.join(ROOT, "Makefile")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def build(kind):
     exe = os.path.join(SAN, "race_driver_" + kind)
-    if not os.path.exists(exe):  # normally prebuilt in the tree that travels to the GPU box
-        subprocess.check_call(["make", "-j8", kind], cwd=ROOT)
+    stamp = os.path.join(SAN, kind + ".stamp")
+    want = sources_hash()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if not os.path.exists(exe) or have != want:  # normally prebuilt (and stamped) in the tree that travels to the GPU box
+        subprocess.check_call(["make", "-B", "-j8", kind], cwd=ROOT)
+        with open(stamp, "w") as f:
+            f.write(want)
     return exe
 
 
