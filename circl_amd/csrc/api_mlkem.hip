@@ -502,7 +502,7 @@ int keygen_dev_impl(const uint8_t *seed64, uint8_t *ek, uint8_t *dk, size_t n, v
 // outputs (seeds, m, private keys, shared secrets: flagged per array) and the per-item workspace slots (the coins r, G's output, m',
 // sigma).  The public keys, the ciphertexts, the matrix scratch and the row cache behind the slots are public and are NOT zeroed
 // (a whole-slot memset was ~390 MB per 2^15-item chunk).
-PipeOpts kem_opts(bool) {
+PipeOpts kem_opts() {
     PipeOpts o;
     o.chunk_items = host_chunk_items(size_t(1) << 15);
     o.wipe_device = true;
@@ -720,7 +720,7 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true),
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(),
                             [&](Chunk &c) { return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -730,7 +730,7 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            kem_ws_fn(), kem_opts(false),
+                            kem_ws_fn(), kem_opts(),
                             [&](Chunk &c) { return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -739,7 +739,7 @@ int circl_hip_mlkem_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(false),
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(),
                             [&](Chunk &c) { return circl_hip_mlkem_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -749,7 +749,7 @@ int circl_hip_mlkem_decaps_shared(int param, const uint8_t *dk, const uint8_t *c
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk, DK, true, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
+                            kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -760,7 +760,7 @@ int circl_hip_mlkem_encaps_shared(int param, const uint8_t *ek, const uint8_t *m
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek, EK, false, true}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_shared_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -777,7 +777,7 @@ int circl_hip_mlkem_encaps_keyed(int param, const uint8_t *ek_table, size_t nkey
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek_table, EK * nkeys, false, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {m + lo * 32, 32, true}}, {},
                             {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(true), [&](Chunk &c) {
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
                                                                         c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -792,7 +792,7 @@ int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkey
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{dk_table, DK * nkeys, true, true}, {reinterpret_cast<const uint8_t *>(key_idx + lo), 4}, {ct + lo * CT, CT}}, {},
                             {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(false), [&](Chunk &c) {
+                            [&](size_t c) { return circl_hip_mlkem_keyed_workspace_size(param, c, nkeys); }, kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_keyed_dev(param, c.in[0], nkeys, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[2], c.out[0],
                                                                         c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -878,7 +878,7 @@ int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *ke
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(true), [&](Chunk &c) {
+                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                         c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -893,7 +893,7 @@ int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *ke
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * CT, CT}}, {},
-                            {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(false), [&](Chunk &c) {
+                            {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                         c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -933,7 +933,7 @@ int circl_hip_kyber_keygen(int param, const uint8_t *seed64, uint8_t *ek, uint8_
     const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(false),
+        return run_pipeline(dev, cnt, {{seed64 + lo * 64, 64, true}}, {}, {{ek + lo * EK, EK}, {dk + lo * DK, DK, true}}, kem_ws_fn(), kem_opts(),
                             [&](Chunk &c) { return circl_hip_kyber_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -942,7 +942,7 @@ int circl_hip_kyber_encaps(int param, const uint8_t *ek, const uint8_t *seed32, 
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {seed32 + lo * 32, 32, true}}, {}, {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}}, kem_ws_fn(),
-                            kem_opts(true),
+                            kem_opts(),
                             [&](Chunk &c) { return circl_hip_kyber_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -950,7 +950,7 @@ int circl_hip_kyber_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}}, kem_ws_fn(), kem_opts(false),
+        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}}, kem_ws_fn(), kem_opts(),
                             [&](Chunk &c) { return circl_hip_kyber_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
