@@ -134,3 +134,15 @@ def test_resident_decapsulation_chain_route_boundaries():
         assert r.returncode == 0 and "chain digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
         digests.append(r.stdout.strip().split()[-1])
     assert len(set(digests)) == 1, digests
+
+
+def test_c_examples_build_and_run():
+    # examples/*.c: the C ABI from plain C, as a cgo stub would call it -- batches of distinct keys, and parsed key objects (resident tables)
+    out = os.path.join(ROOT, "build")
+    os.makedirs(out, exist_ok=True)
+    for name, args, needle in (("encaps_batch", ["3000"], " 0 mismatches"), ("resident_keys", [], "mismatches 0")):
+        exe = os.path.join(out, name)
+        subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"), "-L", os.path.join(ROOT, "circl_amd"),
+                               "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and needle in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
