@@ -73,10 +73,11 @@ size_t kem_ws_min(size_t n) { return kem_ws_base(n) + kem_cache_bytes(1); }
 bool kem_small_route(size_t n, size_t ws_bytes) { return n <= kem_small_batch() && ws_bytes >= kem_ws_base(n) + kem_cache_bytes(n); }
 
 // Items per ring-phase workgroup of a small batch: about two groups per SIMD -- one item per workgroup up to 2 x 4 x CUs items,
-// then as few per group as that allows (measured 2^11 .. 2^15: 8 groups per CU up to 2^14 items, 16 beyond)
-size_t kem_small_group(size_t n) {
+// then as few per group as that allows.  Measured 2^11 .. 2^15 (groups of up to four items run their PRF streams on lane pairs,
+// prf_streams_split, so small groups are cheap): 8 groups per CU up to 2^13 items (the re-encryption: 2^12), 16 beyond.
+size_t kem_small_group(size_t n, bool reencrypt = false) {
     static const size_t per_cu_env = (size_t)env_int("CIRCL_HIP_KEM_SMALL_WGS", 0, 1, 32);  // tuning aid
-    const size_t per_cu = per_cu_env ? per_cu_env : (n <= (size_t(1) << 14) ? 8 : 16);
+    const size_t per_cu = per_cu_env ? per_cu_env : (n <= (size_t(1) << (reencrypt ? 12 : 13)) ? 8 : 16);
     return std::max<size_t>(1, (n + per_cu * (size_t)cu_count() - 1) / (per_cu * (size_t)cu_count()));
 }
 
@@ -310,7 +311,7 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
         }
         const int16_t *key_rows = reinterpret_cast<const int16_t *>(static_cast<uint8_t *>(ws) + kem_small_table_ofs(n));
         auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
-        const size_t want = kem_small_group(n);
+        const size_t want = kem_small_group(n, true);
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
@@ -422,7 +423,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
                                mprime, kbar, r_ws, ssrej, status, (uint8_t *)nullptr, key_rows, n, nb_hash, nb_hash, coop);
         }
         auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
-        const size_t want = kem_small_group(n);
+        const size_t want = kem_small_group(n, true);
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,
@@ -626,7 +627,7 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         auto kern = mlkem_encrypt_kernel<K, REENCRYPT, 0, true, KM_KEYED>;
-        const size_t want = n <= kem_small_shared_batch(true) ? kem_small_group(n) : (size_t)Gm::GS;
+        const size_t want = n <= kem_small_shared_batch(true) ? kem_small_group(n, true) : (size_t)Gm::GS;
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, stride, (const uint8_t *)mprime, (const uint8_t *)r_ws,
                            const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n, key_idx, key_rows);

@@ -699,6 +699,45 @@ __device__ __forceinline__ void prf_streams(uint8_t *lds_noise, const uint8_t *_
     }
 }
 
+// The same streams with a sponge per lane PAIR (keccak_f1600_split: 120 instead of 180 instructions per round) for a group of
+// `count` items whose count * NOISE streams fit the 32 pairs of one pass -- the few-items-per-workgroup groups of a small batch,
+// where the lane-per-stream pass would run mostly empty.  Same bytes in the same slots.
+template <int K, int NOISE, int ETA1_COUNT>
+__device__ __forceinline__ void prf_streams_split(uint8_t *lds_noise, const uint8_t *__restrict__ seed, size_t seed_stride, size_t item0,
+                                                  size_t n, int lane, int count) {
+    using Gm = Geom<K>;
+    const int sidx = lane >> 1, parity = lane & 1;
+    const bool on = sidx < count * NOISE;
+    const int g = on ? sidx / NOISE : 0, nonce = on ? sidx % NOISE : 0;
+    size_t item = item0 + g;
+    if (item >= n) item = n - 1;
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(seed + item * seed_stride) + parity;
+    SplitState s;
+#pragma unroll
+    for (int w = 0; w < 25; w++) s.w[w] = w < 4 ? sw[2 * w] : 0u;
+    if (parity == 0) s.w[4] = (uint32_t)nonce | (kDsShake << 8);
+    else s.w[16] = 0x80000000u;
+    keccak_f1600_split(s, parity != 0);
+    uint32_t *out = reinterpret_cast<uint32_t *>(lds_noise + (on ? sidx : 0) * Gm::NOISE_STRIDE) + parity;
+    const bool eta2 = Params<K>::ETA1 == 2 || nonce >= ETA1_COUNT;
+    if (on) {
+        detail::static_for<0, 16>([&](auto ic) {
+            constexpr int w = decltype(ic)::v;
+            out[2 * w] = eta2 ? kyber::cbd2_bias8_word(s.w[w]) : s.w[w];
+        });
+    }
+    if constexpr (Params<K>::ETA1 == 3) {  // 192 bytes for the eta1 = 3 streams: word 16 of this block, then 7 more of the next
+        if (on && !eta2) out[32] = s.w[16];
+        keccak_f1600_split(s, parity != 0);
+        if (on && !eta2) {
+            detail::static_for<0, 7>([&](auto ic) {
+                constexpr int w = decltype(ic)::v;
+                out[34 + 2 * w] = s.w[w];
+            });
+        }
+    }
+}
+
 // ---- phase C helpers -------------------------------------------------------------------------
 
 // CBD sample of coefficient n from a PRF stream in LDS (sample.go:31-95), as the non-negative representative
@@ -917,7 +956,8 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     const size_t item0 = grp * gi;
     if constexpr (SHARED) {
         __syncthreads();  // phase C of the previous group is done with the noise
-        prf_streams<K, Gm::NOISE, K, Gm::GS>(lds_noise, r_ws, 32, item0, n, lane);
+        if (gi * Gm::NOISE <= 32) prf_streams_split<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane, (int)gi);  // (wave-uniform)
+        else prf_streams<K, Gm::NOISE, K, Gm::GS>(lds_noise, r_ws, 32, item0, n, lane);
         __syncthreads();
     } else if constexpr (SCRATCH && ABLATE == 0 && Gm::HALVES == 1) {
         __syncthreads();  // phase C of the previous group is done with the LDS the FIFO aliases
@@ -1310,7 +1350,9 @@ __global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *_
 // followed by G(m' || hpk) (G takes the STORED hash, kyber.go:158-162, so it does not wait for the key's hash check), the check
 // H(ek) == hpk itself (9 permutations), J(z || ct) (9 permutations) -- plus, for distinct keys, A^T for the re-encryption; the
 // big-batch route runs decrypt, then all three sponges on one lane (19 dependent permutations, ~185 us), then the re-encryption.
-// For small batches ONE launch runs them in different workgroups (J and H first: they are the long ones, at raised priority),
+// For small batches ONE launch runs them in different workgroups (the long chains first: J and H at raised priority, then the
+// expansions; the n short Decrypt + G workgroups fill in around them -- with the expansions dispatched last the launch took 20 %
+// longer at 2^13 items, and a one-key batch waited for its single expansion workgroup),
 // two sponges per wavefront on the cooperative permutation while the chip has SIMDs to spare (`coop`), and the key-table form
 // of the re-encryption follows.  dk_stride = 0: one private key for the batch (its hash check: ONE workgroup, verdict to
 // *key_status; the per-item status bytes are filled by mlkem_fill_status_kernel).
@@ -1403,8 +1445,11 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
         return;
     }
     b -= nb_j + nb_h;
-    if ((size_t)b < n) {  // K-PKE.Decrypt, then (K', r') = G(m' || hpk) by the same wavefront (one state on the cooperative permutation)
-        const size_t item = b;
+    // the long chains first (hashes above, then the expansions: ~20 k instructions a wavefront), the short Decrypt + G workgroups
+    // (~1.5 k) fill the slots around them and make up the tail
+    const unsigned nb_expand = gridDim.x - nb_j - nb_h - (unsigned)n;
+    if (b >= nb_expand) {  // K-PKE.Decrypt, then (K', r') = G(m' || hpk) by the same wavefront (one state on the cooperative permutation)
+        const size_t item = b - nb_expand;
         const uint8_t *dkp = dk + item * dk_stride;
         uint32_t *xch = reinterpret_cast<uint32_t *>(smem);
         mlkem_decrypt_item<K>(dkp, ct + item * Gm::CT, mprime_ws + item * 32, xch, lane);
@@ -1421,8 +1466,7 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
         if (half == 0 && j < 8) reinterpret_cast<uint64_t *>((j < 4 ? kbar_ws : r_ws) + item * 32)[j & 3] = ((uint64_t)vhi << 32) | vlo;
         return;
     }
-    b -= (unsigned)n;  // A^T of G items each into the cache (distinct keys only: the grid has no such workgroups for one key)
-    const size_t e0 = (size_t)b * Gm::G;
+    const size_t e0 = (size_t)b * Gm::G;  // A^T of G items each into the cache (one key: one such workgroup)
     sample_matrix_scratch<K, true>(smem, key_rows + e0 * (size_t)(K * K * 256), dk + 768 * K, dk_stride, e0, n, lane);
 }
 // ---- resident keys, small batches: the whole decapsulation of an item as ONE workgroup of two wavefronts -------------------------

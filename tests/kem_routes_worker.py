@@ -15,7 +15,9 @@ from circl_amd import hostapi  # noqa: E402
 from oracle import orc  # noqa: E402
 
 p = int(sys.argv[1])
-for n in (1, 2, 31, 33, 64, 65, 511, 512, 513, 700, 2049, 2500):  # lane pairs: 32 items per wavefront; cooperative: 2; groups of G = 16 / 7 / 4 items
+# lane pairs: 32 items per wavefront; cooperative: 2; groups of G = 16 / 7 / 4 items; with CIRCL_HIP_KEM_SMALL_WGS=1 (256 ring-phase
+# groups) 511 / 1000 / 1500 items are groups of 2 / 4 / 6: PRF streams on lane pairs while a group's streams fit 32 pairs, on lanes beyond
+for n in (1, 2, 31, 33, 64, 65, 511, 512, 513, 1000, 1500, 2049, 2500):
     rng = np.random.default_rng(p * 131 + n)
     seeds = rng.integers(0, 256, (n, 64), dtype=np.uint8)
     ek, dk = orc.mlkem_keygen(p, seeds)
