@@ -474,8 +474,9 @@ __device__ __forceinline__ void parse23_block_fifo(const KeccakState &s, uint32_
             if constexpr (sh <= 8) v = (word(w) >> sh) & 0x7fffffu;
             else v = alignbit(word(w + 1), word(w), sh) & 0x7fffffu;
             fifo[(cnt & 15) * kFifoLanes] = v;
-            cnt = min(cnt + (v < Q ? 1 : 0), 256);
+            cnt += v < Q ? 1 : 0;
             if constexpr (c % 4 == 3) {
+                cnt = min(cnt, 256);  // capped once per 4 candidates (as mlkem::parse_shake128_block_fifo: the overrun lands in free slots)
                 if (cnt - flushed >= 4) {  // at most 7 pending here, so one flush per check suffices
                     const uint32_t *fr = fifo + (flushed & 15) * kFifoLanes;
                     const uint4 d = make_uint4(fr[0], fr[kFifoLanes], fr[2 * kFifoLanes], fr[3 * kFifoLanes]);

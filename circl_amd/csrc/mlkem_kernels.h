@@ -429,8 +429,12 @@ __device__ __forceinline__ void parse_shake128_block_fifo(const KeccakState &s, 
             if constexpr (sh <= 20) v = (word(w) >> sh) & 0xfffu;
             else v = alignbit(word(w + 1), word(w), sh) & 0xfffu;
             fifo[cnt & (SLOTS - 1)] = (int16_t)v;
-            cnt = min(cnt + (v < (uint32_t)Q ? 1 : 0), 256);
+            cnt += v < (uint32_t)Q ? 1 : 0;
             if constexpr (c % 8 == 7) {
+                // The count is capped at the row length here, once per 8 candidates, not per candidate: between two checks a
+                // finished stream runs at most 8 entries past 256, into FIFO slots that hold nothing pending (fewer than 8
+                // pending entries + 8 new ones <= 16 <= SLOTS), and nothing beyond entry 255 is ever flushed.
+                cnt = min(cnt, 256);
                 if (cnt - flushed >= 8) {  // at most 15 pending here, so one flush per check suffices
                     const uint4 d = *reinterpret_cast<const uint4 *>(fifo + (flushed & (SLOTS - 1)));
                     *reinterpret_cast<uint4 *>(row + flushed) = d;
