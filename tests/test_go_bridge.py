@@ -56,6 +56,11 @@ MUTATIONS = [
      "EncapsulateBatch takes 4 argument(s), called with 3"),
     ("kem/mlkem/hipbatch/scheme.go", "ct, ss, errs, err := EncapsulateBatch(s.Scheme, eks, seeds, device)", "ct, ss, err := EncapsulateBatch(s.Scheme, eks, seeds, device)",
      "assignment mismatch: 3 variables but EncapsulateBatch returns 4 values"),
+    ("kem/mlkem/hipbatch/scheme.go", "return rows(ct, s.CiphertextSize()), rows(ss, s.SharedKeySize()), errs, nil", "return rowz(ct, s.CiphertextSize()), rows(ss, s.SharedKeySize()), errs, nil",
+     "undefined: rowz"),
+    ("kem/mlkem/hipbatch/hipbatch.go", '\t"fmt"\n', "", "undefined: fmt"),
+    ("kem/mlkem/hipbatch/scheme.go", "return rows(ct, s.CiphertextSize()), rows(ss, s.SharedKeySize()), errs, nil", "return rows(ct, s.CiphertextSize()), errs, nil",
+     "wrong number of return values: have 3, want 4"),
     ("xof/hipbatch/hipbatch.go", "/*\n#cgo", "/*\n#include <no_such_header.h>\n#cgo", "cgo preamble does not compile"),
     ("dh/x25519/hipbatch/hipbatch.go", "package hipbatch", "package hipbatch\n\nfunc broken( {", "unclosed {"),
 ]
