@@ -115,6 +115,14 @@ template <int MODE> size_t mldsa_table_bytes(size_t nkeys) {
 // where A and tr are cached in the PublicKey object, internal/dilithium.go:114-126): tr once per launch, ExpandA once per
 // resident workgroup; 9 lane-permutations per item remain (mu, SampleInBall, c').  KM_KEYED: a table of nkeys public keys
 // and an index per item: tr and ExpandA once per TABLE ENTRY, then the shared-key work per item.
+// Resident public keys: batches up to 2^CIRCL_HIP_DSA_CHAIN items (0 = never) are verified in one launch, a workgroup of K + 1
+// wavefronts per item (mldsa_verify_chain_kernel)
+// ... and, with keys that are NOT parsed beforehand (tr and the matrix expansion inside the workgroup), up to 2^CIRCL_HIP_DSA_CHAIN_ITEM
+inline size_t dsa_chain_batch(bool resident = true) {
+    static const int lg_r = env_int("CIRCL_HIP_DSA_CHAIN", 10, 0, 16), lg_i = env_int("CIRCL_HIP_DSA_CHAIN_ITEM", 8, 0, 16);
+    const int lg = resident ? lg_r : lg_i;
+    return lg <= 0 ? size_t(0) : size_t(1) << lg;
+}
 template <int MODE, int KM>
 int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob,
                           const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *ok, size_t n,
@@ -137,6 +145,28 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     LongCtl *lctl = reinterpret_cast<LongCtl *>(tr + 256);
     uint32_t *key_rows = nullptr;
     const uint8_t *tr_arg = nullptr;
+    if (KM == KM_KEYED && cached && n <= dsa_chain_batch()) {
+        // a resident key table, a small batch: the whole verification of an item in ONE launch (mldsa_verify_chain_kernel)
+        const size_t padded = (nkeys + G::IT - 1) / G::IT * G::IT;
+        const uint32_t *rows = reinterpret_cast<const uint32_t *>(cached->d_table);
+        const uint8_t *key_tr = cached->d_table + up256(padded * G::STREAMS * kPackedRowDwords * 4);
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
+        hipLaunchKernelGGL(mldsa_verify_chain_kernel<MODE>, dim3((unsigned)n), dim3((DP<MODE>::K + 1) * 64), 0, st, pk, key_idx, rows, key_tr, sig, msg_blob,
+                           msg_off, ctx_blob, ctx_off, internal, ok, n, (uint8_t *)nullptr, (size_t)G::PK);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
+    if ((KM == KM_ITEM || KM == KM_SHARED) && n <= dsa_chain_batch(false)) {
+        // every item under its own, unparsed key (or all under ONE unparsed key: stride 0), a small batch: the same kernel with tr and
+        // the matrix expansion inside the workgroup (the rows of item t in its part of scratch slice t / IT: the workspace holds a
+        // slice per IT items at these sizes)
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
+        hipLaunchKernelGGL((mldsa_verify_chain_kernel<MODE, false>), dim3((unsigned)n), dim3((DP<MODE>::K + 2) * 64), 0, st, pk, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const uint8_t *)nullptr, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, scratch,
+                           KM == KM_SHARED ? size_t(0) : (size_t)G::PK);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     SideStream side;  // (declared ahead of every early return below: its destructor joins)
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);

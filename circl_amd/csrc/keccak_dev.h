@@ -145,25 +145,30 @@ CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
 // block of SampleInBall): lanes 0..24 own one 64-bit lane each, theta / pi / chi exchange through LDS.  It needs a dozen
 // registers instead of the ~120 of the lane-per-state form, at ~60 instructions and four barriers per round.
 // `ws` = 55 x 8 bytes of LDS: a[25] (the state, in and out), c[5], b[25].  Single-wave workgroups only.
-__device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
+// NW (a workgroup of several wavefronts, `ws` private to this one): the wave-level ordering points are not workgroup barriers
+template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
+    auto sync = [] {
+        if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     uint64_t *a = ws, *c = ws + 25, *b = ws + 30;
     const bool on = lane < 25;
     const int i = on ? lane : 0, x = i % 5, y = i / 5;
     constexpr int rho_t[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     const int rho = rho_t[i], dst = y + 5 * ((2 * x + 3 * y) % 5);
-    __syncthreads();
+    sync();
     uint64_t v = a[i];
 #pragma unroll 1
     for (int r = 0; r < 24; r++) {
         if (lane < 5) c[lane] = a[lane] ^ a[lane + 5] ^ a[lane + 10] ^ a[lane + 15] ^ a[lane + 20];
-        __syncthreads();
+        sync();
         if (on) {
             const uint64_t c1 = c[(x + 1) % 5];
             v ^= c[(x + 4) % 5] ^ ((c1 << 1) | (c1 >> 63));
             if (rho) v = (v << rho) | (v >> (64 - rho));
             b[dst] = v;
         }
-        __syncthreads();
+        sync();
         if (on) {
             v = b[i] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
             if (lane == 0) {
@@ -172,7 +177,7 @@ __device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
             }
             a[i] = v;
         }
-        __syncthreads();
+        sync();
     }
 }
 

@@ -560,7 +560,12 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&out)[4], co
 // one v_readlane; a further SHAKE256 block is squeezed (keccak_f1600_coop: the wave works on the one state through LDS)
 // when the current one runs out.  This sequential form is the fallback of sample_in_ball: the first block practically
 // always holds tau acceptable bytes.  `kws` = 440 B of LDS for the sponge, `blk` >= 136 B for the squeezed block.
-template <int MODE>
+// NW: called from a workgroup of several wavefronts with buffers private to this wavefront (no workgroup barriers inside)
+template <bool NW> __device__ __forceinline__ void ball_sync() {
+    if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+template <int MODE, bool NW = false>
 __device__ __noinline__ uint32_t sample_in_ball_positions_sequential(const uint8_t *st, uint8_t *blk, uint64_t *kws, int lane) {
     using P = DP<MODE>;
     uint32_t b0 = st[lane], b1 = st[64 + lane], b2 = lane < 8 ? (uint32_t)st[128 + lane] : 0xfffu;
@@ -583,14 +588,14 @@ __device__ __noinline__ uint32_t sample_in_ball_positions_sequential(const uint8
             else if (m2) { const int p = __ffsll((long long)m2) - 1; found = 128 + p; jv = (uint32_t)__builtin_amdgcn_readlane((int)b2, p); }
             else {
                 // block exhausted (rare): squeeze the next one
-                __syncthreads();
+                ball_sync<NW>();
                 if (!have_state) {
                     if (lane < 25) kws[lane] = reinterpret_cast<const uint64_t *>(st)[lane];
                     have_state = true;
                 }
-                keccak_f1600_coop(kws, lane);
+                keccak_f1600_coop<NW>(kws, lane);
                 if (lane < 17) reinterpret_cast<uint64_t *>(blk)[lane] = kws[lane];
-                __syncthreads();
+                ball_sync<NW>();
                 b0 = blk[lane]; b1 = blk[64 + lane]; b2 = lane < 8 ? (uint32_t)blk[128 + lane] : 0xfffu;
                 off = 0;
             }
@@ -613,14 +618,14 @@ __device__ __noinline__ uint32_t sample_in_ball_positions_sequential(const uint8
 // and the sequential scan could differ cannot exist); the t-th taken byte is j_t.  ~60 wave-instructions instead of
 // tau dependent steps of ~15.  Fewer than tau taken bytes in the block (essentially never): the sequential fallback.
 // FORCE_SEQUENTIAL (a parity-test aid of circl_hip_mldsa_sample_in_ball) always takes the fallback.
-template <int MODE, bool SCALED = true, bool FORCE_SEQUENTIAL = false, bool WANT_HAT = true>
+template <int MODE, bool SCALED = true, bool FORCE_SEQUENTIAL = false, bool WANT_HAT = true, bool NW = false>
 __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const uint8_t *st, uint8_t *blk, uint32_t *xch,
                                                    const dilithium::LaneZetas &z, int lane) {
     using P = DP<MODE>;
     const unsigned long long signs = *reinterpret_cast<const unsigned long long *>(st);
     uint32_t jt = 0;  // lane t keeps j_t
     if constexpr (FORCE_SEQUENTIAL) {
-        jt = sample_in_ball_positions_sequential<MODE>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);
+        jt = sample_in_ball_positions_sequential<MODE, NW>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);
     } else {
         constexpr uint32_t T0 = 256 - P::TAU;
         // positions lane (valid from 8 on), 64 + lane, 128 + lane (valid below 136): 0xfff never passes a test
@@ -638,14 +643,14 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
             m0 = n0; m1 = n1; m2 = n2;
         }
         if (__popcll(m0) + __popcll(m1) + __popcll(m2) >= P::TAU) {
-            __syncthreads();  // earlier users of blk are done
+            ball_sync<NW>();  // earlier users of blk are done
             if (((m0 >> lane) & 1) && r0 < (uint32_t)P::TAU) blk[r0] = (uint8_t)b0;
             if (((m1 >> lane) & 1) && r1 < (uint32_t)P::TAU) blk[r1] = (uint8_t)b1;
             if (((m2 >> lane) & 1) && r2 < (uint32_t)P::TAU) blk[r2] = (uint8_t)b2;
-            __syncthreads();
+            ball_sync<NW>();
             jt = lane < P::TAU ? (uint32_t)blk[lane] : 0u;
         } else {
-            jt = sample_in_ball_positions_sequential<MODE>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);  // (xch is free until the polynomial is built)
+            jt = sample_in_ball_positions_sequential<MODE, NW>(st, blk, reinterpret_cast<uint64_t *>(xch), lane);  // (xch is free until the polynomial is built)
         }
     }
     // resolve the Fisher-Yates moves in parallel: the +-1 written at step t sits at j_t until a later
@@ -656,11 +661,11 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
         if (t2 > lane && j2 == pos) pos = 256 - P::TAU + t2;
     }
     uint32_t *cpoly = xch;
-    __syncthreads();
+    ball_sync<NW>();
     for (int i = lane; i < 256; i += 64) cpoly[i] = 0;
-    __syncthreads();
+    ball_sync<NW>();
     if (lane < P::TAU) cpoly[pos] = ((signs >> lane) & 1) ? Q - 1 : 1;
-    __syncthreads();
+    ball_sync<NW>();
     uint32_t c[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) c[r] = cpoly[kyber::idx_l1(lane, r)];
@@ -669,7 +674,7 @@ __device__ __forceinline__ void sample_in_ball_hat(uint32_t (&chat)[4], const ui
         for (int r = 0; r < 4; r++) chat[r] = c[r];
         return;
     }
-    dilithium::ntt(c, z, xch, lane);
+    dilithium::ntt<NW>(c, z, xch, lane);
 #pragma unroll
     for (int r = 0; r < 4; r++) chat[r] = SCALED ? dilithium::mont32(c[r], dilithium::R32SQ) : c[r];
 }
@@ -896,6 +901,255 @@ __global__ void __launch_bounds__(64) mldsa_final_coop_kernel(const uint8_t *__r
     const unsigned long long bad = __ballot(!mine);
     const bool same = ((bad >> (32 * half)) & 0xffffffffull) == 0;
     if (live && j == 0) ok[idx] = (same && fail_ws[idx] == 0) ? 1 : 0;
+}
+
+// ---- resident keys, small batches: the whole verification of an item as ONE workgroup of K + 1 wavefronts ----------------------
+// With the key parsed beforehand (a key table: the expanded matrix rows and tr) a verification (dilithium.go:273-332) is two chains
+// that meet twice:
+//   wave K ("hash")  mu = SHAKE256(tr || M') and the first block of SHAKE256(c~) side by side on the two-state cooperative
+//                    permutation -> SampleInBall -> c-hat; the strict hint decoding                         | barrier |
+//   waves j < L      z_j: decode, norm check, NTT (a polynomial per wavefront)                               | barrier |
+//   waves i < K      row i: w1_i = UseHint(InvNTT(sum_j A_ij z-hat_j - c-hat t1-hat_i 2^13)), packed into LDS behind mu | barrier |
+//   wave K           c' = SHAKE256(mu || w1) on the cooperative permutation (7 dependent permutations for ML-DSA-65), compare, ok
+// ONE launch instead of the five of the small-batch route (scan, mu, prep, verify, final) and a side stream.  Every LDS buffer
+// between the barriers belongs to one wavefront and every wave-level ordering point inside is the no-wait form.  Grid = n workgroups.
+// Messages of any length (the hash wave walks M' block by block: what mldsa_mu_long_kernel does for a small batch anyway).
+// RESIDENT = false: keys that are NOT parsed beforehand (circl_hip_mldsa_verify on a small batch: item t has its own public key at
+// pk_table + t PK).  The hash wave first computes tr = SHAKE256(pk) (15 permutations for ML-DSA-65, cooperative), and one more
+// wavefront expands the matrix meanwhile (a stream per lane, the rows into the item's part of the workspace's scratch slices --
+// dilithium.go:114-126 does both in PublicKey.Unpack); the first barrier also publishes the rows.  K + 2 wavefronts.  pk_stride = 0:
+// ONE unparsed key for the whole (small) batch -- every workgroup derives it again, which is shorter than a launch that derives it once.
+template <int MODE, bool RESIDENT = true>
+__global__ void __launch_bounds__((DP<MODE>::K + (RESIDENT ? 1 : 2)) * 64)
+    mldsa_verify_chain_kernel(const uint8_t *__restrict__ pk_table, const uint32_t *__restrict__ key_idx, const uint32_t *__restrict__ key_rows,
+                              const uint8_t *__restrict__ key_tr, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ msg_blob,
+                              const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
+                              int internal, uint8_t *__restrict__ ok, size_t n, uint8_t *__restrict__ scratch, size_t pk_stride) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    constexpr int K = P::K, L = P::L, TRW = P::TR / 8, HB = P::OMEGA + K;
+    constexpr int ZST_DW = G::ZSZ / 4 + 2, HST_DW = (HB + 3) / 4 + 2;
+    __shared__ __attribute__((aligned(16))) uint64_t coopw[100];
+    __shared__ __attribute__((aligned(16))) uint32_t xch_all[K + 1][dilithium::kXchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t zst[L][ZST_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t hst[HST_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t zhat_lds[L][256];
+    __shared__ __attribute__((aligned(16))) uint32_t chat_lds[256];
+    __shared__ uint32_t hintbits[K * 8];
+    __shared__ __attribute__((aligned(16))) uint64_t muw1[G::MUW1 / 8];
+    __shared__ __attribute__((aligned(16))) uint64_t ballst[25];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    __shared__ uint32_t bad_w[K + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t fifo_lds[RESIDENT ? 16 : G::LDS_FIFO];
+    static_assert(G::MUW1 % 8 == 0 && L <= K && G::PK % 8 == 0, "mu || w1 and pk are absorbed as 64-bit words; a wavefront per z polynomial");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;  // (block-uniform)
+    const size_t kq = RESIDENT ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item;
+    // the item's matrix rows: the table's, or its own part of a scratch slice (IT items of STREAMS rows per slice)
+    uint32_t *my_rows = RESIDENT ? nullptr
+                                 : reinterpret_cast<uint32_t *>(scratch + (item / G::IT) * (size_t)G::SCRATCH_BYTES) + (item % G::IT) * (size_t)(G::STREAMS * kPackedRowDwords);
+    const uint8_t *sg = sig + item * G::SIG;
+    uint32_t *xch = xch_all[wave <= K ? wave : 0];  // (the expanding wavefront of unparsed keys has no transform to run)
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    auto handoff = [] {  // what the lanes wrote to LDS (by whatever instruction) is visible to the wavefront's later reads
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    };
+    bool bad = false;
+    if (wave == K) {
+        // ---- mu (half 0) and the SampleInBall sponge's first block (half 1) ----
+        const int half = lane >> 5, j = lane & 31;
+        const CoopLane c = coop_lane(coopw, lane);
+        const size_t mlen = (size_t)(msg_off[item + 1] - msg_off[item]);
+        const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[item] : nullptr;
+        const size_t clen = ctx_blob ? (size_t)(ctx_off[item + 1] - ctx_off[item]) : 0;
+        const bool ctx_unsupported = !P::NIST && !internal && ctx_blob && clen != 0;  // round 3 has no contexts
+        const int internal_eff = P::NIST ? internal : 1;                              // round 3: mu = CRH(tr || msg)
+        bad = (!internal_eff && clen > 255) || ctx_unsupported;                       // mldsa65/dilithium.go:116-118
+        uint32_t vlo = 0, vhi = 0;
+        bool first = true;
+        auto park_ball = [&] {  // half 1 after ITS first permutation: the whole state (further blocks are squeezed from it)
+            if (first && half == 1 && j < 25) ballst[j] = ((uint64_t)vhi << 32) | vlo;
+            first = false;
+        };
+        if (half == 0) {
+            if (RESIDENT && j < TRW) {
+                const uint64_t w = reinterpret_cast<const uint64_t *>(key_tr + kq * 64)[j];
+                vlo = (uint32_t)w;
+                vhi = (uint32_t)(w >> 32);
+            }
+        } else {
+            if (j < P::CT / 8) {
+                uint64_t v = 0;
+                for (int b = 0; b < 8; b++) v |= (uint64_t)sg[8 * j + b] << (8 * b);
+                vlo = (uint32_t)v;
+                vhi = (uint32_t)(v >> 32);
+            }
+            if (j == P::CT / 8) vlo ^= kDsShake;
+            if (j == 16) vhi ^= 0x80000000u;
+        }
+        if constexpr (!RESIDENT) {  // tr = SHAKE256(pk)[:TR] (dilithium.go:123-125) on half 0
+            const uint64_t *pw = reinterpret_cast<const uint64_t *>(pk_table + kq * pk_stride);
+            constexpr int PKW = G::PK / 8, FULL = PKW / 17, REM = PKW % 17;
+            uint64_t next = (half == 0 && j < 17) ? pw[j] : 0;
+#pragma unroll 1
+            for (int b = 0; b < FULL; b++) {
+                vlo ^= (uint32_t)next;
+                vhi ^= (uint32_t)(next >> 32);
+                next = (half == 0 && j < 17 && 17 * (b + 1) + j < PKW) ? pw[17 * (b + 1) + j] : 0;
+                keccak_f1600_coop2<true>(vlo, vhi, c);
+                park_ball();
+            }
+            vlo ^= (uint32_t)next;
+            vhi ^= (uint32_t)(next >> 32);
+            if (half == 0 && j == REM) vlo ^= kDsShake;
+            if (half == 0 && j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2<true>(vlo, vhi, c);
+            park_ball();
+            if (half == 0 && j >= TRW) vlo = vhi = 0;  // the mu sponge starts from tr || 0
+        }
+        const MPrime mpr(msg_blob + msg_off[item], mlen, cp, clen, internal_eff);
+        size_t pos = 0;
+        int w0 = TRW;
+#pragma unroll 1
+        for (;;) {
+            if (half == 0 && j >= w0 && j < 17) {
+                uint32_t lo, hi;
+                mpr.word(pos + 8 * (size_t)(j - w0), lo, hi);
+                vlo ^= lo;
+                vhi ^= hi;
+            }
+            const size_t span = 8 * (size_t)(17 - w0);
+            const bool last = mpr.total < pos + span;  // (wave-uniform: one message)
+            if (half == 0 && last && j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2<true>(vlo, vhi, c);
+            park_ball();
+            if (last) break;
+            pos += span;
+            w0 = 0;
+        }
+        if (half == 0 && j < 8) muw1[j] = ((uint64_t)vhi << 32) | vlo;
+        handoff();
+        // ---- c-hat ----
+        uint32_t chat[4];
+        sample_in_ball_hat<MODE, false, false, true, true>(chat, reinterpret_cast<const uint8_t *>(ballst), blk, xch, z, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) chat_lds[64 * r + lane] = chat[r];
+        // ---- hints: strict decoding (pack.go:113-141) ----
+        if (lane < K * 8) hintbits[lane] = 0;
+        stage_unaligned(hst, sg + P::CT + L * G::ZSZ, HB, lane);
+        handoff();
+        {
+            const uint8_t *hb = reinterpret_cast<const uint8_t *>(hst);
+            uint32_t sop[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) sop[i] = hb[P::OMEGA + i];
+#pragma unroll
+            for (int i = 0; i < K; i++) bad |= sop[i] > (uint32_t)P::OMEGA || (i > 0 && sop[i] < sop[i - 1]);
+            for (int j0 = 0; j0 < P::OMEGA; j0 += 64) {
+                const int jj = j0 + lane;
+                if (jj < P::OMEGA) {
+                    int poly = 0;
+                    uint32_t start = 0;
+#pragma unroll
+                    for (int i = 0; i < K; i++)
+                        if (sop[i] <= (uint32_t)jj) { poly = i + 1; start = sop[i]; }
+                    const uint32_t v = hb[jj];
+                    if (poly < K) {
+                        if ((uint32_t)jj > start && v <= hb[jj - 1]) bad = true;
+                        atomicOr(&hintbits[poly * 8 + (v >> 5)], 1u << (v & 31));
+                    } else if (v != 0) {
+                        bad = true;
+                    }
+                }
+            }
+        }
+    } else if (wave < L) {
+        // ---- z_wave: (gamma1_bits + 1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta ----
+        uint32_t *st = zst[wave];
+        stage_unaligned(st, sg + P::CT + wave * G::ZSZ, G::ZSZ, lane);
+        if (lane == 0) { st[G::ZSZ / 4] = 0; st[G::ZSZ / 4 + 1] = 0; }  // slack dwords for lds_bits
+        handoff();
+        uint32_t cz[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t f = lds_bits<G::ZBITS>(st, 0, kyber::idx_l1(lane, r));
+            uint32_t x = G::GAMMA1 - f;
+            x += (uint32_t)((int32_t)x >> 31) & Q;
+            bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
+            cz[r] = x;
+        }
+        dilithium::ntt<true>(cz, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) zhat_lds[wave][64 * r + lane] = cz[r];  // plain z-hat, < 17q
+    }
+    if (!RESIDENT && wave == K + 1) {  // ExpandA of the item's key (mat.go:15-49), a stream per lane
+        expand_a_scratch<MODE, false, 1>(fifo_lds, my_rows, pk_table + kq * pk_stride, 0, 0, 1, lane);
+    } else if (wave <= K) {
+        const bool any_bad = __any(bad);
+        if (lane == 0) bad_w[wave] = any_bad ? 1u : 0u;
+    }
+    // z-hat, c-hat, the hint bitmap and mu are in LDS -- and, for unparsed keys, the rows have left the CU and no stale L1 line of
+    // the slice survives (rows_acquire: release, barrier, agent-scope acquire)
+    if constexpr (RESIDENT) __syncthreads();
+    else rows_acquire();
+    if (wave < K) {
+        const int i = wave;
+        uint32_t zhat[L][4], chat[4];
+#pragma unroll
+        for (int jj = 0; jj < L; jj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) zhat[jj][r] = zhat_lds[jj][64 * r + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) chat[r] = chat_lds[64 * r + lane];
+        const uint32_t *irows = RESIDENT ? key_rows + kq * (size_t)(G::STREAMS * kPackedRowDwords) : my_rows;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        mac_rows<L>(acc, irows, i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
+        uint32_t t[4], w[4];
+        {
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk_table + kq * (RESIDENT ? (size_t)G::PK : pk_stride) + 32 + 320 * i);  // t1, 10-bit fields (pack.go:52-66)
+            const int b = 5 * lane, d = b >> 2;
+            const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = ((uint32_t)(v >> (10 * r)) & 0x3ffu) << dilithium::D;
+            dilithium::relayout<4, 1, true>(t, xch, lane);
+        }
+        dilithium::ntt<true>(t, z, xch, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t ct1 = dilithium::mont32(t[r], chat[r]);  // 2^-32 c-hat * t1-hat, < 2q
+            w[r] = dilithium::fold(acc[r] + 2 * Q - ct1);
+        }
+        dilithium::invntt<dilithium::INV256_RR, true>(w, z, xch, lane);
+        unsigned w1v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nidx = kyber::idx_l1(lane, r);
+            const uint32_t hbit = (hintbits[i * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
+            w1v[r] = dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
+        }
+        mlkem::stage_bits_l1<G::W1BITS, true>(xch, w1v, lane);
+        mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(muw1 + 8) + (G::W1SZ / 4) * i, xch, lane, false);
+    }
+    __syncthreads();  // w1 is behind mu
+    if (wave == K) {
+        const int half = lane >> 5, j = lane & 31;
+        const CoopLane c = coop_lane(coopw, lane);
+        uint32_t vlo, vhi;
+        mlkem::coop_sponge17<true>(vlo, vhi, [&](int k) { return muw1[k]; }, G::MUW1 / 8, kDsShake, c, j);
+        bool mine = true;
+        if (j < P::CT / 8) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v |= (uint64_t)sg[8 * j + b] << (8 * b);
+            mine = v == (((uint64_t)vhi << 32) | vlo);
+        }
+        const unsigned long long diff = __ballot(!mine) & 0xffffffffull;  // half 0 carries the sponge (half 1 mirrors it)
+        uint32_t failed = 0;
+#pragma unroll
+        for (int k = 0; k <= K; k++) failed |= bad_w[k];
+        if (half == 0 && j == 0) ok[item] = (diff == 0 && failed == 0) ? 1 : 0;
+    }
 }
 
 // ---- kernel F -----------------------------------------------------------------------------------

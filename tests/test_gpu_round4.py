@@ -146,3 +146,112 @@ def test_c_examples_build_and_run():
                                "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and needle in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", ["ML-DSA-44", "ML-DSA-65", "ML-DSA-87"])
+def test_resident_key_verification_in_one_launch(name):
+    """mldsa_verify_chain_kernel (a workgroup of K + 1 wavefronts per item, batches <= 2^CIRCL_HIP_DSA_CHAIN to a resident table):
+    the Wycheproof verification set (malformed hints, out-of-range z, contexts: sign/schemes/wycheproof_test.go:116-151) key by key
+    through resident tables, and a boundary batch with long messages, over-long contexts and several keys against the oracle."""
+    import numpy as np
+    from conftest import hx, load_golden
+    from circl_amd import hostapi
+    from oracle import orc
+    p = {"ML-DSA-44": 44, "ML-DSA-65": 65, "ML-DSA-87": 87}[name]
+    PK, SIG = hostapi.DSA_SIZES[p]
+    checked = valid = 0
+    for g in load_golden("mldsa_wycheproof_verify.json.gz")[name]:
+        pk = hx(g["pk"])
+        if len(pk) != PK:
+            continue
+        tests = [t for t in g["tests"] if len(hx(t["sig"])) == SIG]
+        if not tests:
+            continue
+        t = hostapi.KeyTable("mldsa-public", p, np.frombuffer(pk, np.uint8).reshape(1, PK))
+        sigs = b"".join(hx(x["sig"]) for x in tests)
+        ok = t.verify(sigs, [hx(x["msg"]) for x in tests], ctxs=[hx(x["ctx"]) for x in tests])   # <= 256 per key: the one-launch route
+        t.close()
+        assert len(tests) <= 256
+        bad = [(x["id"], int(o)) for x, o in zip(tests, ok.tolist()) if bool(o) != (x["result"] == "valid")]
+        assert not bad, bad
+        checked += len(tests)
+        valid += int(ok.sum())
+    assert checked >= 45 and 0 < valid < checked
+    # the route boundary (2^8 items), several keys, ragged and long messages, contexts up to 255 bytes and beyond
+    rng = np.random.default_rng(400 + p)
+    nkeys = 5
+    pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (nkeys, 32), dtype=np.uint8))
+    tab = hostapi.KeyTable("mldsa-public", p, pk)
+    for n in (255, 256, 257):
+        idx = rng.integers(0, nkeys, n).astype(np.uint32)
+        msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 400, n)]
+        msgs[5] = bytes(rng.integers(0, 256, 7000, dtype=np.uint8))      # 52 blocks of M'
+        msgs[6] = b""
+        msgs[7] = bytes(70)                                                # tr || M' ends exactly on a block boundary (64 + 2 + 70 = 136)
+        ctxs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 256, n)]
+        ctxs[7] = b""
+        sig = hostapi.mldsa_sign(p, sk[idx], msgs, ctxs=ctxs)
+        want = np.ones(n, bool)
+        sig[10, 0] ^= 1; want[10] = False                                  # c~
+        sig[11, SIG - 1] ^= 0x40; want[11] = False                         # the hint counters
+        sig[12, 40:44] = 0; want[12] = False                               # z
+        z_of_13 = orc.mldsa_verify(p, pk[idx[13:14]], sig[13:14], msgs[13:14], ctxs=ctxs[13:14])
+        assert z_of_13.all()
+        ctx_long = list(ctxs)
+        ctx_long[14] = bytes(256)                                          # a context of 256 bytes never verifies (dilithium.go:116-118)
+        want14 = want.copy(); want14[14] = False
+        ok = tab.verify(sig, msgs, ctxs=ctx_long, key_idx=idx).astype(bool)
+        ref = orc.mldsa_verify(p, pk[idx], sig, msgs, ctxs=ctxs).astype(bool)
+        ref[14] = False
+        assert (ok == ref).all() and (ok == want14).all(), (n, np.nonzero(ok != ref)[0][:8])
+    tab.close()
+
+
+def test_one_launch_verification_routes_agree_with_the_older_ones():
+    """The same seeded batches (valid, corrupted, contexts, a long message) through circl_hip_mldsa_verify and a resident table with the
+    one-launch routes on (default), off, and stretched: identical verdicts, equal to the oracle's."""
+    prog = textwrap.dedent("""
+        import hashlib, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from circl_amd import hostapi
+        from oracle import orc
+        h = hashlib.sha256()
+        for p in (44, 65, 87, 3):
+            r3 = p == 3
+            rng = np.random.default_rng(900 + p)
+            nkeys = 3
+            pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (nkeys, 32), dtype=np.uint8))
+            tab = hostapi.KeyTable("mldsa-public", p, pk)
+            for n in (1, 2, 37, 300):
+                idx = rng.integers(0, nkeys, n).astype(np.uint32)
+                msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 260, n)]
+                if n > 2:
+                    msgs[2] = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+                ctxs = None if r3 else [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 60, n)]
+                sig = hostapi.mldsa_sign(p, sk[idx], msgs, ctxs=ctxs)
+                sig[0::3, 5] ^= 4
+                want = orc.mldsa_verify(p, pk[idx], sig, msgs, ctxs=ctxs).astype(bool)
+                assert not want[0::3].any() and want[1::3].all()
+                got_item = hostapi.mldsa_verify(p, pk[idx], sig, msgs, ctxs).astype(bool)
+                got_tab = tab.verify(sig, msgs, ctxs=ctxs, key_idx=idx).astype(bool)
+                assert (got_item == want).all() and (got_tab == want).all(), (p, n)
+                sig0 = hostapi.mldsa_sign(p, np.tile(sk[:1], (n, 1)), msgs, ctxs=ctxs)      # ONE unparsed key for the batch
+                sig0[1::4, 9] ^= 8
+                got_one = hostapi.mldsa_verify_shared(p, pk[:1], sig0, msgs, ctxs).astype(bool)
+                want_one = np.ones(n, bool)
+                want_one[1::4] = False
+                assert (got_one == want_one).all(), (p, n)
+                h.update(got_item.tobytes() + got_tab.tobytes() + got_one.tobytes())
+            tab.close()
+        print("verify digest", h.hexdigest())
+    """ % ROOT)
+    digests = []
+    for chain in ("", "0", "9"):
+        env = dict(os.environ)
+        if chain:
+            env.update(CIRCL_HIP_DSA_CHAIN=chain, CIRCL_HIP_DSA_CHAIN_ITEM=chain)
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "verify digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+        digests.append(r.stdout.strip().split()[-1])
+    assert len(set(digests)) == 1, digests
