@@ -90,3 +90,19 @@ def test_build_dependencies_follow_the_include_graph(tmp_path):
             assert not build._stale("api_x25519.hip") or not os.path.exists(build._obj("api_x25519.hip"))
         finally:
             os.utime(kt, (st.st_atime, st.st_mtime))
+
+
+def test_every_environment_knob_is_documented():
+    """INTEGRATION.md lists exactly the environment knobs the library reads (they are part of the de-facto ABI)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = set()
+    for p in glob.glob(os.path.join(root, "circl_amd", "csrc", "*")):
+        code |= set(re.findall(r'"(CIRCL_HIP_[A-Z0-9_]+)"', open(p).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for k in sorted(code):
+        tail = k[len("CIRCL_HIP"):]  # the list abbreviates neighbours: `CIRCL_HIP_KEM_CHAIN` / `_KEM_CHAIN_ENCAPS`
+        assert k in doc or ("`%s`" % tail) in doc or ("`_%s`" % tail.split("_", 2)[-1]) in doc, k
+    m = re.search(r"Environment knobs\*\* — exactly these (\d+)", doc)
+    assert m and int(m.group(1)) == len(code), (m and m.group(1), len(code))
