@@ -118,9 +118,10 @@ template <int MODE> size_t mldsa_table_bytes(size_t nkeys) {
 // Resident public keys: batches up to 2^CIRCL_HIP_DSA_CHAIN items (0 = never) are verified in one launch, a workgroup of K + 1
 // wavefronts per item (mldsa_verify_chain_kernel)
 // ... and, with keys that are NOT parsed beforehand (tr and the matrix expansion inside the workgroup), up to 2^CIRCL_HIP_DSA_CHAIN_ITEM
-inline size_t dsa_chain_batch(bool resident = true) {
-    static const int lg_r = env_int("CIRCL_HIP_DSA_CHAIN", 10, 0, 16), lg_i = env_int("CIRCL_HIP_DSA_CHAIN_ITEM", 8, 0, 16);
-    const int lg = resident ? lg_r : lg_i;
+// (measured, tools/dsa_latency.py at 2^9: ML-DSA-44 142 against 224 us, ML-DSA-65 170 / 205, ML-DSA-87 296 / 218 -- so 2^9 up to K = 6, 2^8 beyond)
+inline size_t dsa_chain_batch(bool resident = true, int k = 6) {
+    static const int lg_r = env_int("CIRCL_HIP_DSA_CHAIN", 10, 0, 16), lg_i = env_int("CIRCL_HIP_DSA_CHAIN_ITEM", -1, -1, 16);
+    const int lg = resident ? lg_r : (lg_i >= 0 ? lg_i : (k <= 6 ? 9 : 8));
     return lg <= 0 ? size_t(0) : size_t(1) << lg;
 }
 template <int MODE, int KM>
@@ -156,7 +157,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
-    if ((KM == KM_ITEM || KM == KM_SHARED) && n <= dsa_chain_batch(false)) {
+    if ((KM == KM_ITEM || KM == KM_SHARED) && n <= dsa_chain_batch(false, DP<MODE>::K)) {
         // every item under its own, unparsed key (or all under ONE unparsed key: stride 0), a small batch: the same kernel with tr and
         // the matrix expansion inside the workgroup (the rows of item t in its part of scratch slice t / IT: the workspace holds a
         // slice per IT items at these sizes)

@@ -177,12 +177,12 @@ def test_resident_key_verification_in_one_launch(name):
         checked += len(tests)
         valid += int(ok.sum())
     assert checked >= 45 and 0 < valid < checked
-    # the route boundary (2^8 items), several keys, ragged and long messages, contexts up to 255 bytes and beyond
+    # the route boundary (2^10 items), several keys, ragged and long messages, contexts up to 255 bytes and beyond
     rng = np.random.default_rng(400 + p)
     nkeys = 5
     pk, sk = orc.mldsa_keygen(p, rng.integers(0, 256, (nkeys, 32), dtype=np.uint8))
     tab = hostapi.KeyTable("mldsa-public", p, pk)
-    for n in (255, 256, 257):
+    for n in (257, 1024, 1025):                                           # (2^10 items: the last batch of the one-launch route)
         idx = rng.integers(0, nkeys, n).astype(np.uint32)
         msgs = [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 400, n)]
         msgs[5] = bytes(rng.integers(0, 256, 7000, dtype=np.uint8))      # 52 blocks of M'

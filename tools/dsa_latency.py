@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from circl_amd import device as cdev  # noqa: E402
 
 param = int(sys.argv[1]) if len(sys.argv) > 1 else 65
-for logn in (0, 4, 6, 8, 10, 12, 14):
+for logn in ([int(x) for x in os.environ["CIRCL_LATENCY_LOGNS"].split(",")] if os.environ.get("CIRCL_LATENCY_LOGNS") else (0, 4, 6, 8, 10, 12, 14)):
     n = 1 << logn
     eng = cdev.MLDSADevice(param, n, "cuda", sign=True)
     g = torch.Generator(device="cuda").manual_seed(1)
