@@ -503,6 +503,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     uint8_t *dead = base + lay.o_dead;
     unsigned *tail_work = reinterpret_cast<unsigned *>(base + lay.o_work);
     uint8_t *tail_scratch = base + lay.o_scratch;
+    S.tail_work = tail_work;
     // Speculative rounds: once at most spec_target entries would result, every surviving item gets
     // k = spec_target / items (<= 64) consecutive attempts per round (a round costs its five dependent launches whatever
     // the count).
@@ -577,7 +578,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         // whatever the schedule left unsigned (probability below 2^-40 by construction): one wavefront per item runs that
         // item's remaining rejection iterations to the end
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
-        HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));
+        if (rounds == 0) HIP_TRY(hipMemsetAsync(tail_work, 0, 256, st));  // (otherwise the last round's compaction zeroed the ticket counter)
         const int fin = rounds & 1;
         hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>(lay.tail_units, 512)), dim3(64), SG<MODE>::LDS_TOTAL, st, sk,
                            (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[fin], (const uint32_t *)S.attempts, (size_t)0, 1u,
@@ -586,8 +587,10 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     }
     // The workspace held rho'', the NTT-domain secrets, the accepted attempts' y next to c~ (z - y = c s1) and parked
     // signatures: nothing key-equivalent stays behind in the caller's workspace (the matrix rows are public).
-    HIP_TRY(hipMemsetAsync(S.mr, 0, up256(128 * n), st));
-    HIP_TRY(hipMemsetAsync(tail_scratch, 0, lay.tail_units * SG<MODE>::SCRATCH_BYTES, st));
+    // (mu / rho'', the ticket counter and the tail's scratch slices lie back to back: one fill; the tail kernel's workgroup b works in
+    // slice b and only workgroups below the number of unsigned items -- at most n -- do anything)
+    const size_t tail_used = std::min<size_t>(n, std::min<size_t>(lay.tail_units, 512));
+    HIP_TRY(hipMemsetAsync(S.mr, 0, (size_t)(tail_scratch - S.mr) + tail_used * SG<MODE>::SCRATCH_BYTES, st));
     HIP_TRY(hipMemsetAsync(base + lay.o_sec, 0, lay.o_secret_end - lay.o_sec, st));  // (the workspace's; a prepared key's table stays)
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

@@ -70,6 +70,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
     uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
     const uint32_t *key_idx; // shared == 2 with a table of SEVERAL prepared keys: item i signs with entry key_idx[i] (nullptr: entry 0)
+    unsigned *tail_work;    // the persistent tail kernel's ticket counter (64 words), zeroed by the last round's compaction
     // which entry of A / sec an item uses
     __device__ __forceinline__ size_t key_of(size_t item) const { return shared ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item; }
 };
@@ -819,6 +820,7 @@ __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur
     const unsigned k = st.kk[cur];
     const unsigned k_next = last ? 1u : sign_next_k((count + k - 1) / k, st.spec_target, st.pair);
     if (blockIdx.x == 0 && threadIdx.x == 0) st.kk[cur ^ 1] = k_next;
+    if (last && blockIdx.x == 0 && threadIdx.x < 64) st.tail_work[threadIdx.x] = 0;  // (instead of a memset in front of the tail kernel: one launch less)
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
     for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {
