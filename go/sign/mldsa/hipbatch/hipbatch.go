@@ -31,6 +31,9 @@ func VerifyBatch(s sign.Scheme, pks [][]byte, msgs [][]byte, sigs [][]byte, ctxs
 		panic(sign.ErrTypeMismatch)
 	}
 	n := len(pks)
+	if len(msgs) != n || len(sigs) != n {
+		return nil, sign.ErrTypeMismatch
+	}
 	res := make([]bool, n)
 	pkRows := make([]byte, 0, n*s.PublicKeySize())
 	sigRows := make([]byte, 0, n*s.SignatureSize())
@@ -42,14 +45,18 @@ func VerifyBatch(s sign.Scheme, pks [][]byte, msgs [][]byte, sigs [][]byte, ctxs
 		if len(pks[i]) != s.PublicKeySize() {
 			return nil, sign.ErrPubKeySize
 		}
-		if len(sigs[i]) != s.SignatureSize() || len(ctxs[i]) > 255 {
+		ctx := "" // ctxs may be nil or shorter than pks: the missing contexts are empty
+		if i < len(ctxs) {
+			ctx = ctxs[i]
+		}
+		if len(sigs[i]) != s.SignatureSize() || len(ctx) > 255 {
 			continue // false, without touching the device
 		}
 		idx = append(idx, i)
 		pkRows = append(pkRows, pks[i]...)
 		sigRows = append(sigRows, sigs[i]...)
 		msgBlob = append(msgBlob, msgs[i]...)
-		ctxBlob = append(ctxBlob, ctxs[i]...)
+		ctxBlob = append(ctxBlob, ctx...)
 		msgOff = append(msgOff, uint64(len(msgBlob)))
 		ctxOff = append(ctxOff, uint64(len(ctxBlob)))
 	}
@@ -82,6 +89,12 @@ func SignBatch(s sign.Scheme, sks [][]byte, msgs [][]byte, ctxs []string, rnd []
 		panic(sign.ErrTypeMismatch)
 	}
 	n := len(sks)
+	if len(msgs) != n || (rnd != nil && len(rnd) != 32*n) {
+		return nil, sign.ErrTypeMismatch
+	}
+	if n == 0 {
+		return [][]byte{}, nil
+	}
 	skRows := make([]byte, 0, n*s.PrivateKeySize())
 	defer func() { clear(skRows[:cap(skRows)]) }() // the contiguous copy of the private keys does not outlive the call
 	var msgBlob, ctxBlob []byte
@@ -91,12 +104,16 @@ func SignBatch(s sign.Scheme, sks [][]byte, msgs [][]byte, ctxs []string, rnd []
 		if len(sks[i]) != s.PrivateKeySize() {
 			return nil, sign.ErrPrivKeySize
 		}
-		if len(ctxs[i]) > 255 {
+		ctx := ""
+		if i < len(ctxs) {
+			ctx = ctxs[i]
+		}
+		if len(ctx) > 255 {
 			return nil, sign.ErrContextTooLong
 		}
 		skRows = append(skRows, sks[i]...)
 		msgBlob = append(msgBlob, msgs[i]...)
-		ctxBlob = append(ctxBlob, ctxs[i]...)
+		ctxBlob = append(ctxBlob, ctx...)
 		msgOff = append(msgOff, uint64(len(msgBlob)))
 		ctxOff = append(ctxOff, uint64(len(ctxBlob)))
 	}
@@ -104,7 +121,7 @@ func SignBatch(s sign.Scheme, sks [][]byte, msgs [][]byte, ctxs []string, rnd []
 	ctxBlob = append(ctxBlob, 0)
 	sigRows := make([]byte, n*s.SignatureSize())
 	var rndPtr *C.uint8_t
-	if rnd != nil {
+	if len(rnd) != 0 {
 		rndPtr = (*C.uint8_t)(unsafe.Pointer(&rnd[0]))
 	}
 	rc := C.circl_hip_mldsa_sign(p, (*C.uint8_t)(unsafe.Pointer(&skRows[0])),
@@ -131,6 +148,9 @@ func DeriveKeyBatch(s sign.Scheme, seeds []byte, device int) (pks, sks []byte, e
 		panic(sign.ErrSeedSize)
 	}
 	n := len(seeds) / s.SeedSize()
+	if n == 0 {
+		return []byte{}, []byte{}, nil
+	}
 	pks = make([]byte, n*s.PublicKeySize())
 	sks = make([]byte, n*s.PrivateKeySize())
 	rc := C.circl_hip_mldsa_keygen(p, (*C.uint8_t)(unsafe.Pointer(&seeds[0])), (*C.uint8_t)(unsafe.Pointer(&pks[0])),

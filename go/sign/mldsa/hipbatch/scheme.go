@@ -121,6 +121,9 @@ func (t *PublicKeyTable) VerifyKeyedBatch(idx []uint32, msgs, sigs [][]byte, ctx
 	s := t.scheme
 	p := params[s.Name()]
 	n := len(idx)
+	if len(msgs) != n || len(sigs) != n {
+		return nil, sign.ErrTypeMismatch
+	}
 	res := make([]bool, n)
 	sigRows := make([]byte, 0, n*s.SignatureSize())
 	var msgBlob, ctxBlob []byte
@@ -132,14 +135,18 @@ func (t *PublicKeyTable) VerifyKeyedBatch(idx []uint32, msgs, sigs [][]byte, ctx
 		if int(idx[i]) >= t.n {
 			return nil, fmt.Errorf("circl-hip: key index %d out of range", idx[i])
 		}
-		if len(sigs[i]) != s.SignatureSize() || len(ctxs[i]) > 255 {
+		ctx := "" // ctxs may be nil or shorter than idx: the missing contexts are empty
+		if i < len(ctxs) {
+			ctx = ctxs[i]
+		}
+		if len(sigs[i]) != s.SignatureSize() || len(ctx) > 255 {
 			continue
 		}
 		keep = append(keep, i)
 		kidx = append(kidx, idx[i])
 		sigRows = append(sigRows, sigs[i]...)
 		msgBlob = append(msgBlob, msgs[i]...)
-		ctxBlob = append(ctxBlob, ctxs[i]...)
+		ctxBlob = append(ctxBlob, ctx...)
 		msgOff = append(msgOff, uint64(len(msgBlob)))
 		ctxOff = append(ctxOff, uint64(len(ctxBlob)))
 	}

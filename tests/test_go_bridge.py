@@ -1,7 +1,9 @@
 """The cgo bridge under go/ has never met a Go compiler (no toolchain on any box: profiles/r04_box_probe.txt).  tools/gocheck.py does
 the part of a compiler's front end that can be done here -- C symbols, argument counts and types of every C call, arity of
-package-level calls, unused imports / variables, and every CIRCL identifier and interface method against the names the
-reference exports (tests/golden/go_api_symbols.json, regenerated from the reference by `tools/gocheck.py --update-fixture`).
+package-level calls, unused imports / variables, undefined names, and every CIRCL identifier, interface method, argument count and
+result count against the names and shapes the reference exports (tests/golden/go_api_symbols.json, regenerated from the reference
+by `tools/gocheck.py --update-fixture`).  The bridge's own Go tests (go/*/hipbatch/hipbatch_test.go: batch results against CIRCL's
+scheme objects, the parity test a maintainer runs) are checked the same way.
 The mutation cases prove the checks fire.
 """
 import os
@@ -19,10 +21,10 @@ import gocheck  # noqa: E402
 def test_bridge_is_clean_and_covered():
     findings, stats = gocheck.run()
     assert findings == []
-    assert stats["files"] == 11 and stats["c_calls"] >= 55
+    assert stats["files"] == 13 and stats["c_calls"] >= 55   # 11 bridge files + the two parity tests a maintainer runs
     # every argument of every C call was typed from the Go source and compared with the prototype
     assert stats["c_args_typed"] == stats["c_args"] >= 270, stats["c_args_untyped"]
-    assert stats["api_idents"] >= 120 and stats["api_methods"] >= 90
+    assert stats["api_idents"] >= 140 and stats["api_methods"] >= 140 and stats["api_shapes"] >= 170
 
 
 def test_every_exported_entry_point_family_is_bound():
@@ -61,6 +63,15 @@ MUTATIONS = [
     ("kem/mlkem/hipbatch/hipbatch.go", '\t"fmt"\n', "", "undefined: fmt"),
     ("kem/mlkem/hipbatch/scheme.go", "return rows(ct, s.CiphertextSize()), rows(ss, s.SharedKeySize()), errs, nil", "return rows(ct, s.CiphertextSize()), errs, nil",
      "wrong number of return values: have 3, want 4"),
+    ("kem/mlkem/hipbatch/hipbatch_test.go", "pks, sks, err := s.DeriveKeyPairBatch(seeds, AllDevices)", "pks, sks, err := s.DeriveKeyPairBatch(seeds, AllDevs)", "undefined: AllDevs"),
+    ("sign/mldsa/hipbatch/hipbatch.go", "\tfor k, i := range idx {\n\t\tres[i] = okb[k] == 1\n\t}\n\treturn res, nil", "\tfor k, i := range idx {\n\t\tres[i] = okb[k] == 1\n\t}\n\treturn rez, nil", "undefined: rez"),
+    ("sign/mldsa/hipbatch/hipbatch_test.go", "want := s.Sign(keys[i], msgs[i], &sign.SignatureOpts{Context: ctxs[i]})", "want := s.SignMessage(keys[i], msgs[i], &sign.SignatureOpts{Context: ctxs[i]})",
+     "sign.Scheme has no method SignMessage"),
+    ("kem/mlkem/hipbatch/hipbatch_test.go", "ct, ss, err := s.EncapsulateDeterministically(pk, row(eseeds, s.EncapsulationSeedSize(), i))",
+     "ct, ss, err := s.EncapsulateDeterministically(pk)", "kem.Scheme.EncapsulateDeterministically takes 2 argument(s), called with 1"),
+    ("kem/mlkem/hipbatch/hipbatch_test.go", "pk, sk := s.DeriveKeyPair(row(kseeds, s.SeedSize(), i))", "pk, sk, err := s.DeriveKeyPair(row(kseeds, s.SeedSize(), i))",
+     "assignment mismatch: 3 variables but"),
+    ("sign/mldsa/hipbatch/hipbatch_test.go", "s := schemes.ByName(name)", "s := schemes.ByName(name, 1)", "schemes.ByName takes 1 argument(s), called with 2"),
     ("xof/hipbatch/hipbatch.go", "/*\n#cgo", "/*\n#include <no_such_header.h>\n#cgo", "cgo preamble does not compile"),
     ("dh/x25519/hipbatch/hipbatch.go", "package hipbatch", "package hipbatch\n\nfunc broken( {", "unclosed {"),
 ]
