@@ -74,6 +74,7 @@ MUTATIONS = [
     ("sign/mldsa/hipbatch/hipbatch_test.go", "s := schemes.ByName(name)", "s := schemes.ByName(name, 1)", "schemes.ByName takes 1 argument(s), called with 2"),
     ("kem/hybrid/hipbatch/hipbatch_test.go", 'circl "github.com/cloudflare/circl/kem/schemes"', '"github.com/cloudflare/circl/kem/schemes"',
      "schemes redeclared in this block"),
+    ("kem/mlkem/hipbatch/hipbatch_test.go", 't.Fatalf("key pair %d differs", i)', 't.Fatalf("key pair %d of %d differs", i)', "Fatalf format has 2 verb(s), 1 argument(s)"),
     ("xof/hipbatch/hipbatch.go", "/*\n#cgo", "/*\n#include <no_such_header.h>\n#cgo", "cgo preamble does not compile"),
     ("dh/x25519/hipbatch/hipbatch.go", "package hipbatch", "package hipbatch\n\nfunc broken( {", "unclosed {"),
 ]
