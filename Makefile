@@ -3,7 +3,7 @@ ROCM ?= /opt/rocm
 HIPCC ?= $(ROCM)/bin/hipcc
 ARCH ?= gfx950
 
-UNITS = host_runtime api_mlkem api_mldsa api_prims api_x25519 api_hybrid
+UNITS = host_runtime host_coalesce api_mlkem api_mldsa api_prims api_x25519 api_hybrid
 OBJS = $(UNITS:%=build/%.o)
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable
 

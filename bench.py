@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- ML-KEM-768 encapsulations/sec on MI355X (BASELINE.json's metric), plus every other BASELINE config.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode M] [--no-extras] [--no-cpu-baseline] [--no-pmc]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode M] [--no-extras] [--no-cpu-baseline] [--no-pmc] [--sample-parity]
 
 A "step" is one pass of the hot path over one batch of synthetic inputs that are already resident in HBM when the timed
 region starts.  The headline (default --mode encaps) is BASELINE.json configs[1]: "ML-KEM-768 Encapsulate batch=2^20 on
 1xMI355X", distinct-key form of SURVEY.md section 8(d): ek_i are valid keys from seeded keygen
-(d||z = SHAKE256("circl-hip/keygen" || LE64(i))[:64]) drawn from a pool of 2^16 keys cycled 16x;
-m_i = SHAKE256("circl-hip/m" || LE64(i))[:32] are all distinct.
+(d||z = SHAKE256("circl-hip/keygen" || LE64(i))[:64]), ONE KEY PER ITEM (2^20 keys made by the GPU keygen, untimed);
+m_i = SHAKE256("circl-hip/m" || LE64(i))[:32] are all distinct.  Every ciphertext and shared secret of the batch is compared with the
+oracle (--sample-parity: a 2^16 sample instead).  `configs.pooled` keeps the figure of earlier rounds (a pool of 2^16 keys cycled 16x).
 
 The same JSON line carries, under "configs", a measured figure (own HIP-event kernel times, own roofline against SURVEY
 8(d)'s algorithmic bytes, own sampled oracle parity) for every other BASELINE config on this rank's GPU:
@@ -46,7 +47,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-POOL = 1 << 16
+POOL = 1 << 20                    # keys per rank: one per item at the default batch (SURVEY 8d allowed a pool of 2^16 "for keygen cost reasons":
+POOLED = 1 << 16                  # GPU keygen makes 2^20 keys in 7 ms, so the reason is gone; the old figure stays as configs.pooled)
 # algorithmic bytes per operation = inputs read once + outputs written once
 BYTES = {"mlkem768_encaps": 1184 + 32 + 1088 + 32, "mlkem768_encaps_shared": 32 + 1088 + 32, "mlkem768_decaps": 2400 + 1088 + 32,
          "mlkem1024_encaps": 1568 + 32 + 1568 + 32, "mldsa65_verify": 1952 + 3309 + 32 + 1, "mldsa87_verify": 2592 + 4627 + 32 + 1}
@@ -125,12 +127,12 @@ def roofline(kernel_name, ops_per_step, bytes_per_op, kernel_ms_per_step, note=N
 class KemWork:
     """ML-KEM encaps / decaps over B resident items (distinct keys: pool of min(2^16, B) GPU-generated keys, tiled)."""
 
-    def __init__(self, param, B, rank, dev, shake_inputs=True, window=None):
+    def __init__(self, param, B, rank, dev, shake_inputs=True, window=None, pool_max=None):
         """window = (lo, total): this rank's B = hi - lo items are items [lo, hi) of ONE batch of `total` items (strong scaling:
         the batch is the one rank 0 of a weak run owns -- item i has key pool[i mod pool] and message SHAKE256(label || LE64(i)))."""
         from circl_amd import device as cdev
         self.param, self.B, self.dev = param, B, dev
-        pool = min(POOL, B if window is None else window[1])
+        pool = min(pool_max or POOL, B if window is None else window[1])
         if shake_inputs:
             seeds = torch.from_numpy(shake_seeds("circl-hip/keygen", pool, 64, start=(rank * POOL if window is None else 0))).to(dev)
             self.m = torch.from_numpy(shake_seeds("circl-hip/m", B, 32, start=(rank * B if window is None else window[0]))).to(dev)
@@ -145,8 +147,12 @@ class KemWork:
         reps = (first + B + pool - 1) // pool
         self.pool = pool
         self.seeds = seeds
-        self.ek = ek_pool.repeat(reps, 1)[first:first + B].contiguous()
-        self.dk = dk_pool.repeat(reps, 1)[first:first + B].contiguous()
+        if reps == 1 and first == 0 and pool == B:  # one key per item: the keygen's own arrays
+            self.ek, self.dk = ek_pool, dk_pool
+        else:
+            self.ek = ek_pool.repeat(reps, 1)[first:first + B].contiguous()
+            self.dk = dk_pool.repeat(reps, 1)[first:first + B].contiguous()
+        self.distinct_keys = bool(pool >= B)
         self.eng = cdev.MLKEMDevice(param, B, dev)
         self.ss_dec = torch.empty((B, 32), dtype=torch.uint8, device=dev)
         self.st_dec = torch.empty(B, dtype=torch.uint8, device=dev)
@@ -158,11 +164,19 @@ class KemWork:
         self.eng.decaps(self.dk, self.eng.ct, self.ss_dec, self.st_dec)
 
     def parity_encaps(self, sample):
+        """sample = None: EVERY item of the batch against the oracle (north_star: "every ciphertext, shared secret ... bit-exact")"""
         from oracle import orc
-        idx = torch.from_numpy(np.random.default_rng(0).choice(self.B, size=min(self.B, sample), replace=False)).to(self.dev)
-        ct0, ss0, st0 = orc.mlkem_encaps(self.param, self.ek[idx].cpu().numpy(), self.m[idx].cpu().numpy())
-        ok = bool((self.eng.ct[idx].cpu().numpy() == ct0).all() and (self.eng.ss[idx].cpu().numpy() == ss0).all() and not st0.any())
-        return {"sampled_items": int(idx.numel()), "bit_exact_vs_oracle": ok, "status_nonzero": int(self.eng.status.sum().item())}
+        t = time.perf_counter()
+        if sample is None or sample >= self.B:
+            ct0, ss0, st0 = orc.mlkem_encaps(self.param, self.ek.cpu().numpy(), self.m.cpu().numpy())
+            ct, ss, n = self.eng.ct.cpu().numpy(), self.eng.ss.cpu().numpy(), self.B
+        else:
+            idx = torch.from_numpy(np.random.default_rng(0).choice(self.B, size=sample, replace=False)).to(self.dev)
+            ct0, ss0, st0 = orc.mlkem_encaps(self.param, self.ek[idx].cpu().numpy(), self.m[idx].cpu().numpy())
+            ct, ss, n = self.eng.ct[idx].cpu().numpy(), self.eng.ss[idx].cpu().numpy(), int(idx.numel())
+        ok = bool((ct == ct0).all() and (ss == ss0).all() and not st0.any())
+        return {"sampled_items": n, "of_items": self.B, "whole_batch": n == self.B, "bit_exact_vs_oracle": ok,
+                "status_nonzero": int(self.eng.status.sum().item()), "oracle_seconds": time.perf_counter() - t}
 
     def parity_decaps(self, sample):
         from oracle import orc
@@ -210,13 +224,15 @@ class DsaWork:
     def parity(self, sample, sign_sample):
         from oracle import orc
         rng = np.random.default_rng(2)
-        idx = np.sort(rng.choice(self.n, size=min(self.n, sample), replace=False))
+        t0 = time.perf_counter()
+        idx = np.arange(self.n) if (sample is None or sample >= self.n) else np.sort(rng.choice(self.n, size=sample, replace=False))
         ti = torch.from_numpy(idx).to(self.dev)
         msgs_all = self.msg[:self.n * 32].view(self.n, 32)
         msgs = [bytes(r) for r in msgs_all[ti].cpu().numpy()]
         ok0 = orc.mldsa_verify(self.param, self.pk[ti].cpu().numpy(), self.sig[ti].cpu().numpy(), msgs)
         got = self.eng.ok
-        res = {"sampled_items": int(len(idx)), "bit_exact_vs_oracle": bool((got[ti].cpu().numpy() == ok0).all()),
+        res = {"sampled_items": int(len(idx)), "of_items": self.n, "whole_batch": len(idx) == self.n, "oracle_seconds": time.perf_counter() - t0,
+               "bit_exact_vs_oracle": bool((got[ti].cpu().numpy() == ok0).all()),
                "all_items_as_expected": bool((got == self.want).all().item()), "corrupted_items": self.n_bad,
                "rejected_items": int((got == 0).sum().item())}
         # the GPU-made inputs themselves: signatures equal the oracle's deterministic signatures on a sub-sample
@@ -612,22 +628,57 @@ def pmc_write(live_all, sha, batch):
 VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2 cycles per wave64 VALU op, 2.4 GHz = 1.229e12
 
 
-def valu_issue(insts, launch_ms):
+KECCAK_ROUND_INSTS = 180   # keccak_dev.h: VALU instructions per round; 24 rounds = 4 320 per wave-level permutation (64 sponges)
+# LOWER bounds on the Keccak-f[1600] wave-instructions of one launch over n items: wave-level permutations x 4 320.  (Sponge glue, the
+# rare fourth SHAKE128 block and SampleInBall are not counted: they only raise the Keccak share, i.e. LOWER the ceiling's rate.)
+KECCAK_WAVE_PERMS = {
+    "mlkem768_encrypt": (7, 4),    # a group of 64 / K^2 = 7 items: 3 SHAKE128 blocks of its 63 matrix streams + 1 pass of its 49 PRF streams
+    "mlkem1024_encrypt": (4, 4),   # 4 items: 3 blocks of 64 matrix streams + 1 pass of 36 PRF streams
+    "mldsa65_verify": (2, 5),      # 2 items x K.L = 30 ExpandA streams, 5 SHAKE128 blocks each
+    "mldsa87_verify": (1, 5),      # 1 item x 56 streams
+}
+
+
+def valu_issue(insts, launch_ms, kernel=None, items=None, probe=None):
+    """VALU issue of one launch: against the nominal peak, and against a ceiling built from THIS run's live probe
+    (circl_hip_profile_valu_probe, same process, same chip, 4 waves per SIMD like the kernels): the launch's Keccak instructions
+    (an algorithmic lower bound) cannot issue faster than the library's own Keccak round does on register-resident states, and
+    none of its other VALU instructions faster than two-operand integer ops do:
+        t_min = (N_keccak / R_keccak + (N - N_keccak) / R_simple) / SIMDs ;  frac_of_mix_ceiling = t_min / t_launch  (<= 1 by construction)."""
     if not insts or not launch_ms:
         return None
     simds, nominal_hz = 1024, 2.4e9
     per_s = insts / (launch_ms * 1e-3)
-    cyc = simds * nominal_hz / per_s
-    return {"wave_insts_per_launch": insts, "achieved_Ginst_per_s": per_s / 1e9,
-            "peak_Ginst_per_s": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "frac": per_s / VALU_PEAK_WAVE_INSTS_PER_S,
-            "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
-            "cycles_per_inst_per_simd_at_2.4GHz": cyc,
-            "keccak_probe_cycles_per_inst": {"4_waves_per_simd": 4.12, "8_waves_per_simd": 3.43},
-            "resident_waves_per_simd": 4,
-            # the wall these kernels really face: the issue rate a PURE Keccak-f[1600] instruction mix (V_BITOP3 / V_ALIGNBIT chains) reaches
-            # on this chip at the kernel's residency (profiles/r01_valu_mix_probe.txt, r03_ablation.txt), not the nominal 2 cycles
-            "frac_of_mix_ceiling": {"at_4_waves_per_simd": 4.12 / cyc, "at_8_waves_per_simd": 3.43 / cyc,
-                                    "definition": "(cycles per instruction of the pure-Keccak probe) / (this kernel's cycles per VALU instruction per SIMD)"}}
+    out = {"wave_insts_per_launch": insts, "achieved_Ginst_per_s": per_s / 1e9,
+           "peak_Ginst_per_s": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "frac": per_s / VALU_PEAK_WAVE_INSTS_PER_S,
+           "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+           "cycles_per_inst_per_simd_at_2.4GHz": simds * nominal_hz / per_s, "resident_waves_per_simd": 4}
+    if probe and kernel in KECCAK_WAVE_PERMS and items:
+        group, perms = KECCAK_WAVE_PERMS[kernel]
+        n_k = min(float(insts), -(-items // group) * perms * 24 * KECCAK_ROUND_INSTS)
+        r_k, r_s = probe["keccak_insts_per_s_per_simd"], probe["simple_insts_per_s_per_simd"]
+        t_min = (n_k / r_k + (insts - n_k) / r_s) / simds
+        out.update({"ceiling_source": "live", "probe": probe, "keccak_wave_insts_lower_bound": n_k, "keccak_share_of_valu_insts": n_k / insts,
+                    "mix_ceiling_ms": t_min * 1e3, "frac_of_mix_ceiling": t_min / (launch_ms * 1e-3),
+                    "frac_of_mix_ceiling_definition": "t_min / t_launch, t_min = (N_keccak / R_keccak + (N - N_keccak) / R_simple) / 1024 SIMDs: N = SQ_INSTS_VALU of "
+                                                      "the launch, N_keccak = %d wave-level permutations per %d items x 4320 (a lower bound), R = this run's "
+                                                      "circl_hip_profile_valu_probe rates at 4 waves per SIMD; <= 1 by construction" % (perms, group)})
+    else:
+        out["ceiling_source"] = None
+    return out
+
+
+def live_valu_probe(dev_index):
+    from circl_amd import device as cdev
+    try:
+        k, s_ = cdev.valu_probe(dev_index, 4)
+        return {"keccak_insts_per_s_per_simd": k, "simple_insts_per_s_per_simd": s_, "waves_per_simd": 4,
+                "keccak_cycles_per_inst_at_2.4GHz": 2.4e9 / k, "simple_cycles_per_inst_at_2.4GHz": 2.4e9 / s_,
+                "what": "circl_hip_profile_valu_probe in this process, right after the timed steps: 512 register-resident Keccak-f[1600] permutations "
+                        "per lane / 2M two-operand integer instructions per lane, every SIMD, HIP-event timed, best of 3"}
+    except Exception as e:  # noqa: BLE001
+        print("bench.py: the live VALU probe failed (%s)" % e, file=sys.stderr)
+        return None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -657,6 +708,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic / valu then come from profiles/*.json if they match this build)")
+    ap.add_argument("--sample-parity", action="store_true", help="compare 2^16-item samples with the oracle instead of whole batches (headline: 2^20, config 4: 2^18)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -752,7 +804,8 @@ def main():
         v, el = parallel.whole_job_rate(ranks, B * max(5, min(args.steps, 20)), el)
         out_cfg["encaps"] = {"value": v, "unit": "encaps/s", "ms_per_step": el / max(5, min(args.steps, 20)) * 1e3}
     status_sum = int(kem.eng.status.sum().item())
-    parity_enc = kem.parity_encaps(1 << 16 if rank == 0 else 1 << 12)
+    full = not args.sample_parity
+    parity_enc = kem.parity_encaps((None if full else 1 << 16) if rank == 0 else 1 << 12)
     parity_fail = ranks.sum(0 if parity_enc["bit_exact_vs_oracle"] else 1)
     parity_enc["ranks_failing"] = int(parity_fail)
     per_rank = {"encaps_per_s": ranks.gather(B * args.steps / headline["elapsed"]) if args.mode == "encaps" else None}
@@ -777,6 +830,19 @@ def main():
         strong.update({"unit": "encaps/s", "scaling": "strong", "batch_total": B, "steps": args.steps, "warmup": args.warmup,
                        "workload": "ONE batch of %d ML-KEM-768 encapsulations (distinct-key), contiguous split n/G per rank, same barrier / "
                                    "max-over-ranks protocol as `value`" % B})
+
+    # ---- the figure of rounds 1-4, for continuity: the same step with keys drawn from a pool of 2^16 (77 MB of ek: fits the 256 MB
+    # Infinity Cache, which 1.24 GB of distinct keys does not) ----
+    if extras and args.mode == "encaps" and kem.pool > POOLED:
+        kp = KemWork(768, B, rank, dev, pool_max=POOLED)
+        el_p, kern_p = Timer(ranks, ["mlkem_hash", "mlkem_encrypt"]).run(kp.encaps, 10, 2)
+        v_p, el_p = parallel.whole_job_rate(ranks, B * 10, el_p)
+        pp = kp.parity_encaps(1 << 12)
+        out_cfg["pooled"] = {"value": v_p, "unit": "encaps/s", "ms_per_step": el_p / 10 * 1e3, "key_pool": kp.pool,
+                             "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kern_p.items()}, "parity": pp,
+                             "note": "keys from a pool of %d cycled %dx (what `value` was in rounds 1-4); `value` now has one key per item" % (kp.pool, B // kp.pool)}
+        del kp
+        torch.cuda.empty_cache()
 
     # ---- decaps + config 3 (second half of Encaps + Decaps on the same items) ----
     if extras or args.mode == "config3":
@@ -877,7 +943,7 @@ def main():
         k4 = args.steps if args.mode == "config4" else 5
         el, kv = tm.run(d65.verify, k4, args.warmup if args.mode == "config4" else 1)
         v4, el = parallel.whole_job_rate(ranks, n4 * k4, el)
-        par4 = d65.parity(1 << 16 if rank == 0 else 1 << 10, 1 << 11)
+        par4 = d65.parity((None if full else 1 << 16) if rank == 0 else 1 << 10, 1 << 11)
         par4["ranks_failing"] = int(ranks.sum(0 if (par4["bit_exact_vs_oracle"] and par4["all_items_as_expected"]) else 1))
         cfg4 = {"value": v4, "unit": "verifications/s", "ms_per_step": el / k4 * 1e3, "n_per_gpu": n4, "steps": k4,
                 "workload": "ML-DSA-65 Verify, %d items per GPU, DISTINCT keys (GPU keygen + GPU deterministic signing at %.2e sig/s incl. setup), "
@@ -939,6 +1005,7 @@ def main():
     traffic, valu, pmc_note = None, None, None
     if rank == 0 and enc_kern is not None:
         enc_avg_ms = enc_kern["mlkem_encrypt"]["ms_per_step"]
+        probe = live_valu_probe(local)
         live_all, why = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_live(B)
         live = live_all.get("mlkem768_encrypt") if live_all else None
         committed = pmc_committed()
@@ -953,10 +1020,11 @@ def main():
                 if r and live_all_or_committed.get(pk):
                     r["traffic"] = live_all_or_committed[pk]["bytes"]
                     r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
-                    r["valu"] = valu_issue(live_all_or_committed[pk]["valu_insts"], r["avg_launch_ms"])
+                    r["valu"] = valu_issue(live_all_or_committed[pk]["valu_insts"], r["avg_launch_ms"], pk,
+                                           {"mldsa65_verify": max(B // 4, 64)}.get(pk, max(B // 16, 64)), probe)
                     r["pmc_source"] = "live" if live_all else "profiles/traffic.json + valu.json (this very build)"
         if live:
-            traffic, valu = live["bytes"], valu_issue(live["valu_insts"], enc_avg_ms)
+            traffic, valu = live["bytes"], valu_issue(live["valu_insts"], enc_avg_ms, "mlkem768_encrypt", B, probe)
             pmc_note = {"source": "live", "method": live_all["method"], "read_bytes": live["read_bytes"], "write_bytes": live["write_bytes"]}
             if committed and committed.get("bytes"):
                 dev_pct = abs(committed["bytes"] - traffic) / traffic * 100.0
@@ -965,7 +1033,7 @@ def main():
                     print("bench.py: WARNING profiles/traffic.json is STALE: %.3e B committed vs %.3e B measured now (%.1f %%)" %
                           (committed["bytes"], traffic, dev_pct), file=sys.stderr)
         elif committed and committed.get("lib_sha256") == sha:
-            traffic, valu = committed["bytes"], valu_issue(committed["valu_insts"], enc_avg_ms)
+            traffic, valu = committed["bytes"], valu_issue(committed["valu_insts"], enc_avg_ms, "mlkem768_encrypt", B, probe)
             pmc_note = {"source": "profiles/traffic.json + valu.json (taken from this very build of libcirclhip.so)", "live_pass": why}
         else:
             pmc_note = {"source": None, "live_pass": why,
@@ -984,12 +1052,13 @@ def main():
             "metric": metric, "value": headline["value"], "unit": unit, "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": headline["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": {"encaps": "ML-KEM-768 Encapsulate, distinct-key, batch=%d per GPU, inputs resident in HBM" % B,
+            "config": {"workload": {"encaps": "ML-KEM-768 Encapsulate, distinct-key (one GPU-generated key per item), batch=%d per GPU, inputs resident in HBM "
+                                              "(SURVEY 8d scope i; the PCIe-inclusive host-ABI rate, scope ii, is `value_host_abi`)" % B,
                                     "config3": "ML-KEM-768 Encapsulate + Decapsulate, distinct-key, batch=%d per GPU, inputs resident in HBM" % B,
                                     "config4": "ML-DSA-65 Verify, distinct-key, batch=%d per GPU, inputs resident in HBM" % max(B // 4, 64),
                                     "config5": "ML-KEM-1024 Encapsulate + ML-DSA-87 Verify on two streams, %d + %d per GPU, inputs resident in HBM" % (max(B // 16, 64), max(B // 16, 64)),
                                     "host": "ML-KEM-768 Encapsulate through circl_hip_mlkem_encaps (host pointers, pageable), batch=%d per GPU" % B}[args.mode],
-                       "key_pool": min(POOL, B), "parallelism": "batch split per device, no collectives", "mode": args.mode},
+                       "key_pool": kem.pool, "parallelism": "batch split per device, no collectives", "mode": args.mode},
             "value_is": "weak: every rank times its own batch of %d (per-GPU work fixed as N grows); `strong` = one batch of %d split over the ranks; "
                         "`value_host_abi` = the same metric through the host-pointer C ABI (PCIe-inclusive, pageable caller memory)" % (B, B),
             "strong": strong,

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcirclhip.so")
-UNITS = ["host_runtime.hip", "api_mlkem.hip", "api_mldsa.hip", "api_prims.hip", "api_x25519.hip", "api_hybrid.hip"]
+UNITS = ["host_runtime.hip", "host_coalesce.hip", "api_mlkem.hip", "api_mldsa.hip", "api_prims.hip", "api_x25519.hip", "api_hybrid.hip"]
 _INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
 
 

@@ -870,6 +870,15 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
     if (check_contexts(param, ctx_blob, ctx_off, n) == CTX_UNSUPPORTED) return CIRCL_HIP_EPARAM;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (absent key_idx: zeros; absent contexts: empty rows)
+            const int rc = coalesce_run(r->coalescer, cnt, {{sig + lo * SIG, SIG}, {reinterpret_cast<const uint8_t *>(ki), size_t(4)}},
+                                        {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}},
+                                        [&](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
+                                            return circl_hip_mldsa_verify_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[0], c.blob[0], c.off[0], c.blob[1],
+                                                                                    c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         return run_pipeline(r->device, cnt, {{sig + lo * SIG, SIG}, {reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}},
                             {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}}, [&](size_t c) { return mldsa_ws_any(param, c); },
                             dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {

@@ -878,6 +878,14 @@ int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *ke
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (an absent key_idx: zeros)
+            const int rc = coalesce_run(r->coalescer, cnt, {{reinterpret_cast<const uint8_t *>(ki), size_t(4)}, {m + lo * 32, 32, true}}, {},
+                                        {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
+                                            return circl_hip_mlkem_encaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.out[2],
+                                                                                    c.cnt, c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {m + lo * 32, 32, true}}, {},
                             {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
@@ -893,6 +901,14 @@ int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *ke
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {
+            const int rc = coalesce_run(r->coalescer, cnt, {{reinterpret_cast<const uint8_t *>(ki), size_t(4)}, {ct + lo * CT, CT}}, {},
+                                        {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
+                                            return circl_hip_mlkem_decaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.cnt,
+                                                                                    c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * CT, CT}}, {},
                             {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],

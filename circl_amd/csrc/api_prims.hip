@@ -32,6 +32,50 @@ int circl_hip_keccak_f1600(uint64_t *states, size_t n, int rounds, int device) {
     });
 }
 
+/* Live issue-rate probe (bench.py prices the kernels' VALU time against it): wave-instructions per second PER SIMD sustained by
+ * (a) the library's Keccak-f[1600] round and (b) two-operand integer VALU ops, on every SIMD of `device` with `waves_per_simd`
+ * wavefronts resident each.  HIP-event timed; ~10 ms of GPU time. */
+int circl_hip_profile_valu_probe(int device, int waves_per_simd, double *keccak_insts_per_s_per_simd, double *simple_insts_per_s_per_simd) {
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;
+    if (waves_per_simd < 1 || waves_per_simd > 8) return CIRCL_HIP_EPARAM;
+    HIP_TRY(hipSetDevice(physical_device(device)));
+    const int cus = dev_info(device).cus;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sink), 256));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st = nullptr;
+    auto cleanup = [&] {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipFree(sink);
+    };
+    auto timed = [&](auto kern, int iters, double insts_per_wave, double *out) -> int {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {  // the first repetition also warms the clocks
+            HIP_TRY(hipEventRecord(a, st));
+            hipLaunchKernelGGL(kern, dim3((unsigned)(cus * waves_per_simd)), dim3(256), 0, st, sink, iters);
+            HIP_TRY(hipEventRecord(b, st));
+            HIP_TRY(hipEventSynchronize(b));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, a, b));
+            if (rep > 0) best = std::min(best, ms);
+        }
+        if (out) *out = insts_per_wave * waves_per_simd / (best * 1e-3);  // every SIMD ran waves_per_simd wavefronts side by side
+        return CIRCL_HIP_OK;
+    };
+    int rc = CIRCL_HIP_OK;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        rc = CIRCL_HIP_EHIP;
+    }
+    constexpr int kKeccakIters = 512, kSimpleIters = 8192;
+    if (rc == CIRCL_HIP_OK) rc = timed(circl::prim::keccak_rate_probe_kernel, kKeccakIters, 4320.0 * kKeccakIters, keccak_insts_per_s_per_simd);
+    if (rc == CIRCL_HIP_OK) rc = timed(circl::prim::simple_rate_probe_kernel, kSimpleIters, (double)circl::prim::kSimpleProbePerIter * kSimpleIters, simple_insts_per_s_per_simd);
+    cleanup();
+    return rc;
+}
+
 int circl_hip_keccak_f1600_coop(uint64_t *states, size_t n, int device) {
     uint8_t *p = reinterpret_cast<uint8_t *>(states);
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {

@@ -177,7 +177,7 @@ __device__ __forceinline__ int xch_pad(int i) { return i + 4 * (i >> 5); }
 // s_waitcnt in between (what __syncthreads() costs a single-wave workgroup), only the compiler must keep their order.
 constexpr bool kNWDefault = false;  // (measured neutral, +0.2 %, on the verification kernel: left off there)
 template <bool NW> __device__ __forceinline__ void xch_sync() {
-    if constexpr (NW) __builtin_amdgcn_wave_barrier();
+    if constexpr (NW) wave_lds_order();
     else __syncthreads();
 }
 template <int FROM, int TO, bool NW = kNWDefault> __device__ __forceinline__ void relayout(uint32_t (&c)[4], uint32_t *xch, int lane) {

@@ -114,8 +114,17 @@ struct Slot {
     uint8_t *d = nullptr;     size_t d_cap = 0;      // device staging: inputs, outputs, workspace of one chunk
     uint8_t *hin = nullptr;   size_t hin_cap = 0;    // page-locked staging, host -> device
     uint8_t *hout = nullptr;  size_t hout_cap = 0;   // page-locked staging, device -> host
+    uint8_t *hin_dev = nullptr, *hout_dev = nullptr; // the DEVICE addresses of the two page-locked areas (zero-copy calls: the kernels
+                                                     // of a tiny call read / write them over PCIe themselves, no copy is enqueued)
     int ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes);
 };
+// page-locked, device-mapped host memory (TSan builds: mmap + hipHostRegister, host_runtime.hip) and its address on the device
+hipError_t pinned_alloc(void **p, size_t bytes);
+hipError_t pinned_free(void *p);
+uint8_t *pinned_device_ptr(void *p);  // nullptr if the runtime cannot map it
+// A call (or a coalesced batch) that moves at most this many bytes does not enqueue copies at all: its kernels get the device
+// addresses of the page-locked staging areas.  CIRCL_HIP_ZEROCOPY_KB (0 = never), default 64 KB (profiles/r05_zerocopy.txt).
+size_t zero_copy_bytes();
 // block = true: waits while every slot of the device is in use; false: returns nullptr at once in that case.
 // nullptr with a non-empty g_err = creating a slot failed.
 Slot *slot_acquire(int dev, bool block = true);
@@ -166,6 +175,25 @@ struct PipeOpts {
 int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
                  const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch);
 size_t host_chunk_items(size_t dflt);  // CIRCL_HIP_HOST_CHUNK overrides the default chunk size (tuning aid)
+
+// ---- cross-caller coalescing of small calls through ONE resident key table (host_coalesce.hip) -----------------------------
+// The reference's consumers call kem.Scheme / sign.Scheme one operation at a time from many goroutines (kem/hybrid/hybrid.go:95-99,
+// hpke/algs.go:283-285, kem/mlkem/mlkem768/kyber.go:347-386).  A Coalescer merges such concurrent small calls into one launch:
+// callers reserve rows of an open batch and copy their inputs into its page-locked staging; the caller that opened the batch flushes
+// it as soon as the device has room for another batch (so a batch collects exactly the calls that arrive while the previous ones
+// run: no timer at low load, large batches at high load), or after max_wait_us if that is set; everybody copies their own rows out.
+// Bytes are those of the un-coalesced call: the kernels are the same ones, an item does not know its neighbours.
+struct Coalescer;
+Coalescer *coalescer_new(int dev, size_t max_items, unsigned max_wait_us);
+void coalescer_free(Coalescer *co);
+size_t coalescer_call_max(const Coalescer *co);  // calls of more items than this do not join batches
+void coalescer_stats(const Coalescer *co, uint64_t *calls, uint64_t *items, uint64_t *launches);
+// Same contract as run_pipeline for a call of n <= coalescer_call_max() items.  A NULL input pointer with a non-zero row = rows
+// of zeros (an absent key_idx).  Returns kNotCoalesced (> 0) when the call cannot join (too many blob bytes, a shape that differs
+// from the coalescer's first call): the caller then runs it through run_pipeline.
+constexpr int kNotCoalesced = 1;
+int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
+                 const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch);
 
 // Contiguous split of [0,n) over the visible devices, one host thread each (pinned to the device's NUMA node), no collective.
 int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn);

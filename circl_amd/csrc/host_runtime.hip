@@ -45,7 +45,7 @@ namespace circl {
 namespace host {
 static std::mutex g_pinned_mu;
 static std::map<void *, size_t> g_pinned_sizes;
-static hipError_t pinned_alloc(void **p, size_t bytes) {
+hipError_t pinned_alloc(void **p, size_t bytes) {
     void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) return hipErrorOutOfMemory;
     const hipError_t e = hipHostRegister(m, bytes, hipHostRegisterDefault);
@@ -55,7 +55,7 @@ static hipError_t pinned_alloc(void **p, size_t bytes) {
     *p = m;
     return hipSuccess;
 }
-static hipError_t pinned_free(void *p) {
+hipError_t pinned_free(void *p) {
     size_t bytes = 0;
     {
         std::lock_guard<std::mutex> lk(g_pinned_mu);
@@ -67,9 +67,18 @@ static hipError_t pinned_free(void *p) {
     return e;
 }
 #else
-static hipError_t pinned_alloc(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault); }  // default placement: the device's NUMA node
-static hipError_t pinned_free(void *p) { return hipHostFree(p); }
+hipError_t pinned_alloc(void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault); }  // default placement: the device's NUMA node
+hipError_t pinned_free(void *p) { return hipHostFree(p); }
 #endif
+uint8_t *pinned_device_ptr(void *p) {
+    void *dp = nullptr;
+    if (!p || hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<uint8_t *>(dp);
+}
+size_t zero_copy_bytes() {
+    static const size_t v = (size_t)env_int("CIRCL_HIP_ZEROCOPY_KB", 64, 0, 1 << 20) << 10;
+    return v;
+}
 
 namespace {
 
@@ -438,6 +447,7 @@ int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
         const size_t want = up256(hin_bytes + hin_bytes / 8);
         HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hin), want));
         hin_cap = want;
+        hin_dev = pinned_device_ptr(hin);
     }
     if (hout_bytes > hout_cap) {
         if (hout) HIP_TRY(pinned_free(hout));
@@ -445,6 +455,7 @@ int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
         const size_t want = up256(hout_bytes + hout_bytes / 8);
         HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hout), want));
         hout_cap = want;
+        hout_dev = pinned_device_ptr(hout);
     }
     return CIRCL_HIP_OK;
 }
@@ -533,6 +544,7 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
 
     hipStream_t h2d = nullptr, d2h = nullptr, st = nullptr;
     if (int rc = pipeline_streams(dev, &h2d, &d2h, &st)) return rc;
+    bool tiny = false;
     {
         // A call that is ONE small chunk gains nothing from separate copy streams and pays for them: two cross-stream event hops
         // and two SDMA start-ups are ~20 us of a one-item call's 140 (measured through the Python binding: n = 1 139 -> 120 us, 64 items
@@ -545,6 +557,7 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         for (auto &b : blobs)
             if (b.blob) moved += (size_t)(b.off[n] - b.off[0]) + 8 * (n + 1);
         if (n <= chunk && moved <= inline_bytes) h2d = d2h = st;
+        tiny = n <= chunk && moved <= zero_copy_bytes();
     }
     // ... and such a call moves all its staged inputs with ONE copy and all its outputs with ONE copy: the page-locked staging areas
     // then mirror the device staging's layout (same offsets, padding included), and the cross-stream events are not needed.  A one-item
@@ -555,13 +568,18 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
     for (size_t k = 0; k < ins.size(); k++) merge_in = merge_in && !in_pinned[k];
     for (size_t k = 0; k < blobs.size(); k++) merge_in = merge_in && (!blobs[k].blob || !blob_pinned[k]);
     for (size_t k = 0; k < outs.size(); k++) merge_out = merge_out && (!outs[k].p || !out_pinned[k]);
+    // ... and a TINY such call (<= zero_copy_bytes(), 64 KB) enqueues no copy at all: its kernels read the page-locked input staging and
+    // write the page-locked output staging over PCIe themselves (the areas are device-mapped; their contents are visible to the host
+    // once the stream has drained, like any kernel output).  What is left of a one-item call is the launch and the wait
+    // (profiles/r05_zerocopy.txt).
+    const bool zero_copy = tiny && merge_in && merge_out;
     std::deque<InFlight> inflight;
     // error paths must not recycle a slot (or return to the caller) with copies or kernels still in flight
     struct Drain {
         std::deque<InFlight> &q;
         hipStream_t h2d, d2h, st;
         const std::vector<HOut> &outs;
-        bool wipe_device;
+        bool wipe_device, merge_out;
         ~Drain() {
             if (q.empty()) return;
             (void)hipStreamSynchronize(h2d);
@@ -572,13 +590,14 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             for (auto &f : q) {
                 for (auto &s : f.secret_in) memset(f.slot->hin + s.hofs, 0, s.bytes);
                 for (size_t k = 0; k < outs.size() && k < f.out.size(); k++)
-                    if (outs[k].secret && f.out[k].staged) memset(f.slot->hout + f.out[k].hofs, 0, f.out[k].bytes);
+                    if (outs[k].secret && (f.out[k].staged || merge_out) && f.slot->hout && f.out[k].hofs + f.out[k].bytes <= f.slot->hout_cap)
+                        memset(f.slot->hout + f.out[k].hofs, 0, f.out[k].bytes);
                 if (wipe_device && f.slot->d) (void)hipMemset(f.slot->d, 0, f.slot->d_cap);
                 slot_release(f.slot);
             }
             (void)hipGetLastError();
         }
-    } drain{inflight, h2d, d2h, st, outs, opts.wipe_device};
+    } drain{inflight, h2d, d2h, st, outs, opts.wipe_device, merge_out};
 
     // stage-out of a finished chunk = copy jobs (staging -> caller memory), then wipe jobs (secret staging areas)
     auto out_jobs = [&](InFlight &f, std::vector<CopyJob> &jobs) {
@@ -586,8 +605,9 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             if (outs[k].p && f.out[k].staged) jobs.push_back({outs[k].p + f.lo * outs[k].row, f.slot->hout + f.out[k].hofs, f.out[k].bytes});
     };
     auto wipe_jobs = [&](InFlight &f, std::vector<CopyJob> &jobs) {
+        // (a merged / zero-copy call brings EVERY output segment to the page-locked area, wanted by the caller or not)
         for (size_t k = 0; k < outs.size(); k++)
-            if (outs[k].secret && f.out[k].staged) jobs.push_back({f.slot->hout + f.out[k].hofs, nullptr, f.out[k].bytes});
+            if (outs[k].secret && (f.out[k].staged || merge_out) && f.out[k].bytes) jobs.push_back({f.slot->hout + f.out[k].hofs, nullptr, f.out[k].bytes});
         for (auto &s : f.secret_in) jobs.push_back({f.slot->hin + s.hofs, nullptr, s.bytes});
     };
     auto retire = [&](InFlight &f) -> int {
@@ -672,6 +692,7 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         InFlight &cur = inflight.back();
         int rc = slot->ensure(dofs, hin_ofs, hout_ofs);
         if (rc) return rc;
+        const bool zc = zero_copy && (!in_end || slot->hin_dev) && (out_end == out_begin || slot->hout_dev);
 
         // ---- stage in -- together with the stage-out of the oldest chunk when the call holds `depth` slots: one batch for
         // the byte movers instead of two half-empty ones ----
@@ -706,25 +727,25 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
         c.cnt = cnt; c.st = st;
         c.ws = slot->d + ws_ofs; c.ws_bytes = up256(wsb);
         for (size_t k = 0; k < ins.size(); k++) {
-            uint8_t *dp = slot->d + sin[k].dofs;
+            uint8_t *dp = zc ? slot->hin_dev + sin[k].hofs : slot->d + sin[k].dofs;
             c.in.push_back(dp);
             if (!sin[k].bytes || merge_in) continue;
             const void *src = sin[k].staged ? (const void *)(slot->hin + sin[k].hofs) : (const void *)(ins[k].p + (ins[k].per_call ? 0 : lo * ins[k].row));
             HIP_TRY(hipMemcpyAsync(dp, src, sin[k].bytes, hipMemcpyHostToDevice, h2d));
         }
-        if (merge_in && in_end) HIP_TRY(hipMemcpyAsync(slot->d, slot->hin, in_end, hipMemcpyHostToDevice, h2d));  // every input, blob and offset array at once
+        if (merge_in && in_end && !zc) HIP_TRY(hipMemcpyAsync(slot->d, slot->hin, in_end, hipMemcpyHostToDevice, h2d));  // every input, blob and offset array at once
         for (size_t k = 0; k < blobs.size(); k++) {
             if (!blobs[k].blob) { c.blob.push_back(nullptr); c.off.push_back(nullptr); continue; }
-            uint8_t *dp = slot->d + sblob[k].dofs;
+            uint8_t *dp = zc ? slot->hin_dev + sblob[k].hofs : slot->d + sblob[k].dofs;
             if (sblob[k].bytes && !merge_in) {
                 const void *src = sblob[k].staged ? (const void *)(slot->hin + sblob[k].hofs) : (const void *)(blobs[k].blob + blobs[k].off[lo]);
                 HIP_TRY(hipMemcpyAsync(dp, src, sblob[k].bytes, hipMemcpyHostToDevice, h2d));
             }
             if (!merge_in) HIP_TRY(hipMemcpyAsync(slot->d + soff[k].dofs, slot->hin + soff[k].hofs, soff[k].bytes, hipMemcpyHostToDevice, h2d));
             c.blob.push_back(dp - blobs[k].off[lo]);  // the kernels index it with the caller's absolute offsets
-            c.off.push_back(reinterpret_cast<const uint64_t *>(slot->d + soff[k].dofs));
+            c.off.push_back(reinterpret_cast<const uint64_t *>(zc ? slot->hin_dev + soff[k].hofs : slot->d + soff[k].dofs));
         }
-        for (size_t k = 0; k < outs.size(); k++) c.out.push_back(slot->d + cur.out[k].dofs);
+        for (size_t k = 0; k < outs.size(); k++) c.out.push_back(zc ? slot->hout_dev + cur.out[k].hofs : slot->d + cur.out[k].dofs);
         HIP_TRY(hipEventRecord(slot->ev_in, h2d));  // (the look-ahead bound of the next chunk waits on it)
         if (h2d != st) HIP_TRY(hipStreamWaitEvent(st, slot->ev_in, 0));
         rc = launch(c);
@@ -733,7 +754,7 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             HIP_TRY(hipEventRecord(slot->ev_k, st));
             HIP_TRY(hipStreamWaitEvent(d2h, slot->ev_k, 0));
         }
-        if (merge_out && out_end > out_begin) HIP_TRY(hipMemcpyAsync(slot->hout, slot->d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, d2h));
+        if (merge_out && out_end > out_begin && !zc) HIP_TRY(hipMemcpyAsync(slot->hout, slot->d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, d2h));
         for (size_t k = 0; k < outs.size(); k++) {
             if (!outs[k].p || !cur.out[k].bytes || merge_out) continue;
             void *dst = cur.out[k].staged ? (void *)(slot->hout + cur.out[k].hofs) : (void *)(outs[k].p + lo * outs[k].row);
@@ -743,9 +764,9 @@ int run_pipeline(int dev, size_t n, const std::vector<HIn> &ins, const std::vect
             if (!opts.ws_secret_bytes) {
                 HIP_TRY(hipMemsetAsync(slot->d, 0, dofs, d2h));
             } else {
-                for (size_t k = 0; k < ins.size(); k++)
+                for (size_t k = 0; k < ins.size() && !zc; k++)  // (a zero-copy call left nothing in the device staging but its workspace)
                     if (ins[k].secret && sin[k].bytes) HIP_TRY(hipMemsetAsync(slot->d + sin[k].dofs, 0, sin[k].bytes, d2h));
-                for (size_t k = 0; k < outs.size(); k++)
+                for (size_t k = 0; k < outs.size() && !zc; k++)
                     if (outs[k].secret && cur.out[k].bytes) HIP_TRY(hipMemsetAsync(slot->d + cur.out[k].dofs, 0, cur.out[k].bytes, d2h));
                 const size_t sec = std::min(up256(wsb), opts.ws_secret_bytes(cnt));
                 if (sec) HIP_TRY(hipMemsetAsync(slot->d + ws_ofs, 0, sec, d2h));
@@ -814,6 +835,11 @@ int keytable_replicate(int device, const std::function<int(int dev, circl_hip_ke
     top->scheme = r0->scheme;
     *out = top;
     return CIRCL_HIP_OK;
+}
+
+int next_replica(int nreplica) {
+    static std::atomic<unsigned> rr{0};
+    return (int)(rr.fetch_add(1, std::memory_order_relaxed) % (unsigned)std::max(nreplica, 1));
 }
 
 // ---- shard ----------------------------------------------------------------------------------------
@@ -899,6 +925,7 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
     for (int d = 0; d < t->nreplica; d++) circl_hip_keytable_free(t->replica[d]);
     delete[] t->replica;
     if (t->inner) circl_hip_keytable_free(t->inner);
+    if (t->coalescer) { circl::host::coalescer_free(t->coalescer); t->coalescer = nullptr; }
     if (ndev() > 0 && t->device >= 0 && t->device < ndev() && hipSetDevice(circl::host::physical_device(t->device)) == hipSuccess) {
         if (t->d_keys) {
             if (t->private_keys) (void)hipMemset(t->d_keys, 0, t->keys_bytes);

@@ -49,6 +49,20 @@ struct KeccakState {
     uint32_t lo[25], hi[25];
 };
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// The wave-level ordering point of every "no-wait" exchange (kyber_dev.h wave_sync<true>, dilithium_dev.h xch_sync<true>,
+// keccak_f1600_coop / coop2<true>, the `handoff` points of the chain kernels): LDS stores of this wavefront in front of it, LDS loads
+// of this wavefront behind it.  The hardware needs nothing (a wavefront's LDS instructions execute in order); the COMPILER must
+// not move a load over a store it cannot prove disjoint, and wave_barrier alone (IntrNoMem) does not formally say so.  The two
+// wavefront-scope fences do: they emit no instruction (no s_barrier, no s_waitcnt -- tests/test_abi.py checks the disassembly) and
+// order every memory access of the wavefront around the barrier, as HIP's tiled-group sync does.
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 // Round constants of FIPS 202 (the reference tabulates the same 24 values in
 // internal/sha3/rc.go:4-29), split into (hi,lo) halves.
 #define CIRCL_RC_LIST                                                                              \
@@ -148,7 +162,7 @@ CIRCL_HD void keccak_f1600(KeccakState &s, int first_round = 0) {
 // NW (a workgroup of several wavefronts, `ws` private to this one): the wave-level ordering points are not workgroup barriers
 template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop(uint64_t *ws, int lane) {
     auto sync = [] {
-        if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+        if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); wave_lds_order(); }
         else __syncthreads();
     };
     uint64_t *a = ws, *c = ws + 25, *b = ws + 30;
@@ -269,7 +283,7 @@ __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
 // its own), and its LDS instructions execute in order
 template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi, const CoopLane &c) {
     auto sync = [] {
-        if constexpr (NW) __builtin_amdgcn_wave_barrier();
+        if constexpr (NW) wave_lds_order();
         else __syncthreads();
     };
     auto ld = [](const uint64_t *p, uint32_t &lo, uint32_t &hi) { const uint64_t w = *p; lo = (uint32_t)w; hi = (uint32_t)(w >> 32); };

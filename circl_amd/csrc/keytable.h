@@ -34,6 +34,8 @@ struct circl_hip_keytable {
     // device == CIRCL_HIP_ALL_DEVICES: replica[d] is the same table built on logical device d (owned by this object)
     circl_hip_keytable **replica;
     int nreplica;
+    // circl_hip_keytable_set_coalesce: small host-buffer calls through this table join cross-caller batches (host_common.h)
+    circl::host::Coalescer *coalescer;
 };
 constexpr uint32_t kKeytableMagic = 0x4b544232u;  // "KTB2"
 
@@ -52,8 +54,13 @@ const circl_hip_keytable *keytable_here(const circl_hip_keytable *t);
 int keytable_replicate(int device, const std::function<int(int dev, circl_hip_keytable **one)> &make, circl_hip_keytable **out);
 // the host-buffer form of a table call: items [lo, lo + cnt) on the table's device -- or, with a replicated table, the batch split
 // into contiguous shards, one per device, each on that device's replica (no collective)
+// A SMALL call through a replicated table goes to ONE replica, taken round-robin: splitting a handful of items over every device
+// costs a host thread and a launch per device for no gain (and the contiguous split sent every one-item call to the last device).
+constexpr size_t kSmallTableCall = 1024;
+int next_replica(int nreplica);
 template <class F> int table_shard(const circl_hip_keytable *t, size_t n, F one) {
     if (t->device >= 0) return one(t, size_t(0), n);
+    if (n <= kSmallTableCall && t->nreplica > 0) return one(t->replica[next_replica(t->nreplica)], size_t(0), n);
     return shard(n, CIRCL_HIP_ALL_DEVICES, [&](int dev, size_t lo, size_t cnt) { return one(t->replica[dev], lo, cnt); });
 }
 }  // namespace host

@@ -168,7 +168,7 @@ template <int BOUND> CIRCL_HD void gs(int &a, int &b, uint32_t c) {
 // an exchange need neither a barrier nor an s_waitcnt -- only the compiler must keep their order.  This is the form for
 // workgroups of SEVERAL wavefronts that each work on their own buffers (mlkem_decaps_chain_kernel): no s_barrier is issued.
 template <bool NW = false> __device__ __forceinline__ void wave_sync() {
-    if constexpr (NW) __builtin_amdgcn_wave_barrier();
+    if constexpr (NW) wave_lds_order();
     else __syncthreads();
 }
 

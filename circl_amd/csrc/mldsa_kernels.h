@@ -562,7 +562,7 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&out)[4], co
 // always holds tau acceptable bytes.  `kws` = 440 B of LDS for the sponge, `blk` >= 136 B for the squeezed block.
 // NW: called from a workgroup of several wavefronts with buffers private to this wavefront (no workgroup barriers inside)
 template <bool NW> __device__ __forceinline__ void ball_sync() {
-    if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); }
+    if constexpr (NW) { __builtin_amdgcn_s_waitcnt(0); wave_lds_order(); }
     else __syncthreads();
 }
 template <int MODE, bool NW = false>
@@ -954,7 +954,7 @@ __global__ void __launch_bounds__((DP<MODE>::K + (RESIDENT ? 1 : 2)) * 64)
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     auto handoff = [] {  // what the lanes wrote to LDS (by whatever instruction) is visible to the wavefront's later reads
         __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_order();
     };
     bool bad = false;
     if (wave == K) {

@@ -1512,7 +1512,7 @@ __global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kerne
     constexpr int CTW = Gm::CT / 8;
     auto handoff = [] {  // what the lanes wrote to LDS (by whatever instruction) is visible to the wavefront's later reads
         __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_order();
     };
     bool differs = false;
     if (!RESIDENT && wave == 2) {  // the key's hash check: H(ek) against the stored hash
@@ -1698,7 +1698,7 @@ __global__ void __launch_bounds__(RESIDENT ? 64 : 128) mlkem_encaps_chain_kernel
     const uint8_t *mp = m + item * 32;
     auto handoff = [] {
         __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_order();
     };
     if (!RESIDENT && wave == 1) {  // A^T of the item's key, a stream per lane (sample_matrix for one item)
         const bool on = lane < Gm::PAIRS;
@@ -2027,7 +2027,7 @@ __global__ void __launch_bounds__(128) mlkem_keygen_chain_kernel(const uint8_t *
     uint8_t *ekp = ek + item * Gm::EK, *dkp = dk + item * Gm::DK;
     auto handoff = [] {
         __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_order();
     };
     if (wave == 0) {  // (rho, sigma) = G(d || K) (cpapke.go:72-79 with the FIPS 203 domain byte; round 3: G(d))
         const CoopLane c = coop_lane(coopw, lane);

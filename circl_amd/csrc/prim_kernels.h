@@ -23,6 +23,37 @@ __global__ void __launch_bounds__(256) keccak_f1600_kernel(uint64_t *states, siz
     for (int w = 0; w < 25; w++) p[w] = ((uint64_t)s.hi[w] << 32) | s.lo[w];
 }
 
+// ---- issue-rate probes (circl_hip_profile_valu_probe): what the chip's VALUs sustain, measured where the kernels run ---------------
+// (a) the product's own Keccak-f[1600] round (keccak_dev.h: 180 VALU instructions, V_BITOP3 / V_ALIGNBIT) `iters` times on a state that
+// stays in registers -- no memory traffic, so the time is pure issue; (b) the cheapest VALU instruction there is, a two-operand
+// integer op on VGPRs, 8 independent chains.  Launched as 256-thread workgroups, `waves_per_simd` of them per CU.
+__global__ void __launch_bounds__(256) keccak_rate_probe_kernel(uint32_t *sink, int iters) {
+    KeccakState s;
+#pragma unroll
+    for (int w = 0; w < 25; w++) { s.lo[w] = threadIdx.x * 2654435761u + w; s.hi[w] = blockIdx.x * 40503u ^ (w << 7); }
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) keccak_f1600(s, 0);
+    uint32_t x = 0;
+#pragma unroll
+    for (int w = 0; w < 25; w++) x ^= s.lo[w] ^ s.hi[w];
+    if (x == 0x12345678u) sink[0] = x;  // (never true in practice: keeps the chain alive)
+}
+constexpr int kSimpleProbePerIter = 256;  // VALU instructions per loop iteration of simple_rate_probe_kernel
+__global__ void __launch_bounds__(256) simple_rate_probe_kernel(uint32_t *sink, int iters) {
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t b = threadIdx.x * 2654435761u + blockIdx.x;
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < kSimpleProbePerIter / 8; r++)
+            asm volatile("v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+                         "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(b));
+    }
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345678u) sink[0] = a0;
+}
+
 // The wave-cooperative form of the permutation (keccak_f1600_coop: one state per wavefront, lanes 0..24 own a lane each),
 // which the ML-DSA kernels use on a rare serial path: one state per single-wave workgroup.
 __global__ void __launch_bounds__(64) keccak_f1600_coop_kernel(uint64_t *states) {

@@ -230,6 +230,13 @@ def profile_read(kernel):
     return ms.value, cnt.value
 
 
+def valu_probe(device=0, waves_per_simd=4):
+    """circl_hip_profile_valu_probe -> (Keccak-round, two-operand integer) wave-instructions per second per SIMD, measured now"""
+    k, s = C.c_double(0), C.c_double(0)
+    nat.check(nat.lib().circl_hip_profile_valu_probe(device, waves_per_simd, C.byref(k), C.byref(s)), "profile_valu_probe")
+    return k.value, s.value
+
+
 XWING, X25519MLKEM768, KYBER768_X25519, KYBER512_X25519 = 1, 2, 3, 4
 
 

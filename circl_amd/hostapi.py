@@ -314,6 +314,17 @@ class KeyTable:
         except Exception:
             pass
 
+    def set_coalesce(self, max_items, max_wait_us=0):
+        """circl_hip_keytable_set_coalesce: small calls of concurrent callers through this table share launches (0 = off)"""
+        nat.check(nat.lib().circl_hip_keytable_set_coalesce(self.handle, max_items, max_wait_us), "keytable_set_coalesce")
+
+    def coalesce_stats(self):
+        """(calls, items, launches) that went through the table's coalescer"""
+        import ctypes as C
+        c, i, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        nat.check(nat.lib().circl_hip_keytable_coalesce_stats(self.handle, C.byref(c), C.byref(i), C.byref(l)), "keytable_coalesce_stats")
+        return c.value, i.value, l.value
+
     def _kidx(self, key_idx, n):
         return None if key_idx is None else _p(_idx(key_idx, n))
 

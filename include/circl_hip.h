@@ -222,6 +222,24 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
                                      const uint64_t *d_ctx_off, uint8_t *d_ok, size_t n, void *d_workspace,
                                      size_t workspace_bytes, void *stream);
 
+/* ---- many concurrent ONE-ITEM callers: cross-caller coalescing (opt-in, per table) ------------------------------------------
+ * The reference's consumers do not batch: kem/hybrid (kem/hybrid/hybrid.go:95-99), kem/xwing (kem/xwing/xwing.go:259,288), hpke
+ * (hpke/algs.go:283-285) and every user of kem.Scheme / sign.Scheme call Encapsulate / Decapsulate / Verify with one key and one
+ * item (kem/mlkem/mlkem768/kyber.go:347-386, sign/mldsa/mldsa65/dilithium.go:305) from whichever goroutine owns the connection.
+ * One such call through a resident table costs a launch and a wait (tens of microseconds) however little the kernel does.
+ * circl_hip_keytable_set_coalesce(table, max_items, max_wait_us) lets the small host-buffer *_table calls of CONCURRENT callers
+ * (calls of at most max_items / 4 items) share launches: callers copy their rows into an open batch, the first of them flushes it
+ * as soon as the device has room for another batch -- so a batch holds exactly the calls that arrived while the previous ones ran,
+ * nothing is delayed when the table is idle -- or after max_wait_us microseconds if that is not 0; each caller returns with its own
+ * rows.  Results are byte for byte those of the same calls made one by one (same kernels; items are independent).
+ *   max_items: largest batch (2 .. 8192; 0 switches coalescing off).  Set it before the table is shared between threads (the
+ *   setter itself is not synchronised with calls in flight).  A replicated table coalesces per replica; its small calls (<= 1024
+ *   items) go to one replica each, round-robin.  circl_hip_keytable_coalesce_stats: calls and items that joined batches and the
+ *   launches they became (items / launches = mean batch).  Served today: circl_hip_mlkem_encaps_table, circl_hip_mlkem_decaps_table,
+ *   circl_hip_mldsa_verify_table. */
+int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, unsigned max_wait_us);
+int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *table, uint64_t *calls, uint64_t *items, uint64_t *launches);
+
 /* ---- PrivateKey.Public() over a batch -----------------------------------------------------------
  * circl_hip_mlkem_public_from_private: kem/mlkem/mlkem768/kyber.go:323-328 -- the encapsulation key stored inside each
  *   decapsulation key (a strided copy on the host, no device work).
@@ -520,6 +538,12 @@ int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *table, const uin
 #define CIRCL_HIP_KERNEL_COUNT 12
 int circl_hip_profile_enable(int on);
 int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
+/* The VALU issue rates this chip sustains, measured live (bench.py prices the kernels' VALU time against them instead of against
+ * figures of an earlier round): wave-instructions per second per SIMD of (a) the library's own Keccak-f[1600] round running on
+ * register-resident states (keccak_dev.h: V_BITOP3 / V_ALIGNBIT, no memory traffic) and (b) two-operand integer VALU instructions
+ * (the cheapest class), with `waves_per_simd` (1..8; the Keccak probe needs ~110 VGPRs, so at most 4 are resident) wavefronts
+ * on every SIMD of `device`.  About 10 ms of GPU time.  Either output may be NULL. */
+int circl_hip_profile_valu_probe(int device, int waves_per_simd, double *keccak_insts_per_s_per_simd, double *simple_insts_per_s_per_simd);
 
 /* pinned host memory helpers for callers that want zero-copy-speed transfers */
 void *circl_hip_alloc_host(size_t bytes);

@@ -218,6 +218,45 @@ static void xof_shapes(int device) {
     CHECK(circl_hip_keccak_f1600(st, 77, 7, device) == CIRCL_HIP_EPARAM);
 }
 
+/* go/kem/mlkem/hipbatch/keytable.go ResidentTable.SetCoalesce: eight "goroutines" each encapsulate / decapsulate ONE item per call
+ * (the shape of kem.Scheme.Encapsulate / Decapsulate, kem/mlkem/mlkem768/kyber.go:347-386) through one coalescing table */
+struct co_job { circl_hip_keytable *pub, *prv; const uint8_t *m, *ct, *ss; size_t CT, n; int id; };
+static void *co_thread(void *arg) {
+    const struct co_job *j = arg;
+    uint8_t *ct1 = slice(j->CT, 1 + (size_t)j->id), *ss1 = slice(32, 3), *ss2 = slice(32, 5);
+    for (size_t r = 0; r < 40; r++) {
+        const size_t i = ((size_t)j->id * 29 + r * 7) % j->n;
+        CHECK(circl_hip_mlkem_encaps_table(j->pub, NULL, j->m + 32 * i, ct1, ss1, NULL, 1) == 0);
+        CHECK(memcmp(ct1, j->ct + j->CT * i, j->CT) == 0 && memcmp(ss1, j->ss + 32 * i, 32) == 0);
+        CHECK(circl_hip_mlkem_decaps_table(j->prv, NULL, ct1, ss2, NULL, 1) == 0);
+        CHECK(memcmp(ss1, ss2, 32) == 0);
+    }
+    return NULL;
+}
+static void coalesced_single_calls(void) {
+    const int param = 768;
+    const size_t n = 64, EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    uint8_t *seed = slice(64, 1), *ek = slice(EK, 3), *dk = slice(DK, 5), *m = slice(32 * n, 7), *ct = slice(CT * n, 9), *ss = slice(32 * n, 11);
+    fill(seed, 64, 77);
+    fill(m, 32 * n, 78);
+    CHECK(circl_hip_mlkem_keygen(param, seed, ek, dk, 1, 0) == 0);
+    CHECK(circl_hip_mlkem_encaps_shared(param, ek, m, ct, ss, NULL, n, 0) == 0); /* the answers, from one ordinary batch call */
+    struct co_job j = {NULL, NULL, m, ct, ss, CT, n, 0};
+    CHECK(circl_hip_mlkem_keytable_new(param, 0, ek, 1, CIRCL_HIP_ALL_DEVICES, NULL, &j.pub) == 0);
+    CHECK(circl_hip_mlkem_keytable_new(param, 1, dk, 1, 0, NULL, &j.prv) == 0);
+    CHECK(circl_hip_keytable_set_coalesce(j.pub, 64, 0) == 0 && circl_hip_keytable_set_coalesce(j.prv, 64, 100) == 0);
+    CHECK(circl_hip_keytable_set_coalesce(NULL, 64, 0) == CIRCL_HIP_EPARAM);
+    pthread_t th[8];
+    struct co_job jobs[8];
+    for (int t = 0; t < 8; t++) { jobs[t] = j; jobs[t].id = t; CHECK(pthread_create(&th[t], NULL, co_thread, &jobs[t]) == 0); }
+    for (int t = 0; t < 8; t++) pthread_join(th[t], NULL);
+    uint64_t calls = 0, items = 0, launches = 0;
+    CHECK(circl_hip_keytable_coalesce_stats(j.pub, &calls, &items, &launches) == 0 && calls == 8 * 40 && items == calls && launches >= 1 && launches <= calls);
+    CHECK(circl_hip_keytable_set_coalesce(j.pub, 0, 0) == 0); /* off again */
+    circl_hip_keytable_free(j.pub);
+    circl_hip_keytable_free(j.prv);
+}
+
 int main(void) {
     CHECK(circl_hip_init() > 0);
     /* zero-length batches: nil slices become NULL pointers */
@@ -244,6 +283,7 @@ int main(void) {
     CHECK(circl_hip_xof(168, 0x1f, 24, NULL, NULL, NULL, 32, 0, 0) == 0);
     CHECK(circl_hip_keccak_f1600(NULL, 0, 24, 0) == 0);
     xof_shapes(0);
+    coalesced_single_calls();
     pthread_t th[3];
     for (intptr_t i = 0; i < 3; i++) CHECK(pthread_create(&th[i], NULL, thread_main, (void *)i) == 0);
     for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);

@@ -73,6 +73,18 @@ struct Kem {
         CHECK(circl_hip_mlkem_decaps_table(prv, idx.data(), ct_t.data(), ss3.data(), nullptr, n) == 0);
         CHECK(ss3 == ss_t);
     }
+    // many ONE-ITEM calls (and a few of two or three) through the same tables, which coalesce them across the caller threads
+    // (circl_hip_keytable_set_coalesce: batches, gates and staging rows shared between threads -- host_coalesce.hip)
+    void small_calls(int caller, int count) const {
+        uint8_t ct1[3 * 1568], ss1[3 * 32], ss2[3 * 32], st1[3];
+        for (int i = 0; i < count; i++) {
+            const size_t k = 1 + (size_t)((caller + i) % 3), at = ((size_t)caller * 131 + (size_t)i * 17) % (n - 3);
+            CHECK(circl_hip_mlkem_encaps_table(pub, &idx[at], &m[32 * at], ct1, ss1, st1, k) == 0);
+            CHECK(!memcmp(ct1, &ct_t[CT * at], CT * k) && !memcmp(ss1, &ss_t[32 * at], 32 * k));
+            CHECK(circl_hip_mlkem_decaps_table(prv, &idx[at], &ct_t[CT * at], ss2, i % 2 ? st1 : nullptr, k) == 0);
+            CHECK(!memcmp(ss2, &ss_t[32 * at], 32 * k));
+        }
+    }
     void again(int device) const {
         std::vector<uint8_t> ek2(EK * n), dk2(DK * n), ct2(CT * n), ss2(32 * n), ss3(32 * n), st2(n);
         CHECK(circl_hip_mlkem_keygen(param, seed.data(), ek2.data(), dk2.data(), n, device) == 0);
@@ -122,6 +134,14 @@ struct Dsa {
         CHECK(circl_hip_mldsa_verify_table(verifier, kidx.data(), sig2.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), ok.data(), n) == 0);
         for (size_t i = 0; i < n; i++) CHECK(ok[i] == 1);
     }
+    void small_calls(int caller, int count) const {  // one signature per call, ragged messages and contexts, through the coalescing verifier table
+        for (int i = 0; i < count; i++) {
+            const size_t at = ((size_t)caller * 37 + (size_t)i * 11) % n;
+            uint8_t ok1 = 9;
+            CHECK(circl_hip_mldsa_verify_table(verifier, &kidx[at], &sig_t[SIG * at], mblob.data(), &moff[at], cblob.data(), &coff[at], &ok1, 1) == 0);
+            CHECK(ok1 == 1);
+        }
+    }
     void again(int device) const {
         std::vector<uint8_t> sig2(SIG * n + 4), ok(n);
         CHECK(circl_hip_mldsa_sign(param, sk.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig2.data(), n, device) == 0);
@@ -165,6 +185,10 @@ int main(int argc, char **argv) {
     kem768.tables();
     Dsa dsa65(65, n_dsa), dsa44(44, 9);  // 9 items: shards below the 16-item switch of the signer, and empty shards
     dsa65.tables();
+    // small calls through these tables share launches across the caller threads (the big calls below still take the ordinary path)
+    CHECK(circl_hip_keytable_set_coalesce(kem768.pub, 16, 0) == 0);
+    CHECK(circl_hip_keytable_set_coalesce(kem768.prv, 64, 50) == 0);
+    CHECK(circl_hip_keytable_set_coalesce(dsa65.verifier, 8, 0) == 0);
     const Hyb xwing(1, n_kem / 8 + 5);
     circl_hip_profile_enable(1);  // the profiling records are shared state too
     std::atomic<int> started{0};
@@ -181,6 +205,8 @@ int main(int argc, char **argv) {
                 case 2: kem1024.again(device); xwing.again(device); break;
                 case 3: kem768.again(device); dsa44.again(device); kem768.again_tables(); break;
                 }
+                kem768.small_calls(c, 24);
+                dsa65.small_calls(c, 6);
                 // an error path in the middle of everything: the Drain guard must give its slots back
                 uint8_t junk[64] = {0};
                 CHECK(circl_hip_mlkem_encaps(768, nullptr, junk, junk, junk, junk, 1, 0) == CIRCL_HIP_EPARAM);

@@ -48,6 +48,10 @@ def test_mlkem768_roundtrip_2p20_device_resident():
     assert (ct0 == ct[idx].cpu().numpy()).all() and (ss0 == ss[idx].cpu().numpy()).all()
     ss30, _ = orc.mlkem_decaps(768, dk0, np.ascontiguousarray(ct0 ^ np.eye(1, 1088, 17, dtype=np.uint8) * 0x20))
     assert (ss30 == ss3[idx].cpu().numpy()).all()
+    # ... and the WHOLE batch once (north_star: "every ciphertext, shared secret ... is bit-exact"): all 2^20 distinct-key
+    # encapsulations against the oracle (~7 s on 16 host threads), which bench.py repeats for its headline batch
+    ct_all, ss_all, st_all = orc.mlkem_encaps(768, ek.cpu().numpy(), m.cpu().numpy())
+    assert not st_all.any() and (ct_all == ct.cpu().numpy()).all() and (ss_all == ss.cpu().numpy()).all()
 
 
 def test_mlkem1024_roundtrip_2p18():

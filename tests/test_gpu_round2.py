@@ -392,7 +392,10 @@ def test_bench_py_small_run_emits_every_config():
     out = json.loads(line)
     assert out["metric"].startswith("ML-KEM-768 encapsulations/sec") and out["steps"] == 3 and out["n_gpus"] == 1
     assert out["parity"]["bit_exact_vs_oracle"] and out["parity"]["ranks_failing"] == 0
+    # one key per item, and the WHOLE batch went through the oracle (headline and config 4)
+    assert out["config"]["key_pool"] == 1 << 14 and out["parity"]["whole_batch"] and out["parity"]["sampled_items"] == 1 << 14
     cfg = out["configs"]
+    assert cfg["config4"]["parity"]["whole_batch"]
     for k in ("decaps", "config3", "config4", "config5", "host_abi", "shared_key", "keyed"):
         assert k in cfg, k
     assert cfg["decaps"]["parity"]["bit_exact_vs_oracle"] and cfg["decaps"]["parity"]["all_items_ss_dec_equals_ss_enc"]

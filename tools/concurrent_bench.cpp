@@ -1,0 +1,170 @@
+// tools/concurrent_bench.cpp -- not a test: what MANY concurrent small callers get from one resident key table.
+//
+// The shape of every consumer of the reference's kem.Scheme / sign.Scheme (kem/hybrid/hybrid.go:95-99, hpke/algs.go:283-285,
+// kem/mlkem/mlkem768/kyber.go:347-386): T host threads, each looping calls of `items` items (default 1) through host buffers --
+// circl_hip_mlkem_encaps_table / circl_hip_mlkem_decaps_table / circl_hip_mldsa_verify_table -- closed loop (a thread issues its next
+// call when the previous one has returned, so aggregate <= T / latency: Little's law).  Every result is compared with the answer of
+// ONE ordinary batch call made beforehand (bit-exact under concurrency, whatever batches the calls ended up in).
+//
+//   concurrent_bench <op: encaps|decaps|verify> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
+//
+// Output: one line per T: aggregate ops/s, p50 / p99 / max latency of a call (us), calls per launch when coalescing.
+// Built by tools/build_tools.sh (g++ against libcirclhip.so); profiles/r05_concurrent.txt is its output on one MI355X.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "circl_hip.h"
+
+#define CHECK(c)                                                                                               \
+    do {                                                                                                       \
+        if (!(c)) {                                                                                            \
+            fprintf(stderr, "%s:%d: check failed: %s (%s)\n", __FILE__, __LINE__, #c, circl_hip_last_error()); \
+            exit(1);                                                                                           \
+        }                                                                                                      \
+    } while (0)
+
+static std::vector<uint8_t> bytes(size_t n, unsigned seed) {
+    std::vector<uint8_t> v(n + 16);
+    uint32_t x = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        v[i] = (uint8_t)(x >> 24);
+    }
+    return v;
+}
+using Clock = std::chrono::steady_clock;
+
+int main(int argc, char **argv) {
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s <encaps|decaps|verify> <coalesce max_items> <max_wait_us> <items per call> <seconds> <T> [T ...]\n", argv[0]);
+        return 2;
+    }
+    const std::string op = argv[1];
+    const size_t co_items = (size_t)atol(argv[2]);
+    const unsigned co_wait = (unsigned)atoi(argv[3]);
+    const size_t per_call = (size_t)std::max(1L, atol(argv[4]));
+    const double seconds = atof(argv[5]);
+    std::vector<int> Ts;
+    for (int a = 6; a < argc; a++) Ts.push_back(atoi(argv[a]));
+    CHECK(circl_hip_init() > 0);
+
+    // ---- the pool of work: POOL items with known answers, NK resident keys ----
+    const size_t NK = 8, POOL = 4096;
+    const int kem = 768, dsa = 65;
+    const size_t EK = circl_hip_mlkem_ek_size(kem), DK = circl_hip_mlkem_dk_size(kem), CT = circl_hip_mlkem_ct_size(kem);
+    const size_t PK = circl_hip_mldsa_pk_size(dsa), SK = circl_hip_mldsa_sk_size(dsa), SIG = circl_hip_mldsa_sig_size(dsa);
+    std::vector<uint32_t> kidx(POOL);
+    for (size_t i = 0; i < POOL; i++) kidx[i] = (uint32_t)((i * 5 + i / 7) % NK);
+    circl_hip_keytable *table = nullptr;
+    std::vector<uint8_t> m, ct, ss, st, sig, ok, mblob;
+    std::vector<uint64_t> moff;
+    const size_t MSG = 32;
+    if (op == "encaps" || op == "decaps") {
+        std::vector<uint8_t> seed = bytes(64 * NK, 1), ek(EK * NK), dk(DK * NK);
+        CHECK(circl_hip_mlkem_keygen(kem, seed.data(), ek.data(), dk.data(), NK, 0) == 0);
+        m = bytes(32 * POOL, 2);
+        ct.resize(CT * POOL); ss.resize(32 * POOL); st.resize(POOL);
+        circl_hip_keytable *pub = nullptr;
+        CHECK(circl_hip_mlkem_keytable_new(kem, 0, ek.data(), NK, 0, nullptr, &pub) == 0);
+        CHECK(circl_hip_mlkem_encaps_table(pub, kidx.data(), m.data(), ct.data(), ss.data(), st.data(), POOL) == 0);  // the reference answers
+        if (op == "encaps") table = pub;
+        else {
+            circl_hip_keytable_free(pub);
+            CHECK(circl_hip_mlkem_keytable_new(kem, 1, dk.data(), NK, 0, nullptr, &table) == 0);
+        }
+    } else if (op == "verify") {
+        std::vector<uint8_t> seed = bytes(32 * NK, 3), pk(PK * NK), sk(SK * NK);
+        CHECK(circl_hip_mldsa_keygen(dsa, seed.data(), pk.data(), sk.data(), NK, 0) == 0);
+        circl_hip_keytable *signer = nullptr;
+        CHECK(circl_hip_mldsa_privkeys_new(dsa, sk.data(), NK, 0, &signer) == 0);
+        mblob = bytes(MSG * POOL, 4);
+        moff.resize(POOL + 1);
+        for (size_t i = 0; i <= POOL; i++) moff[i] = MSG * i;
+        sig.resize(SIG * POOL + 16);
+        CHECK(circl_hip_mldsa_sign_table_keyed(signer, kidx.data(), mblob.data(), moff.data(), nullptr, nullptr, nullptr, sig.data(), POOL) == 0);
+        circl_hip_keytable_free(signer);
+        for (size_t i = 0; i < POOL; i += 5) sig[SIG * i + 40 + (i % 64)] ^= 1;  // a fifth of the signatures are bad: both verdicts occur
+        ok.resize(POOL);
+        CHECK(circl_hip_mldsa_keytable_new(dsa, pk.data(), NK, 0, &table) == 0);
+        CHECK(circl_hip_mldsa_verify_table(table, kidx.data(), sig.data(), mblob.data(), moff.data(), nullptr, nullptr, ok.data(), POOL) == 0);
+        size_t good = 0;
+        for (size_t i = 0; i < POOL; i++) good += ok[i];
+        CHECK(good == POOL - (POOL + 4) / 5);
+    } else {
+        fprintf(stderr, "unknown op %s\n", op.c_str());
+        return 2;
+    }
+    if (co_items) CHECK(circl_hip_keytable_set_coalesce(table, co_items, co_wait) == 0);
+    printf("# %s, %zu item(s) per call, %zu resident keys, coalesce max_items=%zu max_wait_us=%u, %.1f s per point\n", op.c_str(), per_call, NK, co_items,
+           co_wait, seconds);
+
+    for (int T : Ts) {
+        std::atomic<int> started{0};
+        std::atomic<bool> stop{false};
+        std::vector<std::vector<float>> lat(T);
+        std::vector<uint64_t> calls(T, 0);
+        std::atomic<uint64_t> mismatches{0};
+        uint64_t c0 = 0, i0 = 0, l0 = 0;
+        circl_hip_keytable_coalesce_stats(table, &c0, &i0, &l0);
+        std::vector<std::thread> th;
+        Clock::time_point t_begin;
+        for (int t = 0; t < T; t++) {
+            th.emplace_back([&, t] {
+                std::vector<uint8_t> o_ct(CT * per_call), o_ss(32 * per_call), o_st(per_call), o_ok(per_call);
+                std::vector<uint64_t> off(per_call + 1);
+                lat[t].reserve(1 << 16);
+                size_t at = ((size_t)t * 997) % (POOL - per_call);
+                started.fetch_add(1);
+                while (started.load() < T + 1) std::this_thread::yield();
+                while (!stop.load(std::memory_order_relaxed)) {
+                    const auto a = Clock::now();
+                    bool good = true;
+                    if (op == "encaps") {
+                        CHECK(circl_hip_mlkem_encaps_table(table, &kidx[at], &m[32 * at], o_ct.data(), o_ss.data(), o_st.data(), per_call) == 0);
+                        good = !memcmp(o_ct.data(), &ct[CT * at], CT * per_call) && !memcmp(o_ss.data(), &ss[32 * at], 32 * per_call);
+                    } else if (op == "decaps") {
+                        CHECK(circl_hip_mlkem_decaps_table(table, &kidx[at], &ct[CT * at], o_ss.data(), o_st.data(), per_call) == 0);
+                        good = !memcmp(o_ss.data(), &ss[32 * at], 32 * per_call);
+                    } else {
+                        CHECK(circl_hip_mldsa_verify_table(table, &kidx[at], &sig[SIG * at], mblob.data(), &moff[at], nullptr, nullptr, o_ok.data(), per_call) == 0);
+                        good = !memcmp(o_ok.data(), &ok[at], per_call);
+                    }
+                    const auto b = Clock::now();
+                    if (!good) mismatches.fetch_add(1);
+                    if (lat[t].size() < lat[t].capacity() || (calls[t] & 15) == 0) lat[t].push_back(std::chrono::duration<float, std::micro>(b - a).count());
+                    calls[t]++;
+                    at = (at + per_call * 131 + 1) % (POOL - per_call);
+                }
+            });
+        }
+        while (started.load() < T) std::this_thread::yield();
+        t_begin = Clock::now();
+        started.fetch_add(1);
+        std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+        stop.store(true);
+        for (auto &x : th) x.join();
+        const double el = std::chrono::duration<double>(Clock::now() - t_begin).count();
+        uint64_t total = 0;
+        std::vector<float> all;
+        for (int t = 0; t < T; t++) { total += calls[t]; all.insert(all.end(), lat[t].begin(), lat[t].end()); }
+        std::sort(all.begin(), all.end());
+        auto q = [&](double f) { return all.empty() ? 0.f : all[std::min(all.size() - 1, (size_t)(f * all.size()))]; };
+        uint64_t c1 = 0, i1 = 0, l1 = 0;
+        circl_hip_keytable_coalesce_stats(table, &c1, &i1, &l1);
+        printf("T=%-4d %10.0f ops/s  (%8.0f calls/s)  latency us p50 %7.1f  p99 %7.1f  max %8.1f", T, total * per_call / el, total / el, q(0.50), q(0.99),
+               all.empty() ? 0.f : all.back());
+        if (l1 > l0) printf("  | %.1f calls, %.1f items per launch", (double)(c1 - c0) / (l1 - l0), (double)(i1 - i0) / (l1 - l0));
+        printf("  mismatches %llu\n", (unsigned long long)mismatches.load());
+        fflush(stdout);
+        CHECK(mismatches.load() == 0);
+    }
+    circl_hip_keytable_free(table);
+    return 0;
+}
