@@ -162,6 +162,9 @@ size_t circl_hip_hybrid_workspace_size(int scheme, size_t n) {
     if (!desc_of(scheme, d)) return 0;
     return tmp_bytes(d, n) + circl_hip_mlkem_workspace_size(d.param, n);
 }
+// what a call cannot do without: the ML-KEM half then takes its scratch routes (no row cache: 256 MB less for a chunk of 2^16 items).
+// The _dev entry points accept this much; circl_hip_hybrid_workspace_size stays what callers are told to bring.
+static size_t hybrid_ws_min(const Desc &d, size_t n) { return tmp_bytes(d, n) + mlkem_ws_min_bytes(n); }
 
 int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk, uint8_t *d_sk, size_t n, void *d_ws, size_t ws_bytes, void *stream) {
     Desc d;
@@ -169,7 +172,7 @@ int circl_hip_hybrid_keygen_dev(int scheme, const uint8_t *d_seed, uint8_t *d_pk
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_seed || !d_pk || !d_sk || !d_ws) return CIRCL_HIP_EPARAM;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < hybrid_ws_min(d, n)) return CIRCL_HIP_EWORKSPACE;
     if (!args_ok(d_seed, d_pk, d_sk, nullptr, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
@@ -205,7 +208,7 @@ int circl_hip_hybrid_encaps_dev(int scheme, const uint8_t *d_pk, const uint8_t *
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || !d_pk || !d_eseed || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < hybrid_ws_min(d, n)) return CIRCL_HIP_EWORKSPACE;
     if (!args_ok(d_pk, d_eseed, d_ct, d_ss, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
@@ -252,7 +255,7 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
     if (ndev() <= 0) return CIRCL_HIP_ENODEV;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || !d_sk || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < hybrid_ws_min(d, n)) return CIRCL_HIP_EWORKSPACE;
     if (!args_ok(d_sk, d_ct, d_ss, nullptr, d_ws)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
@@ -320,6 +323,17 @@ static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, 
     // the lattice halves, contiguous on the host, for the inner ML-KEM table
     const size_t KROW = private_keys ? d.DK : d.EK;
     std::vector<uint8_t> krows, xrows(nkeys * 32);
+    // X-Wing private keys: the expanded decapsulation keys come back from the device into PAGE-LOCKED memory of the library's own (a
+    // copy into pageable memory would bounce through the runtime's staging, which nobody wipes) and go from there into the inner table
+    struct Pinned {
+        uint8_t *p = nullptr; size_t bytes = 0;
+        ~Pinned() {
+            if (!p) return;
+            volatile uint8_t *z = p;
+            for (size_t i = 0; i < bytes; i++) z[i] = 0;
+            (void)hipHostFree(p);
+        }
+    } kpin;
     int rc = CIRCL_HIP_OK;
     if (hipMalloc(reinterpret_cast<void **>(&t->d_x), t->x_bytes) != hipSuccess) { (void)hipGetLastError(); rc = CIRCL_HIP_ENOMEM; }
     if (rc == CIRCL_HIP_OK && private_keys && d.xwing) {
@@ -332,18 +346,19 @@ static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, 
             Carve c{tmp.p};
             uint8_t *seed = c.take(nkeys * 32), *seedm = c.take(nkeys * 64), *ek = c.take(nkeys * d.EK), *dk = c.take(nkeys * d.DK), *kws = c.p;
             uint8_t *skx = t->d_x, *pkx = t->d_x + nkeys * 32;
-            krows.resize(nkeys * d.DK);
+            kpin.bytes = nkeys * d.DK;
+            if (hipHostMalloc(reinterpret_cast<void **>(&kpin.p), kpin.bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); kpin.p = nullptr; rc = CIRCL_HIP_ENOMEM; }
             auto build = [&]() -> int {
                 TRY(upload_secret(seed, keys, nkeys * 32, st));  // (the seeds ARE the private keys)
                 hipLaunchKernelGGL(hk::xwing_expand_kernel, g256(nkeys), dim3(256), 0, st, w(seed), w(seedm), w(skx), nkeys);
                 HIP_TRY(hipGetLastError());
                 TRY(kem_keygen(d, seedm, ek, dk, nkeys, kws, ws_bytes, st));
                 TRY(circl_hip_x25519_dev(skx, nullptr, pkx, nullptr, nkeys, st));
-                HIP_TRY(hipMemcpyAsync(krows.data(), dk, nkeys * d.DK, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(kpin.p, dk, nkeys * d.DK, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 return CIRCL_HIP_OK;
             };
-            rc = build();
+            if (rc == CIRCL_HIP_OK) rc = build();
         }
     } else if (rc == CIRCL_HIP_OK) {
         krows.resize(nkeys * KROW);
@@ -359,7 +374,7 @@ static int hybrid_keytable_new_one(int scheme, const Desc &d, int private_keys, 
             rc = CIRCL_HIP_EHIP;
         }
     }
-    if (rc == CIRCL_HIP_OK) rc = circl_hip_mlkem_keytable_new(d.param, private_keys ? 1 : 0, krows.data(), nkeys, device, key_status, &t->inner);
+    if (rc == CIRCL_HIP_OK) rc = circl_hip_mlkem_keytable_new(d.param, private_keys ? 1 : 0, kpin.p ? kpin.p : krows.data(), nkeys, device, key_status, &t->inner);
     if (private_keys) {  // the host copies of the private rows do not outlive the build
         volatile uint8_t *z = krows.data();
         for (size_t i = 0; i < krows.size(); i++) z[i] = 0;
@@ -390,7 +405,7 @@ int circl_hip_hybrid_encaps_table_dev(const circl_hip_keytable *t, const uint32_
     if (!desc_of(t->scheme, d)) return CIRCL_HIP_EPARAM;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || !d_eseed || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(t->scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < hybrid_ws_min(d, n)) return CIRCL_HIP_EWORKSPACE;
     if (!args_ok(d_eseed, d_ct, d_ss, nullptr, d_ws) || (reinterpret_cast<uintptr_t>(d_key_idx) & 3)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
@@ -434,7 +449,7 @@ int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *t, const uint32_
     if (!desc_of(t->scheme, d)) return CIRCL_HIP_EPARAM;
     if (n == 0) return CIRCL_HIP_OK;
     if (!d_status || !d_ct || !d_ss || !d_ws) return CIRCL_HIP_EPARAM;
-    if (ws_bytes < circl_hip_hybrid_workspace_size(t->scheme, n)) return CIRCL_HIP_EWORKSPACE;
+    if (ws_bytes < hybrid_ws_min(d, n)) return CIRCL_HIP_EWORKSPACE;
     if (!args_ok(d_ct, d_ss, nullptr, nullptr, d_ws) || (reinterpret_cast<uintptr_t>(d_key_idx) & 3)) return misaligned();
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carve c{static_cast<uint8_t *>(d_ws)};
@@ -465,12 +480,27 @@ int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *t, const uint32_
 }
 
 // ---- host-buffer forms on the staging pipeline ----
-static PipeOpts hybrid_opts() {
+// Every chunk wipes what is secret in its device staging: the secret inputs / outputs (flagged per array), this file's own rows (seeds,
+// dk, scalars, halves of shared secrets: all of tmp_bytes) and the per-item slots at the head of the ML-KEM workspace behind them -- not
+// the matrix scratch and the row cache further back, which are public (a whole-slot memset was several hundred MB per chunk).
+static PipeOpts hybrid_opts(int scheme) {
     PipeOpts o;
     o.chunk_items = host_chunk_items(size_t(1) << 16);  // 2 x 1024 ladder waves per launch: a ladder is 0.9 ms however few items
     o.depth = 3;  // measured (tools/hybrid_bench.py 20 host): 2.8e7 X-Wing encapsulations/s at 3, 2.4e7 at 4 or 6, 2.1e7 at 2
     o.wipe_device = true;
+    o.ws_secret_bytes = [scheme](size_t cnt) {
+        Desc d;
+        return desc_of(scheme, d) ? tmp_bytes(d, cnt) + mlkem_ws_secret_bytes(cnt) : size_t(0);
+    };
     return o;
+}
+// (a chunk beyond 2^13 items is PCIe-bound whichever ML-KEM route it takes: it gets the workspace of the scratch routes)
+static std::function<size_t(size_t)> hybrid_ws_fn(int scheme) {
+    return [scheme](size_t k) {
+        Desc d;
+        if (!desc_of(scheme, d)) return size_t(0);
+        return k <= (size_t(1) << 13) ? circl_hip_hybrid_workspace_size(scheme, k) : hybrid_ws_min(d, k);
+    };
 }
 
 int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_t *sk, size_t n, int device) {
@@ -479,7 +509,7 @@ int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_
     if (n && (!seed || !pk || !sk)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{seed + lo * s.seed, s.seed, true}}, {}, {{pk + lo * s.pk, s.pk}, {sk + lo * s.sk, s.sk, true}},
-                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(),
+                            hybrid_ws_fn(scheme), hybrid_opts(scheme),
                             [&](Chunk &c) { return circl_hip_hybrid_keygen_dev(scheme, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
     });
 }
@@ -491,7 +521,7 @@ int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed,
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}}, {},
                             {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
                                 return circl_hip_hybrid_encaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -504,7 +534,7 @@ int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, ui
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
         return run_pipeline(dev, cnt, {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}}, {},
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
                                 return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
@@ -529,7 +559,7 @@ int circl_hip_hybrid_encaps_table(const circl_hip_keytable *t, const uint32_t *k
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {eseed + lo * s.eseed, s.eseed, true}}, {},
                             {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
                                 return circl_hip_hybrid_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                          c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
@@ -547,7 +577,7 @@ int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *k
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * s.ct, s.ct}}, {},
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            [&](size_t k) { return circl_hip_hybrid_workspace_size(scheme, k); }, hybrid_opts(), [&](Chunk &c) {
+                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
                                 return circl_hip_hybrid_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                          c.cnt, c.ws, c.ws_bytes, c.st);
                             });

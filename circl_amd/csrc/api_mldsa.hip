@@ -157,7 +157,9 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
-    if ((KM == KM_ITEM || KM == KM_SHARED) && n <= dsa_chain_batch(false, DP<MODE>::K)) {
+    // (the route writes item t's rows into scratch slice t / IT: only while the workspace holds a slice per IT items -- a
+    // CIRCL_HIP_DSA_CHAIN_ITEM beyond the slices the workspace guarantees falls through to the scratch routes)
+    if ((KM == KM_ITEM || KM == KM_SHARED) && n <= dsa_chain_batch(false, DP<MODE>::K) && mldsa_groups<MODE>(n) <= mldsa_scratch_blocks<MODE>(n)) {
         // every item under its own, unparsed key (or all under ONE unparsed key: stride 0), a small batch: the same kernel with tr and
         // the matrix expansion inside the workgroup (the rows of item t in its part of scratch slice t / IT: the workspace holds a
         // slice per IT items at these sizes)
@@ -464,6 +466,15 @@ template <int MODE> size_t mldsa_sign_ws_bytes(size_t n) {
 thread_local const circl_hip_keytable *tl_sign_prepared = nullptr;
 // ... and, for a table of SEVERAL prepared keys, the device array that names every item's entry (nullptr: entry 0)
 thread_local const uint32_t *tl_sign_key_idx = nullptr;
+// The host-buffer signing entry points have checked every context on the host (check_contexts == CTX_OK) before anything reaches the
+// device: no item can be "dead" (mldsa_sign_prep_kernel), so the launch that zeroes dead items' signatures is not enqueued.  Set for the
+// length of the _dev call by the host path's launch callback, on the thread that makes it.
+thread_local bool tl_sign_ctx_ok = false;
+struct SignCtxOk {
+    bool prev;
+    SignCtxOk() : prev(tl_sign_ctx_ok) { tl_sign_ctx_ok = true; }
+    ~SignCtxOk() { tl_sign_ctx_ok = prev; }
+};
 
 template <int MODE>
 int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob,
@@ -531,13 +542,18 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
                                                           ctx_off, DP<MODE>::NIST ? internal : 1, S.mr, 128, lctl, n, st))
             return rc;
-        hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                           S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
+        // (a prepared key: the prep kernel also sets up the round signer's lists -- sign_secrets_kernel has nothing else to do then)
+        if (prep)
+            hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
+                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx, S.attempts, S.best, S.list[0], S.count, k0);
+        else
+            hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
+                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
     }
-    {
+    if (!prep) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         const size_t nkeys = shared ? 1 : n;
-        if (!prep) hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
+        hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nkeys * K * L + 255) / 256)), dim3(256), 0, st, sk, S, nkeys);
         hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)n), dim3(64), 0, st, sk, S, n, k0);
     }
     // grids: the kernels loop over the device-side count, so any grid is correct; the schedule's upper estimate of a
@@ -561,7 +577,11 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         if (coop_mask) hipLaunchKernelGGL(sign_mask_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (upper * L + 1) / 2)), dim3(64), 0, st, S, cur);
         else if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
-        hipLaunchKernelGGL(sign_w_kernel<MODE>, dim3(gw), dim3(64), 0, st, S, cur);
+        // long rounds (the list is longer than the speculation threshold and pairs are off: one entry per item) take the form of the w
+        // kernel without the paired path: 4 wavefronts per SIMD for L = 7 instead of 3 (CIRCL_HIP_SIGN_W_SINGLES=0: always the general form)
+        static const bool w_singles = env_int("CIRCL_HIP_SIGN_W_SINGLES", 1, 0, 1) != 0;
+        if (w_singles && !S.pair && upper > S.spec_target) hipLaunchKernelGGL((sign_w_kernel<MODE, false>), dim3(gw), dim3(64), 0, st, S, cur);
+        else hipLaunchKernelGGL((sign_w_kernel<MODE, true>), dim3(gw), dim3(64), 0, st, S, cur);
         if (coop_ch) hipLaunchKernelGGL(sign_challenge_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (pass0 + 1) / 2)), dim3(64), 0, st, S, cur, 0);
         else if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);
         else hipLaunchKernelGGL((sign_challenge_kernel<MODE, false>), dim3(g256(pass0)), dim3(256), 0, st, S, cur, 0);
@@ -583,7 +603,10 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>(lay.tail_units, 512)), dim3(64), SG<MODE>::LDS_TOTAL, st, sk,
                            (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[fin], (const uint32_t *)S.attempts, (size_t)0, 1u,
                            (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin), key_idx);
-        hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
+        // (an item is dead only when it brings a context the scheme refuses: impossible without contexts, for the internal form, and
+        // after the host path's own check)
+        if (ctx_blob && !internal && !tl_sign_ctx_ok)
+            hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }
     // The workspace held rho'', the NTT-domain secrets, the accepted attempts' y next to c~ (z - y = c s1) and parked
     // signatures: nothing key-equivalent stays behind in the caller's workspace (the matrix rows are public).
@@ -684,7 +707,8 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0,
                            (const uint32_t *)nullptr, key_idx);
-        hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
+        if (ctx_blob && !internal && !tl_sign_ctx_ok)
+            hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }
     HIP_TRY(hipMemsetAsync(mr, 0, up256(128 * n), st));  // rho'' and the NTT-domain secrets do not stay behind
     HIP_TRY(hipMemsetAsync(scratch, 0, std::min<size_t>(n, lay.tail_units) * S::SCRATCH_BYTES, st));
@@ -751,6 +775,7 @@ int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const
         ins.push_back(rnd ? HIn{rnd + lo * 32, 32, true} : HIn{zeros.data(), zeros.size(), false, true});
         return run_pipeline(dev, cnt, ins, {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{sig + lo * SIG, SIG}},
                             [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
+                                SignCtxOk checked;  // (check_contexts above)
                                 return mldsa_sign_dev_any(param, c.in[0], c.blob[0], c.off[0], c.blob[1], c.off[1], c.in[1], internal, c.out[0], c.cnt, c.ws,
                                                           c.ws_bytes, c.st, shared);
                             });
@@ -954,11 +979,22 @@ int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *t, const uint32_t
     if (!rnd) zeros.assign(32 * std::min(n, opts.chunk_items), 0);  // deterministic signing: 32 zero bytes per item
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (absent rnd / key_idx: zeros)
+            const int rc = coalesce_run(r->coalescer, cnt, {{rnd ? rnd + lo * 32 : nullptr, size_t(32), true}, {reinterpret_cast<const uint8_t *>(ki), size_t(4)}},
+                                        {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{sig + lo * SIG, SIG}},
+                                        [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
+                                            SignCtxOk checked;  // (every caller of the batch passed check_contexts)
+                                            return circl_hip_mldsa_sign_table_keyed_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.blob[0], c.off[0], c.blob[1],
+                                                                                        c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         std::vector<HIn> ins;
         ins.push_back(rnd ? HIn{rnd + lo * 32, 32, true} : HIn{zeros.data(), zeros.size(), false, true});
         ins.push_back(HIn{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)});
         return run_pipeline(r->device, cnt, ins, {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{sig + lo * SIG, SIG}},
                             [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
+                                SignCtxOk checked;  // (check_contexts above)
                                 return circl_hip_mldsa_sign_table_keyed_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.blob[0], c.off[0], c.blob[1],
                                                                             c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
                             });

@@ -641,6 +641,15 @@ bool kem_table_ok(const circl_hip_keytable *t, int want_private) {
 
 }  // namespace
 
+// for the hybrid KEMs' host pipeline (api_hybrid.hip), which carries an ML-KEM workspace behind its own rows: the smallest workspace a
+// chunk of n items can run in (the scratch routes: no 8 KB-per-item row cache) and how much of a workspace's head is secret
+namespace circl {
+namespace host {
+size_t mlkem_ws_min_bytes(size_t n) { return kem_ws_min(n); }
+size_t mlkem_ws_secret_bytes(size_t n) { return up256(kKemWsPerItem * n); }
+}  // namespace host
+}  // namespace circl
+
 // =============================================================================================
 extern "C" {
 

@@ -21,7 +21,6 @@
 
 #include <immintrin.h>
 #include <linux/futex.h>
-#include <sched.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -38,16 +37,22 @@ long futex_op(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec 
     return syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), op | FUTEX_PRIVATE_FLAG, val, ts, nullptr, 0);
 }
 
+// The lock around a reservation (tens of nanoseconds held): spins a few dozen times, then SLEEPS on its word -- callers may outnumber
+// the CPUs the process may use by far (a container's CPU quota: threads that spin or yield there burn the quota of the threads that
+// hold the lock or run the launch; measured, profiles/r05_concurrent.txt).  0 free, 1 held, 2 held with sleepers (Drepper's mutex).
 struct SpinLock {
-    std::atomic<bool> held{false};
+    std::atomic<uint32_t> word{0};
     void lock() {
-        for (int spins = 0;; spins++) {
-            if (!held.load(std::memory_order_relaxed) && !held.exchange(true, std::memory_order_acquire)) return;
-            if (spins < 128) _mm_pause();
-            else sched_yield();  // the holder was descheduled: more callers than CPUs
+        for (int spins = 0; spins < 64; spins++) {
+            uint32_t z = 0;
+            if (word.load(std::memory_order_relaxed) == 0 && word.compare_exchange_weak(z, 1, std::memory_order_acquire)) return;
+            _mm_pause();
         }
+        while (word.exchange(2, std::memory_order_acquire) != 0) futex_op(&word, FUTEX_WAIT, 2);
     }
-    void unlock() { held.store(false, std::memory_order_release); }
+    void unlock() {
+        if (word.exchange(0, std::memory_order_release) == 2) futex_op(&word, FUTEX_WAKE, 1);
+    }
 };
 
 // One-shot gate: wait() returns once open() was called.  Sleepers are woken as a tree.
@@ -92,6 +97,7 @@ struct CoBatch {
     uint8_t *hin = nullptr, *hout = nullptr, *d = nullptr;
     uint8_t *hin_dev = nullptr, *hout_dev = nullptr;
     hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;  // blocking-sync event (the leader sleeps until the batch is done instead of polling the stream)
 };
 
 }  // namespace
@@ -102,6 +108,7 @@ struct Coalescer {
     unsigned max_wait_us = 0;
     int inflight_max = 2;
     int spin = 0;  // gate spins before sleeping (0 when callers may outnumber the CPUs)
+    bool blocking = false;  // the leader sleeps on an interrupt-driven event instead of hipStreamSynchronize's polling
 
     SpinLock lock;
     std::atomic<uint32_t> seq{0};  // bumped whenever something a leader / a caller without a batch waits for has changed
@@ -175,6 +182,7 @@ int lay_out(Coalescer *co, const std::vector<HIn> &ins, const std::vector<HBlob>
         b->hout_dev = pinned_device_ptr(b->hout);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d), co->d_bytes));
         HIP_TRY(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
+        if (co->blocking) HIP_TRY(hipEventCreateWithFlags(&b->ev, hipEventBlockingSync | hipEventDisableTiming));
     }
     return CIRCL_HIP_OK;
 }
@@ -257,7 +265,14 @@ void flush(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_by
     };
     g_err.clear();
     int rc = run();
-    if (hipStreamSynchronize(b->st) != hipSuccess && rc == CIRCL_HIP_OK) {
+    hipError_t se = hipSuccess;
+    if (b->ev) {
+        se = hipEventRecord(b->ev, b->st);
+        if (se == hipSuccess) se = hipEventSynchronize(b->ev);
+    } else {
+        se = hipStreamSynchronize(b->st);
+    }
+    if (se != hipSuccess && rc == CIRCL_HIP_OK) {
         rc = CIRCL_HIP_EHIP;
         g_err = "coalesced batch: hipStreamSynchronize failed";
         (void)hipGetLastError();
@@ -307,6 +322,7 @@ Coalescer *coalescer_new(int dev, size_t max_items, unsigned max_wait_us) {
     co->max_wait_us = std::min(max_wait_us, 100000u);
     co->inflight_max = env_int("CIRCL_HIP_COALESCE_INFLIGHT", 2, 1, 8);
     co->spin = env_int("CIRCL_HIP_COALESCE_SPIN", 0, 0, 1 << 20);
+    co->blocking = env_int("CIRCL_HIP_COALESCE_BLOCKING", 0, 0, 1) != 0;
     return co;
 }
 void coalescer_free(Coalescer *co) {
@@ -315,6 +331,7 @@ void coalescer_free(Coalescer *co) {
     if (!co->batches.empty() && hipSetDevice(physical_device(co->dev)) == hipSuccess) {
         for (CoBatch *b : co->batches) {
             if (b->st) { (void)hipStreamSynchronize(b->st); (void)hipStreamDestroy(b->st); }
+            if (b->ev) (void)hipEventDestroy(b->ev);
             if (b->hin) { memset(b->hin, 0, co->hin_bytes); (void)pinned_free(b->hin); }
             if (b->hout) { memset(b->hout, 0, co->hout_bytes); (void)pinned_free(b->hout); }
             if (b->d) (void)hipFree(b->d);
@@ -447,7 +464,7 @@ using namespace circl::host;
 
 extern "C" {
 
-int circl_hip_keytable_set_coalesce(circl_hip_keytable *t, size_t max_items, unsigned max_wait_us) {
+int circl_hip_keytable_set_coalesce(circl_hip_keytable *t, size_t max_items, uint32_t max_wait_us) {
     if (!t || t->magic != kKeytableMagic) return CIRCL_HIP_EPARAM;
     if (t->device < 0) {  // a replicated table: every replica batches the small calls routed to it
         for (int d = 0; d < t->nreplica; d++)

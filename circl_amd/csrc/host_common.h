@@ -203,6 +203,10 @@ int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size
 int aux_streams(int dev, hipStream_t (&s)[2]);
 int pipeline_streams(int dev, hipStream_t *h2d, hipStream_t *d2h, hipStream_t *compute);  // the device's shared copy / compute streams
 
+// api_mlkem.hip: the smallest ML-KEM workspace for n items (scratch routes only) and the secret prefix of any ML-KEM workspace
+size_t mlkem_ws_min_bytes(size_t n);
+size_t mlkem_ws_secret_bytes(size_t n);
+
 // api_x25519.hip: both X25519 ladders of a hybrid KEM operation (base point and peer point, same scalar) in one launch
 int x25519_pair_dev(const uint8_t *d_scalar, const uint8_t *d_point, uint8_t *d_out_base, uint8_t *d_out_shared, uint8_t *d_ok, size_t n,
                     hipStream_t st);

@@ -433,28 +433,39 @@ int max_slots() {
 }
 }  // namespace
 
+namespace {
+// what the staging pools of all devices hold right now (circl_hip_host_pool_stats: sizing a node's host memory)
+std::atomic<long long> g_pool_pinned{0}, g_pool_device{0};
+std::atomic<int> g_pool_slots{0};
+}  // namespace
 int Slot::ensure(size_t d_bytes, size_t hin_bytes, size_t hout_bytes) {
     if (d_bytes > d_cap) {
         if (d) HIP_TRY(hipFree(d));  // (a slot is idle whenever it is resized: its last chunk was retired)
+        g_pool_device -= (long long)d_cap;
         d = nullptr; d_cap = 0;
         const size_t want = up256(d_bytes + d_bytes / 8);  // a little head-room: ragged chunks differ in size
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), want));
         d_cap = want;
+        g_pool_device += (long long)want;
     }
     if (hin_bytes > hin_cap) {
         if (hin) HIP_TRY(pinned_free(hin));
+        g_pool_pinned -= (long long)hin_cap;
         hin = nullptr; hin_cap = 0;
         const size_t want = up256(hin_bytes + hin_bytes / 8);
         HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hin), want));
         hin_cap = want;
+        g_pool_pinned += (long long)want;
         hin_dev = pinned_device_ptr(hin);
     }
     if (hout_bytes > hout_cap) {
         if (hout) HIP_TRY(pinned_free(hout));
+        g_pool_pinned -= (long long)hout_cap;
         hout = nullptr; hout_cap = 0;
         const size_t want = up256(hout_bytes + hout_bytes / 8);
         HIP_TRY(pinned_alloc(reinterpret_cast<void **>(&hout), want));
         hout_cap = want;
+        g_pool_pinned += (long long)want;
         hout_dev = pinned_device_ptr(hout);
     }
     return CIRCL_HIP_OK;
@@ -477,6 +488,7 @@ Slot *slot_acquire(int dev, bool block) {
     }
     Slot *s = new Slot;
     s->dev = dev;
+    g_pool_slots++;
     if (hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming) != hipSuccess) {
@@ -485,6 +497,7 @@ Slot *slot_acquire(int dev, bool block) {
         for (hipEvent_t e : {s->done, s->ev_in, s->ev_k})
             if (e) (void)hipEventDestroy(e);
         delete s;
+        g_pool_slots--;
         std::lock_guard<std::mutex> lk(p->mu);
         p->created--;
         p->cv.notify_one();
@@ -946,6 +959,13 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
 int circl_hip_keytable_device(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->device : CIRCL_HIP_ENODEV; }
 size_t circl_hip_keytable_nkeys(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->nkeys : 0; }
 const circl_hip_keytable *circl_hip_keytable_on_device(const circl_hip_keytable *t, int device) { return circl::host::keytable_on(t, device); }
+
+int circl_hip_host_pool_stats(int *slots, uint64_t *pinned_bytes, uint64_t *device_bytes) {
+    if (slots) *slots = g_pool_slots.load();
+    if (pinned_bytes) *pinned_bytes = (uint64_t)std::max<long long>(0, g_pool_pinned.load());
+    if (device_bytes) *device_bytes = (uint64_t)std::max<long long>(0, g_pool_device.load());
+    return CIRCL_HIP_OK;
+}
 
 void *circl_hip_alloc_host(size_t bytes) {
     void *p = nullptr;

@@ -1474,13 +1474,23 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
                                                               int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key,
                                                               uint8_t *__restrict__ dead_ws, const LongCtl *__restrict__ long_ctl,
-                                                              const uint32_t *__restrict__ key_idx) {
+                                                              const uint32_t *__restrict__ key_idx, uint32_t *__restrict__ rl_attempts = nullptr,
+                                                              uint32_t *__restrict__ rl_best = nullptr, uint32_t *__restrict__ rl_list0 = nullptr,
+                                                              uint32_t *__restrict__ rl_ctl = nullptr, unsigned rl_k0 = 1) {
     using Kg = KG<MODE>;
     using P = DP<MODE>;
     __shared__ uint32_t stage_lds[256 * kStageStride];
     uint32_t *stage = stage_lds + threadIdx.x * kStageStride;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    if (rl_attempts) {
+        // PREPARED keys (a key table brings A and the transformed secrets): nothing is left of sign_secrets_kernel but the set-up of the
+        // round signer's lists and control words (mldsa_sign_batched.h), done here -- one launch less in front of the first round
+        rl_attempts[idx] = 0;
+        rl_best[idx] = 0xffffffffu;                                                       // kNoSuccess
+        for (unsigned o = 0; o < rl_k0; o++) rl_list0[idx * rl_k0 + o] = (uint32_t)idx | (o << 26);  // item | off << kEntryShift
+        if (idx == 0) { rl_ctl[0] = (uint32_t)(n * rl_k0); rl_ctl[1] = 0; rl_ctl[2] = rl_k0; rl_ctl[3] = 1; }  // count[0..1], kk[0..1]
+    }
     {
         // sign.ErrContextTooLong (mldsa65/dilithium.go:63-65) / sign.ErrContextNotSupported (round 3): the host-buffer entry
         // points refuse such a batch up front; device-resident callers get an all-zero signature for the item

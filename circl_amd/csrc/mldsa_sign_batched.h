@@ -76,7 +76,7 @@ struct SignState {          // device pointers into the workspace, passed by val
 };
 
 constexpr uint32_t kNoSuccess = 0xffffffffu;
-constexpr int kEntryShift = 26;
+constexpr int kEntryShift = 26;  // (mldsa_sign_prep_kernel, which sets the lists up for prepared keys, spells the 26 out)
 constexpr uint32_t kEntryItemMask = (1u << kEntryShift) - 1;
 constexpr unsigned kMaxSpec = 64;  // 6 bits of `off`
 // Small and medium batches speculate widely: a round is four dependent Keccak-latency launches (~250 us) whatever its length, so a
@@ -474,12 +474,16 @@ __device__ __forceinline__ void sign_w_entries(const SignState &st, size_t slot,
     }
     __syncthreads();  // the exchange buffers are reused by the next entry
 }
-template <int MODE>
-__global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
+// PAIRS = false: the form for the LONG rounds, whose lists hold one entry per item (the host knows from its schedule; a pair that turns
+// up anyway is two single entries: same bytes).  Without the paired path the kernel needs neither its registers nor the 2 L rows of
+// parked y-hat: ML-DSA-87 / Dilithium5 (L = 7) run 4 wavefronts per SIMD instead of 3 -- the general kernel is held at 3 both by its
+// 155 VGPRs and by 13 KB of LDS per wavefront (profiles/r05_sign_ab.txt).
+template <int MODE, bool PAIRS = true>
+__global__ void __launch_bounds__(64, (PAIRS && DP<MODE>::L > 5) ? 3 : 4) sign_w_kernel(SignState st, int cur) {
     constexpr int L = DP<MODE>::L;
     __shared__ __attribute__((aligned(16))) uint32_t xch0[dilithium::kXchWords];
     __shared__ __attribute__((aligned(16))) uint32_t xch1[dilithium::kXchWords];
-    __shared__ __attribute__((aligned(16))) uint32_t yl[2 * L * kPackedRowDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t yl[PAIRS ? 2 * L * kPackedRowDwords : 4];
     const int lane = threadIdx.x;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const size_t count = st.count[cur];
@@ -488,8 +492,8 @@ __global__ void __launch_bounds__(64, 4) sign_w_kernel(SignState st, int cur) {
         const size_t item0 = st.list[cur][s0] & kEntryItemMask;
         const bool two = s0 + 1 < count;
         const size_t item1 = two ? (size_t)(st.list[cur][s0 + 1] & kEntryItemMask) : item0;
-        if (two && item1 == item0) {
-            sign_w_entries<MODE, 2>(st, s0, item0, xch0, xch1, yl, z, lane);
+        if (PAIRS && two && item1 == item0) {
+            if constexpr (PAIRS) sign_w_entries<MODE, 2>(st, s0, item0, xch0, xch1, yl, z, lane);
         } else {
             sign_w_entries<MODE, 1>(st, s0, item0, xch0, xch1, yl, z, lane);
             if (two) sign_w_entries<MODE, 1>(st, s0 + 1, item1, xch0, xch1, yl, z, lane);

@@ -170,7 +170,9 @@ int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_
  *       verdicts (0 | 2 = kem.ErrPrivKey) are written to key_status[nkeys] if it is not NULL.  A public key's canonicity is
  *       reported per item by the encapsulation (status 1 = kem.ErrPubKey), as everywhere in this ABI.
  *   _dev variants: pointers are device memory on the TABLE's device; workspace = circl_hip_mlkem_workspace_size(param, n) /
- *       circl_hip_mldsa_workspace_size(param, n) bytes (no table tail: the table brings its own).
+ *       circl_hip_mldsa_workspace_size(param, n) bytes (no table tail: the table brings its own).  Like every keyed _dev entry point
+ *       they TRUST d_key_idx (the host forms check it: an index >= nkeys is CIRCL_HIP_EPARAM; a device array cannot be checked without
+ *       a synchronisation, and an index beyond the table reads past it).
  *   circl_hip_keytable_free wipes the key rows of a private table before releasing them.
  *   device = CIRCL_HIP_ALL_DEVICES in any *_new below REPLICATES the table: it is built once on every device, and the host-buffer
  *       *_table calls then split a batch into contiguous shards, one per device, like every other entry point (a table made for
@@ -236,8 +238,8 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
  *   setter itself is not synchronised with calls in flight).  A replicated table coalesces per replica; its small calls (<= 1024
  *   items) go to one replica each, round-robin.  circl_hip_keytable_coalesce_stats: calls and items that joined batches and the
  *   launches they became (items / launches = mean batch).  Served today: circl_hip_mlkem_encaps_table, circl_hip_mlkem_decaps_table,
- *   circl_hip_mldsa_verify_table. */
-int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, unsigned max_wait_us);
+ *   circl_hip_mldsa_verify_table, circl_hip_mldsa_sign_table / _sign_table_keyed (a server signing one handshake transcript per call). */
+int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us);
 int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *table, uint64_t *calls, uint64_t *items, uint64_t *launches);
 
 /* ---- PrivateKey.Public() over a batch -----------------------------------------------------------
@@ -544,6 +546,11 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
  * (the cheapest class), with `waves_per_simd` (1..8; the Keccak probe needs ~110 VGPRs, so at most 4 are resident) wavefronts
  * on every SIMD of `device`.  About 10 ms of GPU time.  Either output may be NULL. */
 int circl_hip_profile_valu_probe(int device, int waves_per_simd, double *keccak_insts_per_s_per_simd, double *simple_insts_per_s_per_simd);
+
+/* What the host-buffer pipeline's staging pools hold right now, over all (logical) devices: slots created, page-locked host bytes,
+ * device bytes.  The pools grow on demand (up to CIRCL_HIP_HOST_SLOTS slots per device) and are never shrunk: after a process's largest
+ * calls this is the high-water mark a node has to budget for (profiles/r05_logical8.txt).  Any pointer may be NULL. */
+int circl_hip_host_pool_stats(int *slots, uint64_t *pinned_bytes, uint64_t *device_bytes);
 
 /* pinned host memory helpers for callers that want zero-copy-speed transfers */
 void *circl_hip_alloc_host(size_t bytes);

@@ -106,3 +106,40 @@ def test_every_environment_knob_is_documented():
         assert k in doc or ("`%s`" % tail) in doc or ("`_%s`" % tail.split("_", 2)[-1]) in doc, k
     m = re.search(r"Environment knobs\*\* — exactly these (\d+)", doc)
     assert m and int(m.group(1)) == len(code), (m and m.group(1), len(code))
+
+
+def test_no_wait_lds_ordering_point_is_a_compiler_fence_and_emits_nothing(tmp_path):
+    """wave_lds_order() (keccak_dev.h) is what every "no-wait" exchange of a wave-private LDS buffer hangs on: the hardware needs
+    nothing (a wavefront's LDS instructions execute in order), the COMPILER must keep each exchange's stores in front of its loads.
+    Compiled for gfx950 here (hipcc cross-compiles): the disassembly of four store -> order -> load -> order rounds must show the
+    LDS writes and reads strictly alternating, and no s_barrier (the point of the no-wait form)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "order_probe.hip"
+    src.write_text(r'''
+#include "keccak_dev.h"
+__global__ void order_probe(uint32_t *out, const uint32_t *in) {
+    __shared__ uint32_t xch[256];
+    const int lane = threadIdx.x;
+    uint32_t v = in[lane];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        xch[lane] = v;                       // every lane stores its own word ...
+        circl::wave_lds_order();
+        v = xch[(lane * 5 + r) & 63] + r;    // ... and loads ANOTHER lane's: nothing but the ordering point says the store comes first
+        circl::wave_lds_order();
+    }
+    out[lane] = v;
+}
+''')
+    asm = tmp_path / "order_probe.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-I", os.path.join(root, "circl_amd", "csrc"),
+                           str(src), "-o", str(asm)], stderr=subprocess.DEVNULL)
+    body = asm.read_text().split("order_probe", 1)[1].split(".amdhsa_kernel", 1)[0]
+    lds = re.findall(r"^\s*(ds_write_b32|ds_read_b32|ds_store_b32|ds_load_b32)\b", body, re.M)
+    kinds = ["w" if ("write" in x or "store" in x) else "r" for x in lds]
+    assert kinds == ["w", "r"] * 4, kinds
+    assert "s_barrier" not in body

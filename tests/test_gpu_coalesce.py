@@ -127,6 +127,29 @@ def test_mldsa_coalesced_verifications_equal_the_oracle(param):
                 ok = tab.verify(sig[lo:lo + 1], msgs[lo:lo + 1], None, idx[lo:lo + 1])
                 assert ok[0] == (1 if (len(ctxs[lo]) == 0 and want[lo]) else 0)
     _run_threads(T, body)
+    # the signer of the same keys: one message per call from every thread, deterministic and hedged (rnd) next to each other
+    signer = hostapi.KeyTable("mldsa-private", param, sk)
+    signer.set_coalesce(32)
+    rnd = rng.integers(0, 256, (pool, 32), dtype=np.uint8)
+    want_det = orc.mldsa_sign(param, sk[idx], msgs, ctxs)
+    want_rnd = orc.mldsa_sign(param, sk[idx], msgs, ctxs, rnd)
+
+    def sign_body(t):
+        r = np.random.default_rng(50 + t)
+        for _ in range(6):
+            n = int(r.choice([1, 1, 3]))
+            lo = int(r.integers(0, pool - n))
+            if r.integers(0, 2):
+                got = signer.sign(msgs[lo:lo + n], ctxs[lo:lo + n], None, idx[lo:lo + n])
+                assert (got == want_det[lo:lo + n]).all(), (t, n, lo)
+            else:
+                got = signer.sign(msgs[lo:lo + n], ctxs[lo:lo + n], rnd[lo:lo + n], idx[lo:lo + n])
+                assert (got == want_rnd[lo:lo + n]).all(), (t, n, lo)
+    _run_threads(T, sign_body)
+    assert signer.coalesce_stats()[0] > 0
+    with pytest.raises(Exception):                           # a context of 256 bytes is refused on the host, coalescing or not
+        signer.sign(msgs[:1], [bytes(256)], None, idx[:1])
+    signer.close()
     # a message too long for a shared batch takes the ordinary path
     long_msg = [bytes(rng.integers(0, 256, 300000, dtype=np.uint8))]
     s1 = orc.mldsa_sign(param, sk[:1], long_msg, [b""])

@@ -6,7 +6,7 @@
 // call when the previous one has returned, so aggregate <= T / latency: Little's law).  Every result is compared with the answer of
 // ONE ordinary batch call made beforehand (bit-exact under concurrency, whatever batches the calls ended up in).
 //
-//   concurrent_bench <op: encaps|decaps|verify> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
+//   concurrent_bench <op: encaps|decaps|verify|sign> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
 //
 // Output: one line per T: aggregate ops/s, p50 / p99 / max latency of a call (us), calls per launch when coalescing.
 // Built by tools/build_tools.sh (g++ against libcirclhip.so); profiles/r05_concurrent.txt is its output on one MI355X.
@@ -41,9 +41,26 @@ static std::vector<uint8_t> bytes(size_t n, unsigned seed) {
 }
 using Clock = std::chrono::steady_clock;
 
+// CPU time of the whole process and what the container's CPU quota did to it (cgroup v2 cpu.stat; zeros where there is none)
+struct CpuStat { double usage_us = 0, throttled_us = 0; long nr_throttled = 0; };
+static CpuStat cpu_stat() {
+    CpuStat c;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
+    if (!f) return c;
+    char key[64];
+    double v;
+    while (fscanf(f, "%63s %lf", key, &v) == 2) {
+        if (!strcmp(key, "usage_usec")) c.usage_us = v;
+        else if (!strcmp(key, "throttled_usec")) c.throttled_us = v;
+        else if (!strcmp(key, "nr_throttled")) c.nr_throttled = (long)v;
+    }
+    fclose(f);
+    return c;
+}
+
 int main(int argc, char **argv) {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s <encaps|decaps|verify> <coalesce max_items> <max_wait_us> <items per call> <seconds> <T> [T ...]\n", argv[0]);
+        fprintf(stderr, "usage: %s <encaps|decaps|verify|sign> <coalesce max_items> <max_wait_us> <items per call> <seconds> <T> [T ...]\n", argv[0]);
         return 2;
     }
     const std::string op = argv[1];
@@ -97,6 +114,15 @@ int main(int argc, char **argv) {
         size_t good = 0;
         for (size_t i = 0; i < POOL; i++) good += ok[i];
         CHECK(good == POOL - (POOL + 4) / 5);
+    } else if (op == "sign") {
+        std::vector<uint8_t> seed = bytes(32 * NK, 3), pk(PK * NK), sk(SK * NK);
+        CHECK(circl_hip_mldsa_keygen(dsa, seed.data(), pk.data(), sk.data(), NK, 0) == 0);
+        CHECK(circl_hip_mldsa_privkeys_new(dsa, sk.data(), NK, 0, &table) == 0);
+        mblob = bytes(MSG * POOL, 4);
+        moff.resize(POOL + 1);
+        for (size_t i = 0; i <= POOL; i++) moff[i] = MSG * i;
+        sig.resize(SIG * POOL + 16);
+        CHECK(circl_hip_mldsa_sign_table_keyed(table, kidx.data(), mblob.data(), moff.data(), nullptr, nullptr, nullptr, sig.data(), POOL) == 0);  // the answers
     } else {
         fprintf(stderr, "unknown op %s\n", op.c_str());
         return 2;
@@ -117,7 +143,7 @@ int main(int argc, char **argv) {
         Clock::time_point t_begin;
         for (int t = 0; t < T; t++) {
             th.emplace_back([&, t] {
-                std::vector<uint8_t> o_ct(CT * per_call), o_ss(32 * per_call), o_st(per_call), o_ok(per_call);
+                std::vector<uint8_t> o_ct(CT * per_call), o_ss(32 * per_call), o_st(per_call), o_ok(per_call), o_sig(SIG * per_call + 16);
                 std::vector<uint64_t> off(per_call + 1);
                 lat[t].reserve(1 << 16);
                 size_t at = ((size_t)t * 997) % (POOL - per_call);
@@ -132,6 +158,9 @@ int main(int argc, char **argv) {
                     } else if (op == "decaps") {
                         CHECK(circl_hip_mlkem_decaps_table(table, &kidx[at], &ct[CT * at], o_ss.data(), o_st.data(), per_call) == 0);
                         good = !memcmp(o_ss.data(), &ss[32 * at], 32 * per_call);
+                    } else if (op == "sign") {
+                        CHECK(circl_hip_mldsa_sign_table_keyed(table, &kidx[at], mblob.data(), &moff[at], nullptr, nullptr, nullptr, o_sig.data(), per_call) == 0);
+                        good = !memcmp(o_sig.data(), &sig[SIG * at], SIG * per_call);
                     } else {
                         CHECK(circl_hip_mldsa_verify_table(table, &kidx[at], &sig[SIG * at], mblob.data(), &moff[at], nullptr, nullptr, o_ok.data(), per_call) == 0);
                         good = !memcmp(o_ok.data(), &ok[at], per_call);
@@ -145,12 +174,14 @@ int main(int argc, char **argv) {
             });
         }
         while (started.load() < T) std::this_thread::yield();
+        const CpuStat cs0 = cpu_stat();
         t_begin = Clock::now();
         started.fetch_add(1);
         std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
         stop.store(true);
         for (auto &x : th) x.join();
         const double el = std::chrono::duration<double>(Clock::now() - t_begin).count();
+        const CpuStat cs1 = cpu_stat();
         uint64_t total = 0;
         std::vector<float> all;
         for (int t = 0; t < T; t++) { total += calls[t]; all.insert(all.end(), lat[t].begin(), lat[t].end()); }
@@ -161,6 +192,9 @@ int main(int argc, char **argv) {
         printf("T=%-4d %10.0f ops/s  (%8.0f calls/s)  latency us p50 %7.1f  p99 %7.1f  max %8.1f", T, total * per_call / el, total / el, q(0.50), q(0.99),
                all.empty() ? 0.f : all.back());
         if (l1 > l0) printf("  | %.1f calls, %.1f items per launch", (double)(c1 - c0) / (l1 - l0), (double)(i1 - i0) / (l1 - l0));
+        if (cs1.usage_us > cs0.usage_us)
+            printf("  | CPU %.1f us per call, %.1f CPUs busy, throttled %ld x %.0f ms", (cs1.usage_us - cs0.usage_us) / std::max<uint64_t>(total, 1),
+                   (cs1.usage_us - cs0.usage_us) / (el * 1e6), cs1.nr_throttled - cs0.nr_throttled, (cs1.throttled_us - cs0.throttled_us) / 1e3);
         printf("  mismatches %llu\n", (unsigned long long)mismatches.load());
         fflush(stdout);
         CHECK(mismatches.load() == 0);
