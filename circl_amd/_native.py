@@ -14,7 +14,7 @@ SYMBOLS = [
     "circl_hip_mlkem_encaps_keyed", "circl_hip_mlkem_decaps_keyed", "circl_hip_mlkem_keyed_workspace_size",
     "circl_hip_mlkem_encaps_keyed_dev", "circl_hip_mlkem_decaps_keyed_dev",
     "circl_hip_mldsa_verify_keyed", "circl_hip_mldsa_keyed_workspace_size", "circl_hip_mldsa_verify_keyed_dev",
-    "circl_hip_mlkem_keytable_new", "circl_hip_mldsa_keytable_new", "circl_hip_keytable_free", "circl_hip_keytable_set_coalesce", "circl_hip_keytable_coalesce_stats", "circl_hip_profile_valu_probe", "circl_hip_host_pool_stats", "circl_hip_mlkem_encaps_table", "circl_hip_mlkem_decaps_table",
+    "circl_hip_mlkem_keytable_new", "circl_hip_mldsa_keytable_new", "circl_hip_keytable_free", "circl_hip_keytable_set_coalesce", "circl_hip_set_coalesce", "circl_hip_keytable_coalesce_stats", "circl_hip_profile_valu_probe", "circl_hip_host_pool_stats", "circl_hip_mlkem_encaps_table", "circl_hip_mlkem_decaps_table",
     "circl_hip_mldsa_verify_table", "circl_hip_mldsa_privkey_new", "circl_hip_mldsa_sign_table", "circl_hip_mldsa_sign_table_dev", "circl_hip_mlkem_encaps_table_dev", "circl_hip_mlkem_decaps_table_dev", "circl_hip_mldsa_verify_table_dev",
     "circl_hip_mlkem_ek_size", "circl_hip_mlkem_dk_size", "circl_hip_mlkem_ct_size",
     "circl_hip_mldsa_pk_size", "circl_hip_mldsa_sig_size", "circl_hip_mldsa_sk_size",
@@ -119,6 +119,7 @@ def lib():
         L.circl_hip_keytable_free.argtypes = [vp]
         L.circl_hip_keytable_free.restype = None
         L.circl_hip_keytable_set_coalesce.argtypes = [vp, sz, C.c_uint32]
+        L.circl_hip_set_coalesce.argtypes = [sz, C.c_uint32]
         L.circl_hip_keytable_coalesce_stats.argtypes = [vp, vp, vp, vp]
         L.circl_hip_mlkem_encaps_table.argtypes = [vp, vp, vp, vp, vp, vp, sz]
         L.circl_hip_mlkem_decaps_table.argtypes = [vp, vp, vp, vp, vp, sz]

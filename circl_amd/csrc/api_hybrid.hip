@@ -519,11 +519,16 @@ int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed,
     if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
     if (n && (!pk || !eseed || !ct || !ss)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}}, {},
-                            {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
-                                return circl_hip_hybrid_encaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
-                            });
+        const std::vector<HIn> ins = {{pk + lo * s.pk, s.pk}, {eseed + lo * s.eseed, s.eseed, true}};
+        const std::vector<HOut> outs = {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}};
+        auto launch = [&](Chunk &c) { return circl_hip_hybrid_encaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); };
+        // circl_hip_set_coalesce: what a TLS 1.3 server does per X25519MLKEM768 handshake -- one encapsulation to the client's ephemeral
+        // share -- from many connections at once (kem/hybrid/hybrid.go:271-300); a ladder costs ~0.8 ms however few items share it
+        if (Coalescer *co = call_coalescer(kCoHybEncaps, scheme - 1, dev)) {
+            const int rc = coalesce_run(co, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
+            if (rc != kNotCoalesced) return rc;
+        }
+        return run_pipeline(dev, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
     });
 }
 
@@ -532,11 +537,14 @@ int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, ui
     if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
     if (n && (!sk || !ct || !ss)) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}}, {},
-                            {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
-                            hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
-                                return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
-                            });
+        const std::vector<HIn> ins = {{sk + lo * s.sk, s.sk, true}, {ct + lo * s.ct, s.ct}};
+        const std::vector<HOut> outs = {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}};
+        auto launch = [&](Chunk &c) { return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); };
+        if (Coalescer *co = call_coalescer(kCoHybDecaps, scheme - 1, dev)) {
+            const int rc = coalesce_run(co, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
+            if (rc != kNotCoalesced) return rc;
+        }
+        return run_pipeline(dev, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
     });
 }
 

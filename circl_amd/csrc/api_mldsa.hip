@@ -366,12 +366,21 @@ int mldsa_verify_host_one(int param, int dev, const uint8_t *pk, size_t nkeys, c
     else ins.push_back({pk, PK * (KM == KM_KEYED ? nkeys : 1), false, true});
     ins.push_back({sig, SIG});
     if (KM == KM_KEYED) ins.push_back({reinterpret_cast<const uint8_t *>(key_idx), 4});
-    return run_pipeline(dev, n, ins, {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{ok, 1}},
-                        [&](size_t c) { return mldsa_ws_any(param, c) + (KM == KM_KEYED ? mldsa_table_any(param, nkeys) : 0); },
-                        dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
-                            return mldsa_verify_dev_any<KM>(param, c.in[0], nkeys, KM == KM_KEYED ? reinterpret_cast<const uint32_t *>(c.in[2]) : nullptr,
-                                                            c.in[1], c.blob[0], c.off[0], c.blob[1], c.off[1], internal, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
-                        });
+    const std::vector<HBlob> blobs = {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}};
+    const std::vector<HOut> outs = {{ok, 1}};
+    auto ws_fn = [&](size_t c) { return mldsa_ws_any(param, c) + (KM == KM_KEYED ? mldsa_table_any(param, nkeys) : 0); };
+    auto launch = [&](Chunk &c) {
+        return mldsa_verify_dev_any<KM>(param, c.in[0], nkeys, KM == KM_KEYED ? reinterpret_cast<const uint32_t *>(c.in[2]) : nullptr, c.in[1], c.blob[0], c.off[0],
+                                        c.blob[1], c.off[1], internal, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+    };
+    if (KM == KM_ITEM && msg_blob && all_inputs_present(ins)) {  // circl_hip_set_coalesce: every item brings its own key, so calls of different callers mix freely
+        const int slot = param == 44 ? 0 : param == 65 ? 1 : param == 87 ? 2 : -1;  // (round-3 Dilithium: no slot, never coalesced)
+        if (Coalescer *co = call_coalescer(internal ? kCoDsaVerifyInternal : kCoDsaVerify, slot, dev)) {
+            const int rc = coalesce_run(co, n, ins, blobs, outs, ws_fn, dsa_opts(size_t(1) << 13, false), launch);
+            if (rc != kNotCoalesced) return rc;
+        }
+    }
+    return run_pipeline(dev, n, ins, blobs, outs, ws_fn, dsa_opts(size_t(1) << 13, false), launch);
 }
 
 // ---- ML-DSA sign ------------------------------------------------------------------------------
@@ -577,10 +586,13 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         if (coop_mask) hipLaunchKernelGGL(sign_mask_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (upper * L + 1) / 2)), dim3(64), 0, st, S, cur);
         else if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
-        // long rounds (the list is longer than the speculation threshold and pairs are off: one entry per item) take the form of the w
-        // kernel without the paired path: 4 wavefronts per SIMD for L = 7 instead of 3 (CIRCL_HIP_SIGN_W_SINGLES=0: always the general form)
+        // L = 7 (ML-DSA-87, Dilithium5): the long rounds (the list is longer than the speculation threshold and pairs are off: one entry
+        // per item) take the form of the w kernel without the paired path: 4 wavefronts per SIMD instead of 3.  Measured on one box,
+        // alternating: ML-DSA-87 6.836 / 6.867 -> 6.873 / 6.888e6 signatures/s (+0.4 %: the kernel sits on its matrix reads either way);
+        // where the general form already runs 4 wavefronts nothing moves (ML-DSA-65 8.92 / 8.88 -> 8.90 / 8.94e6) or it loses (ML-DSA-44
+        // 1.343 -> 1.315e7), so only L = 7 takes it (profiles/r05_sign_ab.txt; CIRCL_HIP_SIGN_W_SINGLES=0: always the general form)
         static const bool w_singles = env_int("CIRCL_HIP_SIGN_W_SINGLES", 1, 0, 1) != 0;
-        if (w_singles && !S.pair && upper > S.spec_target) hipLaunchKernelGGL((sign_w_kernel<MODE, false>), dim3(gw), dim3(64), 0, st, S, cur);
+        if (w_singles && L > 5 && !S.pair && upper > S.spec_target) hipLaunchKernelGGL((sign_w_kernel<MODE, false>), dim3(gw), dim3(64), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_w_kernel<MODE, true>), dim3(gw), dim3(64), 0, st, S, cur);
         if (coop_ch) hipLaunchKernelGGL(sign_challenge_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (pass0 + 1) / 2)), dim3(64), 0, st, S, cur, 0);
         else if (split_ch) hipLaunchKernelGGL((sign_challenge_kernel<MODE, true>), dim3(g256(2 * pass0)), dim3(256), 0, st, S, cur, 0);

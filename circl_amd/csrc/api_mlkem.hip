@@ -729,9 +729,17 @@ int circl_hip_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8
     const size_t EK = circl_hip_mlkem_ek_size(param), CT = circl_hip_mlkem_ct_size(param);
     if (!EK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{ek + lo * EK, EK}, {m + lo * 32, 32, true}}, {},
-                            {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(),
-                            [&](Chunk &c) { return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); });
+        const std::vector<HIn> ins = {{ek + lo * EK, EK}, {m + lo * 32, 32, true}};
+        const std::vector<HOut> outs = {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}};
+        auto launch = [&](Chunk &c) { return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st); };
+        // circl_hip_set_coalesce: the small calls of concurrent callers share launches -- a TLS server's shape: every handshake
+        // encapsulates once, to a key of its own (kem/hybrid/hybrid.go:95-99 -> kem/mlkem/mlkem768/kyber.go:359-370)
+        Coalescer *co = all_inputs_present(ins) ? call_coalescer(kCoKemEncaps, kem_k(param) - 2, dev) : nullptr;
+        if (co) {
+            const int rc = coalesce_run(co, cnt, ins, {}, outs, kem_ws_fn(), kem_opts(), launch);
+            if (rc != kNotCoalesced) return rc;
+        }
+        return run_pipeline(dev, cnt, ins, {}, outs, kem_ws_fn(), kem_opts(), launch);
     });
 }
 
@@ -739,9 +747,15 @@ int circl_hip_mlkem_decaps(int param, const uint8_t *dk, const uint8_t *ct, uint
     const size_t DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
     if (!DK) return CIRCL_HIP_EPARAM;
     return shard(n, device, [&](int dev, size_t lo, size_t cnt) {
-        return run_pipeline(dev, cnt, {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}}, {}, {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}},
-                            kem_ws_fn(), kem_opts(),
-                            [&](Chunk &c) { return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
+        const std::vector<HIn> ins = {{dk + lo * DK, DK, true}, {ct + lo * CT, CT}};
+        const std::vector<HOut> outs = {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}};
+        auto launch = [&](Chunk &c) { return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); };
+        Coalescer *co = all_inputs_present(ins) ? call_coalescer(kCoKemDecaps, kem_k(param) - 2, dev) : nullptr;
+        if (co) {  // circl_hip_set_coalesce: the small calls of concurrent callers share launches
+            const int rc = coalesce_run(co, cnt, ins, {}, outs, kem_ws_fn(), kem_opts(), launch);
+            if (rc != kNotCoalesced) return rc;
+        }
+        return run_pipeline(dev, cnt, ins, {}, outs, kem_ws_fn(), kem_opts(), launch);
     });
 }
 

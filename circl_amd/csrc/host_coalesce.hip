@@ -89,6 +89,8 @@ struct CoBatch {
     bool full = false;                // flush without lingering
     std::atomic<int> writers{0};      // callers still copying their inputs in
     std::atomic<uint32_t> wseq{0};    // the leader sleeps on it while writers != 0
+    std::atomic<bool> leader_waits{false};  // ... and says so: only then is the last writer's wake a system call
+    int callers = 0;                  // (under Coalescer::lock) calls that joined
     std::atomic<int> readers{0};      // callers that have not copied their results out yet
     Gate done;
     int rc = 0;
@@ -223,13 +225,19 @@ void flush(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_by
     b->state = CoBatch::CLOSED;
     if (co->open == b) co->open = nullptr;
     const size_t cnt = b->count;
+    co->n_calls.fetch_add((uint64_t)b->callers, std::memory_order_relaxed);  // (the statistics: once per batch, not per call)
+    co->n_items.fetch_add(cnt, std::memory_order_relaxed);
     co->lock.unlock();
     bump(co);  // (the next batch's leader may now be first in line)
     // ---- the batch's callers have copied their rows in ----
-    for (;;) {
-        const uint32_t s = b->wseq.load();
-        if (b->writers.load() == 0) break;
-        futex_op(&b->wseq, FUTEX_WAIT, s);
+    if (b->writers.load() != 0) {
+        b->leader_waits.store(true);
+        for (;;) {
+            const uint32_t s = b->wseq.load();
+            if (b->writers.load() == 0) break;
+            futex_op(&b->wseq, FUTEX_WAIT, s);
+        }
+        b->leader_waits.store(false);
     }
     for (size_t k = 0; k < co->nblob; k++) reinterpret_cast<uint64_t *>(b->hin + co->off_ofs[k])[cnt] = b->blob_used[k];
 
@@ -397,6 +405,7 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
             b->count = 0;
             b->blob_used[0] = b->blob_used[1] = 0;
             b->full = false;
+            b->callers = 0;
             b->rc = 0;
             b->done.reset();
             b->opened = Clock::now();
@@ -414,12 +423,11 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
     for (size_t k = 0; k < blobs.size(); k++) { bpos[k] = b->blob_used[k]; b->blob_used[k] += bb[k]; }
     b->writers.fetch_add(1);
     b->readers.fetch_add(1);
+    b->callers++;
     const bool filled = b->count >= co->max_items;
     if (filled) { b->full = true; co->open = nullptr; }
     co->lock.unlock();
     if (filled && !leader) bump(co);  // a lingering leader need not wait any longer
-    co->n_calls.fetch_add(1, std::memory_order_relaxed);
-    co->n_items.fetch_add(n, std::memory_order_relaxed);
 
     // ---- copy this call's rows in ----
     for (size_t k = 0; k < ins.size(); k++) {
@@ -439,7 +447,7 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
     }
     if (b->writers.fetch_sub(1) == 1) {
         b->wseq.fetch_add(1);
-        futex_op(&b->wseq, FUTEX_WAKE, 1);
+        if (b->leader_waits.load()) futex_op(&b->wseq, FUTEX_WAKE, 1);  // (seq_cst on both sides: a leader that missed the count sees the new wseq)
     }
 
     if (leader) flush(co, b, ws_bytes, opts, launch);
@@ -453,6 +461,32 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
             if (outs[k].p && outs[k].row) memcpy(outs[k].p, b->hout + co->out_ofs[k] + pos * outs[k].row, outs[k].row * n);
     if (b->readers.fetch_sub(1) == 1) recycle(co, b);
     return rc;
+}
+
+// ---- process-wide coalescers of the non-table entry points ----
+namespace {
+constexpr int kCallParams = 4, kCallDevs = 64;
+std::atomic<size_t> g_call_items{0};
+std::atomic<uint32_t> g_call_wait{0};
+std::atomic<Coalescer *> g_call[kCoOps][kCallParams][kCallDevs];
+std::mutex g_call_mu;
+}  // namespace
+Coalescer *call_coalescer(int op, int param_slot, int dev) {
+    const size_t items = g_call_items.load(std::memory_order_acquire);
+    if (!items || op < 0 || op >= kCoOps || param_slot < 0 || param_slot >= kCallParams || dev < 0 || dev >= kCallDevs) return nullptr;
+    Coalescer *co = g_call[op][param_slot][dev].load(std::memory_order_acquire);
+    if (co) return co;
+    std::lock_guard<std::mutex> lk(g_call_mu);
+    co = g_call[op][param_slot][dev].load();
+    if (!co) {
+        co = coalescer_new(dev, items, g_call_wait.load());  // (never freed: calls may be in flight at any time)
+        g_call[op][param_slot][dev].store(co, std::memory_order_release);
+    }
+    return co;
+}
+void call_coalescing_set(size_t max_items, uint32_t max_wait_us) {
+    g_call_wait.store(max_wait_us);
+    g_call_items.store(max_items, std::memory_order_release);
 }
 
 }  // namespace host
@@ -475,6 +509,10 @@ int circl_hip_keytable_set_coalesce(circl_hip_keytable *t, size_t max_items, uin
     if (max_items == 0) return CIRCL_HIP_OK;
     t->coalescer = coalescer_new(t->device, max_items, max_wait_us);
     return t->coalescer ? CIRCL_HIP_OK : CIRCL_HIP_ENOMEM;
+}
+int circl_hip_set_coalesce(size_t max_items, uint32_t max_wait_us) {
+    circl::host::call_coalescing_set(max_items, max_wait_us);
+    return CIRCL_HIP_OK;
 }
 int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *t, uint64_t *calls, uint64_t *items, uint64_t *launches) {
     if (calls) *calls = 0;

@@ -123,7 +123,7 @@ hipError_t pinned_alloc(void **p, size_t bytes);
 hipError_t pinned_free(void *p);
 uint8_t *pinned_device_ptr(void *p);  // nullptr if the runtime cannot map it
 // A call (or a coalesced batch) that moves at most this many bytes does not enqueue copies at all: its kernels get the device
-// addresses of the page-locked staging areas.  CIRCL_HIP_ZEROCOPY_KB (0 = never), default 64 KB (profiles/r05_zerocopy.txt).
+// addresses of the page-locked staging areas.  CIRCL_HIP_ZEROCOPY_KB (0 = never), default 1 MB (profiles/r05_zerocopy.txt).
 size_t zero_copy_bytes();
 // block = true: waits while every slot of the device is in use; false: returns nullptr at once in that case.
 // nullptr with a non-empty g_err = creating a slot failed.
@@ -194,6 +194,19 @@ void coalescer_stats(const Coalescer *co, uint64_t *calls, uint64_t *items, uint
 constexpr int kNotCoalesced = 1;
 int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
                  const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch);
+
+// ... and process-wide, for the entry points that take their keys with every call (circl_hip_set_coalesce): a TLS server encapsulates
+// to a DIFFERENT, ephemeral key in every handshake -- there is no table to attach a coalescer to.  One coalescer per (entry point,
+// parameter set, device), created at its first small call.  nullptr: switched off (the default) or an unknown slot.
+enum CallOp : int { kCoKemEncaps = 0, kCoKemDecaps, kCoDsaVerify, kCoDsaVerifyInternal, kCoHybEncaps, kCoHybDecaps, kCoOps };
+Coalescer *call_coalescer(int op, int param_slot, int dev);  // param_slot: 0..3 (the entry point's own numbering of its parameter sets)
+// (coalesce_run reads a NULL input as rows of zeros -- right for an absent key_idx, wrong for a missing key array: these entry points
+// only join a batch with every input present and leave the complaint about a NULL pointer to run_pipeline)
+inline bool all_inputs_present(const std::vector<HIn> &ins) {
+    for (auto &in : ins)
+        if (!in.p) return false;
+    return true;
+}
 
 // Contiguous split of [0,n) over the visible devices, one host thread each (pinned to the device's NUMA node), no collective.
 int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn);

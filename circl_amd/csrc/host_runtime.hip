@@ -76,7 +76,9 @@ uint8_t *pinned_device_ptr(void *p) {
     return static_cast<uint8_t *>(dp);
 }
 size_t zero_copy_bytes() {
-    static const size_t v = (size_t)env_int("CIRCL_HIP_ZEROCOPY_KB", 64, 0, 1 << 20) << 10;
+    // measured (profiles/r05_zerocopy.txt): against enqueued copies a resident-key call of 64 items takes 41 instead of 64 us, of 256
+    // items 64 instead of 90; at 1 MB the two meet, and beyond it kernels that read an input more than once (a decapsulation's dk) lose
+    static const size_t v = (size_t)env_int("CIRCL_HIP_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10;
     return v;
 }
 
@@ -281,8 +283,10 @@ Pool *pool_of(int dev) {
     if (g_pools.empty()) g_pools.assign(nd, nullptr);
     if (!g_pools[dev]) {
         Pool *p = new Pool;
-        // the calling thread works too, so a pool of T threads gives T + 1 movers; the CPUs are shared by all devices
-        const int dflt = std::min(16, std::max(1, usable_cpus() / nd));
+        // the calling thread works too, so a pool of T threads gives T + 1 movers; the CPUs are shared by all devices.  The copies are
+        // memory-bound: 4 movers reach the PCIe-bound rate (3.98e7 ML-KEM-768 encapsulations/s with 4.9 CPUs busy), 16 reach the same
+        // rate with 12.8 CPUs busy, 2 reach 3.66e7 with 3.8 (profiles/r05_logical8.txt) -- an 8-GPU node spends ~40 CPUs, not 130
+        const int dflt = std::min(4, std::max(1, usable_cpus() / nd));
         p->nthreads = env_int("CIRCL_HIP_HOST_THREADS", dflt, 0, 256);
         const std::vector<int> cpus = dev_info(dev).cpus;
         for (int t = 0; t < p->nthreads; t++) std::thread(worker_main, p, cpus).detach();
@@ -862,6 +866,9 @@ int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size
     if (device >= 0) return device < nd ? fn(device, size_t(0), n) : CIRCL_HIP_ENODEV;
     if (device != CIRCL_HIP_ALL_DEVICES) return CIRCL_HIP_EPARAM;
     if (nd == 1) return fn(0, size_t(0), n);
+    // a SMALL call goes to ONE device, taken round-robin (keytable.h table_shard does the same): a thread and a launch per device
+    // for a handful of items cost more than they return, and the contiguous split sent every one-item call to the last device
+    if (n <= kSmallTableCall) return fn(next_replica(nd), size_t(0), n);
     std::vector<int> rcs(nd, 0);
     std::vector<std::string> errs(nd);
     std::vector<std::thread> th;

@@ -240,6 +240,14 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
  *   launches they became (items / launches = mean batch).  Served today: circl_hip_mlkem_encaps_table, circl_hip_mlkem_decaps_table,
  *   circl_hip_mldsa_verify_table, circl_hip_mldsa_sign_table / _sign_table_keyed (a server signing one handshake transcript per call). */
 int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us);
+/* The same for the entry points that take their keys WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the
+ * client's ephemeral key share (kem/hybrid/hybrid.go:271-300 -> kem/mlkem/mlkem768/kyber.go:359-370): nothing resident to attach a
+ * batch to.  circl_hip_set_coalesce(max_items, max_wait_us), process-wide, default off: small calls (<= max_items / 4 items) of
+ * circl_hip_mlkem_encaps, circl_hip_mlkem_decaps, circl_hip_mldsa_verify / _verify_internal, circl_hip_hybrid_encaps and
+ * circl_hip_hybrid_decaps from concurrent threads share launches per (entry point, parameter set, device); every item still brings
+ * its own key, the bytes are those of the un-coalesced calls.  Call it once, before the threads start (later calls only affect
+ * (entry point, parameter set, device) combinations that have not been used yet; 0 switches new joins off). */
+int circl_hip_set_coalesce(size_t max_items, uint32_t max_wait_us);
 int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *table, uint64_t *calls, uint64_t *items, uint64_t *launches);
 
 /* ---- PrivateKey.Public() over a batch -----------------------------------------------------------

@@ -83,6 +83,11 @@ struct Kem {
             CHECK(!memcmp(ct1, &ct_t[CT * at], CT * k) && !memcmp(ss1, &ss_t[32 * at], 32 * k));
             CHECK(circl_hip_mlkem_decaps_table(prv, &idx[at], &ct_t[CT * at], ss2, i % 2 ? st1 : nullptr, k) == 0);
             CHECK(!memcmp(ss2, &ss_t[32 * at], 32 * k));
+            // ... and with keys that come with the call (circl_hip_set_coalesce: process-wide batches per entry point and device)
+            CHECK(circl_hip_mlkem_encaps(param, &ek[EK * at], &m[32 * at], ct1, ss1, st1, k, (caller + i) % 2 ? 0 : CIRCL_HIP_ALL_DEVICES) == 0);
+            CHECK(!memcmp(ct1, &ct[CT * at], CT * k) && !memcmp(ss1, &ss[32 * at], 32 * k));
+            CHECK(circl_hip_mlkem_decaps(param, &dk[DK * at], &ct[CT * at], ss2, nullptr, k, CIRCL_HIP_ALL_DEVICES) == 0);
+            CHECK(!memcmp(ss2, &ss[32 * at], 32 * k));
         }
     }
     void again(int device) const {
@@ -189,6 +194,7 @@ int main(int argc, char **argv) {
     CHECK(circl_hip_keytable_set_coalesce(kem768.pub, 16, 0) == 0);
     CHECK(circl_hip_keytable_set_coalesce(kem768.prv, 64, 50) == 0);
     CHECK(circl_hip_keytable_set_coalesce(dsa65.verifier, 8, 0) == 0);
+    CHECK(circl_hip_set_coalesce(16, 0) == 0);
     const Hyb xwing(1, n_kem / 8 + 5);
     circl_hip_profile_enable(1);  // the profiling records are shared state too
     std::atomic<int> started{0};

@@ -192,3 +192,71 @@ print("ok")
         env = dict(os.environ, CIRCL_HIP_ZEROCOPY_KB=kb, PYTHONPATH=ROOT)
         out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "ok" in out.stdout, (kb, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_process_wide_coalescing_of_calls_that_bring_their_own_keys():
+    """circl_hip_set_coalesce: the TLS-server shape -- every handshake encapsulates ONCE, to the peer's ephemeral key (kem/hybrid/hybrid.go:
+    271-300 -> kem/mlkem/mlkem768/kyber.go:359-370), so there is no resident key to hang a batch on.  Threads calling the ordinary host
+    entry points with one or a few items each share launches; every call's bytes are checked against the oracle.  In a process of its
+    own (the switch is process-wide)."""
+    code = r"""
+import threading
+import numpy as np
+from circl_amd import hostapi, _native as nat
+from oracle import orc, hybrid as ohyb
+assert nat.lib().circl_hip_set_coalesce(128, 0) == 0
+rng = np.random.default_rng(11)
+pool = 96
+ek, dk = orc.mlkem_keygen(768, rng.integers(0, 256, (pool, 64), dtype=np.uint8))
+m = rng.integers(0, 256, (pool, 32), dtype=np.uint8)
+ct0, ss0, _ = orc.mlkem_encaps(768, ek, m)
+ct_bad = ct0.copy(); ct_bad[::3, 5] ^= 1
+ssd0, _ = orc.mlkem_decaps(768, dk, ct_bad)
+ek[7, 0] = 0xff; ek[7, 1] |= 0x0f                       # one non-canonical public key: its caller alone gets status 1 (kem.ErrPubKey)
+pk, sk = orc.mldsa_keygen(65, rng.integers(0, 256, (pool, 32), dtype=np.uint8))
+msgs = [bytes(rng.integers(0, 256, 1 + 3 * i, dtype=np.uint8)) for i in range(pool)]
+ctxs = [bytes(rng.integers(0, 256, i % 9, dtype=np.uint8)) for i in range(pool)]
+sig = orc.mldsa_sign(65, sk, msgs, ctxs)
+sig[::5, 77] ^= 2
+okv = orc.mldsa_verify(65, pk, sig, msgs, ctxs)
+hs = hostapi.HYBRID_SIZES[hostapi.X25519MLKEM768]
+hseed = rng.integers(0, 256, (16, hs["seed"]), dtype=np.uint8)
+hpk, hsk = hostapi.hybrid_keygen(hostapi.X25519MLKEM768, hseed)
+hes = rng.integers(0, 256, (16, hs["eseed"]), dtype=np.uint8)
+hct0, hss0, _ = ohyb.hybrid_encaps(hpk, hes)
+errs = []
+def body(t):
+    try:
+        r = np.random.default_rng(t)
+        for _ in range(12):
+            n = int(r.choice([1, 1, 1, 2, 5]))
+            lo = int(r.integers(0, pool - n))
+            ct, ss, st = hostapi.mlkem_encaps(768, ek[lo:lo + n], m[lo:lo + n])
+            for i in range(n):
+                if lo + i == 7:
+                    assert st[i] == 1 and not ct[i].any() and not ss[i].any()
+                else:
+                    assert st[i] == 0 and (ct[i] == ct0[lo + i]).all() and (ss[i] == ss0[lo + i]).all()
+            got, st = hostapi.mlkem_decaps(768, dk[lo:lo + n], ct_bad[lo:lo + n])
+            assert not st.any() and (got == ssd0[lo:lo + n]).all()
+            ok = hostapi.mldsa_verify(65, pk[lo:lo + n], sig[lo:lo + n], msgs[lo:lo + n], ctxs[lo:lo + n])
+            assert (ok == okv[lo:lo + n]).all()
+        for i in range(t % 4, 16, 4):
+            ct, ss, st = hostapi.hybrid_encaps(hostapi.X25519MLKEM768, hpk[i:i + 1], hes[i:i + 1])
+            assert not st.any() and (ct[0] == hct0[i]).all() and (ss[0] == hss0[i]).all()
+            ss2, st2 = hostapi.hybrid_decaps(hostapi.X25519MLKEM768, hsk[i:i + 1], ct)
+            assert not st2.any() and (ss2[0] == hss0[i]).all()
+    except Exception as e:
+        errs.append((t, repr(e)))
+th = [threading.Thread(target=body, args=(t,)) for t in range(10)]
+[x.start() for x in th]; [x.join() for x in th]
+assert not errs, errs[:3]
+# a NULL key array is still an error, not a batch of zero keys
+import ctypes as C
+out = np.zeros(2000, np.uint8)
+assert nat.lib().circl_hip_mlkem_encaps(768, None, out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), None, 1, 0) == nat.EPARAM
+print("ok")
+"""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

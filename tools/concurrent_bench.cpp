@@ -6,7 +6,7 @@
 // call when the previous one has returned, so aggregate <= T / latency: Little's law).  Every result is compared with the answer of
 // ONE ordinary batch call made beforehand (bit-exact under concurrency, whatever batches the calls ended up in).
 //
-//   concurrent_bench <op: encaps|decaps|verify|sign> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
+//   concurrent_bench <op: encaps|decaps|verify|sign|encaps_item> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
 //
 // Output: one line per T: aggregate ops/s, p50 / p99 / max latency of a call (us), calls per launch when coalescing.
 // Built by tools/build_tools.sh (g++ against libcirclhip.so); profiles/r05_concurrent.txt is its output on one MI355X.
@@ -60,7 +60,7 @@ static CpuStat cpu_stat() {
 
 int main(int argc, char **argv) {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s <encaps|decaps|verify|sign> <coalesce max_items> <max_wait_us> <items per call> <seconds> <T> [T ...]\n", argv[0]);
+        fprintf(stderr, "usage: %s <encaps|decaps|verify|sign|encaps_item> <coalesce max_items> <max_wait_us> <items per call> <seconds> <T> [T ...]\n", argv[0]);
         return 2;
     }
     const std::string op = argv[1];
@@ -83,7 +83,17 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> m, ct, ss, st, sig, ok, mblob;
     std::vector<uint64_t> moff;
     const size_t MSG = 32;
-    if (op == "encaps" || op == "decaps") {
+    std::vector<uint8_t> ek_rows;  // encaps_item: every item's own key (the rows a caller without a resident table passes)
+    if (op == "encaps_item") {
+        // the TLS-server shape: every call encapsulates ONCE, to a key that comes with the call (POOL distinct keys)
+        std::vector<uint8_t> seed = bytes(64 * POOL, 1), dk(DK * POOL);
+        ek_rows.resize(EK * POOL);
+        CHECK(circl_hip_mlkem_keygen(kem, seed.data(), ek_rows.data(), dk.data(), POOL, 0) == 0);
+        m = bytes(32 * POOL, 2);
+        ct.resize(CT * POOL); ss.resize(32 * POOL); st.resize(POOL);
+        CHECK(circl_hip_mlkem_encaps(kem, ek_rows.data(), m.data(), ct.data(), ss.data(), st.data(), POOL, 0) == 0);  // the answers
+        if (co_items) CHECK(circl_hip_set_coalesce(co_items, co_wait) == 0);
+    } else if (op == "encaps" || op == "decaps") {
         std::vector<uint8_t> seed = bytes(64 * NK, 1), ek(EK * NK), dk(DK * NK);
         CHECK(circl_hip_mlkem_keygen(kem, seed.data(), ek.data(), dk.data(), NK, 0) == 0);
         m = bytes(32 * POOL, 2);
@@ -127,7 +137,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "unknown op %s\n", op.c_str());
         return 2;
     }
-    if (co_items) CHECK(circl_hip_keytable_set_coalesce(table, co_items, co_wait) == 0);
+    if (co_items && table) CHECK(circl_hip_keytable_set_coalesce(table, co_items, co_wait) == 0);
     printf("# %s, %zu item(s) per call, %zu resident keys, coalesce max_items=%zu max_wait_us=%u, %.1f s per point\n", op.c_str(), per_call, NK, co_items,
            co_wait, seconds);
 
@@ -138,7 +148,7 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> calls(T, 0);
         std::atomic<uint64_t> mismatches{0};
         uint64_t c0 = 0, i0 = 0, l0 = 0;
-        circl_hip_keytable_coalesce_stats(table, &c0, &i0, &l0);
+        if (table) circl_hip_keytable_coalesce_stats(table, &c0, &i0, &l0);
         std::vector<std::thread> th;
         Clock::time_point t_begin;
         for (int t = 0; t < T; t++) {
@@ -152,7 +162,10 @@ int main(int argc, char **argv) {
                 while (!stop.load(std::memory_order_relaxed)) {
                     const auto a = Clock::now();
                     bool good = true;
-                    if (op == "encaps") {
+                    if (op == "encaps_item") {
+                        CHECK(circl_hip_mlkem_encaps(kem, &ek_rows[EK * at], &m[32 * at], o_ct.data(), o_ss.data(), o_st.data(), per_call, 0) == 0);
+                        good = !memcmp(o_ct.data(), &ct[CT * at], CT * per_call) && !memcmp(o_ss.data(), &ss[32 * at], 32 * per_call);
+                    } else if (op == "encaps") {
                         CHECK(circl_hip_mlkem_encaps_table(table, &kidx[at], &m[32 * at], o_ct.data(), o_ss.data(), o_st.data(), per_call) == 0);
                         good = !memcmp(o_ct.data(), &ct[CT * at], CT * per_call) && !memcmp(o_ss.data(), &ss[32 * at], 32 * per_call);
                     } else if (op == "decaps") {
@@ -188,7 +201,7 @@ int main(int argc, char **argv) {
         std::sort(all.begin(), all.end());
         auto q = [&](double f) { return all.empty() ? 0.f : all[std::min(all.size() - 1, (size_t)(f * all.size()))]; };
         uint64_t c1 = 0, i1 = 0, l1 = 0;
-        circl_hip_keytable_coalesce_stats(table, &c1, &i1, &l1);
+        if (table) circl_hip_keytable_coalesce_stats(table, &c1, &i1, &l1);
         printf("T=%-4d %10.0f ops/s  (%8.0f calls/s)  latency us p50 %7.1f  p99 %7.1f  max %8.1f", T, total * per_call / el, total / el, q(0.50), q(0.99),
                all.empty() ? 0.f : all.back());
         if (l1 > l0) printf("  | %.1f calls, %.1f items per launch", (double)(c1 - c0) / (l1 - l0), (double)(i1 - i0) / (l1 - l0));
@@ -199,6 +212,6 @@ int main(int argc, char **argv) {
         fflush(stdout);
         CHECK(mismatches.load() == 0);
     }
-    circl_hip_keytable_free(table);
+    if (table) circl_hip_keytable_free(table);
     return 0;
 }
