@@ -284,9 +284,10 @@ Pool *pool_of(int dev) {
     if (!g_pools[dev]) {
         Pool *p = new Pool;
         // the calling thread works too, so a pool of T threads gives T + 1 movers; the CPUs are shared by all devices.  The copies are
-        // memory-bound: 4 movers reach the PCIe-bound rate (3.98e7 ML-KEM-768 encapsulations/s with 4.9 CPUs busy), 16 reach the same
-        // rate with 12.8 CPUs busy, 2 reach 3.66e7 with 3.8 (profiles/r05_logical8.txt) -- an 8-GPU node spends ~40 CPUs, not 130
-        const int dflt = std::min(4, std::max(1, usable_cpus() / nd));
+        // memory-bound (profiles/r05_logical8.txt, 2^20 ML-KEM-768 encapsulations from byte-misaligned pageable arrays): 2 movers 3.42e7/s
+        // with 3.6 CPUs busy, 4 3.82e7 / 4.8, 8 3.76e7 / 6.2, 16 3.78e7 / 12.0 -- but with 4 a caller whose arrays live on the other
+        // socket fell to 3.27e7/s (bench.py's process, one run), so 8: ~50 CPUs for an 8-GPU node instead of ~100
+        const int dflt = std::min(8, std::max(1, usable_cpus() / nd));
         p->nthreads = env_int("CIRCL_HIP_HOST_THREADS", dflt, 0, 256);
         const std::vector<int> cpus = dev_info(dev).cpus;
         for (int t = 0; t < p->nthreads; t++) std::thread(worker_main, p, cpus).detach();

@@ -27,9 +27,20 @@ pool = 1 << 12
 seeds = rng.integers(0, 256, (pool, 64), dtype=np.uint8)
 ekp, dkp = np.empty((pool, EK), np.uint8), np.empty((pool, 2400), np.uint8)
 assert L.circl_hip_mlkem_keygen(768, seeds.ctypes.data, ekp.ctypes.data, dkp.ctypes.data, pool, 0) == 0
-ek = np.tile(ekp, (n // pool, 1))                      # pageable, touched
-m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-ct, ss, st = np.zeros((n, CT), np.uint8), np.zeros((n, 32), np.uint8), np.zeros(n, np.uint8)
+mis = len(sys.argv) > 2 and sys.argv[2] == "misaligned"  # a Go sub-slice is 1-byte aligned: arrays 1, 3, 5, 7, 9 bytes into their allocations
+
+
+def arr(rows, cols, off, fill=None):
+    raw = np.zeros(rows * cols + 64, np.uint8)         # pageable, touched
+    a = raw[off:off + rows * cols].reshape(rows, cols) if mis else raw[:rows * cols].reshape(rows, cols)
+    if fill is not None:
+        a[:] = fill
+    return a
+
+
+ek = arr(n, EK, 1, np.tile(ekp, (n // pool, 1)))
+m = arr(n, 32, 3, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+ct, ss, st = arr(n, CT, 5), arr(n, 32, 7), arr(n, 1, 9).reshape(-1)
 
 
 def cpu():
@@ -45,7 +56,8 @@ def run(dev):
 
 
 print(f"{nd} logical device(s) on {L.circl_hip_physical_device(nd - 1) + 1} HIP device(s); 2^{lg} ML-KEM-768 encapsulations from pageable memory, "
-      f"{len(os.sched_getaffinity(0))} CPUs in the affinity mask, CIRCL_HIP_HOST_THREADS={os.environ.get('CIRCL_HIP_HOST_THREADS', 'default')}")
+      f"{len(os.sched_getaffinity(0))} CPUs in the affinity mask, CIRCL_HIP_HOST_THREADS={os.environ.get('CIRCL_HIP_HOST_THREADS', 'default')}, "
+      f"arrays {'byte-misaligned (1, 3, 5, 7, 9)' if mis else 'aligned'}")
 for dev, name in ((-1, "device = -1 (all logical devices)"), (0, "device = 0")):
     run(dev)                                           # warm: pools, streams
     best = None
@@ -62,7 +74,7 @@ for dev, name in ((-1, "device = -1 (all logical devices)"), (0, "device = 0")):
     if dev == -1:
         for rate in (3.5e7, 4.0e7):
             print(f"    8 GPUs at {rate:.1e}/s each through host buffers = {8 * rate:.1e}/s need {8 * rate * per_m / 1e6:.1f} CPUs for the byte movers + shard threads")
-ref = np.empty_like(ct[:4096])
+ref = np.zeros((4096, CT), np.uint8)
 assert L.circl_hip_mlkem_encaps(768, ek.ctypes.data, m.ctypes.data, ref.ctypes.data, ss.ctypes.data, st.ctypes.data, 4096, 0) == 0
 assert (ref == ct[:4096]).all()
 print("bytes equal device 0's")
