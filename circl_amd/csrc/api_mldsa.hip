@@ -519,6 +519,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     S.list[1] = reinterpret_cast<uint32_t *>(base + lay.o_list1);
     S.count = reinterpret_cast<uint32_t *>(base + lay.o_ctl);
     S.kk = S.count + 2;
+    S.chain_done = S.count + 8;
     S.capacity = (uint32_t)lay.E;
     uint8_t *dead = base + lay.o_dead;
     unsigned *tail_work = reinterpret_cast<unsigned *>(base + lay.o_work);
@@ -545,7 +546,15 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     static const double eps = __builtin_ldexp(1.0, -env_int("CIRCL_HIP_SIGN_EPS_LOG2", 16, 1, 60));  // expected unsigned items behind the schedule
     const int rounds = sign_round_schedule<MODE>(n, k0, S.spec_target, S.pair, entries_upper, lazy, kMaxRounds, eps);
     const unsigned nb256 = (unsigned)((n + 255) / 256);
-    {
+    // small batches: mu, rho'', the dead flags (and a prepared key's list set-up) in ONE launch, two items per wavefront on the
+    // cooperative permutation (mldsa_sign_front_kernel) instead of fill + scan + mu + prep; CIRCL_HIP_SIGN_FRONT=0: the separate kernels
+    static const bool one_front = env_int("CIRCL_HIP_SIGN_FRONT", 1, 0, 1) != 0;
+    if (one_front && n <= kSmallMu) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
+        hipLaunchKernelGGL(mldsa_sign_front_kernel<MODE>, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, sk, (shared && !key_idx) ? size_t(0) : (size_t)KG<MODE>::SK,
+                           key_idx, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, S.mr, n, dead, prep ? S.attempts : nullptr, prep ? S.best : nullptr,
+                           prep ? S.list[0] : nullptr, prep ? S.count : nullptr, k0);
+    } else {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
         if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
@@ -583,6 +592,13 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         // hash chains of short rounds on lane pairs (sign_mask_kernel): while a lane per stream leaves the SIMDs at or below one wavefront each
         const bool split_mask = upper * L <= sign_split_lanes(), split_ch = upper <= sign_split_lanes();
         const bool coop_mask = upper * L <= sign_coop_streams(), coop_ch = upper <= sign_coop_streams();
+        // a SHORT round in one launch: a workgroup of K wavefronts per entry runs mask -> w -> challenge -> finish (sign_round_chain_kernel);
+        // up to 2^CIRCL_HIP_SIGN_CHAIN_LOG2 entries (0: never), never a lazy round
+        static const size_t chain_entries = [] { const int lg = env_int("CIRCL_HIP_SIGN_CHAIN_LOG2", 8, 0, 16); return lg <= 0 ? size_t(0) : size_t(1) << lg; }();
+        if (upper <= chain_entries && !lazy[round]) {
+            hipLaunchKernelGGL(sign_round_chain_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, upper)), dim3(K * 64), 0, st, S, cur, sig, round == rounds - 1 ? 1 : 0);
+            continue;  // (its last workgroup commits and compacts)
+        }
         if (coop_mask) hipLaunchKernelGGL(sign_mask_coop_kernel<MODE>, dim3((unsigned)std::max<size_t>(1, (upper * L + 1) / 2)), dim3(64), 0, st, S, cur);
         else if (split_mask) hipLaunchKernelGGL((sign_mask_kernel<MODE, true>), dim3((unsigned)std::max<size_t>(1, std::min((upper * L + 127) / 128, lane_cap))), dim3(256), 0, st, S, cur);
         else hipLaunchKernelGGL((sign_mask_kernel<MODE, false>), dim3(gm), dim3(256), 0, st, S, cur);
@@ -625,8 +641,14 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     // (mu / rho'', the ticket counter and the tail's scratch slices lie back to back: one fill; the tail kernel's workgroup b works in
     // slice b and only workgroups below the number of unsigned items -- at most n -- do anything)
     const size_t tail_used = std::min<size_t>(n, std::min<size_t>(lay.tail_units, 512));
-    HIP_TRY(hipMemsetAsync(S.mr, 0, (size_t)(tail_scratch - S.mr) + tail_used * SG<MODE>::SCRATCH_BYTES, st));
-    HIP_TRY(hipMemsetAsync(base + lay.o_sec, 0, lay.o_secret_end - lay.o_sec, st));  // (the workspace's; a prepared key's table stays)
+    const size_t wipe_a = (size_t)(tail_scratch - S.mr) + tail_used * SG<MODE>::SCRATCH_BYTES, wipe_b = lay.o_secret_end - lay.o_sec;
+    if (wipe_a + wipe_b <= (size_t(8) << 20) && wipe_a % 16 == 0 && wipe_b % 16 == 0) {  // a small call: both ranges in one launch
+        hipLaunchKernelGGL(sign_wipe2_kernel, dim3((unsigned)std::min<size_t>((wipe_a + wipe_b) / 16 / 256 + 1, (size_t)cus * 8)), dim3(256), 0, st,
+                           reinterpret_cast<uint4 *>(S.mr), wipe_a / 16, reinterpret_cast<uint4 *>(base + lay.o_sec), wipe_b / 16);
+    } else {
+        HIP_TRY(hipMemsetAsync(S.mr, 0, wipe_a, st));
+        HIP_TRY(hipMemsetAsync(base + lay.o_sec, 0, wipe_b, st));  // (the workspace's; a prepared key's table stays)
+    }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -765,7 +787,7 @@ template <int MODE> int mldsa_privkey_build(circl_hip_keytable *t, const uint8_t
     S.shared = 0u;
     S.A = reinterpret_cast<uint32_t *>(t->d_table);
     S.sec = reinterpret_cast<uint32_t *>(t->d_table + o_sec);
-    S.count = scratch; S.kk = scratch + 2; S.attempts = scratch + 64; S.best = scratch + 64 + nk; S.list[0] = scratch + 64 + 2 * nk; S.list[1] = S.list[0];
+    S.count = scratch; S.kk = scratch + 2; S.chain_done = scratch + 8; S.attempts = scratch + 64; S.best = scratch + 64 + nk; S.list[0] = scratch + 64 + 2 * nk; S.list[1] = S.list[0];
     hipLaunchKernelGGL(sign_expand_a_kernel<MODE>, dim3((unsigned)((nk * K * L + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_keys, S, nk);
     hipLaunchKernelGGL(sign_secrets_kernel<MODE>, dim3((unsigned)nk), dim3(64), 0, st, (const uint8_t *)t->d_keys, S, nk, 1u);
     HIP_TRY(hipGetLastError());

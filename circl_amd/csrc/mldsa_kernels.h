@@ -1489,7 +1489,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
         rl_attempts[idx] = 0;
         rl_best[idx] = 0xffffffffu;                                                       // kNoSuccess
         for (unsigned o = 0; o < rl_k0; o++) rl_list0[idx * rl_k0 + o] = (uint32_t)idx | (o << 26);  // item | off << kEntryShift
-        if (idx == 0) { rl_ctl[0] = (uint32_t)(n * rl_k0); rl_ctl[1] = 0; rl_ctl[2] = rl_k0; rl_ctl[3] = 1; }  // count[0..1], kk[0..1]
+        if (idx == 0) { rl_ctl[0] = (uint32_t)(n * rl_k0); rl_ctl[1] = 0; rl_ctl[2] = rl_k0; rl_ctl[3] = 1; rl_ctl[8] = 0; }  // count[0..1], kk[0..1], chain_done
     }
     {
         // sign.ErrContextTooLong (mldsa65/dilithium.go:63-65) / sign.ErrContextNotSupported (round 3): the host-buffer entry
@@ -1528,6 +1528,101 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
     h.hi[16] ^= 0x80000000u;
     keccak_f1600(h);
     store_words<0, 8>(reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64), h);  // rho''
+}
+
+// The signing front end of a SMALL batch in one launch: what the long-message scan, mldsa_mu_long_kernel and mldsa_sign_prep_kernel do in
+// three (plus a fill) -- mu = H(tr || M') and rho'' = H(key || rnd || mu), two items per wavefront on the cooperative permutation (three
+// dependent permutations of ~3.5 us for a short message instead of two launches and a lane-form permutation), the "dead" flags, and for
+// prepared keys the set-up of the round signer's lists.  Same bytes as the three kernels (tests/test_gpu_round3.py forces both ways).
+template <int MODE>
+__global__ void __launch_bounds__(64) mldsa_sign_front_kernel(const uint8_t *__restrict__ sk, size_t sk_stride, const uint32_t *__restrict__ key_idx,
+                                                             const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
+                                                             const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
+                                                             const uint8_t *__restrict__ rnd, int internal, uint8_t *__restrict__ mr_ws, size_t n,
+                                                             uint8_t *__restrict__ dead_ws, uint32_t *__restrict__ rl_attempts, uint32_t *__restrict__ rl_best,
+                                                             uint32_t *__restrict__ rl_list0, uint32_t *__restrict__ rl_ctl, unsigned rl_k0) {
+    using P = DP<MODE>;
+    constexpr int TRW = P::TR / 8, MU0 = P::NIST ? 8 : 4;  // round 3: rho'' = CRH(key || mu), no rnd (dilithium.go:357-364)
+    __shared__ uint64_t ws[100];
+    const int lane = threadIdx.x, half = lane >> 5, j = lane & 31;
+    const CoopLane c = coop_lane(ws, lane);
+    const int eff_internal = P::NIST ? internal : 1;  // round 3: mu = CRH(tr || msg)
+#pragma unroll 1
+    for (size_t pair = blockIdx.x; 2 * pair < n; pair += gridDim.x) {  // block-uniform
+        const size_t e = 2 * pair + (size_t)half;
+        const bool live = e < n;
+        const size_t idx = live ? e : n - 1;  // the odd one out is done twice, stored once
+        const size_t q = key_idx ? (size_t)key_idx[idx] : idx;
+        const uint8_t *skp = sk + q * sk_stride;
+        const size_t mlen = (size_t)(msg_off[idx + 1] - msg_off[idx]);
+        const uint8_t *cp = ctx_blob ? ctx_blob + ctx_off[idx] : nullptr;
+        const size_t clen = ctx_blob ? (size_t)(ctx_off[idx + 1] - ctx_off[idx]) : 0;
+        if (live && j == 0) {  // sign.ErrContextTooLong / ErrContextNotSupported: see mldsa_sign_prep_kernel
+            const size_t cl = (ctx_blob && !internal) ? clen : 0;
+            dead_ws[idx] = (cl > 255 || (!P::NIST && cl > 0)) ? 1 : 0;
+        }
+        // ---- mu = SHAKE256(tr || M')[:64] (the loop of mldsa_mu_long_kernel) ----
+        uint32_t vlo = 0, vhi = 0, mu_lo = 0, mu_hi = 0;
+        if (j < TRW) {
+            const uint64_t w = reinterpret_cast<const uint64_t *>(skp + 64)[j];
+            vlo = (uint32_t)w;
+            vhi = (uint32_t)(w >> 32);
+        }
+        const MPrime mpr(msg_blob + msg_off[idx], mlen, cp, clen, eff_internal);
+        size_t pos = 0;
+        int w0 = TRW;
+        bool done = false;
+#pragma unroll 1
+        for (;;) {
+            if (!done && j >= w0 && j < 17) {
+                uint32_t lo, hi;
+                mpr.word(pos + 8 * (size_t)(j - w0), lo, hi);
+                vlo ^= lo;
+                vhi ^= hi;
+            }
+            const size_t span = 8 * (size_t)(17 - w0);
+            const bool last = mpr.total < pos + span;
+            if (!done && last && j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2(vlo, vhi, c);
+            if (!done && last) {
+                mu_lo = vlo;  // (word j of mu in lane j of the half, j < 8)
+                mu_hi = vhi;
+                done = true;
+            }
+            if (!__any(!done)) break;
+            pos += span;
+            w0 = 0;
+        }
+        // ---- rho'' = SHAKE256(key || rnd || mu)[:64]: mu moves up to words MU0 .. MU0 + 7 ----
+        const int src = (lane & 32) | ((j - MU0) & 31);
+        const uint32_t m_lo = (uint32_t)__shfl((int)mu_lo, src), m_hi = (uint32_t)__shfl((int)mu_hi, src);
+        vlo = vhi = 0;
+        if (j < 4) {
+            const uint64_t w = reinterpret_cast<const uint64_t *>(skp + 32)[j];  // key
+            vlo = (uint32_t)w;
+            vhi = (uint32_t)(w >> 32);
+        } else if (P::NIST && j < 8) {
+            const uint64_t w = reinterpret_cast<const uint64_t *>(rnd + idx * 32)[j - 4];  // rnd (zero = deterministic)
+            vlo = (uint32_t)w;
+            vhi = (uint32_t)(w >> 32);
+        } else if (j >= MU0 && j < MU0 + 8) {
+            vlo = m_lo;
+            vhi = m_hi;
+        }
+        if (j == MU0 + 8) vlo ^= kDsShake;
+        if (j == 16) vhi ^= 0x80000000u;
+        keccak_f1600_coop2(vlo, vhi, c);
+        if (live && j < 8) {
+            reinterpret_cast<uint64_t *>(mr_ws + idx * 128)[j] = ((uint64_t)mu_hi << 32) | mu_lo;
+            reinterpret_cast<uint64_t *>(mr_ws + idx * 128 + 64)[j] = ((uint64_t)vhi << 32) | vlo;
+        }
+        if (rl_attempts && live && j == 0) {  // prepared keys: the round signer's lists (what is left of sign_secrets_kernel)
+            rl_attempts[idx] = 0;
+            rl_best[idx] = 0xffffffffu;                                                       // kNoSuccess
+            for (unsigned o = 0; o < rl_k0; o++) rl_list0[idx * rl_k0 + o] = (uint32_t)idx | (o << 26);  // item | off << kEntryShift
+            if (idx == 0) { rl_ctl[0] = (uint32_t)(n * rl_k0); rl_ctl[1] = 0; rl_ctl[2] = rl_k0; rl_ctl[3] = 1; rl_ctl[8] = 0; }
+        }
+    }
 }
 
 // lane = item: items whose context the scheme refuses (see mldsa_sign_prep_kernel) leave with an all-zero signature

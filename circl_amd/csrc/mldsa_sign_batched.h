@@ -71,6 +71,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
     const uint32_t *key_idx; // shared == 2 with a table of SEVERAL prepared keys: item i signs with entry key_idx[i] (nullptr: entry 0)
     unsigned *tail_work;    // the persistent tail kernel's ticket counter (64 words), zeroed by the last round's compaction
+    unsigned *chain_done;   // workgroups of a one-launch round that are through (sign_round_chain_kernel); zero between rounds
     // which entry of A / sec an item uses
     __device__ __forceinline__ size_t key_of(size_t item) const { return shared ? (key_idx ? (size_t)key_idx[item] : size_t(0)) : item; }
 };
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(64) sign_secrets_kernel(const uint8_t *__restr
         st.count[1] = 0;
         st.kk[0] = k0;
         st.kk[1] = 1;
+        *st.chain_done = 0;
     }
 }
 
@@ -596,14 +598,20 @@ __global__ void __launch_bounds__(64) sign_challenge_coop_kernel(SignState st, i
 // wave = entry: the three rejection tests, hints, signature (dilithium.go:407-455, :84-88).
 // One entry's work (sign_finish_kernel below runs it inlined for a workgroup's first entry and through a non-inlined copy for
 // any further one).
-template <int MODE>
+// WS (wave sync): the body runs on ONE wavefront of a multi-wavefront workgroup (sign_round_chain_kernel) whose buffers here are private to
+// it: every ordering point is the wave-level no-wait form instead of a workgroup barrier.
+template <int MODE, bool WS = false>
 __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t slot, bool direct, uint32_t *xch,
                                                  uint8_t *zpk, uint8_t *hbytes, uint8_t *blk) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using B = SB<MODE>;
     constexpr int K = P::K, L = P::L;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    auto fsync = [] {
+        if constexpr (WS) { __builtin_amdgcn_s_waitcnt(0); wave_lds_order(); }
+        else __syncthreads();
+    };
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     const uint32_t e = st.list[cur][slot];
     const size_t item = e & kEntryItemMask;
@@ -611,7 +619,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     if (st.best[item] < off) return;  // a lower attempt of the item has already succeeded (the challenge kernel skipped it too)
     const uint8_t *cb = st.cb + slot * B::CB_BYTES;
     uint32_t chat[4];
-    sample_in_ball_hat<MODE>(chat, cb + 120, blk, xch, z, lane);
+    sample_in_ball_hat<MODE, true, false, true, WS>(chat, cb + 120, blk, xch, z, lane);
     const uint32_t *sec = st.sec + st.key_of(item) * (L + 2 * K) * kPackedRowDwords;
     constexpr bool NW = true;  // (wave-private exchange buffer: see sign_w_entries)
     uint32_t *w0 = st.w0 + slot * B::W0_SLOT_DW;
@@ -663,9 +671,9 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
             for (int r = 0; r < 3; r++) { raw[r] = raw_n[r]; wraw[r] = wraw_n[r]; }
         }
         if (__any(bad)) return;
-        __syncthreads();
+        fsync();
         for (int d = lane; d < K * kPackedRowDwords; d += 64) w0[d] = r0l[d];
-        __syncthreads();  // ... before z is packed into the same area
+        fsync();  // ... before z is packed into the same area
     }
     if (__any(bad)) return;
     // z = y + c s1.  A polynomial that passes its norm test is bit-packed at once as it will appear in the signature (pack.go:202-254)
@@ -700,7 +708,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
                 f[r] = fr;
             }
             if (__any(bad)) break;
-            mlkem::stage_bits_l1<G::ZBITS>(xch, f, lane);
+            mlkem::stage_bits_l1<G::ZBITS, WS>(xch, f, lane);
             for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
 #pragma unroll
             for (int r = 0; r < 3; r++) raw[r] = raw_n[r];
@@ -711,9 +719,9 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
     if (__any(bad)) return;
     // c t0, hints
     unsigned pop = 0;
-    __syncthreads();
+    fsync();
     for (int i = lane; i < 24; i += 64) reinterpret_cast<uint32_t *>(hbytes)[i] = 0;
-    __syncthreads();
+    fsync();
     {
         uint32_t raw[3];
         load_row(raw, sec + (L + K) * kPackedRowDwords);
@@ -749,7 +757,7 @@ __device__ __forceinline__ void sign_finish_body(const SignState &st, int cur, u
         }
     }
     if (__any(bad) || pop > (unsigned)P::OMEGA) return;
-    __syncthreads();       // every lane is done with w0
+    fsync();       // every lane is done with w0
     // `direct`: this attempt is the lowest one of its item that can still succeed (one attempt per item, or a lazy pair,
     // whose second attempt only runs after the first was rejected): the signature goes straight out.  Otherwise it is parked
     // in the slot's w0 area and the commit kernel copies the lowest successful attempt's.
@@ -792,42 +800,202 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
     }
 }
 
+template <int MODE>
+__device__ __forceinline__ void sign_commit_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t first, size_t stride);
+__device__ __forceinline__ void sign_compact_body(const SignState &st, int cur, int last, unsigned block, unsigned nblocks, unsigned nthreads);
+
+// ---- a short round in ONE launch -------------------------------------------------------------------------------------------
+// mask -> w -> challenge -> finish of one list entry by one workgroup of K wavefronts, for rounds of a few hundred entries at most
+// (one signature with a prepared key: 64 speculative attempts).  Such a round is latency from end to end -- four dependent launches
+// of a few microseconds of work each -- and a single wavefront per entry walks L + K transforms one after the other.  Here:
+//   A   ExpandMask: two streams per wavefront on the cooperative permutation, ceil(L / 2) wavefronts side by side (as sign_mask_coop_kernel)
+//   B1  y-hat_l = NTT(y_l): a wavefront per l, parked in LDS (pack24)
+//   B2  w_i = InvNTT(sum_j A_ij y-hat_j), Decompose, w0 / w1: a wavefront per ROW i
+//   C   c~ = H(mu || w1) and the first SampleInBall block: wavefront 0 on the cooperative permutation (7-9 dependent permutations)
+//   D   the norm tests, hints and the signature: wavefront 0, the body of sign_finish_kernel with wave-level ordering points
+// with a workgroup barrier between the phases (data crosses wavefronts there: y through global memory -- the finish phase wants it
+// there anyway --, y-hat through LDS, w0 / w1 through the entry's global slots).  Same bytes as the four kernels (the per-entry
+// arithmetic is theirs); commit and compact follow as separate launches.
+template <int MODE>
+__global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(SignState st, int cur, uint8_t *__restrict__ sig, int last_round) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    constexpr int K = P::K, L = P::L, MW = (L + 1) / 2;
+    static_assert(K >= L, "a wavefront per row also gives a wavefront per mask polynomial");
+    __shared__ __attribute__((aligned(16))) uint32_t xch_all[K][dilithium::kXchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t yhat[L * kPackedRowDwords];
+    __shared__ __attribute__((aligned(16))) uint64_t coop_ws[MW][100];
+    __shared__ __attribute__((aligned(16))) uint8_t zpk[K * kPackedRowDwords * 4 > L * G::ZSZ ? K * kPackedRowDwords * 4 : L * G::ZSZ];
+    __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
+    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *xch = xch_all[wave];
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    const size_t count = st.count[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.count[cur ^ 1] = 0;  // filled by this round's compact kernel (the mask kernel's duty otherwise)
+    const bool direct = st.kk[cur] == 1;  // (lazy rounds never come here)
+    constexpr bool NW = true;
+#pragma unroll 1
+    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {  // block-uniform
+        const uint32_t e = st.list[cur][slot];
+        const size_t item = e & kEntryItemMask;
+        const uint32_t off = e >> kEntryShift;
+        // ---- A: y = ExpandMask(rho'', L * attempt + l), two polynomials per wavefront ----
+        if (wave < MW) {
+            const int half = lane >> 5, j = lane & 31;
+            const CoopLane c = coop_lane(coop_ws[wave], lane);
+            const int l = 2 * wave + half;
+            const bool on = l < L;
+            const uint32_t nonce = (((st.attempts[item] + off) * L + (on ? l : 0)) & 0xffff) | (kDsShake << 16);
+            const uint64_t *seed = reinterpret_cast<const uint64_t *>(st.mr + item * 128 + 64);
+            const uint64_t w0 = j < 8 ? seed[j] : j == 8 ? (uint64_t)nonce : j == 16 ? 0x8000000000000000ull : 0ull;
+            uint32_t vlo = (uint32_t)w0, vhi = (uint32_t)(w0 >> 32);
+            uint32_t *yrow = st.y + (slot * L + (on ? l : 0)) * B::YROW_DW;
+#pragma unroll 1
+            for (int blk_i = 0; blk_i < 5; blk_i++) {
+                keccak_f1600_coop2<NW>(vlo, vhi, c);
+                const int d = 34 * blk_i + 2 * j;
+                if (on && j < 17) {  // only the ZSZ payload bytes are kept
+                    if (d < G::ZSZ / 4) yrow[d] = vlo;
+                    if (d + 1 < G::ZSZ / 4) yrow[d + 1] = vhi;
+                }
+            }
+        }
+        if (wave == K - 1 && lane < 16)  // mu in front of the w1 bytes that follow (an idle wavefront's job)
+            reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES)[lane] = reinterpret_cast<const uint32_t *>(st.mr + item * 128)[lane];
+        __threadfence_block();
+        __syncthreads();
+        // ---- B1: y-hat_l, a wavefront per polynomial ----
+        if (wave < L) {
+            const uint32_t *yrow = st.y + (slot * L + wave) * B::YROW_DW;
+            uint32_t yh[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t x = G::GAMMA1 - gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+                x += (uint32_t)((int32_t)x >> 31) & Q;
+                yh[r] = x;
+            }
+            dilithium::ntt<NW>(yh, z, xch, lane);  // plain y-hat, < 17q
+            const uint32_t f[4] = {dilithium::fold(yh[0]), dilithium::fold(yh[1]), dilithium::fold(yh[2]), dilithium::fold(yh[3])};
+            store_poly24(yhat + wave * kPackedRowDwords, f, lane);
+        }
+        __syncthreads();
+        // ---- B2: row `wave` of w = A y-hat, Decompose ----
+        {
+            const int i = wave;
+            const uint32_t *arow = st.A + st.key_of(item) * K * L * kPackedRowDwords + (size_t)i * L * kPackedRowDwords;
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                uint32_t a[4], y0[4];
+                load_poly24(a, arow + j * kPackedRowDwords, lane);
+                load_poly24(y0, yhat + j * kPackedRowDwords, lane);
+                asm volatile("" : "+v"(y0[0]), "+v"(y0[1]), "+v"(y0[2]), "+v"(y0[3]));  // keep y opaque: see sign_w_entries (24-bit multiply selection)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] += (uint64_t)a[r] * y0[r];
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] = dilithium::mont64(acc[r]);
+            dilithium::invntt<dilithium::INV256_RR, NW>(w, z, xch, lane);
+            unsigned w1v[4];
+            uint32_t a0v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t a1;
+                dilithium::decompose<P::GAMMA2>(dilithium::csubq(w[r]), a0v[r], a1);
+                w1v[r] = a1;
+            }
+            store_poly24(st.w0 + slot * B::W0_SLOT_DW + i * kPackedRowDwords, a0v, lane);
+            mlkem::stage_bits_l1<G::W1BITS, NW>(xch, w1v, lane);
+            mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i), xch, lane, false);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- C + D: wavefront 0 alone ----
+        if (wave == 0) {
+            const int j = lane & 31;
+            const CoopLane c = coop_lane(coop_ws[0], lane);
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(st.muw1 + slot * B::MUW1_BYTES);
+            uint32_t vlo, vhi;
+            mlkem::coop_sponge17<true>(vlo, vhi, [&](int k) { return src[k]; }, G::MUW1 / 8, kDsShake, c, j);  // (both halves carry the same sponge)
+            uint64_t *cb = reinterpret_cast<uint64_t *>(st.cb + slot * B::CB_BYTES);
+            if (lane < P::CT / 8) cb[lane] = ((uint64_t)vhi << 32) | vlo;
+            if (j >= P::CT / 8) { vlo = 0; vhi = 0; }  // the SampleInBall sponge absorbs c~: same state
+            if (j == P::CT / 8) vlo ^= kDsShake;
+            if (j == 16) vhi ^= 0x80000000u;
+            keccak_f1600_coop2<true>(vlo, vhi, c);
+            if (lane < 25) cb[15 + lane] = ((uint64_t)vhi << 32) | vlo;  // ball state at byte 120
+            __threadfence_block();  // (the finish body reads c~ and the ball state back from the slot)
+            sign_finish_body<MODE, true>(st, cur, sig, slot, direct, xch, zpk, hbytes, blk);
+        }
+        __syncthreads();  // the LDS buffers are reused by the workgroup's next entry
+    }
+    // ---- the LAST workgroup to get here commits the round's lowest successful attempts and builds the next list itself (two launches
+    // less): every workgroup releases its writes (signatures parked in its slots, best[]) at agent scope and takes a ticket; the one
+    // that draws the last ticket acquires and does what sign_commit_kernel / sign_compact_kernel do, on a list of a few hundred entries ----
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned ticket = atomicAdd(st.chain_done, 1u);
+        is_last = ticket == gridDim.x - 1;
+        if (is_last) __threadfence();
+    }
+    __syncthreads();
+    if (!is_last) return;
+    sign_commit_body<MODE>(st, cur, sig, (size_t)wave, (size_t)K);
+    __threadfence_block();
+    __syncthreads();
+    sign_compact_body(st, cur, last_round, 0u, 1u, (unsigned)(K * 64));
+    if (threadIdx.x == 0) *st.chain_done = 0;  // for the next one-launch round (kernels of a stream run one after the other)
+}
+
 // wave = entry, rounds with several attempts per item only (k == 1: every block leaves at once): the lowest successful
 // attempt's parked signature -> sig
+// (first / stride: which entries this wavefront takes -- blockIdx.x / gridDim.x for sign_commit_kernel; the wavefront's number / the
+// workgroup's wavefronts when the last workgroup of a one-launch round commits itself)
 template <int MODE>
-__global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+__device__ __forceinline__ void sign_commit_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t first, size_t stride) {
     using G = DG<MODE>;
-    constexpr int K = DP<MODE>::K;
     const size_t count = st.count[cur];
     if (st.kk[cur] == 1 || sign_round_lazy(count, st.kk[cur], st.spec_target)) return;  // those rounds wrote their signatures directly
+    const int lane = threadIdx.x & 63;
 #pragma unroll 1
-    for (size_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    for (size_t slot = first; slot < count; slot += stride) {
         const uint32_t e = st.list[cur][slot];
         const uint32_t item = e & kEntryItemMask;
         if (st.best[item] != (e >> kEntryShift)) continue;
         const uint32_t *src = st.w0 + slot * SB<MODE>::W0_SLOT_DW;
         uint8_t *dst = sig + (size_t)item * G::SIG;   // SIG is not a multiple of 4 for every parameter set: dwords, then the tail bytes
-        for (int d = threadIdx.x; d < G::SIG / 4; d += 64) {
+        for (int d = lane; d < G::SIG / 4; d += 64) {
             const uint32_t w = src[d];
             dst[4 * d] = (uint8_t)w; dst[4 * d + 1] = (uint8_t)(w >> 8); dst[4 * d + 2] = (uint8_t)(w >> 16); dst[4 * d + 3] = (uint8_t)(w >> 24);
         }
-        for (int b = (G::SIG / 4) * 4 + threadIdx.x; b < G::SIG; b += 64) dst[b] = reinterpret_cast<const uint8_t *>(src)[b];
+        for (int b = (G::SIG / 4) * 4 + lane; b < G::SIG; b += 64) dst[b] = reinterpret_cast<const uint8_t *>(src)[b];
     }
+}
+template <int MODE>
+__global__ void __launch_bounds__(64) sign_commit_kernel(SignState st, int cur, uint8_t *__restrict__ sig) {
+    sign_commit_body<MODE>(st, cur, sig, blockIdx.x, gridDim.x);
 }
 
 // lane = entry: the next active list.  Every item of the current one that is still unsigned has spent k attempts and gets
 // k_next entries; k_next follows from the current list's item count (an upper bound on the survivors), the same for every
 // lane.  One atomic per wavefront reserves the survivors' entries.  `last`: the list is for the persistent tail kernel, which
 // wants one entry per item.
-__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, int last) {
+// (block / nblocks / nthreads: the launch's own for sign_compact_kernel; 0 / 1 / the workgroup's size when the last workgroup of a
+// one-launch round does the compaction itself)
+__device__ __forceinline__ void sign_compact_body(const SignState &st, int cur, int last, unsigned block, unsigned nblocks, unsigned nthreads) {
     const size_t count = st.count[cur];
     const unsigned k = st.kk[cur];
     const unsigned k_next = last ? 1u : sign_next_k((count + k - 1) / k, st.spec_target, st.pair);
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.kk[cur ^ 1] = k_next;
-    if (last && blockIdx.x == 0 && threadIdx.x < 64) st.tail_work[threadIdx.x] = 0;  // (instead of a memset in front of the tail kernel: one launch less)
+    if (block == 0 && threadIdx.x == 0) st.kk[cur ^ 1] = k_next;
+    if (last && block == 0 && threadIdx.x < 64) st.tail_work[threadIdx.x] = 0;  // (instead of a memset in front of the tail kernel: one launch less)
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
-    for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {
+    for (size_t base = (size_t)block * nthreads; base < count; base += (size_t)nblocks * nthreads) {
         const size_t a = base + threadIdx.x;
         uint32_t item = 0;
         bool survivor = false;
@@ -846,6 +1014,16 @@ __global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur
             const uint32_t at = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1)) * k_next;
             for (unsigned j = 0; j < k_next; j++) st.list[cur ^ 1][at + j] = item | (j << kEntryShift);
         }
+    }
+}
+__global__ void __launch_bounds__(256) sign_compact_kernel(SignState st, int cur, int last) { sign_compact_body(st, cur, last, blockIdx.x, gridDim.x, 256); }
+
+// two ranges zeroed by one launch (the end of a small signing call: one launch instead of two fills); 16-byte aligned, sizes multiples of 16
+__global__ void __launch_bounds__(256) sign_wipe2_kernel(uint4 *__restrict__ a, size_t na, uint4 *__restrict__ b, size_t nb) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * 256) {
+        if (i < na) a[i] = z;
+        else b[i - na] = z;
     }
 }
 

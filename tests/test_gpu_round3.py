@@ -94,10 +94,11 @@ def test_randomised_soak_against_the_oracle():
 @pytest.mark.parametrize("env_extra", [{"CIRCL_HIP_SIGN_SPEC": "1", "CIRCL_HIP_SIGN_PAIR": "1"}, {"CIRCL_HIP_SIGN_SPEC": "1"},
                                        {"CIRCL_HIP_SIGN_SPEC": "4", "CIRCL_HIP_SIGN_PAIR": "1"}, {}, {"CIRCL_HIP_SIGN_BATCHED_MIN": "100000"},
                                        {"CIRCL_HIP_SIGN_SPLIT_LOG2": "0", "CIRCL_HIP_SIGN_EPS_LOG2": "40", "CIRCL_HIP_SIGN_COOP_LOG2": "0"},
-                                       {"CIRCL_HIP_SIGN_COOP_LOG2": "0"}, {"CIRCL_HIP_SIGN_COOP_LOG2": "16"}],
+                                       {"CIRCL_HIP_SIGN_COOP_LOG2": "0"}, {"CIRCL_HIP_SIGN_COOP_LOG2": "16"},
+                                       {"CIRCL_HIP_SIGN_CHAIN_LOG2": "0"}, {"CIRCL_HIP_SIGN_CHAIN_LOG2": "16"}, {"CIRCL_HIP_SIGN_FRONT": "0"}],
                          ids=["lazy-pairs", "single-attempts", "pairs-then-speculation", "default", "persistent-kernel", "lane-per-stream",
-                              "lane-pairs-in-short-rounds", "cooperative-everywhere"])
-@pytest.mark.parametrize("param,n,shared", [(65, 1500, ""), (44, 777, ""), (87, 600, ""), (3, 640, ""), (65, 900, "shared")])
+                              "lane-pairs-in-short-rounds", "cooperative-everywhere", "no-one-launch-rounds", "one-launch-rounds-everywhere", "front-end-in-three-launches"])
+@pytest.mark.parametrize("param,n,shared", [(65, 1500, ""), (44, 777, ""), (87, 600, ""), (3, 640, ""), (65, 900, "shared"), (65, 1, ""), (87, 5, ""), (44, 3, "shared")])
 def test_sign_round_modes(env_extra, param, n, shared):
     # sign/mldsa/mldsa65/internal/dilithium.go:340-470: the signature is the one of the FIRST attempt that passes the norm tests,
     # whatever the round structure: lazy pairs (two attempts share the matrix reads, the second one's tests run only after the
