@@ -313,6 +313,35 @@ def small_batches(dev):
     return out
 
 
+def concurrent_callers(seconds=1.0):
+    """The shape of every existing kem.Scheme consumer (kem/hybrid/hybrid.go:95-99, hpke/algs.go:283-285): T host threads, each calling ONE
+    resident-key encapsulation at a time through host buffers, closed loop -- with and without cross-caller coalescing
+    (circl_hip_keytable_set_coalesce).  tools/bin/concurrent_bench (C++, built by __graft_entry__.build()) does the calling and compares every
+    result with an ordinary batch call; this only parses its lines.  None when the tool is not there."""
+    import re
+    exe = os.path.join(ROOT, "tools", "bin", "concurrent_bench")
+    if not os.path.exists(exe):
+        return None
+    out = {"unit": "ops/s", "what": "ML-KEM-768, one item per call, 8 resident keys, T caller threads in a closed loop (aggregate <= T / latency), "
+                                    "%.0f s per point; latencies in us; host CPUs usable by this process: %d" % (seconds, len(os.sched_getaffinity(0)))}
+    for name, args in (("encaps_coalesced", ["encaps", "256", "0"]), ("encaps_uncoalesced", ["encaps", "0", "0"]), ("decaps_coalesced", ["decaps", "256", "0"])):
+        try:
+            r = subprocess.run([exe] + args + ["1", str(seconds), "1", "32", "64"], capture_output=True, text=True, timeout=120)
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)[-200:]}
+            continue
+        pts = {}
+        for ln in r.stdout.splitlines():
+            m = re.match(r"T=(\d+)\s+(\d+) ops/s.*p50\s+([0-9.]+)\s+p99\s+([0-9.]+).*mismatches (\d+)", ln)
+            if m:
+                pts["T%s" % m.group(1)] = {"ops_per_s": float(m.group(2)), "p50_us": float(m.group(3)), "p99_us": float(m.group(4)), "mismatches": int(m.group(5))}
+                cpu = re.search(r"CPU ([0-9.]+) us per call", ln)
+                if cpu:
+                    pts["T%s" % m.group(1)]["host_cpu_us_per_call"] = float(cpu.group(1))
+        out[name] = pts if (r.returncode == 0 and pts) else {"error": (r.stdout + r.stderr)[-300:]}
+    return out
+
+
 def host_abi(work, dev_index, runs=3):
     """End to end through circl_hip_mlkem_encaps (host pointers): H2D + kernels + D2H, first with buffers from
     circl_hip_alloc_host (page-locked), then with ordinary pageable numpy memory, as a Go caller's []byte would be."""
@@ -1000,6 +1029,9 @@ def main():
 
     if extras and rank == 0 and world == 1:
         out_cfg["small_batches"] = small_batches(dev)
+        cc = concurrent_callers()
+        if cc:
+            out_cfg["concurrent_callers"] = cc
 
     # ---- PMC: traffic / VALU instructions of the dominant kernels ----
     traffic, valu, pmc_note = None, None, None
