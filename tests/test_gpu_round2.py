@@ -399,7 +399,7 @@ def test_bench_py_small_run_emits_every_config():
     # the many-concurrent-callers leg (tools/bin/concurrent_bench, built by build()): coalesced beats uncoalesced, nothing mismatches
     cc = cfg.get("concurrent_callers")
     assert cc and cc["encaps_coalesced"]["T64"]["mismatches"] == 0 and cc["encaps_coalesced"]["T64"]["ops_per_s"] > 2 * cc["encaps_uncoalesced"]["T64"]["ops_per_s"]
-    assert out["roofline"]["valu"]["ceiling_source"] in ("live", None)
+    assert out["roofline"]["valu"] is None or out["roofline"]["valu"]["ceiling_source"] in ("live", None)  # (--no-pmc: no instruction count to price)
     for k in ("decaps", "config3", "config4", "config5", "host_abi", "shared_key", "keyed"):
         assert k in cfg, k
     assert cfg["decaps"]["parity"]["bit_exact_vs_oracle"] and cfg["decaps"]["parity"]["all_items_ss_dec_equals_ss_enc"]
