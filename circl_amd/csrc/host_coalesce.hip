@@ -6,14 +6,17 @@
 // One such call costs a launch and a wait whatever the kernel does (~30 us), so a GPU serves them only if the calls of MANY
 // callers become one launch.  No compute happens here: callers copy bytes, one of them launches the table's ordinary batch kernels.
 //
-//   caller      reserve rows of the OPEN batch (spin lock, tens of ns) -> copy inputs into its page-locked staging -> the caller that
-//               opened the batch LEADS it, the others sleep on the batch's gate -> copy own rows out -> last one out recycles the batch
+//   caller      reserve rows of the OPEN batch (one compare-and-swap on the batch's packed reservation word: no lock, no system call) ->
+//               copy inputs into its page-locked staging -> the caller that opened the batch LEADS it, the others sleep on the batch's
+//               gate -> copy own rows out -> the one that returns the batch's last rows recycles it
 //   leader      waits until it is its turn and the device has room (at most kInflight batches run at a time): the batch thus
 //               collects exactly the calls that arrive while its predecessors run -- no timer at low load, big batches at high load
 //               (group commit).  max_wait_us > 0 additionally lingers that long for company.  Then: close, wait for the copies of
 //               the batch's callers, launch (zero-copy below zero_copy_bytes(), else one H2D per array, kernels, one D2H per array),
 //               drain the stream, open the gate.
-//   gate        a futex word; woken callers wake two more each (a tree: the leader pays one system call, not one per caller)
+//   gate        a futex word; the leader wakes every sleeper with ONE system call.  (Measured, profiles/r05_concurrent.txt: with the
+//               reservation under a lock and woken callers waking two more each -- a tree -- the callers' SYSTEM time grew from 4 us per
+//               call at 32 callers to 19 at 64 and 73 at 128: lock convoys and futex-bucket contention; that is what this form removes.)
 //
 // Secrets: the page-locked rows of secret inputs / outputs are zeroed by the last caller out, the device staging by the leader
 // (same rule as run_pipeline).
@@ -55,7 +58,7 @@ struct SpinLock {
     }
 };
 
-// One-shot gate: wait() returns once open() was called.  Sleepers are woken as a tree.
+// One-shot gate: wait() returns once open() was called.
 struct Gate {
     std::atomic<uint32_t> word{0};
     std::atomic<int> sleepers{0};
@@ -68,14 +71,21 @@ struct Gate {
         sleepers.fetch_add(1);  // (seq_cst: ordered against open()'s store / load pair)
         while (!word.load()) futex_op(&word, FUTEX_WAIT, 0);
         sleepers.fetch_sub(1);
-        if (sleepers.load() > 0) futex_op(&word, FUTEX_WAKE, 2);
     }
     void open() {
         word.store(1);
-        if (sleepers.load() > 0) futex_op(&word, FUTEX_WAKE, 2);
+        if (sleepers.load() > 0) futex_op(&word, FUTEX_WAKE, INT_MAX);
     }
     void reset() { word.store(0); }
 };
+
+// A batch's reservation word: items (16 bits), bytes of its two ragged arrays (24 + 23 bits), and the CLOSED bit.  Joining a batch is one
+// compare-and-swap on it; closing it (the leader, once) is one fetch_or, which also tells the leader the final counts.
+constexpr uint64_t kRsvClosed = 1ull << 63;
+inline size_t rsv_items(uint64_t r) { return (size_t)(r & 0xffff); }
+inline size_t rsv_blob0(uint64_t r) { return (size_t)((r >> 16) & 0xffffff); }
+inline size_t rsv_blob1(uint64_t r) { return (size_t)((r >> 40) & 0x7fffff); }
+inline uint64_t rsv_pack(size_t items, size_t b0, size_t b1) { return (uint64_t)items | ((uint64_t)b0 << 16) | ((uint64_t)b1 << 40); }
 
 constexpr int kMaxBlobs = 2;
 using Clock = std::chrono::steady_clock;
@@ -84,14 +94,15 @@ struct CoBatch {
     enum State { FREE, OPEN, CLOSED };
     State state = FREE;               // (under Coalescer::lock)
     uint64_t ticket = 0;              // flush order
-    size_t count = 0;                 // items reserved
+    std::atomic<uint64_t> rsv{kRsvClosed};  // the reservation word (above); closed whenever the batch is not open
+    size_t count = 0;                 // items / ragged bytes of the closed batch (written by the leader when it closes it)
     size_t blob_used[kMaxBlobs] = {0, 0};
-    bool full = false;                // flush without lingering
-    std::atomic<int> writers{0};      // callers still copying their inputs in
-    std::atomic<uint32_t> wseq{0};    // the leader sleeps on it while writers != 0
-    std::atomic<bool> leader_waits{false};  // ... and says so: only then is the last writer's wake a system call
-    int callers = 0;                  // (under Coalescer::lock) calls that joined
-    std::atomic<int> readers{0};      // callers that have not copied their results out yet
+    std::atomic<bool> full{false};    // flush without lingering
+    std::atomic<uint64_t> copied{0};  // items whose inputs are in the staging
+    std::atomic<uint32_t> wseq{0};    // the leader sleeps on it while copied != count
+    std::atomic<bool> leader_waits{false};  // ... and says so: only then is a writer's wake a system call
+    std::atomic<uint32_t> callers{0}; // calls that joined (statistics)
+    std::atomic<uint64_t> returned{0};  // items whose results were taken: the caller that brings it to `count` recycles the batch
     Gate done;
     int rc = 0;
     std::string err;
@@ -116,7 +127,7 @@ struct Coalescer {
     std::atomic<uint32_t> seq{0};  // bumped whenever something a leader / a caller without a batch waits for has changed
     int inflight = 0;
     uint64_t next_ticket = 0, serving = 0;
-    CoBatch *open = nullptr;
+    std::atomic<CoBatch *> open{nullptr};  // the batch new calls join (may be stale: the reservation word decides)
     std::vector<CoBatch *> batches;
 
     // layout, fixed by the first call (all calls through one table have the same arrays)
@@ -205,7 +216,7 @@ void flush(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_by
     co->lock.lock();
     for (;;) {
         const bool turn = co->serving == b->ticket && co->inflight < co->inflight_max;
-        const bool ripe = b->full || co->max_wait_us == 0 || Clock::now() >= deadline;
+        const bool ripe = b->full.load() || co->max_wait_us == 0 || Clock::now() >= deadline;
         if (turn && ripe) break;
         const uint32_t s = co->seq.load();
         co->lock.unlock();
@@ -223,18 +234,22 @@ void flush(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_by
     co->inflight++;
     co->serving++;
     b->state = CoBatch::CLOSED;
-    if (co->open == b) co->open = nullptr;
-    const size_t cnt = b->count;
-    co->n_calls.fetch_add((uint64_t)b->callers, std::memory_order_relaxed);  // (the statistics: once per batch, not per call)
+    CoBatch *expect = b;
+    co->open.compare_exchange_strong(expect, nullptr);
+    const uint64_t r = b->rsv.fetch_or(kRsvClosed);  // no call joins from here on; what was reserved so far is the batch
+    const size_t cnt = rsv_items(r);
+    b->count = cnt;
+    b->blob_used[0] = rsv_blob0(r);
+    b->blob_used[1] = rsv_blob1(r);
     co->n_items.fetch_add(cnt, std::memory_order_relaxed);
     co->lock.unlock();
     bump(co);  // (the next batch's leader may now be first in line)
     // ---- the batch's callers have copied their rows in ----
-    if (b->writers.load() != 0) {
+    if (b->copied.load() != cnt) {
         b->leader_waits.store(true);
         for (;;) {
             const uint32_t s = b->wseq.load();
-            if (b->writers.load() == 0) break;
+            if (b->copied.load() == cnt) break;
             futex_op(&b->wseq, FUTEX_WAIT, s);
         }
         b->leader_waits.store(false);
@@ -313,6 +328,7 @@ void recycle(Coalescer *co, CoBatch *b) {
         if (co->in_secret[k]) memset(b->hin + co->in_ofs[k], 0, co->in_row[k] * b->count);
     for (size_t k = 0; k < co->out_row.size(); k++)
         if (co->out_secret[k]) memset(b->hout + co->out_ofs[k], 0, co->out_row[k] * b->count);
+    co->n_calls.fetch_add(b->callers.load(), std::memory_order_relaxed);  // (the statistics: once per batch)
     co->lock.lock();
     b->state = CoBatch::FREE;
     co->lock.unlock();
@@ -379,55 +395,65 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
         if (bb[k] > co->blob_cap / 4) return kNotCoalesced;  // a long message: its own call
     }
 
-    // ---- reserve rows ----
+    // ---- reserve rows: one compare-and-swap on the open batch's reservation word; the lock only to open a new batch ----
     CoBatch *b = nullptr;
     bool leader = false;
     size_t pos = 0, bpos[kMaxBlobs] = {0, 0};
-    co->lock.lock();
     for (;;) {
-        b = co->open;
+        b = co->open.load(std::memory_order_acquire);
+        bool joined = false, crowded = false;
         if (b) {
-            bool fits = b->count + n <= co->max_items;
-            for (size_t k = 0; k < blobs.size(); k++) fits = fits && b->blob_used[k] + bb[k] <= co->blob_cap;
-            if (fits) break;
-            b->full = true;  // its leader flushes it as soon as it may; this call opens the next batch
-            co->open = nullptr;
+            uint64_t r = b->rsv.load(std::memory_order_relaxed);
+            while (!(r & kRsvClosed)) {
+                if (rsv_items(r) + n > co->max_items || rsv_blob0(r) + bb[0] > co->blob_cap || rsv_blob1(r) + bb[1] > co->blob_cap) { crowded = true; break; }
+                if (b->rsv.compare_exchange_weak(r, r + rsv_pack(n, bb[0], bb[1]), std::memory_order_acq_rel, std::memory_order_relaxed)) {
+                    pos = rsv_items(r);
+                    bpos[0] = rsv_blob0(r);
+                    bpos[1] = rsv_blob1(r);
+                    joined = true;
+                    if (pos + n >= co->max_items && !b->full.exchange(true)) bump(co);  // filled up: a lingering leader need not wait any longer
+                    break;
+                }
+            }
+        }
+        if (joined) break;
+        // no open batch, or this call does not fit into it: open the next one (under the lock: once per batch, not per call)
+        co->lock.lock();
+        CoBatch *cur = co->open.load();
+        if (cur != b) { co->lock.unlock(); continue; }  // somebody else already did
+        if (b && crowded && !b->full.exchange(true)) {  // its leader flushes it as soon as it may
             co->lock.unlock();
             bump(co);
             co->lock.lock();
+            if (co->open.load() != b) { co->lock.unlock(); continue; }
+        }
+        CoBatch *fresh = nullptr;
+        for (CoBatch *c : co->batches)
+            if (c->state == CoBatch::FREE) { fresh = c; break; }
+        if (!fresh) {  // every batch is busy: wait for one to come back
+            const uint32_t sq = co->seq.load();
+            co->lock.unlock();
+            futex_op(&co->seq, FUTEX_WAIT, sq);
             continue;
         }
-        for (CoBatch *c : co->batches)
-            if (c->state == CoBatch::FREE) { b = c; break; }
-        if (b) {
-            b->state = CoBatch::OPEN;
-            b->ticket = co->next_ticket++;
-            b->count = 0;
-            b->blob_used[0] = b->blob_used[1] = 0;
-            b->full = false;
-            b->callers = 0;
-            b->rc = 0;
-            b->done.reset();
-            b->opened = Clock::now();
-            co->open = b;
-            leader = true;
-            break;
-        }
-        const uint32_t s = co->seq.load();  // every batch is busy: wait for one to come back
+        fresh->state = CoBatch::OPEN;
+        fresh->ticket = co->next_ticket++;
+        fresh->full.store(false);
+        fresh->copied.store(0);
+        fresh->returned.store(0);
+        fresh->callers.store(0);
+        fresh->rc = 0;
+        fresh->done.reset();
+        fresh->opened = Clock::now();
+        fresh->rsv.store(rsv_pack(n, bb[0], bb[1]), std::memory_order_release);  // open, with this call's rows at its head
+        co->open.store(fresh, std::memory_order_release);
         co->lock.unlock();
-        futex_op(&co->seq, FUTEX_WAIT, s);
-        co->lock.lock();
+        b = fresh;
+        leader = true;
+        if (n >= co->max_items) b->full.store(true);
+        break;
     }
-    pos = b->count;
-    b->count += n;
-    for (size_t k = 0; k < blobs.size(); k++) { bpos[k] = b->blob_used[k]; b->blob_used[k] += bb[k]; }
-    b->writers.fetch_add(1);
-    b->readers.fetch_add(1);
-    b->callers++;
-    const bool filled = b->count >= co->max_items;
-    if (filled) { b->full = true; co->open = nullptr; }
-    co->lock.unlock();
-    if (filled && !leader) bump(co);  // a lingering leader need not wait any longer
+    b->callers.fetch_add(1, std::memory_order_relaxed);
 
     // ---- copy this call's rows in ----
     for (size_t k = 0; k < ins.size(); k++) {
@@ -445,10 +471,9 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
             for (size_t i = 0; i < n; i++) off[i] = bpos[k];  // absent: empty rows
         }
     }
-    if (b->writers.fetch_sub(1) == 1) {
-        b->wseq.fetch_add(1);
-        if (b->leader_waits.load()) futex_op(&b->wseq, FUTEX_WAKE, 1);  // (seq_cst on both sides: a leader that missed the count sees the new wseq)
-    }
+    b->copied.fetch_add(n);
+    b->wseq.fetch_add(1);
+    if (b->leader_waits.load()) futex_op(&b->wseq, FUTEX_WAKE, 1);  // (seq_cst on both sides: a leader that missed the count sees the new wseq)
 
     if (leader) flush(co, b, ws_bytes, opts, launch);
     else b->done.wait(co->spin);
@@ -459,7 +484,10 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
     else
         for (size_t k = 0; k < outs.size(); k++)
             if (outs[k].p && outs[k].row) memcpy(outs[k].p, b->hout + co->out_ofs[k] + pos * outs[k].row, outs[k].row * n);
-    if (b->readers.fetch_sub(1) == 1) recycle(co, b);
+    // (count: written by the leader before the gate opened -- and read BEFORE this call's rows are handed back: once they are, the last
+    // caller may recycle the batch and the next generation's leader overwrite it)
+    const size_t total = b->count;
+    if (b->returned.fetch_add(n) + n == total) recycle(co, b);
     return rc;
 }
 

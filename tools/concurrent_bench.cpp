@@ -20,6 +20,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/resource.h>
+
 #include "circl_hip.h"
 
 #define CHECK(c)                                                                                               \
@@ -147,6 +149,9 @@ int main(int argc, char **argv) {
         std::vector<std::vector<float>> lat(T);
         std::vector<uint64_t> calls(T, 0);
         std::atomic<uint64_t> mismatches{0};
+        std::atomic<uint64_t> thr_user_us{0}, thr_sys_us{0};  // CPU of the caller threads themselves (the rest of the process: the HIP runtime's threads)
+        rusage ru0{};
+        getrusage(RUSAGE_SELF, &ru0);
         uint64_t c0 = 0, i0 = 0, l0 = 0;
         if (table) circl_hip_keytable_coalesce_stats(table, &c0, &i0, &l0);
         std::vector<std::thread> th;
@@ -184,6 +189,11 @@ int main(int argc, char **argv) {
                     calls[t]++;
                     at = (at + per_call * 131 + 1) % (POOL - per_call);
                 }
+                rusage ru{};
+                if (getrusage(RUSAGE_THREAD, &ru) == 0) {
+                    thr_user_us.fetch_add((uint64_t)ru.ru_utime.tv_sec * 1000000 + ru.ru_utime.tv_usec);
+                    thr_sys_us.fetch_add((uint64_t)ru.ru_stime.tv_sec * 1000000 + ru.ru_stime.tv_usec);
+                }
             });
         }
         while (started.load() < T) std::this_thread::yield();
@@ -208,6 +218,14 @@ int main(int argc, char **argv) {
         if (cs1.usage_us > cs0.usage_us)
             printf("  | CPU %.1f us per call, %.1f CPUs busy, throttled %ld x %.0f ms", (cs1.usage_us - cs0.usage_us) / std::max<uint64_t>(total, 1),
                    (cs1.usage_us - cs0.usage_us) / (el * 1e6), cs1.nr_throttled - cs0.nr_throttled, (cs1.throttled_us - cs0.throttled_us) / 1e3);
+        {
+            rusage ru1{};
+            getrusage(RUSAGE_SELF, &ru1);
+            auto us = [](const timeval &a, const timeval &b) { return (double)(a.tv_sec - b.tv_sec) * 1e6 + (a.tv_usec - b.tv_usec); };
+            const double pu = us(ru1.ru_utime, ru0.ru_utime), ps = us(ru1.ru_stime, ru0.ru_stime), n = (double)std::max<uint64_t>(total, 1);
+            printf("  | callers user %.1f sys %.1f, other threads user %.1f sys %.1f us per call", thr_user_us.load() / n, thr_sys_us.load() / n,
+                   (pu - thr_user_us.load()) / n, (ps - thr_sys_us.load()) / n);
+        }
         printf("  mismatches %llu\n", (unsigned long long)mismatches.load());
         fflush(stdout);
         CHECK(mismatches.load() == 0);
