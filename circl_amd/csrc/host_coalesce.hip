@@ -40,9 +40,10 @@ long futex_op(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec 
     return syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), op | FUTEX_PRIVATE_FLAG, val, ts, nullptr, 0);
 }
 
-// The lock around a reservation (tens of nanoseconds held): spins a few dozen times, then SLEEPS on its word -- callers may outnumber
-// the CPUs the process may use by far (a container's CPU quota: threads that spin or yield there burn the quota of the threads that
-// hold the lock or run the launch; measured, profiles/r05_concurrent.txt).  0 free, 1 held, 2 held with sleepers (Drepper's mutex).
+// The lock of the slow paths (opening a batch, a leader taking its turn, recycling: a few times per BATCH, never per call -- a call joins
+// with a compare-and-swap): spins a few dozen times, then SLEEPS on its word -- callers may outnumber the CPUs the process may use by far
+// (a container's CPU quota: threads that spin or yield there burn the quota of the threads that hold the lock or run the launch;
+// measured, profiles/r05_concurrent.txt).  0 free, 1 held, 2 held with sleepers (Drepper's mutex).
 struct SpinLock {
     std::atomic<uint32_t> word{0};
     void lock() {

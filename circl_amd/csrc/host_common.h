@@ -179,8 +179,8 @@ size_t host_chunk_items(size_t dflt);  // CIRCL_HIP_HOST_CHUNK overrides the def
 // ---- cross-caller coalescing of small calls through ONE resident key table (host_coalesce.hip) -----------------------------
 // The reference's consumers call kem.Scheme / sign.Scheme one operation at a time from many goroutines (kem/hybrid/hybrid.go:95-99,
 // hpke/algs.go:283-285, kem/mlkem/mlkem768/kyber.go:347-386).  A Coalescer merges such concurrent small calls into one launch:
-// callers reserve rows of an open batch and copy their inputs into its page-locked staging; the caller that opened the batch flushes
-// it as soon as the device has room for another batch (so a batch collects exactly the calls that arrive while the previous ones
+// callers reserve rows of an open batch (one compare-and-swap) and copy their inputs into its page-locked staging; the caller that opened the
+// batch flushes it as soon as the device has room for another batch (so a batch collects exactly the calls that arrive while the previous ones
 // run: no timer at low load, large batches at high load), or after max_wait_us if that is set; everybody copies their own rows out.
 // Bytes are those of the un-coalesced call: the kernels are the same ones, an item does not know its neighbours.
 struct Coalescer;
