@@ -800,6 +800,135 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
     }
 }
 
+// The norm tests, hints and the signature of ONE entry by a workgroup of K wavefronts (sign_round_chain_kernel): what sign_finish_body does
+// on one wavefront -- 2K + L inverse transforms one after the other -- with a wavefront per polynomial: r0 = w0 - c s2 row by row, z = y + c s1
+// polynomial by polynomial, c t0 and the hints row by row, a workgroup barrier and a shared verdict between the three tests (their order
+// is free: all three must pass), the rows' hint counts prefix-summed through LDS.  Every wavefront builds c-hat itself (SampleInBall + one
+// transform, ~3 us side by side instead of a broadcast).  Same bytes as sign_finish_body.  `fin`: [0] the shared verdict, [1 + i] row i's
+// hint count.  Every branch on `fin` is workgroup-uniform (read behind a barrier).
+template <int MODE>
+__device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *__restrict__ sig, size_t slot, size_t item, uint32_t off, bool direct,
+                                                 int wave, int lane, uint32_t *xch, const dilithium::LaneZetas &z, uint8_t *zpk, uint8_t *hbytes,
+                                                 uint8_t *blk, unsigned *fin) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using B = SB<MODE>;
+    constexpr int K = P::K, L = P::L;
+    constexpr bool NW = true;
+    const uint8_t *cb = st.cb + slot * B::CB_BYTES;
+    uint32_t chat[4];
+    sample_in_ball_hat<MODE, true, false, true, true>(chat, cb + 120, blk, xch, z, lane);
+    const uint32_t *sec = st.sec + st.key_of(item) * (L + 2 * K) * kPackedRowDwords;
+    uint32_t *w0 = st.w0 + slot * B::W0_SLOT_DW;
+    auto mul_c = [&](uint32_t (&t)[4], const uint32_t *row) {
+        uint32_t sv[4];
+        load_poly24(sv, row, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = dilithium::fold(dilithium::mont32(sv[r], chat[r]));
+        dilithium::invntt<dilithium::INV256_R, NW>(t, z, xch, lane);
+    };
+    auto veto = [&](bool bad) {
+        if (__any(bad) && lane == 0) atomicOr(&fin[0], 1u);
+    };
+    // ---- r0 = w0 - c s2, row `wave`; parked in LDS (the area that will hold the packed z) and written back only when every row is in range ----
+    uint32_t *r0l = reinterpret_cast<uint32_t *>(zpk);
+    {
+        const int i = wave;
+        uint32_t t[4], wv[4], v[4];
+        load_poly24(wv, w0 + i * kPackedRowDwords, lane);
+        mul_c(t, sec + (L + i) * kPackedRowDwords);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] = dilithium::normalize(wv[r] + (2 * Q - t[r]));
+            bad |= dilithium::exceeds(v[r], P::GAMMA2 - G::BETA);
+        }
+        store_poly24(r0l + i * kPackedRowDwords, v, lane);
+        veto(bad);
+    }
+    if (threadIdx.x < 24) reinterpret_cast<uint32_t *>(hbytes)[threadIdx.x] = 0;
+    __syncthreads();
+    if (fin[0]) return;
+    for (int d = threadIdx.x; d < K * kPackedRowDwords; d += K * 64) w0[d] = r0l[d];
+    __threadfence_block();
+    __syncthreads();  // ... before z is packed into the same area; the hint phase reads r0 back from the slot
+    // ---- z = y + c s1, polynomial `wave`, bit-packed as it will appear in the signature (pack.go:202-254) ----
+    if (wave < L) {
+        const int l = wave;
+        const uint32_t *yrow = st.y + (slot * L + l) * B::YROW_DW;
+        uint32_t yv[4], t[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) yv[r] = gbits<G::ZBITS>(yrow, kyber::idx_l1(lane, r), G::ZSZ / 4);
+        mul_c(t, sec + l * kPackedRowDwords);
+        unsigned f[4];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t y = G::GAMMA1 - yv[r];
+            y += (uint32_t)((int32_t)y >> 31) & Q;
+            const uint32_t zz = dilithium::normalize(t[r] + y);
+            bad |= dilithium::exceeds(zz, G::GAMMA1 - G::BETA);
+            uint32_t fr = G::GAMMA1 - zz;
+            fr += (uint32_t)((int32_t)fr >> 31) & Q;
+            f[r] = fr;
+        }
+        mlkem::stage_bits_l1<G::ZBITS, NW>(xch, f, lane);
+        for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
+        veto(bad);
+    }
+    __syncthreads();
+    if (fin[0]) return;
+    // ---- c t0 and the hints of row `wave` (dilithium.go:431-450): the row's hint bits as four ballots, its count to LDS ----
+    unsigned long long hmask[4];
+    unsigned count = 0;
+    {
+        const int i = wave;
+        uint32_t t[4], wv[4];
+        load_poly24(wv, w0 + i * kPackedRowDwords, lane);
+        mul_c(t, sec + (L + K + i) * kPackedRowDwords);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t r1 = get_bits32<G::W1BITS>(st.muw1 + slot * B::MUW1_BYTES + 64 + G::W1SZ * i, kyber::idx_l1(lane, r));  // w1 as packed in phase B2
+            const uint32_t ct0 = dilithium::csubq(t[r]);
+            bad |= dilithium::exceeds(ct0, P::GAMMA2);
+            const uint32_t v = dilithium::csubq(wv[r] + ct0);
+            hmask[r] = __ballot(dilithium::make_hint<P::GAMMA2>(v, r1));
+            count += (unsigned)__popcll(hmask[r]);
+        }
+        if (lane == 0) fin[1 + i] = count;
+        veto(bad);
+    }
+    __syncthreads();
+    if (fin[0]) return;
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const unsigned ci = fin[1 + i];
+        if (i < wave) before += ci;
+        total += ci;
+    }
+    if (total > (unsigned)P::OMEGA) return;  // (workgroup-uniform: every wavefront sums the same counts)
+    {
+        unsigned pop = before;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if ((hmask[r] >> lane) & 1) hbytes[pop + (unsigned)__popcll(hmask[r] & ((1ull << lane) - 1))] = (uint8_t)kyber::idx_l1(lane, r);
+            pop += (unsigned)__popcll(hmask[r]);
+        }
+        if (lane == 0) hbytes[P::OMEGA + wave] = (uint8_t)pop;
+    }
+    __syncthreads();
+    // `direct`: the signature goes straight out; otherwise it is parked in the slot's w0 area and the commit step copies the lowest
+    // successful attempt's (sign_finish_body)
+    uint8_t *sg = direct ? sig + item * G::SIG : reinterpret_cast<uint8_t *>(w0);
+    const int nthr = K * 64;
+    for (int b = threadIdx.x; b < P::CT; b += nthr) sg[b] = cb[b];
+    for (int b = threadIdx.x; b < L * G::ZSZ; b += nthr) sg[P::CT + b] = zpk[b];
+    for (int b = threadIdx.x; b < P::OMEGA + K; b += nthr) sg[P::CT + L * G::ZSZ + b] = hbytes[b];
+    if (threadIdx.x == 0) atomicMin(&st.best[item], off);
+}
+
 template <int MODE>
 __device__ __forceinline__ void sign_commit_body(const SignState &st, int cur, uint8_t *__restrict__ sig, size_t first, size_t stride);
 __device__ __forceinline__ void sign_compact_body(const SignState &st, int cur, int last, unsigned block, unsigned nblocks, unsigned nthreads);
@@ -812,7 +941,7 @@ __device__ __forceinline__ void sign_compact_body(const SignState &st, int cur, 
 //   B1  y-hat_l = NTT(y_l): a wavefront per l, parked in LDS (pack24)
 //   B2  w_i = InvNTT(sum_j A_ij y-hat_j), Decompose, w0 / w1: a wavefront per ROW i
 //   C   c~ = H(mu || w1) and the first SampleInBall block: wavefront 0 on the cooperative permutation (7-9 dependent permutations)
-//   D   the norm tests, hints and the signature: wavefront 0, the body of sign_finish_kernel with wave-level ordering points
+//   D   the norm tests, hints and the signature: a wavefront per polynomial again (sign_finish_rows)
 // with a workgroup barrier between the phases (data crosses wavefronts there: y through global memory -- the finish phase wants it
 // there anyway --, y-hat through LDS, w0 / w1 through the entry's global slots).  Same bytes as the four kernels (the per-entry
 // arithmetic is theirs); commit and compact follow as separate launches.
@@ -828,7 +957,8 @@ __global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(Sign
     __shared__ __attribute__((aligned(16))) uint64_t coop_ws[MW][100];
     __shared__ __attribute__((aligned(16))) uint8_t zpk[K * kPackedRowDwords * 4 > L * G::ZSZ ? K * kPackedRowDwords * 4 : L * G::ZSZ];
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
-    __shared__ __attribute__((aligned(16))) uint8_t blk[144];
+    __shared__ __attribute__((aligned(16))) uint8_t blk_all[K][144];
+    __shared__ unsigned fin[1 + K];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *xch = xch_all[wave];
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
@@ -913,7 +1043,8 @@ __global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(Sign
         }
         __threadfence_block();
         __syncthreads();
-        // ---- C + D: wavefront 0 alone ----
+        // ---- C: the challenge, wavefront 0 alone (a chain of dependent permutations) ----
+        if (threadIdx.x == 0) fin[0] = 0;
         if (wave == 0) {
             const int j = lane & 31;
             const CoopLane c = coop_lane(coop_ws[0], lane);
@@ -927,9 +1058,11 @@ __global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(Sign
             if (j == 16) vhi ^= 0x80000000u;
             keccak_f1600_coop2<true>(vlo, vhi, c);
             if (lane < 25) cb[15 + lane] = ((uint64_t)vhi << 32) | vlo;  // ball state at byte 120
-            __threadfence_block();  // (the finish body reads c~ and the ball state back from the slot)
-            sign_finish_body<MODE, true>(st, cur, sig, slot, direct, xch, zpk, hbytes, blk);
         }
+        __threadfence_block();  // (every wavefront reads c~ and the ball state back from the slot)
+        __syncthreads();
+        // ---- D: the norm tests, hints and the signature, a wavefront per polynomial ----
+        sign_finish_rows<MODE>(st, sig, slot, item, off, direct, wave, lane, xch, z, zpk, hbytes, blk_all[wave], fin);
         __syncthreads();  // the LDS buffers are reused by the workgroup's next entry
     }
     // ---- the LAST workgroup to get here commits the round's lowest successful attempts and builds the next list itself (two launches
