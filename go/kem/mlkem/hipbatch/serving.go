@@ -2,6 +2,13 @@
 
 package hipbatch
 
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../../include
+#cgo LDFLAGS: -lcirclhip
+#include <circl_hip.h>
+*/
+import "C"
+
 // ServingScheme is a kem.Scheme for UNMODIFIED callers: code that holds a kem.Scheme value and calls Encapsulate /
 // Decapsulate one key and one item at a time from whatever goroutine owns the connection -- the shape of every consumer
 // in the reference (kem/mlkem/mlkem768/kyber.go:347-386; hpke/algs.go:283-285 picks its kem.Scheme from a table).
@@ -156,4 +163,13 @@ func (s *ServingScheme) Decapsulate(sk kem.PrivateKey, ct []byte) ([]byte, error
 		return nil, kem.ErrCiphertextSize
 	}
 	return r.DecapsulateBatch(ct)
+}
+
+// SetCallCoalescing is the same switch for keys that come WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the
+// client's ephemeral key share (kem/hybrid/hybrid.go:271-300), so there is no key object to attach a table to: small EncapsulateBatch /
+// DecapsulateBatch calls (one or a few items) from concurrent goroutines share launches per scheme and device
+// (circl_hip_set_coalesce; also covers sign/mldsa's VerifyBatch and kem/hybrid's batches, which live in the same library).
+// Process-wide; call it once at start-up.  maxItems = 0 switches new joins off.
+func SetCallCoalescing(maxItems int, maxWait time.Duration) error {
+	return status(C.circl_hip_set_coalesce(C.size_t(maxItems), C.uint32_t(maxWait.Microseconds())), "set_coalesce")
 }
