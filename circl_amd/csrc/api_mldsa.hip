@@ -247,6 +247,15 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     uint8_t *es = static_cast<uint8_t *>(ws);
     unsigned *work = reinterpret_cast<unsigned *>(es + mldsa_item_ws_bytes<MODE>(n));
     uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
+    // small batches: the whole key generation of an item in ONE launch, a workgroup of K wavefronts per key (mldsa_keygen_chain_kernel);
+    // up to 2^CIRCL_HIP_DSA_KEYGEN_CHAIN keys (0: never), and only while the workspace holds a scratch slice per IT items
+    static const size_t chain_keys = [] { const int lg = env_int("CIRCL_HIP_DSA_KEYGEN_CHAIN", 8, 0, 12); return lg <= 0 ? size_t(0) : size_t(1) << lg; }();
+    if (n <= chain_keys && mldsa_groups<MODE>(n) <= mldsa_scratch_blocks<MODE>(n)) {
+        ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYGEN, st);
+        hipLaunchKernelGGL(mldsa_keygen_chain_kernel<MODE>, dim3((unsigned)n), dim3(DP<MODE>::K * 64), 0, st, seed32, es, pk, sk, scratch, n);
+        HIP_TRY(hipGetLastError());
+        return CIRCL_HIP_OK;
+    }
     HIP_TRY(hipMemsetAsync(work, 0, 256, st));
     const unsigned hb = (unsigned)((n + 255) / 256);
     {

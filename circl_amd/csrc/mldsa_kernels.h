@@ -1394,6 +1394,155 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
   }
 }
 
+// ---- a key pair in ONE launch (small batches) --------------------------------------------------------------------------------
+// NewKeyFromSeed (dilithium.go:181-267) of one seed by a workgroup of K wavefronts, instead of fill + seed + keygen + tr as four
+// launches with every stage on one wavefront:
+//   0  (rho, rho', key) = H(seed || K || L): wavefront 0, one cooperative permutation
+//   1  ExpandA (K L streams, a stream per lane, 5 SHAKE128 blocks -- the long pole) on wavefront 1  BESIDE  ExpandS (L + K streams,
+//      nibble rejection) on wavefront 0
+//   2  s1-hat = NTT(s1) and the eta-packing of s1, s2: a wavefront per secret polynomial
+//   3  t_i = InvNTT(A_i s1-hat) + s2_i, Power2Round, t1 -> pk, t0 -> sk: a wavefront per ROW
+//   4  tr = H(pk): wavefront 0 on the cooperative permutation (10 / 15 / 20 dependent permutations: what is left)
+// with a workgroup barrier between the phases.  Same bytes as the four kernels (their per-polynomial code); the item's matrix rows go
+// through its part of a scratch slice as in the verification chain kernel.
+template <int MODE>
+__global__ void __launch_bounds__(DP<MODE>::K * 64) mldsa_keygen_chain_kernel(const uint8_t *__restrict__ seed32, uint8_t *__restrict__ es_ws,
+                                                                              uint8_t *__restrict__ pk, uint8_t *__restrict__ sk,
+                                                                              uint8_t *__restrict__ scratch, size_t n) {
+    using G = DG<MODE>;
+    using P = DP<MODE>;
+    using Kg = KG<MODE>;
+    constexpr int K = P::K, L = P::L, NS = Kg::NS, TRW = P::TR / 8;
+    static_assert(K >= 2 && NS <= 2 * K && NS <= 64, "two secret polynomials per wavefront at most; a sampling stream per lane");
+    __shared__ __attribute__((aligned(16))) uint8_t fifo_lds[G::LDS_FIFO];
+    __shared__ __attribute__((aligned(16))) int8_t sec[NS * Kg::S_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t xch_all[K][dilithium::kXchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t shat_lds[L][256];
+    __shared__ __attribute__((aligned(16))) uint64_t coop_ws[100];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t item = blockIdx.x;
+    if (item >= n) return;  // (block-uniform)
+    uint32_t *xch = xch_all[wave];
+    const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
+    uint32_t *rows = reinterpret_cast<uint32_t *>(scratch + (item / G::IT) * (size_t)G::SCRATCH_BYTES) + (item % G::IT) * (size_t)(G::STREAMS * kPackedRowDwords);
+    uint8_t *es = es_ws + item * 128, *pkp = pk + item * G::PK, *skp = sk + item * Kg::SK;
+    // ---- 0: the seed ----
+    if (wave == 0) {
+        const int j = lane & 31;
+        const CoopLane c = coop_lane(coop_ws, lane);
+        const uint64_t w = j < 4 ? reinterpret_cast<const uint64_t *>(seed32 + item * 32)[j] : 0ull;
+        uint32_t vlo = (uint32_t)w, vhi = (uint32_t)(w >> 32);
+        if (j == 4) vlo ^= P::NIST ? ((uint32_t)P::K | ((uint32_t)P::L << 8) | (kDsShake << 16)) : kDsShake;  // dilithium.go:191-193
+        if (j == 16) vhi ^= 0x80000000u;
+        keccak_f1600_coop2<true>(vlo, vhi, c);
+        if (lane < 16) reinterpret_cast<uint64_t *>(es)[lane] = ((uint64_t)vhi << 32) | vlo;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 1: the matrix beside the secrets ----
+    if (wave == 1) {
+        expand_a_scratch<MODE, false, 1>(fifo_lds, rows, es, 0, 0, 1, lane);
+    } else if (wave == 0) {  // sample.go:125-175: SHAKE256(rho' || LE16(nonce)), nibble rejection, a stream per lane
+        const bool on = lane < NS;
+        KeccakState s;
+        keccak_zero(s);
+        xor_words<0, 8>(s, reinterpret_cast<const uint64_t *>(es + 32));
+        s.lo[8] = (uint32_t)(on ? lane : 0) | (kDsShake << 16);
+        s.hi[16] = 0x80000000u;
+        int8_t *row = sec + (on ? lane : 0) * Kg::S_STRIDE;
+        int cnt = on ? 0 : 256;
+#pragma unroll 1
+        while (__any(cnt < 256)) {
+            keccak_f1600(s);
+            if (on) {
+                detail::static_for<0, 34>([&](auto ic) {
+                    constexpr int w = decltype(ic)::v;  // 32-bit word w of the 136-byte block
+                    const uint32_t word = (w & 1) ? s.hi[w >> 1] : s.lo[w >> 1];
+#pragma unroll
+                    for (int nb = 0; nb < 8; nb++) {  // low nibble of each byte first (t1 then t2)
+                        uint32_t t = (word >> (4 * nb)) & 15u;
+                        bool ok;
+                        if constexpr (P::ETA == 2) {
+                            ok = t <= 14;
+                            t -= ((205 * t) >> 10) * 5;
+                        } else {
+                            ok = t <= 8;
+                        }
+                        row[cnt] = (int8_t)(P::ETA - (int)t);
+                        cnt = min(cnt + (ok ? 1 : 0), 256);
+                    }
+                });
+            }
+        }
+    }
+    mlkem::rows_acquire();  // the rows have left the CU and no stale L1 line of the slice survives; the secrets are in LDS
+    // ---- 2: a wavefront per secret polynomial: eta-packing into sk, s1-hat ----
+#pragma unroll 1
+    for (int k = wave; k < NS; k += K) {
+        const int8_t *row = sec + k * Kg::S_STRIDE;
+        unsigned fld[4];
+        uint32_t c[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int v = row[kyber::idx_l1(lane, r)];   // in [-eta, eta]
+            fld[r] = (unsigned)(P::ETA - v);              // pack.go:9-37: field = q + eta - coefficient
+            c[r] = v < 0 ? Q + v : (uint32_t)v;
+        }
+        mlkem::stage_bits_l1<Kg::ETABITS, true>(xch, fld, lane);
+        mlkem::store_staged<Kg::ETABITS>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * k), xch, lane, false);
+        if (k < L) {
+            dilithium::ntt<true>(c, z, xch, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) shat_lds[k][64 * r + lane] = c[r];  // plain s1-hat
+        }
+    }
+    __syncthreads();
+    // ---- 3: row `wave`: t = InvNTT(A s1-hat) + s2, Power2Round, pack ----
+    {
+        const int i = wave;
+        uint32_t shat[L][4];
+#pragma unroll
+        for (int jj = 0; jj < L; jj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) shat[jj][r] = shat_lds[jj][64 * r + lane];
+        uint32_t w[4] = {0, 0, 0, 0};
+        mac_rows<L>(w, rows, i * L, shat, lane);  // 2^-32 A s1-hat, < 2q
+        dilithium::invntt<dilithium::INV256_RR, true>(w, z, xch, lane);
+        const int8_t *s2 = sec + (L + i) * Kg::S_STRIDE;
+        unsigned t1[4], t0[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int v = s2[kyber::idx_l1(lane, r)];
+            const uint32_t a = dilithium::csubq(dilithium::fold(w[r] + (v < 0 ? Q + v : (uint32_t)v)));
+            uint32_t a0q, a1;
+            dilithium::power2round(a, a0q, a1);  // field.go:35-52
+            t1[r] = a1;
+            t0[r] = ((1u << (dilithium::D - 1)) - (a0q - Q)) & ((1u << dilithium::D) - 1);  // pack.go:23-50 PackT0 field
+        }
+        mlkem::stage_bits_l1<10, true>(xch, t1, lane);
+        mlkem::store_staged<10>(reinterpret_cast<uint32_t *>(pkp + 32 + 320 * i), xch, lane, false);
+        mlkem::stage_bits_l1<13, true>(xch, t0, lane);
+        mlkem::store_staged<13>(reinterpret_cast<uint32_t *>(skp + Kg::SKHDR + Kg::ETASZ * NS + 416 * i), xch, lane, false);
+        if (wave == K - 1 && lane < 8) {
+            const uint32_t r = reinterpret_cast<const uint32_t *>(es)[lane];
+            reinterpret_cast<uint32_t *>(pkp)[lane] = r;                                                   // rho
+            reinterpret_cast<uint32_t *>(skp)[lane] = r;
+            reinterpret_cast<uint32_t *>(skp + 32)[lane] = reinterpret_cast<const uint32_t *>(es + 96)[lane];  // key
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 4: tr = SHAKE256(pk)[:TR] -> sk (dilithium.go:257-262) ----
+    if (wave == 0) {
+        const int j = lane & 31;
+        const CoopLane c = coop_lane(coop_ws, lane);
+        const uint64_t *pkw = reinterpret_cast<const uint64_t *>(pkp);
+        uint32_t vlo, vhi;
+        mlkem::coop_sponge17<true>(vlo, vhi, [&](int k) { return pkw[k]; }, G::PK / 8, kDsShake, c, j);
+        if (lane < TRW) reinterpret_cast<uint64_t *>(skp + 64)[lane] = ((uint64_t)vhi << 32) | vlo;
+    }
+}
+
 // lane = item: tr = SHAKE256(pk)[:64] -> sk[64:128]  (dilithium.go:257-262)
 template <int MODE>
 __global__ void __launch_bounds__(256) mldsa_keygen_finish_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ sk, size_t n) {

@@ -255,3 +255,26 @@ def test_one_launch_verification_routes_agree_with_the_older_ones():
         assert r.returncode == 0 and "verify digest" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
         digests.append(r.stdout.strip().split()[-1])
     assert len(set(digests)) == 1, digests
+
+
+@pytest.mark.parametrize("chain", ["0", "8", "10"], ids=["four-launches", "default", "one-launch-up-to-1024"])
+def test_mldsa_keygen_routes_equal_the_oracle(chain):
+    """NewKeyFromSeed (sign/mldsa/mldsa65/internal/dilithium.go:181-267) as ONE launch per small batch (mldsa_keygen_chain_kernel: a workgroup of K
+    wavefronts per key) against the four-launch path: the same pk / sk bytes as the oracle on both, every parameter set incl. round-3 Dilithium,
+    sizes on both sides of the switch (the knob is read once: a process per setting)."""
+    code = r"""
+import numpy as np
+from circl_amd import hostapi
+from oracle import orc
+rng = np.random.default_rng(7)
+for param in (44, 65, 87, 2, 3, 5):
+    for n in (1, 3, 40, 65, 300):
+        seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pk, sk = hostapi.mldsa_keygen(param, seeds)
+        pk0, sk0 = orc.mldsa_keygen(param, seeds)
+        assert (pk == pk0).all() and (sk == sk0).all(), (param, n)
+print("ok")
+"""
+    env = dict(os.environ, CIRCL_HIP_DSA_KEYGEN_CHAIN=chain, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
