@@ -11,6 +11,7 @@
 #include "keytable.h"
 
 using namespace circl::host;
+using circl::KeyIdx;
 namespace hk = circl::hybridk;
 
 namespace {
@@ -297,8 +298,8 @@ int circl_hip_hybrid_decaps_dev(int scheme, const uint8_t *d_sk, const uint8_t *
 // (xwing.go:20-25), its PublicKey the parsed ML-KEM key (:28-31); kem/hybrid's keys hold the component schemes' parsed keys
 // (hybrid.go:101-114).  A hybrid table is that: an ML-KEM key table (A^T, H(ek), the private key's hash verdict) of the lattice
 // halves plus the X25519 rows, built once; a call then moves only seeds / ciphertexts and runs the shared-key ML-KEM work.
-static int gather_rows(hipStream_t st, uint8_t *dst, const uint8_t *table, const uint32_t *key_idx, size_t n) {
-    hipLaunchKernelGGL(hk::rows_gather_kernel, g256(n * 8), dim3(256), 0, st, w(dst), w(table), key_idx, 8u, n);
+static int gather_rows(hipStream_t st, uint8_t *dst, const uint8_t *table, size_t nkeys, const uint32_t *key_idx, size_t n) {
+    hipLaunchKernelGGL(hk::rows_gather_kernel, g256(n * 8), dim3(256), 0, st, w(dst), w(table), KeyIdx{key_idx, (uint32_t)(nkeys - 1)}, 8u, n);
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
 }
@@ -415,7 +416,7 @@ int circl_hip_hybrid_encaps_table_dev(const circl_hip_keytable *t, const uint32_
     const size_t kws_bytes = ws_bytes - tmp_bytes(d, n);
     SecretWipe wipe{st};
     wipe.add(m, n * 32); wipe.add(ekx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32);
-    TRY(gather_rows(st, pkx, t->d_x, d_key_idx, n));
+    TRY(gather_rows(st, pkx, t->d_x, t->nkeys, d_key_idx, n));
     if (d.xwing) {
         TRY(copy_rows(st, m, 32, d_eseed, 64, 32, n));
         TRY(copy_rows(st, ekx, 32, d_eseed + 32, 64, 32, n));
@@ -461,8 +462,8 @@ int circl_hip_hybrid_decaps_table_dev(const circl_hip_keytable *t, const uint32_
     wipe.add(skx, n * 32); wipe.add(ssm, n * 32); wipe.add(ssx, n * 32);
     TRY(copy_rows(st, ctm, d.CTM, d_ct + d.kem_off(32), d.ct, d.CTM, n));
     TRY(copy_rows(st, ctx, 32, d_ct + d.x_off(d.CTM), d.ct, 32, n));
-    TRY(gather_rows(st, skx, t->d_x, d_key_idx, n));
-    if (d.xwing) TRY(gather_rows(st, pkx, t->d_x + t->nkeys * 32, d_key_idx, n));  // sk.xpk, computed when the table was built
+    TRY(gather_rows(st, skx, t->d_x, t->nkeys, d_key_idx, n));
+    if (d.xwing) TRY(gather_rows(st, pkx, t->d_x + t->nkeys * 32, t->nkeys, d_key_idx, n));  // sk.xpk, computed when the table was built
     TRY(circl_hip_x25519_dev(skx, ctx, ssx, okx, n, st));
     TRY(circl_hip_mlkem_decaps_table_dev(t->inner, d_key_idx, ctm, ssm, d_status, n, kws, kws_bytes, st));
     if (d.xwing) {

@@ -8,6 +8,7 @@
 #include "mldsa_sign_batched.h"
 
 using namespace circl::host;
+using circl::KeyIdx;
 
 namespace {
 
@@ -48,7 +49,7 @@ inline int mldsa_long_scan(const uint64_t *msg_off, const uint8_t *ctx_blob, con
     return CIRCL_HIP_OK;
 }
 template <int TRW>
-int mldsa_long_mu(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
+int mldsa_long_mu(const uint8_t *tr_base, size_t tr_stride, KeyIdx key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
                   const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *mu_out,
                   size_t mu_stride, const circl::mldsa::LongCtl *ctl, size_t n, hipStream_t st) {
     using namespace circl::mldsa;
@@ -59,7 +60,7 @@ int mldsa_long_mu(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_
     return CIRCL_HIP_OK;
 }
 template <int TRW>
-int mldsa_long_prepass(const uint8_t *tr_base, size_t tr_stride, const uint32_t *key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
+int mldsa_long_prepass(const uint8_t *tr_base, size_t tr_stride, KeyIdx key_idx, const uint8_t *pk, size_t pk_stride, int pk_words,
                        const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, int internal, uint8_t *mu_out,
                        size_t mu_stride, circl::mldsa::LongCtl *ctl, size_t n, hipStream_t st) {
     if (int rc = mldsa_long_scan(msg_off, ctx_blob, ctx_off, internal, ctl, n, st)) return rc;
@@ -137,6 +138,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     if (cached) pk = cached->d_keys;
     const size_t need = mldsa_ws_bytes<MODE>(n) + (KM == KM_KEYED && !cached ? mldsa_table_bytes<MODE>(nkeys) : 0);
     if (ws_bytes < need || !aligned16(ws) || !aligned16(pk) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
+    const KeyIdx kx{KM == KM_KEYED ? key_idx : nullptr, nkeys ? (uint32_t)(nkeys - 1) : 0u};  // a device index vector is bounded to the table on every read
     uint8_t *muw1 = static_cast<uint8_t *>(ws);
     uint8_t *ball = muw1 + up256(n * G::MUW1);
     uint8_t *fail = ball + up256(n * kBallStateBytes);
@@ -152,7 +154,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         const uint32_t *rows = reinterpret_cast<const uint32_t *>(cached->d_table);
         const uint8_t *key_tr = cached->d_table + up256(padded * G::STREAMS * kPackedRowDwords * 4);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
-        hipLaunchKernelGGL(mldsa_verify_chain_kernel<MODE>, dim3((unsigned)n), dim3((DP<MODE>::K + 1) * 64), 0, st, pk, key_idx, rows, key_tr, sig, msg_blob,
+        hipLaunchKernelGGL(mldsa_verify_chain_kernel<MODE>, dim3((unsigned)n), dim3((DP<MODE>::K + 1) * 64), 0, st, pk, kx, rows, key_tr, sig, msg_blob,
                            msg_off, ctx_blob, ctx_off, internal, ok, n, (uint8_t *)nullptr, (size_t)G::PK);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -164,7 +166,7 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         // the matrix expansion inside the workgroup (the rows of item t in its part of scratch slice t / IT: the workspace holds a
         // slice per IT items at these sizes)
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
-        hipLaunchKernelGGL((mldsa_verify_chain_kernel<MODE, false>), dim3((unsigned)n), dim3((DP<MODE>::K + 2) * 64), 0, st, pk, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL((mldsa_verify_chain_kernel<MODE, false>), dim3((unsigned)n), dim3((DP<MODE>::K + 2) * 64), 0, st, pk, KeyIdx{},
                            (const uint32_t *)nullptr, (const uint8_t *)nullptr, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, ok, n, scratch,
                            KM == KM_SHARED ? size_t(0) : (size_t)G::PK);
         HIP_TRY(hipGetLastError());
@@ -187,7 +189,6 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         const int internal_eff = DP<MODE>::NIST ? internal : 1;  // round 3: mu = CRH(tr || msg)
-        const uint32_t *kidx = KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr;
         if (int rc = mldsa_long_scan(msg_off, ctx_blob, ctx_off, internal_eff, lctl, n, st)) return rc;
         // small batches: every mu comes from the cooperative pre-pass (kSmallMu), and nothing before the final hash reads it --
         // so tr and mu run on a side stream next to SampleInBall's sponge and the verify kernel (n=1: ~75 us off the chain)
@@ -198,9 +199,9 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
             tr_arg = tr;
         }
         {
-            const int rc = tr_arg ? mldsa_long_mu<DP<MODE>::TR / 8>(tr_arg, KM == KM_KEYED && kidx ? 64 : 0, kidx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
+            const int rc = tr_arg ? mldsa_long_mu<DP<MODE>::TR / 8>(tr_arg, kx ? 64 : 0, kx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob, ctx_off,
                                                                     internal_eff, muw1, G::MUW1, lctl, n, mu_st)
-                                  : mldsa_long_mu<DP<MODE>::TR / 8>(nullptr, 0, nullptr, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
+                                  : mldsa_long_mu<DP<MODE>::TR / 8>(nullptr, 0, KeyIdx{}, pk, G::PK, G::PK / 8, msg_blob, msg_off, ctx_blob, ctx_off, internal_eff,
                                                                     muw1, G::MUW1, lctl, n, mu_st);
             if (rc) return rc;
         }
@@ -214,13 +215,13 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
             tr_stride = kBallStateBytes;
         }
         hipLaunchKernelGGL(mldsa_prep_kernel<MODE>, dim3(hb), dim3(256), 0, st, pk, sig, msg_blob, msg_off, ctx_blob, ctx_off, internal, muw1, ball,
-                           fail, n, tr_arg, KM == KM_KEYED ? key_idx : (const uint32_t *)nullptr, (const LongCtl *)lctl, tr_stride);
+                           fail, n, tr_arg, kx, (const LongCtl *)lctl, tr_stride);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
         auto kern = mldsa_verify_kernel<MODE, 0, KM>;
         const unsigned vb = std::min<unsigned>((unsigned)mldsa_scratch_blocks<MODE>(n), dsa_resident_blocks(kern, G::LDS_V_TOTAL));
-        hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n, key_idx,
+        hipLaunchKernelGGL(kern, dim3(vb), dim3(64), G::LDS_V_TOTAL, st, pk, sig, muw1, (const uint8_t *)ball, fail, scratch, work, n, kx,
                            (const uint32_t *)key_rows);
     }
     side.join();
@@ -508,7 +509,8 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     S.shared = shared ? 1u : 0u;
     const circl_hip_keytable *prep = shared ? tl_sign_prepared : nullptr;
     const uint32_t *key_idx = prep ? tl_sign_key_idx : nullptr;
-    S.key_idx = nullptr;
+    const KeyIdx kx{key_idx, prep ? (uint32_t)(prep->nkeys - 1) : 0u};  // a device index vector is bounded to the table on every read
+    S.key_idx = KeyIdx{};
     S.mr = base + lay.o_mr;
     S.A = reinterpret_cast<uint32_t *>(base + lay.o_A);
     S.sec = reinterpret_cast<uint32_t *>(base + lay.o_sec);
@@ -516,7 +518,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         S.A = reinterpret_cast<uint32_t *>(prep->d_table);
         S.sec = reinterpret_cast<uint32_t *>(prep->d_table + up256(prep->nkeys * SB<MODE>::A_BYTES));
         S.shared = 2u;
-        S.key_idx = key_idx;
+        S.key_idx = kx;
     }
     S.y = reinterpret_cast<uint32_t *>(base + lay.o_y);
     S.w0 = reinterpret_cast<uint32_t *>(base + lay.o_w0);
@@ -561,21 +563,21 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
     if (one_front && n <= kSmallMu) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         hipLaunchKernelGGL(mldsa_sign_front_kernel<MODE>, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, sk, (shared && !key_idx) ? size_t(0) : (size_t)KG<MODE>::SK,
-                           key_idx, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, S.mr, n, dead, prep ? S.attempts : nullptr, prep ? S.best : nullptr,
+                           kx, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, S.mr, n, dead, prep ? S.attempts : nullptr, prep ? S.best : nullptr,
                            prep ? S.list[0] : nullptr, prep ? S.count : nullptr, k0);
     } else {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
-        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, kx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
                                                           ctx_off, DP<MODE>::NIST ? internal : 1, S.mr, 128, lctl, n, st))
             return rc;
         // (a prepared key: the prep kernel also sets up the round signer's lists -- sign_secrets_kernel has nothing else to do then)
         if (prep)
             hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx, S.attempts, S.best, S.list[0], S.count, k0);
+                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, kx, S.attempts, S.best, S.list[0], S.count, k0);
         else
             hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3(nb256), dim3(256), 0, st, sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal,
-                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
+                               S.mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, kx);
     }
     if (!prep) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
@@ -639,7 +641,7 @@ int mldsa_sign_batched_part(const uint8_t *sk, const uint8_t *msg_blob, const ui
         const int fin = rounds & 1;
         hipLaunchKernelGGL(mldsa_sign_kernel<MODE>, dim3((unsigned)std::min<size_t>(lay.tail_units, 512)), dim3(64), SG<MODE>::LDS_TOTAL, st, sk,
                            (const uint8_t *)S.mr, sig, tail_scratch, tail_work, (const uint32_t *)S.list[fin], (const uint32_t *)S.attempts, (size_t)0, 1u,
-                           (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin), key_idx);
+                           (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0, (const uint32_t *)(S.count + fin), kx);
         // (an item is dead only when it brings a context the scheme refuses: impossible without contexts, for the internal form, and
         // after the host path's own check)
         if (ctx_blob && !internal && !tl_sign_ctx_ok)
@@ -728,6 +730,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     if (n >= sign_batched_min()) return mldsa_sign_batched<MODE>(sk, msg_blob, msg_off, ctx_blob, ctx_off, rnd, internal, sig, n, ws, st, shared);
     const SignLayout<MODE> lay(n);
     const uint32_t *key_idx = (shared && tl_sign_prepared) ? tl_sign_key_idx : nullptr;
+    const KeyIdx kx{key_idx, key_idx ? (uint32_t)(tl_sign_prepared->nkeys - 1) : 0u};
     uint8_t *base = static_cast<uint8_t *>(ws);
     uint8_t *mr = base + lay.o_mr, *dead = base + lay.o_dead, *scratch = base + lay.o_scratch;
     unsigned *work = reinterpret_cast<unsigned *>(base + lay.o_work);
@@ -735,11 +738,11 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_HASH, st);
         LongCtl *lctl = reinterpret_cast<LongCtl *>(base + lay.o_long);
-        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, key_idx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
+        if (int rc = mldsa_long_prepass<DP<MODE>::TR / 8>(sk + 64, (shared && !key_idx) ? 0 : KG<MODE>::SK, kx, nullptr, 0, 0, msg_blob, msg_off, ctx_blob,
                                                           ctx_off, DP<MODE>::NIST ? internal : 1, mr, 128, lctl, n, st))
             return rc;
         hipLaunchKernelGGL(mldsa_sign_prep_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sk, msg_blob,
-                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, key_idx);
+                           msg_off, ctx_blob, ctx_off, rnd, internal, mr, n, shared ? 1 : 0, dead, (const LongCtl *)lctl, kx);
     }
     {
         auto kern = mldsa_sign_kernel<MODE>;
@@ -749,7 +752,7 @@ int mldsa_sign_dev_impl(const uint8_t *sk, const uint8_t *msg_blob, const uint64
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_SIGN, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), S::LDS_TOTAL, st, sk, (const uint8_t *)mr, sig, scratch, work,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, n, 1u, (uint32_t *)nullptr, (uint8_t *)nullptr, shared ? 1 : 0,
-                           (const uint32_t *)nullptr, key_idx);
+                           (const uint32_t *)nullptr, kx);
         if (ctx_blob && !internal && !tl_sign_ctx_ok)
             hipLaunchKernelGGL(mldsa_sign_zero_dead_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sig, (const uint8_t *)dead, n);
     }

@@ -7,6 +7,7 @@
 #include "mlkem_kernels.h"
 
 using namespace circl::host;
+using circl::KeyIdx;
 
 namespace {
 
@@ -129,7 +130,7 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
     const unsigned hb = (unsigned)((n + 255) / 256);
     if (!R3 && n <= kem_chain_item_batch()) {  // one launch: H(ek) -> G -> PRF beside A^T, then K-PKE.Encrypt, two wavefronts per item
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)Gm::EK, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)Gm::EK, KeyIdx{},
                            (const int16_t *)nullptr, (const uint8_t *)nullptr, m, ct, ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -153,7 +154,7 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)key_rows);
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, KeyIdx{}, (const int16_t *)key_rows);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -168,7 +169,7 @@ int encaps_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *s
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, ek, (size_t)Gm::EK, R3 ? (const uint8_t *)m_ws : m, (const uint8_t *)r_ws,
-                           ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr,
+                           ct, ss, status, (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, KeyIdx{},
                            (const int16_t *)nullptr);
     }
     if (R3) {
@@ -193,7 +194,7 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
     uint8_t *r_ws = w.slot0, *h_ws = w.slot1;
     if (n <= kem_chain_item_batch()) {  // one launch, the key work inside every item's workgroup (key stride 0: the one key)
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)0, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL((mlkem_encaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(128), 0, st, ek, (size_t)0, KeyIdx{},
                            (const int16_t *)nullptr, (const uint8_t *)nullptr, m, ct, ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -212,7 +213,7 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)0, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)key_rows);
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, KeyIdx{}, (const int16_t *)key_rows);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -220,14 +221,14 @@ int encaps_shared_dev_impl(const uint8_t *ek, const uint8_t *m, uint8_t *ct, uin
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(mlkem_hek_kernel<K>, dim3(1), dim3(64), 0, st, ek, h_ws);
         hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)h_ws, m, ss,
-                           r_ws, n, (const uint32_t *)nullptr);
+                           r_ws, n, KeyIdx{});
     }
     {
         auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_SHARED>;
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek, (size_t)0, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, (const uint32_t *)nullptr,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, KeyIdx{},
                            (const int16_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
@@ -248,6 +249,7 @@ int encaps_keyed_dev_impl(const uint8_t *ek_table, size_t nkeys, const uint32_t 
         !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
+    const KeyIdx kx{key_idx, (uint32_t)(nkeys - 1)};  // a device index vector is bounded to the table on every read
     uint8_t *r_ws = w.slot0;
     const size_t padded = (nkeys + Gm::G - 1) / Gm::G * Gm::G;
     int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_ws_bytes(n));
@@ -262,14 +264,14 @@ int encaps_keyed_dev_impl(const uint8_t *ek_table, size_t nkeys, const uint32_t 
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)key_h, m, ss, r_ws, n, key_idx);
+        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)key_h, m, ss, r_ws, n, kx);
     }
     {
         auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, ek_table, (size_t)Gm::EK, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, key_idx, (const int16_t *)key_rows);
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, kx, (const int16_t *)key_rows);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -289,7 +291,7 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
     uint8_t *key_status = reinterpret_cast<uint8_t *>(w.work) + 128;  // second half of the ticket-counter slot
     if (n <= kem_chain_item_batch()) {  // one launch, four wavefronts per item, key stride 0: every workgroup checks and expands the one key
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)0, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)0, KeyIdx{},
                            (const int16_t *)nullptr, (const uint8_t *)nullptr, ct, ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -316,19 +318,19 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
                            const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
-                           (const uint32_t *)nullptr, key_rows);
+                           KeyIdx{}, key_rows);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)0, ct, mprime, n, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)0, ct, mprime, n, KeyIdx{});
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(mlkem_dk_check_kernel<K>, dim3(1), dim3(64), 0, st, dk, key_status);
         hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)0, ct, (const uint8_t *)mprime, kbar,
-                           r_ws, ssrej, status, n, (const uint8_t *)key_status, (const uint32_t *)nullptr);
+                           r_ws, ssrej, status, n, (const uint8_t *)key_status, KeyIdx{});
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -336,7 +338,7 @@ int decaps_shared_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, ui
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)0, (const uint8_t *)mprime, (const uint8_t *)r_ws,
                            const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
-                           (const uint32_t *)nullptr, (const int16_t *)nullptr);
+                           KeyIdx{}, (const int16_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -355,6 +357,7 @@ int decaps_keyed_dev_impl(const uint8_t *dk_table, size_t nkeys, const uint32_t 
         (reinterpret_cast<uintptr_t>(key_idx) & 3))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
+    const KeyIdx kx{key_idx, (uint32_t)(nkeys - 1)};
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     const size_t padded = (nkeys + Gm::G - 1) / Gm::G * Gm::G;
     int16_t *key_rows = reinterpret_cast<int16_t *>(static_cast<uint8_t *>(ws) + kem_ws_bytes(n));
@@ -371,12 +374,12 @@ int decaps_keyed_dev_impl(const uint8_t *dk_table, size_t nkeys, const uint32_t 
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk_table, (size_t)Gm::DK, ct, mprime, n, key_idx);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk_table, (size_t)Gm::DK, ct, mprime, n, kx);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk_table, (size_t)Gm::DK, ct, (const uint8_t *)mprime, kbar,
-                           r_ws, ssrej, status, n, (const uint8_t *)key_status, key_idx);
+                           r_ws, ssrej, status, n, (const uint8_t *)key_status, kx);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -384,7 +387,7 @@ int decaps_keyed_dev_impl(const uint8_t *dk_table, size_t nkeys, const uint32_t 
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::GS - 1) / Gm::GS), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk_table + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
                            (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch,
-                           w.work, n, key_idx, (const int16_t *)key_rows);
+                           w.work, n, kx, (const int16_t *)key_rows);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -404,7 +407,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
     if (R3) status = w.status_slot;
     if (!R3 && n <= kem_chain_item_batch()) {  // one launch, four wavefronts per item: [Decrypt -> G -> PRF] J, H(ek) check, A^T, then the re-encryption
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)Gm::DK, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL((mlkem_decaps_chain_kernel<K, false>), dim3((unsigned)n), dim3(256), 0, st, dk, (size_t)Gm::DK, KeyIdx{},
                            (const int16_t *)nullptr, (const uint8_t *)nullptr, ct, ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -428,13 +431,13 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime, (const uint8_t *)r_ws,
                            const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n,
-                           (const uint32_t *)nullptr, (const int16_t *)key_rows);
+                           KeyIdx{}, (const int16_t *)key_rows);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)Gm::DK, ct, mprime, n, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, (size_t)Gm::DK, ct, mprime, n, KeyIdx{});
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -443,7 +446,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
                                ssrej, status, n);
         else
             hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, (size_t)Gm::DK, ct, (const uint8_t *)mprime,
-                               kbar, r_ws, ssrej, status, n, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+                               kbar, r_ws, ssrej, status, n, (const uint8_t *)nullptr, KeyIdx{});
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -451,7 +454,7 @@ int decaps_dev_impl(const uint8_t *dk, const uint8_t *ct, uint8_t *ss, uint8_t *
         const unsigned eb = std::min<unsigned>((unsigned)((n + Gm::G - 1) / Gm::G), resident_blocks(kern, Gm::LDS_SCRATCH_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SCRATCH_TOTAL, st, dk + 384 * K, (size_t)Gm::DK, (const uint8_t *)mprime,
                            (const uint8_t *)r_ws, const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej,
-                           w.scratch, w.work, n, (const uint32_t *)nullptr, (const int16_t *)nullptr);
+                           w.scratch, w.work, n, KeyIdx{}, (const int16_t *)nullptr);
     }
     if (R3) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
@@ -551,6 +554,7 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(m) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3))
         return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
+    const KeyIdx kx{key_idx, (uint32_t)(t->nkeys - 1)};
     uint8_t *r_ws = w.slot0;
     const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
     const int16_t *key_rows = reinterpret_cast<const int16_t *>(t->d_table);
@@ -558,7 +562,7 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     const size_t stride = key_idx ? (size_t)Gm::EK : 0;
     if (n <= kem_chain_batch(false)) {  // one launch, a wavefront per item: G -> PRF -> K-PKE.Encrypt (mlkem_encaps_chain_kernel)
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
-        hipLaunchKernelGGL(mlkem_encaps_chain_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, (const uint8_t *)t->d_keys, (size_t)Gm::EK, key_idx, key_rows, key_h, m, ct,
+        hipLaunchKernelGGL(mlkem_encaps_chain_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, (const uint8_t *)t->d_keys, (size_t)Gm::EK, kx, key_rows, key_h, m, ct,
                            ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
@@ -566,7 +570,7 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     HIP_TRY(hipMemsetAsync(w.work, 0, 256, st));
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
-        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key_h, m, ss, r_ws, n, key_idx);
+        hipLaunchKernelGGL(mlkem_g_shared_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, key_h, m, ss, r_ws, n, kx);
     }
     {
         auto kern = mlkem_encrypt_kernel<K, ENCAPS, 0, true, KM_KEYED>;
@@ -575,7 +579,7 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, (const uint8_t *)t->d_keys, stride, m, (const uint8_t *)r_ws, ct, ss, status,
-                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, key_idx, key_rows);
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, w.scratch, w.work, n, kx, key_rows);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;
@@ -588,6 +592,7 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     if (n == 0) return CIRCL_HIP_OK;
     if (ws_bytes < kem_ws_min(n) || !aligned16(ws) || !aligned16(ct) || !aligned16(ss) || (reinterpret_cast<uintptr_t>(key_idx) & 3)) return CIRCL_HIP_EWORKSPACE;
     KemWs w(ws, n);
+    const KeyIdx kx{key_idx, (uint32_t)(t->nkeys - 1)};
     uint8_t *mprime = w.slot0, *r_ws = w.slot1, *kbar = w.slot2, *ssrej = w.slot3;
     const size_t padded = (t->nkeys + Gm::G - 1) / Gm::G * Gm::G;
     const int16_t *key_rows = reinterpret_cast<const int16_t *>(t->d_table);
@@ -600,7 +605,7 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     // (mlkem_decaps_chain_kernel: J beside Decrypt -> G -> PRF -> re-encryption, one barrier, then the select)
     if (n <= kem_chain_batch()) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(mlkem_decaps_chain_kernel<K>, dim3((unsigned)n), dim3(128), 0, st, dk, (size_t)Gm::DK, key_idx, key_rows, key_status, ct, ss, status, n);
+        hipLaunchKernelGGL(mlkem_decaps_chain_kernel<K>, dim3((unsigned)n), dim3(128), 0, st, dk, (size_t)Gm::DK, kx, key_rows, key_status, ct, ss, status, n);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -618,11 +623,11 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     } else {
         {
             ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-            hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, stride, ct, mprime, n, key_idx);
+            hipLaunchKernelGGL(mlkem_decrypt_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, dk, stride, ct, mprime, n, kx);
         }
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_HASH, st);
         hipLaunchKernelGGL(mlkem_decaps_hash_kernel<K>, dim3(hb), dim3(256), 0, st, dk, stride, ct, (const uint8_t *)mprime, kbar, r_ws, ssrej, status, n,
-                           key_status, key_idx);
+                           key_status, kx);
     }
     {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
@@ -630,7 +635,7 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
         const size_t want = n <= kem_small_shared_batch(true) ? kem_small_group(n, true) : (size_t)Gm::GS;
         const unsigned eb = std::min<unsigned>((unsigned)((n + want - 1) / want), resident_blocks(kern, Gm::LDS_SHARED_TOTAL));
         hipLaunchKernelGGL(kern, dim3(eb), dim3(64), Gm::LDS_SHARED_TOTAL, st, dk + 384 * K, stride, (const uint8_t *)mprime, (const uint8_t *)r_ws,
-                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n, key_idx, key_rows);
+                           const_cast<uint8_t *>(ct), ss, status, (const uint8_t *)kbar, (const uint8_t *)ssrej, w.scratch, w.work, n, kx, key_rows);
     }
     HIP_TRY(hipGetLastError());
     return CIRCL_HIP_OK;

@@ -44,7 +44,7 @@ static __global__ __launch_bounds__(256) void rows_copy_kernel(uint32_t *__restr
 }
 // dst[r] = table[key_idx ? key_idx[r] : 0]: rows of `width` dwords gathered from a key table (a resident hybrid key table's X25519 rows)
 static __global__ __launch_bounds__(256) void rows_gather_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ table,
-                                                                 const uint32_t *__restrict__ key_idx, unsigned width, size_t n) {
+                                                                 const KeyIdx key_idx, unsigned width, size_t n) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t r = t / width;
     const unsigned c = (unsigned)(t - r * width);

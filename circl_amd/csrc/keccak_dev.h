@@ -63,6 +63,18 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 #endif
 
+// The index vector of a key-table batch as the kernels see it: item i uses table entry key_idx[i].  The host entry points check the
+// vector before a launch (an index >= nkeys is CIRCL_HIP_EPARAM); a device-resident vector cannot be checked without a round
+// trip, so every read goes through operator[], which bounds it to the table: an index past the end reads the LAST entry, never
+// memory behind the table (a private-key table sits next to other tenants' keys).  p == nullptr: no vector (entry 0 / item i,
+// as the kernel documents).  `last` = nkeys - 1.
+struct KeyIdx {
+    const uint32_t *p;
+    uint32_t last;
+    CIRCL_HD explicit operator bool() const { return p != nullptr; }
+    CIRCL_HD uint32_t operator[](size_t i) const { const uint32_t k = p[i]; return k < last ? k : last; }
+};
+
 // Round constants of FIPS 202 (the reference tabulates the same 24 values in
 // internal/sha3/rc.go:4-29), split into (hi,lo) halves.
 #define CIRCL_RC_LIST                                                                              \

@@ -228,7 +228,7 @@ __device__ __forceinline__ void absorb_message_and_squeeze(KeccakState &h, const
 // TRW words at tr_base + q * tr_stride with q = key_idx ? key_idx[t] : t (tr_stride 0: one key for the batch) -- or, when pk
 // is given, SHAKE256(pk_t)[:8 TRW] computed here (pk_words 64-bit words at pk + t * pk_stride).  mu -> mu_out + t * mu_stride.
 template <int TRW>
-__global__ void __launch_bounds__(64) mldsa_mu_long_kernel(const uint8_t *__restrict__ tr_base, size_t tr_stride, const uint32_t *__restrict__ key_idx,
+__global__ void __launch_bounds__(64) mldsa_mu_long_kernel(const uint8_t *__restrict__ tr_base, size_t tr_stride, const KeyIdx key_idx,
                                                           const uint8_t *__restrict__ pk, size_t pk_stride, int pk_words,
                                                           const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
                                                           const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off, int internal,
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) mldsa_prep_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                          int internal, uint8_t *__restrict__ muw1_ws, uint8_t *__restrict__ ball_ws,
                                                          uint8_t *__restrict__ fail_ws, size_t n, const uint8_t *__restrict__ tr_shared,
-                                                         const uint32_t *__restrict__ key_idx, const LongCtl *__restrict__ long_ctl,
+                                                         const KeyIdx key_idx, const LongCtl *__restrict__ long_ctl,
                                                          size_t tr_item_stride = 0) {
     using G = DG<MODE>;
     using P = DP<MODE>;
@@ -725,7 +725,7 @@ template <int MODE, int ABLATE = 0, int KM = mlkem::KM_ITEM>
 __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     mldsa_verify_kernel(const uint8_t *__restrict__ pk, const uint8_t *__restrict__ sig, uint8_t *__restrict__ muw1_ws,
                         const uint8_t *__restrict__ ball_ws, uint8_t *__restrict__ fail_ws, uint8_t *__restrict__ scratch,
-                        unsigned *__restrict__ work, size_t n, const uint32_t *__restrict__ key_idx, const uint32_t *__restrict__ key_rows) {
+                        unsigned *__restrict__ work, size_t n, const KeyIdx key_idx, const uint32_t *__restrict__ key_rows) {
     constexpr bool SHARED = KM == mlkem::KM_SHARED, KEYED = KM == mlkem::KM_KEYED;
     using G = DG<MODE>;
     using P = DP<MODE>;
@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(64) mldsa_final_coop_kernel(const uint8_t *__r
 // ONE unparsed key for the whole (small) batch -- every workgroup derives it again, which is shorter than a launch that derives it once.
 template <int MODE, bool RESIDENT = true>
 __global__ void __launch_bounds__((DP<MODE>::K + (RESIDENT ? 1 : 2)) * 64)
-    mldsa_verify_chain_kernel(const uint8_t *__restrict__ pk_table, const uint32_t *__restrict__ key_idx, const uint32_t *__restrict__ key_rows,
+    mldsa_verify_chain_kernel(const uint8_t *__restrict__ pk_table, const KeyIdx key_idx, const uint32_t *__restrict__ key_rows,
                               const uint8_t *__restrict__ key_tr, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ msg_blob,
                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                               int internal, uint8_t *__restrict__ ok, size_t n, uint8_t *__restrict__ scratch, size_t pk_stride) {
@@ -1623,7 +1623,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
                                                               const uint64_t *__restrict__ ctx_off, const uint8_t *__restrict__ rnd,
                                                               int internal, uint8_t *__restrict__ mr_ws, size_t n, int shared_key,
                                                               uint8_t *__restrict__ dead_ws, const LongCtl *__restrict__ long_ctl,
-                                                              const uint32_t *__restrict__ key_idx, uint32_t *__restrict__ rl_attempts = nullptr,
+                                                              const KeyIdx key_idx, uint32_t *__restrict__ rl_attempts = nullptr,
                                                               uint32_t *__restrict__ rl_best = nullptr, uint32_t *__restrict__ rl_list0 = nullptr,
                                                               uint32_t *__restrict__ rl_ctl = nullptr, unsigned rl_k0 = 1) {
     using Kg = KG<MODE>;
@@ -1684,7 +1684,7 @@ __global__ void __launch_bounds__(256) mldsa_sign_prep_kernel(const uint8_t *__r
 // dependent permutations of ~3.5 us for a short message instead of two launches and a lane-form permutation), the "dead" flags, and for
 // prepared keys the set-up of the round signer's lists.  Same bytes as the three kernels (tests/test_gpu_round3.py forces both ways).
 template <int MODE>
-__global__ void __launch_bounds__(64) mldsa_sign_front_kernel(const uint8_t *__restrict__ sk, size_t sk_stride, const uint32_t *__restrict__ key_idx,
+__global__ void __launch_bounds__(64) mldsa_sign_front_kernel(const uint8_t *__restrict__ sk, size_t sk_stride, const KeyIdx key_idx,
                                                              const uint8_t *__restrict__ msg_blob, const uint64_t *__restrict__ msg_off,
                                                              const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
                                                              const uint8_t *__restrict__ rnd, int internal, uint8_t *__restrict__ mr_ws, size_t n,
@@ -1796,7 +1796,7 @@ __global__ void __launch_bounds__(64) mldsa_sign_kernel(const uint8_t *__restric
                                                        unsigned *__restrict__ work, const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ attempts, size_t n, unsigned spec_w,
                                                        uint32_t *__restrict__ best, uint8_t *__restrict__ spec_sig, int shared_key,
-                                                       const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ key_idx) {
+                                                       const uint32_t *__restrict__ count_ptr, const KeyIdx key_idx) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     using Kg = KG<MODE>;

@@ -69,7 +69,7 @@ struct SignState {          // device pointers into the workspace, passed by val
     uint32_t spec_target;   // rounds speculate (k > 1) once at most this many entries would result
     uint32_t capacity;      // entries the per-attempt buffers and the lists can hold
     uint32_t pair;          // 1: rounds too long to speculate widely still try TWO attempts per item (see sign_next_k)
-    const uint32_t *key_idx; // shared == 2 with a table of SEVERAL prepared keys: item i signs with entry key_idx[i] (nullptr: entry 0)
+    KeyIdx key_idx;          // shared == 2 with a table of SEVERAL prepared keys: item i signs with entry key_idx[i] (nullptr: entry 0)
     unsigned *tail_work;    // the persistent tail kernel's ticket counter (64 words), zeroed by the last round's compaction
     unsigned *chain_done;   // workgroups of a one-launch round that are through (sign_round_chain_kernel); zero between rounds
     // which entry of A / sec an item uses

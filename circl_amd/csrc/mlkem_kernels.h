@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) mlkem_hek_table_kernel(const uint8_t *__r
 // key_idx != nullptr (key-table batches): item idx uses the hash of table entry key_idx[idx].
 static __global__ void __launch_bounds__(256) mlkem_g_shared_kernel(const uint8_t *__restrict__ h_ws, const uint8_t *__restrict__ m,
                                                              uint8_t *__restrict__ ss, uint8_t *__restrict__ r_ws, size_t n,
-                                                             const uint32_t *__restrict__ key_idx) {
+                                                             const KeyIdx key_idx) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     KeccakState g;
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                           uint8_t *__restrict__ status, const uint8_t *__restrict__ kbar_ws,
                                                           const uint8_t *__restrict__ ssrej_ws, uint8_t *__restrict__ scratch, unsigned *__restrict__ work, size_t n,
-                                                          const uint32_t *__restrict__ key_idx, const int16_t *__restrict__ key_rows) {
+                                                          const KeyIdx key_idx, const int16_t *__restrict__ key_rows) {
     using Gm = Geom<K>;
     using P = Params<K>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void mlkem_decrypt_item(const uint8_t *__restrict__ d
 // one item per single-wave workgroup: m' -> workspace
 template <int K>
 __global__ void __launch_bounds__(64) mlkem_decrypt_kernel(const uint8_t *__restrict__ dk, size_t dk_stride, const uint8_t *__restrict__ ct,
-                                                          uint8_t *__restrict__ mprime_ws, size_t n, const uint32_t *__restrict__ key_idx) {
+                                                          uint8_t *__restrict__ mprime_ws, size_t n, const KeyIdx key_idx) {
     using Gm = Geom<K>;
     __shared__ __attribute__((aligned(16))) uint32_t xch[256];
     const size_t item = blockIdx.x;
@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(256) mlkem_decaps_hash_kernel(const uint8_t *_
                                                                 const uint8_t *__restrict__ mprime_ws, uint8_t *__restrict__ kbar_ws,
                                                                 uint8_t *__restrict__ r_ws, uint8_t *__restrict__ ssrej_ws,
                                                                 uint8_t *__restrict__ status, size_t n, const uint8_t *__restrict__ key_status,
-                                                                const uint32_t *__restrict__ key_idx) {
+                                                                const KeyIdx key_idx) {
     using Gm = Geom<K>;
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < n;
@@ -1489,7 +1489,7 @@ __global__ void __launch_bounds__(64, CIRCL_KEM_WAVES_PER_EU) mlkem_small_decaps
 // of the re-encryption.  Four wavefronts, 256 threads.
 template <int K, bool RESIDENT = true>
 __global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kernel(const uint8_t *__restrict__ dk, size_t dk_stride,
-                                                                 const uint32_t *__restrict__ key_idx,
+                                                                 const KeyIdx key_idx,
                                                                  const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_status,
                                                                  const uint8_t *__restrict__ ct, uint8_t *__restrict__ ss, uint8_t *__restrict__ status,
                                                                  size_t n) {
@@ -1678,7 +1678,7 @@ __global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kerne
 // LDS meanwhile, and one barrier sits in front of the ring phase.  128 threads.
 template <int K, bool RESIDENT = true>
 __global__ void __launch_bounds__(RESIDENT ? 64 : 128) mlkem_encaps_chain_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
-                                                                const uint32_t *__restrict__ key_idx,
+                                                                const KeyIdx key_idx,
                                                                 const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_h,
                                                                 const uint8_t *__restrict__ m, uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
                                                                 uint8_t *__restrict__ status, size_t n) {

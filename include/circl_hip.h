@@ -145,7 +145,8 @@ int circl_hip_mlkem_decaps_shared_dev(int param, const uint8_t *d_dk, const uint
  * private key's hash check once per TABLE ENTRY, then the shared-key work per item.  Results are identical to
  * circl_hip_mlkem_encaps / _decaps on the gathered rows ek_table[key_idx[i]] / dk_table[key_idx[i]]; status[i] is the
  * verdict of item i's key.  Host entry points return CIRCL_HIP_EPARAM for an index >= nkeys; the _dev variants
- * trust d_key_idx (4-byte aligned) and need circl_hip_mlkem_keyed_workspace_size(param, n, nkeys) bytes. */
+ * bound d_key_idx (4-byte aligned) to the table -- an index >= nkeys uses the last entry -- and need
+ * circl_hip_mlkem_keyed_workspace_size(param, n, nkeys) bytes. */
 int circl_hip_mlkem_encaps_keyed(int param, const uint8_t *ek_table, size_t nkeys, const uint32_t *key_idx,
                                  const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device);
 int circl_hip_mlkem_decaps_keyed(int param, const uint8_t *dk_table, size_t nkeys, const uint32_t *key_idx,
@@ -171,8 +172,9 @@ int circl_hip_mlkem_decaps_keyed_dev(int param, const uint8_t *d_dk_table, size_
  *       reported per item by the encapsulation (status 1 = kem.ErrPubKey), as everywhere in this ABI.
  *   _dev variants: pointers are device memory on the TABLE's device; workspace = circl_hip_mlkem_workspace_size(param, n) /
  *       circl_hip_mldsa_workspace_size(param, n) bytes (no table tail: the table brings its own).  Like every keyed _dev entry point
- *       they TRUST d_key_idx (the host forms check it: an index >= nkeys is CIRCL_HIP_EPARAM; a device array cannot be checked without
- *       a synchronisation, and an index beyond the table reads past it).
+ *       they cannot REPORT a bad d_key_idx (the host forms check it: an index >= nkeys is CIRCL_HIP_EPARAM; a device array cannot be
+ *       checked without a synchronisation), so the kernels BOUND it: an index >= nkeys uses the table's LAST entry -- never memory
+ *       behind the table.
  *   circl_hip_keytable_free wipes the key rows of a private table before releasing them.
  *   device = CIRCL_HIP_ALL_DEVICES in any *_new below REPLICATES the table: it is built once on every device, and the host-buffer
  *       *_table calls then split a batch into contiguous shards, one per device, like every other entry point (a table made for
@@ -193,7 +195,7 @@ int circl_hip_mldsa_keytable_new(int param, const uint8_t *pks, size_t nkeys, in
 int circl_hip_mldsa_privkey_new(int param, const uint8_t *sk, int device, circl_hip_keytable **out);
 /* ... and a table of nkeys prepared private keys (a signer that holds several identities): message i is signed with entry
  * key_idx[i]; key_idx == NULL: entry 0.  Same signatures as circl_hip_mldsa_sign on the gathered rows sks[key_idx[i]].  The host
- * form returns CIRCL_HIP_EPARAM for an index >= nkeys; the _dev form trusts d_key_idx (4-byte aligned). */
+ * form returns CIRCL_HIP_EPARAM for an index >= nkeys; the _dev form bounds d_key_idx (4-byte aligned) to the table (>= nkeys: the last entry). */
 int circl_hip_mldsa_privkeys_new(int param, const uint8_t *sks, size_t nkeys, int device, circl_hip_keytable **out);
 int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *msg_blob, const uint64_t *msg_off,
                                      const uint8_t *ctx_blob, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sig, size_t n);
@@ -330,7 +332,7 @@ int circl_hip_mldsa_verify_shared_dev(int param, const uint8_t *d_pk, const uint
  * sees a few CA keys across a large batch.  tr and ExpandA (what PublicKey.Unpack caches per key,
  * sign/mldsa/mldsa65/internal/dilithium.go:114-126; benchmark note internal/dilithium_test.go:37-39) run once per TABLE
  * ENTRY.  Same results as circl_hip_mldsa_verify on the gathered rows.  The _dev variant needs
- * circl_hip_mldsa_keyed_workspace_size(param, n, nkeys) bytes and trusts d_key_idx. */
+ * circl_hip_mldsa_keyed_workspace_size(param, n, nkeys) bytes and bounds d_key_idx to the table (>= nkeys: the last entry). */
 int circl_hip_mldsa_verify_keyed(int param, const uint8_t *pk_table, size_t nkeys, const uint32_t *key_idx,
                                  const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
                                  const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n, int device);
