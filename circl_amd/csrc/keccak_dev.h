@@ -36,6 +36,13 @@ CIRCL_HD uint32_t bitop3_chi(uint32_t a, uint32_t b, uint32_t c) {  // a ^ (~b &
     return a ^ (~b & c);
 #endif
 }
+CIRCL_HD uint32_t bitop3_xor_and(uint32_t a, uint32_t b, uint32_t c) {  // a ^ (b & c)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78);
+#else
+    return a ^ (b & c);
+#endif
+}
 // ({hi,lo} >> s)[31:0], 0 < s < 32
 CIRCL_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -258,17 +265,26 @@ __device__ __forceinline__ void keccak_f1600_split(SplitState &s, bool hi_lane) 
 
 // Keccak-f[1600] on TWO states by one wavefront, for latency-bound chains (H(ek) || G of a small ML-KEM batch: ten dependent
 // permutations).  Lanes 0..24 hold the 25 lanes of state A, lanes 32..56 those of state B, each as a (lo, hi) register pair
-// that STAYS in its lane across rounds and across absorbed blocks; a round is ~25 VALU instructions and two exchanges through
-// LDS -- every lane reads the two columns theta needs (10 words), then the three words of its row chi needs -- against 180
-// instructions of the lane-per-state form: a lone wavefront, which issues one instruction per ~5.4 cycles whatever their
-// dependences, finishes a permutation in well under half the time.  (keccak_f1600_coop above is the older single-state
-// form with three exchanges per round.)  `ws`: 2 x 50 x 8 bytes of LDS.  Single-wave workgroups only.
+// that STAYS in its lane across rounds and across absorbed blocks; a round is two exchanges through LDS -- every lane reads the
+// two columns theta needs (10 words), then the three words of its row chi needs -- and ~45 instructions against 180 of the
+// lane-per-state form: a lone wavefront issues one instruction per ~5.4 cycles whatever their dependences, so the length of a
+// dependent chain IS its instruction count.  Round 5 took the round from ~70 instructions to 43 (3.7 -> 2.3 us per permutation):
+//   * the round constant comes out of a register (lane r of c.rcl / c.rch, v_readlane) and goes in with one V_BITOP3 per half
+//     (a ^ (rc & mask-of-the-lane-that-owns-a[0])) -- it was a pc-relative scalar load, waited for, every round;
+//   * no lane is ever masked off: the seven idle lanes of a half store into words that are dead at that point (the other area
+//     of the exchange: b while a is written, a while b is) -- every `if (on)` was an exec save / restore;
+//   * rho = 0 (the lane of a[0]) is a funnel shift by 0 of the SWAPPED halves, like every other offset -- no select for it;
+//   * the ordering points are compiler fences in BOTH forms (the exchange area belongs to one wavefront, whose LDS instructions
+//     execute in order); the workgroup barrier form waited for every store to land before the loads were issued.
+// (keccak_f1600_coop above is the older single-state form with three exchanges per round.)  `ws`: 2 x 50 x 8 bytes of LDS.
 struct CoopLane {
     bool on;             // this lane owns a state lane
     int i;               // which one (x + 5 y)
     uint64_t *a_self, *a_cm, *a_cp, *b_dst, *b0, *b1, *b2;
-    uint32_t rot;        // rho offset mod 32
-    bool swap, unrot;    // rho offset >= 32; rho offset == 0
+    uint32_t rsh;        // rho as a right funnel shift: 32 - (rho mod 32) (V_ALIGNBIT reads 5 bits: 32 is 0)
+    bool swap;           // the halves trade places first: rho >= 32 -- and rho == 0, where the shift by 0 returns the OTHER half
+    uint32_t iota;       // all ones in the lane that owns a[0], 0 elsewhere
+    uint32_t rcl, rch;   // wavefront lane r < 24: round constant r
 };
 __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     constexpr int rho_t[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
@@ -278,53 +294,51 @@ __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     c.i = c.on ? j : 0;
     const int x = c.i % 5, y = c.i / 5;
     uint64_t *a = ws + 50 * half, *b = a + 25;
-    c.a_self = a + c.i;
+    c.a_self = c.on ? a + c.i : b + (j - 25);  // (idle lanes: a word of the area nobody reads before it is rewritten)
     c.a_cm = a + (x + 4) % 5;
     c.a_cp = a + (x + 1) % 5;
-    c.b_dst = b + y + 5 * ((2 * x + 3 * y) % 5);
+    c.b_dst = c.on ? b + y + 5 * ((2 * x + 3 * y) % 5) : a + (j - 25);
     c.b0 = b + c.i;
     c.b1 = b + (x + 1) % 5 + 5 * y;
     c.b2 = b + (x + 2) % 5 + 5 * y;
     const int rho = rho_t[c.i];
-    c.rot = (uint32_t)(rho & 31);
-    c.swap = rho >= 32;
-    c.unrot = rho == 0;
+    c.rsh = 32u - (uint32_t)(rho & 31);
+    c.swap = rho >= 32 || rho == 0;
+    c.iota = (c.on && c.i == 0) ? 0xffffffffu : 0u;
+    const RcPair rc = rc_pair(lane < 24 ? lane : 24);  // (entry 24 is zero)
+    c.rcl = rc.lo;
+    c.rch = rc.hi;
     return c;
 }
-// NW: see kyber_dev.h wave_sync -- the exchange area belongs to this wavefront alone (a workgroup of several wavefronts gives each
-// its own), and its LDS instructions execute in order
+// NW: called by ONE wavefront of a workgroup of several (no workgroup barrier may be executed); otherwise the whole (single-
+// wavefront) workgroup calls it, and a barrier on entry and on exit orders it against whatever else the caller keeps in LDS.
 template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi, const CoopLane &c) {
-    auto sync = [] {
-        if constexpr (NW) wave_lds_order();
-        else __syncthreads();
-    };
     auto ld = [](const uint64_t *p, uint32_t &lo, uint32_t &hi) { const uint64_t w = *p; lo = (uint32_t)w; hi = (uint32_t)(w >> 32); };
+    if constexpr (!NW) __syncthreads();
 #pragma unroll 1
     for (int r = 0; r < 24; r++) {
-        const RcPair rc = rc_pair(r);
-        sync();  // chi's reads of the previous round are done
-        if (c.on) *c.a_self = ((uint64_t)vhi << 32) | vlo;
-        sync();
+        const uint32_t rcl = (uint32_t)__builtin_amdgcn_readlane((int)c.rcl, r), rch = (uint32_t)__builtin_amdgcn_readlane((int)c.rch, r);
+        wave_lds_order();  // chi's reads of the previous round are done
+        *c.a_self = ((uint64_t)vhi << 32) | vlo;
+        wave_lds_order();
         uint32_t ml[5], mh[5], pl[5], ph[5];
 #pragma unroll
         for (int y = 0; y < 5; y++) { ld(c.a_cm + 5 * y, ml[y], mh[y]); ld(c.a_cp + 5 * y, pl[y], ph[y]); }
         const uint32_t cml = bitop3_xor(bitop3_xor(ml[0], ml[1], ml[2]), ml[3], ml[4]), cmh = bitop3_xor(bitop3_xor(mh[0], mh[1], mh[2]), mh[3], mh[4]);
         const uint32_t cpl = bitop3_xor(bitop3_xor(pl[0], pl[1], pl[2]), pl[3], pl[4]), cph = bitop3_xor(bitop3_xor(ph[0], ph[1], ph[2]), ph[3], ph[4]);
         // theta: v ^= C[x-1] ^ rol(C[x+1], 1)
-        uint32_t tl = bitop3_xor(vlo, cml, alignbit(cpl, cph, 31)), th = bitop3_xor(vhi, cmh, alignbit(cph, cpl, 31));
+        const uint32_t tl = bitop3_xor(vlo, cml, alignbit(cpl, cph, 31)), th = bitop3_xor(vhi, cmh, alignbit(cph, cpl, 31));
         // rho: rotate left by the lane's offset (a per-lane amount: swap the halves for offsets >= 32, funnel-shift by the rest)
         const uint32_t sl = c.swap ? th : tl, sh = c.swap ? tl : th;
-        const uint32_t rl = alignbit(sl, sh, 32 - c.rot), rh = alignbit(sh, sl, 32 - c.rot);
-        tl = c.unrot ? tl : rl;
-        th = c.unrot ? th : rh;
-        if (c.on) *c.b_dst = ((uint64_t)th << 32) | tl;  // pi
-        sync();
+        const uint32_t rl = alignbit(sl, sh, c.rsh), rh = alignbit(sh, sl, c.rsh);
+        *c.b_dst = ((uint64_t)rh << 32) | rl;  // pi
+        wave_lds_order();
         uint32_t b0l, b0h, b1l, b1h, b2l, b2h;
         ld(c.b0, b0l, b0h); ld(c.b1, b1l, b1h); ld(c.b2, b2l, b2h);
-        vlo = bitop3_chi(b0l, b1l, b2l);
-        vhi = bitop3_chi(b0h, b1h, b2h);
-        if (c.i == 0) { vlo ^= rc.lo; vhi ^= rc.hi; }  // iota (lanes 0 and 32; idle lanes carry garbage nobody reads)
+        vlo = bitop3_xor_and(bitop3_chi(b0l, b1l, b2l), rcl, c.iota);  // chi, iota (idle lanes carry garbage nobody reads)
+        vhi = bitop3_xor_and(bitop3_chi(b0h, b1h, b2h), rch, c.iota);
     }
+    if constexpr (!NW) __syncthreads();
 }
 #endif
 
