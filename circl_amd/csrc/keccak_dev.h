@@ -265,27 +265,31 @@ __device__ __forceinline__ void keccak_f1600_split(SplitState &s, bool hi_lane) 
 
 // Keccak-f[1600] on TWO states by one wavefront, for latency-bound chains (H(ek) || G of a small ML-KEM batch: ten dependent
 // permutations).  Lanes 0..24 hold the 25 lanes of state A, lanes 32..56 those of state B, each as a (lo, hi) register pair
-// that STAYS in its lane across rounds and across absorbed blocks; a round is two exchanges through LDS -- every lane reads the
-// two columns theta needs (10 words), then the three words of its row chi needs -- and ~45 instructions against 180 of the
-// lane-per-state form: a lone wavefront issues one instruction per ~5.4 cycles whatever their dependences, so the length of a
-// dependent chain IS its instruction count.  Round 5 took the round from ~70 instructions to 43 (3.7 -> 2.3 us per permutation):
-//   * the round constant comes out of a register (lane r of c.rcl / c.rch, v_readlane) and goes in with one V_BITOP3 per half
-//     (a ^ (rc & mask-of-the-lane-that-owns-a[0])) -- it was a pc-relative scalar load, waited for, every round;
-//   * no lane is ever masked off: the seven idle lanes of a half store into words that are dead at that point (the other area
-//     of the exchange: b while a is written, a while b is) -- every `if (on)` was an exec save / restore;
-//   * rho = 0 (the lane of a[0]) is a funnel shift by 0 of the SWAPPED halves, like every other offset -- no select for it;
-//   * the ordering points are compiler fences in BOTH forms (the exchange area belongs to one wavefront, whose LDS instructions
-//     execute in order); the workgroup barrier form waited for every store to land before the loads were issued.
+// that STAYS in its lane across rounds and across absorbed blocks.  A lone wavefront issues one instruction per ~5.4 cycles
+// whatever their dependences, so the length of a dependent chain IS its instruction count: 180 per round in the lane-per-state
+// form, ~70 in round 3's version of this one (3.7 us per permutation), 27 now (1.5 us).  A round:
+//   theta  the five lanes of a column XOR their word into ONE LDS word (DS_XOR_B64, the LDS serialises the five; the buffer was
+//          cleared a round earlier, two buffers alternate), then every lane reads C[x-1] and C[x+1]: 1 + 1 + 2 LDS instructions
+//          and 4 VALU -- it was a store, ten loads and eight three-input XORs;
+//   rho    a funnel shift by 32 - rho of the (swapped, for rho >= 32) halves; rho = 0 -- the lane of a[0] -- is a shift by 0 of
+//          the SWAPPED halves, so it needs no select of its own;
+//   pi     one store to the word's new place;  chi  three loads, one V_BITOP3 per half;
+//   iota   the round constant comes out of a register (lane r of c.rcl / c.rch, v_readlane) and goes in with one V_BITOP3 per half,
+//          a ^ (rc & mask-of-the-lane-that-owns-a[0]) -- it was a pc-relative scalar load, waited for, every round.
+// No lane is ever masked off (the seven idle lanes of a half store into words nobody reads: every `if (on)` was an exec save /
+// restore), and the ordering points are compiler fences in BOTH forms (the exchange area belongs to one wavefront, whose LDS
+// instructions execute in order; the workgroup-barrier form waited for every store to land before the loads were issued).
 // (keccak_f1600_coop above is the older single-state form with three exchanges per round.)  `ws`: 2 x 50 x 8 bytes of LDS.
 struct CoopLane {
     bool on;             // this lane owns a state lane
     int i;               // which one (x + 5 y)
-    uint64_t *a_self, *a_cm, *a_cp, *b_dst, *b0, *b1, *b2;
+    uint64_t *c_self, *c_m, *c_p, *b_dst, *b0, *b1, *b2;  // column-parity words (two buffers, 8 words apart), pi / chi words
     uint32_t rsh;        // rho as a right funnel shift: 32 - (rho mod 32) (V_ALIGNBIT reads 5 bits: 32 is 0)
     bool swap;           // the halves trade places first: rho >= 32 -- and rho == 0, where the shift by 0 returns the OTHER half
     uint32_t iota;       // all ones in the lane that owns a[0], 0 elsewhere
     uint32_t rcl, rch;   // wavefront lane r < 24: round constant r
 };
+// Per half of the wavefront (50 words): b[25] | C0[8] | C1[8] | 7 words the idle lanes store into | 2 unused.
 __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     constexpr int rho_t[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     CoopLane c;
@@ -293,11 +297,11 @@ __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     c.on = j < 25;
     c.i = c.on ? j : 0;
     const int x = c.i % 5, y = c.i / 5;
-    uint64_t *a = ws + 50 * half, *b = a + 25;
-    c.a_self = c.on ? a + c.i : b + (j - 25);  // (idle lanes: a word of the area nobody reads before it is rewritten)
-    c.a_cm = a + (x + 4) % 5;
-    c.a_cp = a + (x + 1) % 5;
-    c.b_dst = c.on ? b + y + 5 * ((2 * x + 3 * y) % 5) : a + (j - 25);
+    uint64_t *b = ws + 50 * half, *col = b + 25, *dump = b + 41;
+    c.c_self = col + (c.on ? x : 5 + (j - 25) % 3);  // (idle lanes: the three column words nobody reads)
+    c.c_m = col + (x + 4) % 5;
+    c.c_p = col + (x + 1) % 5;
+    c.b_dst = c.on ? b + y + 5 * ((2 * x + 3 * y) % 5) : dump + (j - 25);
     c.b0 = b + c.i;
     c.b1 = b + (x + 1) % 5 + 5 * y;
     c.b2 = b + (x + 2) % 5 + 5 * y;
@@ -310,33 +314,41 @@ __device__ __forceinline__ CoopLane coop_lane(uint64_t *ws, int lane) {
     c.rch = rc.hi;
     return c;
 }
+// One round; BUF: which of the two column-parity buffers this round accumulates into (the other one is cleared for the next).
+template <int BUF> __device__ __forceinline__ void coop2_round(uint32_t &vlo, uint32_t &vhi, const CoopLane &c, int r) {
+    auto ld = [](const uint64_t *p, uint32_t &lo, uint32_t &hi) { const uint64_t w = *p; lo = (uint32_t)w; hi = (uint32_t)(w >> 32); };
+    const uint32_t rcl = (uint32_t)__builtin_amdgcn_readlane((int)c.rcl, r), rch = (uint32_t)__builtin_amdgcn_readlane((int)c.rch, r);
+    wave_lds_order();  // chi's reads of the previous round are done
+    // theta's column parities: the five lanes of a column XOR their word into ONE LDS word (DS_XOR_B64: the LDS serialises the five)
+    __hip_atomic_fetch_xor(reinterpret_cast<unsigned long long *>(c.c_self + 8 * BUF), ((unsigned long long)vhi << 32) | vlo, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+    c.c_self[8 * (BUF ^ 1)] = 0;
+    wave_lds_order();
+    uint32_t cml, cmh, cpl, cph;
+    ld(c.c_m + 8 * BUF, cml, cmh);
+    ld(c.c_p + 8 * BUF, cpl, cph);
+    // theta: v ^= C[x-1] ^ rol(C[x+1], 1)
+    const uint32_t tl = bitop3_xor(vlo, cml, alignbit(cpl, cph, 31)), th = bitop3_xor(vhi, cmh, alignbit(cph, cpl, 31));
+    // rho: rotate left by the lane's offset (a per-lane amount: swap the halves for offsets >= 32, funnel-shift by the rest)
+    const uint32_t sl = c.swap ? th : tl, sh = c.swap ? tl : th;
+    const uint32_t rl = alignbit(sl, sh, c.rsh), rh = alignbit(sh, sl, c.rsh);
+    *c.b_dst = ((uint64_t)rh << 32) | rl;  // pi
+    wave_lds_order();
+    uint32_t b0l, b0h, b1l, b1h, b2l, b2h;
+    ld(c.b0, b0l, b0h); ld(c.b1, b1l, b1h); ld(c.b2, b2l, b2h);
+    vlo = bitop3_xor_and(bitop3_chi(b0l, b1l, b2l), rcl, c.iota);  // chi, iota (idle lanes carry garbage nobody reads)
+    vhi = bitop3_xor_and(bitop3_chi(b0h, b1h, b2h), rch, c.iota);
+}
 // NW: called by ONE wavefront of a workgroup of several (no workgroup barrier may be executed); otherwise the whole (single-
 // wavefront) workgroup calls it, and a barrier on entry and on exit orders it against whatever else the caller keeps in LDS.
 template <bool NW = false> __device__ __forceinline__ void keccak_f1600_coop2(uint32_t &vlo, uint32_t &vhi, const CoopLane &c) {
-    auto ld = [](const uint64_t *p, uint32_t &lo, uint32_t &hi) { const uint64_t w = *p; lo = (uint32_t)w; hi = (uint32_t)(w >> 32); };
     if constexpr (!NW) __syncthreads();
+    wave_lds_order();
+    c.c_self[0] = 0;
 #pragma unroll 1
-    for (int r = 0; r < 24; r++) {
-        const uint32_t rcl = (uint32_t)__builtin_amdgcn_readlane((int)c.rcl, r), rch = (uint32_t)__builtin_amdgcn_readlane((int)c.rch, r);
-        wave_lds_order();  // chi's reads of the previous round are done
-        *c.a_self = ((uint64_t)vhi << 32) | vlo;
-        wave_lds_order();
-        uint32_t ml[5], mh[5], pl[5], ph[5];
-#pragma unroll
-        for (int y = 0; y < 5; y++) { ld(c.a_cm + 5 * y, ml[y], mh[y]); ld(c.a_cp + 5 * y, pl[y], ph[y]); }
-        const uint32_t cml = bitop3_xor(bitop3_xor(ml[0], ml[1], ml[2]), ml[3], ml[4]), cmh = bitop3_xor(bitop3_xor(mh[0], mh[1], mh[2]), mh[3], mh[4]);
-        const uint32_t cpl = bitop3_xor(bitop3_xor(pl[0], pl[1], pl[2]), pl[3], pl[4]), cph = bitop3_xor(bitop3_xor(ph[0], ph[1], ph[2]), ph[3], ph[4]);
-        // theta: v ^= C[x-1] ^ rol(C[x+1], 1)
-        const uint32_t tl = bitop3_xor(vlo, cml, alignbit(cpl, cph, 31)), th = bitop3_xor(vhi, cmh, alignbit(cph, cpl, 31));
-        // rho: rotate left by the lane's offset (a per-lane amount: swap the halves for offsets >= 32, funnel-shift by the rest)
-        const uint32_t sl = c.swap ? th : tl, sh = c.swap ? tl : th;
-        const uint32_t rl = alignbit(sl, sh, c.rsh), rh = alignbit(sh, sl, c.rsh);
-        *c.b_dst = ((uint64_t)rh << 32) | rl;  // pi
-        wave_lds_order();
-        uint32_t b0l, b0h, b1l, b1h, b2l, b2h;
-        ld(c.b0, b0l, b0h); ld(c.b1, b1l, b1h); ld(c.b2, b2l, b2h);
-        vlo = bitop3_xor_and(bitop3_chi(b0l, b1l, b2l), rcl, c.iota);  // chi, iota (idle lanes carry garbage nobody reads)
-        vhi = bitop3_xor_and(bitop3_chi(b0h, b1h, b2h), rch, c.iota);
+    for (int r = 0; r < 24; r += 2) {
+        coop2_round<0>(vlo, vhi, c, r);
+        coop2_round<1>(vlo, vhi, c, r + 1);
     }
     if constexpr (!NW) __syncthreads();
 }
