@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liborc.so")
+_VLIB = os.path.join(_HERE, "liborcvec.so")  # oracle/vec: the batch-vectorised encapsulation of bench.py's cpu_baseline
 
 KEM_SIZES = {512: (800, 1632, 768), 768: (1184, 2400, 1088), 1024: (1568, 3168, 1568)}  # ek, dk, ct
 DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 4627),  # pk, sk, sig
@@ -22,8 +23,10 @@ DSA_SIZES = {44: (1312, 2560, 2420), 65: (1952, 4032, 3309), 87: (2592, 4896, 46
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("keccak.c", "kyber.c", "dilithium.c", "batch.c", "x25519.c", "keccak.h", "oracle.h")]
-    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    vsrcs = [os.path.join(_HERE, "vec", f) for f in ("mlkem_vec.c", "dispatch.c")] + [os.path.join(_HERE, "Makefile")]
+    if (force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+            or not os.path.exists(_VLIB) or any(os.path.getmtime(s) > os.path.getmtime(_VLIB) for s in vsrcs)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
 
@@ -141,6 +144,45 @@ def mlkem_encaps(param, ek, m, threads=None):
     r = lib().orc_mlkem_encaps_batch(param, _p(ek), _p(m), _p(ct), _p(ss), _p(st), C.c_size_t(n), threads or ncpu())
     assert r == 0
     return ct, ss, st
+
+
+_vlib = None
+
+
+def vec_isa(want=0):
+    """2 = AVX-512 (F/BW/VL/DQ/VBMI/VBMI2), 1 = AVX2, 0 = this CPU has neither (oracle/vec/dispatch.c); `want` caps it."""
+    global _vlib
+    if _vlib is None:
+        build()
+        _vlib = C.CDLL(_VLIB)
+    return int(_vlib.orcv_isa(int(want)))
+
+
+def mlkem_encaps_vec(param, ek, m, threads=None, isa=0):
+    """The batch-vectorised CPU encapsulation (oracle/vec/mlkem_vec.c: W items per vector, Keccak on 4 / 8 states) -- ML-KEM-768 / -1024,
+    same bytes as mlkem_encaps (tests/test_oracle_vec.py).  Only bench.py's cpu_baseline times it. -> ct, ss, status"""
+    EK, _, CT = KEM_SIZES[param]
+    ek = _u8(ek).reshape(-1, EK)
+    m = _u8(m).reshape(-1, 32)
+    n = len(ek)
+    assert len(m) == n
+    if not vec_isa(isa):
+        raise RuntimeError("oracle/vec needs AVX2")
+    ct = np.zeros((n, CT), np.uint8)
+    ss = np.zeros((n, 32), np.uint8)
+    st = np.zeros(n, np.uint8)
+    r = _vlib.orcv_mlkem_encaps(param, _p(ek), _p(m), _p(ct), _p(ss), _p(st), C.c_size_t(n), threads or ncpu(), int(isa))
+    assert r == 0, r
+    return ct, ss, st
+
+
+def vec_keccak_f1600(states, isa):
+    """Keccak-f[1600] of oracle/vec on N = 4 (isa 1) / 8 (isa 2) states at once; states: (N, 25) uint64 -> (N, 25)"""
+    vec_isa()
+    n = int(_vlib.orcv_states(int(isa)))
+    a = np.ascontiguousarray(np.asarray(states, dtype=np.uint64).reshape(n, 25).T)  # word-major
+    _vlib.orcv_f1600(int(isa), _p(a))
+    return np.ascontiguousarray(a.T)
 
 
 def mlkem_encaps_shared(param, ek, m, threads=None):

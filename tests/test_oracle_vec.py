@@ -1,0 +1,56 @@
+"""oracle/vec (the batch-vectorised CPU encapsulation that bench.py's cpu_baseline times next to the scalar oracle) is pinned
+against the oracle: same ciphertexts, shared secrets and status bytes for both instruction sets, ragged batch sizes, several
+threads, keys that kem.ErrPubKey rejects (kem/mlkem/mlkem768/kyber.go:247-263), and the reference's own ACVP encapsulation
+vectors; its Keccak-f[1600] x4 / x8 against the scalar permutation (simd/keccakf1600/f1600x_test.go:13-60's shape)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import orc
+
+ISAS = [i for i in (1, 2) if orc.vec_isa(i) == i]
+pytestmark = pytest.mark.skipif(not ISAS, reason="this CPU has no AVX2")
+
+
+@pytest.mark.parametrize("isa", ISAS)
+def test_permutation_on_four_or_eight_states(isa):
+    n = 4 if isa == 1 else 8
+    st = np.random.default_rng(isa).integers(0, 1 << 63, (n, 25), dtype=np.uint64)
+    st[0] = 0  # keccak_f1600_of_zero is one of the golden vectors
+    got = orc.vec_keccak_f1600(st, isa)
+    for l in range(n):
+        assert (got[l] == orc.keccak_f1600(st[l].copy(), 24)).all()
+    assert (got[0] == np.array(load_golden("fixed_vectors.json.gz")["keccak_f1600_of_zero"], dtype=np.uint64)).all()
+
+
+@pytest.mark.parametrize("param", [768, 1024])
+@pytest.mark.parametrize("isa", ISAS)
+def test_batches_equal_the_oracle(param, isa):
+    rng = np.random.default_rng(100 * isa + param)
+    n = 2 * 32 * 3 + 19  # whole groups for three threads and a ragged tail
+    ek, _ = orc.mlkem_keygen(param, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ek = ek.copy()
+    ek[3, 0:2] = 0xff         # a coefficient of 4095: ErrPubKey
+    ek[n - 1, 382:384] = 0xff  # ... in the ragged tail
+    ct0, ss0, st0 = orc.mlkem_encaps(param, ek, m)
+    assert st0.sum() == 2
+    for threads in (1, 3):
+        ct, ss, st = orc.mlkem_encaps_vec(param, ek, m, threads=threads, isa=isa)
+        assert (st == st0).all() and (ct == ct0).all() and (ss == ss0).all()
+    for k in (1, 15, 33):  # batches smaller than a vector, one thread per group
+        ct, ss, st = orc.mlkem_encaps_vec(param, ek[:k], m[:k], threads=4, isa=isa)
+        assert (st == st0[:k]).all() and (ct == ct0[:k]).all() and (ss == ss0[:k]).all()
+
+
+@pytest.mark.parametrize("name", ["ML-KEM-768", "ML-KEM-1024"])
+@pytest.mark.parametrize("isa", ISAS)
+def test_acvp_encapsulation_vectors(name, isa):
+    # the reference's ACVP encapsulation vectors (kem/mlkem/acvp_test.go), the cases the scalar oracle is pinned by
+    cases = load_golden("mlkem_acvp.json.gz")[name]["encap"]
+    ek = np.stack([np.frombuffer(bytes.fromhex(t["ek"]), np.uint8) for t in cases])
+    m = np.stack([np.frombuffer(bytes.fromhex(t["m"]), np.uint8) for t in cases])
+    ct, ss, st = orc.mlkem_encaps_vec(int(name.split("-")[-1]), ek, m, threads=2, isa=isa)
+    assert not st.any()
+    for i, t in enumerate(cases):
+        assert ct[i].tobytes() == bytes.fromhex(t["c"]) and ss[i].tobytes() == bytes.fromhex(t["k"])
