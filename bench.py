@@ -29,6 +29,11 @@ owns its own batch of --batch items (`value`: weak scaling, per-GPU work fixed a
 --batch items split n/G per rank (the metric read literally: SURVEY.md 8e); `value_host_abi` is the same metric through the
 host-pointer C ABI (PCIe-inclusive).  There is no data-path collective (the only collectives are the timing barrier and the
 reductions of timings: RCCL); rank 0 prints ONE JSON line with whole-job aggregates and per-rank rates.
+
+`cpu_baseline` (rank 0, N = 1): the same workload on the host cores this process may use -- `value` = oracle/vec, a batch-vectorised
+port (16 / 32 items per AVX2 / AVX-512 vector, Keccak on 4 / 8 states; bytes checked against the scalar oracle in the run), with the
+scalar oracle (the restatement of CIRCL's generic Go the parity legs use) as `scalar_oracle`; CIRCL's own AVX2 path needs a Go toolchain
+(`cpu_baseline_reference` runs it when $CIRCL_REFERENCE and `go` exist).
 """
 import argparse
 import ctypes as C
