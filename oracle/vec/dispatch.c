@@ -63,7 +63,15 @@ int orcv_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *c
             run(&jobs[0]);
             return jobs[0].rc;
         }
-        if (pthread_create(&th[t], 0, run, &jobs[t])) return -2;
+        if (pthread_create(&th[t], 0, run, &jobs[t])) { /* finish what was started, then do the rest on this thread */
+            for (int u = 0; u < t; u++) pthread_join(th[u], 0);
+            jobs[t].hi = n;
+            run(&jobs[t]);
+            int rc = jobs[t].rc;
+            for (int u = 0; u < t; u++)
+                if (jobs[u].rc) rc = jobs[u].rc;
+            return rc;
+        }
     }
     int rc = 0;
     for (int t = 0; t < threads; t++) {
