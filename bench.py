@@ -451,8 +451,19 @@ def cpu_baseline(work, budget_s=10.0):
             for _ in range(reps):
                 orc.mlkem_encaps_vec(work.param, ek_np[:vs], m_np[:vs], threads=cores)
             dtv = (time.perf_counter() - t) / reps
+            # one parsed key for the batch: the shape of the reference's own BenchmarkEncapsulate (kem/schemes/schemes_test.go:28-38)
+            ct_s0, ss_s0 = orc.mlkem_encaps_shared(work.param, ek_np[:1], m_np[:probe], threads=cores)
+            ct_s, ss_s, st_s = orc.mlkem_encaps_vec(work.param, ek_np[:1], m_np[:probe], threads=cores, shared=True)
+            same_s = bool((ct_s == ct_s0).all() and (ss_s == ss_s0).all() and not st_s.any())
+            reps_s = max(1, min(32, int(2.5 * vrate * budget_s * 0.2 / len(m_np))))
+            t = time.perf_counter()
+            for _ in range(reps_s):
+                orc.mlkem_encaps_vec(work.param, ek_np[:1], m_np, threads=cores, shared=True)
+            dts = (time.perf_counter() - t) / reps_s
             vec = {"value": vs / dtv, "per_thread": vs / dtv / cores, "isa": {1: "AVX2 (16 items per vector, Keccak x4)", 2: "AVX-512 (32 items per vector, Keccak x8)"}[isa],
                    "equals_scalar_oracle_on_first_items": [probe, same],
+                   "shared_key": {"value": len(m_np) / dts, "unit": "encaps/s", "per_thread": len(m_np) / dts / cores, "equals_scalar_oracle_on_first_items": [probe, same_s],
+                                  "sample": f"all {len(m_np)} messages to one parsed key (th, A^T, H(ek) once per thread), {reps_s} pass(es) of {dts:.2f} s"},
                    "sample": f"first {vs} items of the same batch, {reps} pass(es) of {dtv:.2f} s, oracle/liborcvec.so with {where}"}
     except Exception as e:  # the scalar figure stands on its own
         vec = {"error": repr(e)[:200]}
@@ -463,7 +474,9 @@ def cpu_baseline(work, budget_s=10.0):
                     "sample": vec["sample"] + f"; {vec['isa']}: oracle/vec/mlkem_vec.c, the batch-vectorised port (items side by side in the vector lanes; bytes equal "
                               "to the scalar oracle's, tests/test_oracle_vec.py).  Not CIRCL's own AVX2 assembler (no Go toolchain on any box), which vectorises "
                               "inside one operation; the scalar restatement of its generic Go is `scalar_oracle`",
-                    "vectorized": vec, "scalar_oracle": {k: scalar[k] for k in ("value", "unit", "per_thread", "sample")}})
+                    "vectorized": vec, "scalar_oracle": {k: scalar[k] for k in ("value", "unit", "per_thread", "sample", "shared_key")}})
+        if vec["shared_key"]["equals_scalar_oracle_on_first_items"][1]:
+            out["shared_key"] = vec["shared_key"]
     elif vec:
         out["vectorized"] = vec
     return out

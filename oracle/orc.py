@@ -158,20 +158,21 @@ def vec_isa(want=0):
     return int(_vlib.orcv_isa(int(want)))
 
 
-def mlkem_encaps_vec(param, ek, m, threads=None, isa=0):
+def mlkem_encaps_vec(param, ek, m, threads=None, isa=0, shared=False):
     """The batch-vectorised CPU encapsulation (oracle/vec/mlkem_vec.c: W items per vector, Keccak on 4 / 8 states) -- ML-KEM-768 / -1024,
-    same bytes as mlkem_encaps (tests/test_oracle_vec.py).  Only bench.py's cpu_baseline times it. -> ct, ss, status"""
+    same bytes as mlkem_encaps (tests/test_oracle_vec.py).  shared: ONE key (ek of one row) for all messages, parsed once per thread --
+    the shape of mlkem_encaps_shared.  Only bench.py's cpu_baseline times it. -> ct, ss, status"""
     EK, _, CT = KEM_SIZES[param]
     ek = _u8(ek).reshape(-1, EK)
     m = _u8(m).reshape(-1, 32)
-    n = len(ek)
-    assert len(m) == n
+    n = len(m)
+    assert len(ek) == (1 if shared else n)
     if not vec_isa(isa):
         raise RuntimeError("oracle/vec needs AVX2")
     ct = np.zeros((n, CT), np.uint8)
     ss = np.zeros((n, 32), np.uint8)
     st = np.zeros(n, np.uint8)
-    r = _vlib.orcv_mlkem_encaps(param, _p(ek), _p(m), _p(ct), _p(ss), _p(st), C.c_size_t(n), threads or ncpu(), int(isa))
+    r = _vlib.orcv_mlkem_encaps2(param, _p(ek), 1 if shared else 0, _p(m), _p(ct), _p(ss), _p(st), C.c_size_t(n), threads or ncpu(), int(isa))
     assert r == 0, r
     return ct, ss, st
 

@@ -6,8 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-int orcv_mlkem_encaps_avx2(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
-int orcv_mlkem_encaps_avx512(int, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
+int orcv_mlkem_encaps_avx2(int, const uint8_t *, int, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
+int orcv_mlkem_encaps_avx512(int, const uint8_t *, int, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
 void orcv_tables_avx2(int);
 void orcv_tables_avx512(int);
 int orcv_width_avx2(void);
@@ -29,7 +29,7 @@ int orcv_isa(int want) {
 }
 
 typedef struct {
-    int isa, param, rc;
+    int isa, param, rc, shared;
     const uint8_t *ek, *m;
     uint8_t *ct, *ss, *st;
     size_t lo, hi;
@@ -37,13 +37,14 @@ typedef struct {
 
 static void *run(void *a) {
     job *j = (job *)a;
-    j->rc = (j->isa == 2 ? orcv_mlkem_encaps_avx512 : orcv_mlkem_encaps_avx2)(j->param, j->ek, j->m, j->ct, j->ss, j->st, j->lo, j->hi);
+    j->rc = (j->isa == 2 ? orcv_mlkem_encaps_avx512 : orcv_mlkem_encaps_avx2)(j->param, j->ek, j->shared, j->m, j->ct, j->ss, j->st, j->lo, j->hi);
     return 0;
 }
 
-/* n encapsulations (distinct keys: ek[n][384K+32], m[n][32] -> ct, ss, status[n] (may be NULL)); slices are multiples of the vector
- * width so that only the last group of the batch is ragged.  Returns 0, -1 (parameter set), -2 (memory), -3 (no AVX2). */
-int orcv_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int threads, int isa_want) {
+/* n encapsulations (distinct keys: ek[n][384K+32], or shared != 0: ONE key ek[1][384K+32] for all; m[n][32] -> ct, ss, status[n] (may be
+ * NULL)); slices are multiples of the vector width so that only the last group of the batch is ragged.  Returns 0, -1 (parameter set),
+ * -2 (memory), -3 (no AVX2). */
+int orcv_mlkem_encaps2(int param, const uint8_t *ek, int shared, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int threads, int isa_want) {
     const int isa = orcv_isa(isa_want);
     if (!isa) return -3;
     if (param != 768 && param != 1024) return -1;
@@ -58,7 +59,7 @@ int orcv_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *c
     for (int t = 0; t < threads; t++) {
         size_t lo = groups * (size_t)t / (size_t)threads * W, hi = groups * (size_t)(t + 1) / (size_t)threads * W;
         if (hi > n) hi = n;
-        jobs[t] = (job){isa, param, 0, ek, m, ct, ss, status, lo, hi};
+        jobs[t] = (job){isa, param, 0, shared, ek, m, ct, ss, status, lo, hi};
         if (threads == 1) {
             run(&jobs[0]);
             return jobs[0].rc;
@@ -79,6 +80,10 @@ int orcv_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *c
         if (jobs[t].rc) rc = jobs[t].rc;
     }
     return rc;
+}
+
+int orcv_mlkem_encaps(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int threads, int isa_want) {
+    return orcv_mlkem_encaps2(param, ek, 0, m, ct, ss, status, n, threads, isa_want);
 }
 
 int orcv_states(int isa) { return isa == 2 ? orcv_states_avx512() : orcv_states_avx2(); }

@@ -354,48 +354,56 @@ typedef struct {
     int16_t rej[N64][416];
     uint64_t st[25 * N64];
     uint8_t kr[W16][64]; /* K-bar || r per item (G = SHA3-512: kyber.go:118-121) */
+    uint64_t h[W16][4];  /* H(ek) per item */
     uint8_t bad[W16];
+    int have_key;        /* one key for the whole batch (ekstride 0): th, aT, H(ek) and the verdict are those of the first group */
 } scratch;
 
-/* W16 encapsulations: item of lane l is it[l] (lanes >= cnt repeat it[0] and write nothing) */
-static void FN(group)(scratch *S, int K, int du, int dv, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
+/* W16 encapsulations: item of lane l is it[l] (lanes >= cnt repeat it[0] and write nothing).  ekstride: bytes between the items' keys, or 0 =
+ * ONE key for the batch -- the parsed-key shape of the reference's BenchmarkEncapsulate (kem/schemes/schemes_test.go:28-38; kyber.go:39-43
+ * caches H(ek), cpapke.go:19-25 th and aT): the key's stages run with the first group only */
+static void FN(group)(scratch *S, int K, int du, int dv, const uint8_t *ek, size_t ekstride, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
                       const size_t *it, int cnt) {
     const size_t eksz = (size_t)(384 * K + 32), ctsz = (size_t)(32 * (du * K + dv));
     uint64_t *st = S->st;
+    const int skip = ekstride == 0 && S->have_key;
     /* kyber.go:247-263 Unpack: t-hat (12-bit), the >= q check */
-    memset(S->bad, 0, sizeof S->bad);
-    for (int j = 0; j < K; j++) {
-        for (int l = 0; l < W16; l++) S->bad[l] |= (uint8_t)unpack12(S->aos[l], ek + eksz * it[l] + 384 * j);
-        to_soa(&S->th[j], &S->aos[0][0]);
+    if (!skip) {
+        memset(S->bad, 0, sizeof S->bad);
+        for (int j = 0; j < K; j++) {
+            for (int l = 0; l < W16; l++) S->bad[l] |= (uint8_t)unpack12(S->aos[l], ek + ekstride * it[l] + 384 * j);
+            to_soa(&S->th[j], &S->aos[0][0]);
+        }
     }
     /* H(ek) = SHA3-256 (kyber.go:39-43), then (K-bar, r) = G(m || H(ek)) = SHA3-512 (kyber.go:118-121); N64 items per permutation */
     for (int b0 = 0; b0 < W16; b0 += N64) {
+        if (skip) goto have_h;
         memset(st, 0, sizeof S->st);
         size_t off = 0;
         for (; off + 136 <= eksz; off += 136) {
             for (int l = 0; l < N64; l++) {
-                const uint8_t *p = ek + eksz * it[b0 + l] + off;
+                const uint8_t *p = ek + ekstride * it[b0 + l] + off;
                 for (int w = 0; w < 17; w++) st[w * N64 + l] ^= ld64(p + 8 * w);
             }
             FN(f1600)(st);
         }
         const int remw = (int)((eksz - off) / 8); /* 96 (K = 3) / 72 (K = 4) bytes: whole words */
         for (int l = 0; l < N64; l++) {
-            const uint8_t *p = ek + eksz * it[b0 + l] + off;
+            const uint8_t *p = ek + ekstride * it[b0 + l] + off;
             for (int w = 0; w < remw; w++) st[w * N64 + l] ^= ld64(p + 8 * w);
             st[remw * N64 + l] ^= 0x06;
             st[16 * N64 + l] ^= 0x8000000000000000ull;
         }
         FN(f1600)(st);
-        uint64_t h[N64][4];
         for (int l = 0; l < N64; l++)
-            for (int w = 0; w < 4; w++) h[l][w] = st[w * N64 + l];
+            for (int w = 0; w < 4; w++) S->h[b0 + l][w] = st[w * N64 + l];
+    have_h:
         memset(st, 0, sizeof S->st);
         for (int l = 0; l < N64; l++) {
             const uint8_t *p = m + 32 * it[b0 + l];
             for (int w = 0; w < 4; w++) {
                 st[w * N64 + l] = ld64(p + 8 * w);
-                st[(4 + w) * N64 + l] = h[l][w];
+                st[(4 + w) * N64 + l] = S->h[b0 + l][w];
             }
             st[8 * N64 + l] = 0x8000000000000006ull; /* 0x06 at byte 64, 0x80 at byte 71 (rate 72) */
         }
@@ -404,13 +412,13 @@ static void FN(group)(scratch *S, int K, int du, int dv, const uint8_t *ek, cons
             for (int w = 0; w < 8; w++) memcpy(&S->kr[b0 + l][8 * w], &st[w * N64 + l], 8);
     }
     /* mat.go:13-74 Derive(rho, transpose = true): aT[i][j] = SHAKE128(rho || i || j), rejection-sampled */
-    for (int i = 0; i < K; i++)
+    for (int i = 0; i < K && !skip; i++)
         for (int j = 0; j < K; j++) {
             for (int b0 = 0; b0 < W16; b0 += N64) {
                 memset(st, 0, sizeof S->st);
                 unsigned ctr[N64];
                 for (int l = 0; l < N64; l++) {
-                    const uint8_t *rho = ek + eksz * it[b0 + l] + 384 * K;
+                    const uint8_t *rho = ek + ekstride * it[b0 + l] + 384 * K;
                     for (int w = 0; w < 4; w++) st[w * N64 + l] = ld64(rho + 8 * w);
                     st[4 * N64 + l] = (uint64_t)i | ((uint64_t)j << 8) | (0x1full << 16);
                     st[20 * N64 + l] = 0x8000000000000000ull;
@@ -433,6 +441,7 @@ static void FN(group)(scratch *S, int K, int du, int dv, const uint8_t *ek, cons
             }
             to_soa(&S->at[i * K + j], &S->aos[0][0]);
         }
+    if (ekstride == 0) S->have_key = 1;
     /* cpapke.go:137-181 EncryptTo: r-hat, e1, e2 = CBD(PRF(r, nonce)) with nonces 0 .. 2K (eta1 = eta2 = 2) */
     for (int nonce = 0; nonce <= 2 * K; nonce++) {
         for (int b0 = 0; b0 < W16; b0 += N64) {
@@ -485,18 +494,19 @@ static void FN(group)(scratch *S, int K, int du, int dv, const uint8_t *ek, cons
 }
 
 /* items [lo, hi) of a batch; returns 0, -1 (parameter set), -2 (memory) */
-int FN(orcv_mlkem_encaps)(int param, const uint8_t *ek, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t lo, size_t hi) {
+int FN(orcv_mlkem_encaps)(int param, const uint8_t *ek, int shared, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t lo, size_t hi) {
     int K, du, dv;
     if (param == 768) { K = 3; du = 10; dv = 4; }
     else if (param == 1024) { K = 4; du = 11; dv = 5; }
     else return -1; /* ML-KEM-512 has eta1 = 3: not needed by any BASELINE config */
     scratch *S = 0;
     if (posix_memalign((void **)&S, 64, sizeof *S)) return -2;
+    S->have_key = 0;
     for (size_t g = lo; g < hi; g += W16) {
         size_t it[W16];
         const int cnt = (int)(hi - g < W16 ? hi - g : W16);
         for (int l = 0; l < W16; l++) it[l] = l < cnt ? g + (size_t)l : g;
-        FN(group)(S, K, du, dv, ek, m, ct, ss, status, it, cnt);
+        FN(group)(S, K, du, dv, ek, shared ? 0 : (size_t)(384 * K + 32), m, ct, ss, status, it, cnt);
     }
     free(S);
     return 0;

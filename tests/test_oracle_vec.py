@@ -43,6 +43,24 @@ def test_batches_equal_the_oracle(param, isa):
         assert (st == st0[:k]).all() and (ct == ct0[:k]).all() and (ss == ss0[:k]).all()
 
 
+@pytest.mark.parametrize("param", [768, 1024])
+@pytest.mark.parametrize("isa", ISAS)
+def test_one_key_for_the_batch(param, isa):
+    # the parsed-key shape of the reference's BenchmarkEncapsulate (kem/schemes/schemes_test.go:28-38): the key's stages once per thread
+    rng = np.random.default_rng(7 * isa + param)
+    n = 5 * 32 + 3
+    ek, _ = orc.mlkem_keygen(param, rng.integers(0, 256, (2, 64), dtype=np.uint8))
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct0, ss0 = orc.mlkem_encaps_shared(param, ek[:1], m)
+    for threads in (1, 2):
+        ct, ss, st = orc.mlkem_encaps_vec(param, ek[:1], m, threads=threads, isa=isa, shared=True)
+        assert not st.any() and (ct == ct0).all() and (ss == ss0).all()
+    bad = ek[1:2].copy()
+    bad[0, 0:2] = 0xff
+    ct, ss, st = orc.mlkem_encaps_vec(param, bad, m, threads=2, isa=isa, shared=True)
+    assert (st == 1).all() and not ct.any() and not ss.any()
+
+
 @pytest.mark.parametrize("name", ["ML-KEM-768", "ML-KEM-1024"])
 @pytest.mark.parametrize("isa", ISAS)
 def test_acvp_encapsulation_vectors(name, isa):
