@@ -72,3 +72,28 @@ def test_acvp_encapsulation_vectors(name, isa):
     assert not st.any()
     for i, t in enumerate(cases):
         assert ct[i].tobytes() == bytes.fromhex(t["c"]) and ss[i].tobytes() == bytes.fromhex(t["k"])
+
+
+def test_bench_cpu_baseline_leg_reports_both_ports():
+    # bench.py's cpu_baseline on a stand-in workload (no GPU): the vectorised figure in `value`, the scalar oracle beside it, the bytes compared
+    import importlib.util
+    import os
+    import types
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(11)
+    n = 1 << 11
+    ek, _ = orc.mlkem_keygen(768, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    work = types.SimpleNamespace(param=768, ek=torch.from_numpy(ek), m=torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    r = bench.cpu_baseline(work, budget_s=0.5)
+    assert r["kind"] == "port" and r["unit"] == "encaps/s" and r["cores"] >= 1 and r["value"] > 0 and "sample" in r
+    v = r["vectorized"]
+    assert v["equals_scalar_oracle_on_first_items"][1] and v["shared_key"]["equals_scalar_oracle_on_first_items"][1]
+    assert r["value"] == v["value"] and r["shared_key"] == v["shared_key"]
+    assert r["scalar_oracle"]["value"] > 0 and r["scalar_oracle"]["shared_key"]["value"] > 0
+    assert r["value"] > r["scalar_oracle"]["value"]  # a vectorised port slower than the scalar restatement would be a bug
