@@ -97,3 +97,17 @@ def test_bench_cpu_baseline_leg_reports_both_ports():
     assert r["value"] == v["value"] and r["shared_key"] == v["shared_key"]
     assert r["scalar_oracle"]["value"] > 0 and r["scalar_oracle"]["shared_key"]["value"] > 0
     assert r["value"] > r["scalar_oracle"]["value"]  # a vectorised port slower than the scalar restatement would be a bug
+
+
+@pytest.mark.parametrize("isa", ISAS)
+def test_two_independent_cpu_implementations_agree_on_a_large_batch(isa):
+    # 2^14 distinct keys: ~1 % of the 9 * 2^14 SHAKE128 streams need a fourth block (the straggler loop of the vectorised sampler), every
+    # compression / packing residue occurs; the scalar oracle and oracle/vec share no code below the Keccak round constants
+    rng = np.random.default_rng(2024 + isa)
+    n = 1 << 14
+    ek, _ = orc.mlkem_keygen(768, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    m = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ct0, ss0, st0 = orc.mlkem_encaps(768, ek, m)
+    ct, ss, st = orc.mlkem_encaps_vec(768, ek, m, isa=isa)
+    assert not st0.any() and not st.any()
+    assert (ct == ct0).all() and (ss == ss0).all()
