@@ -33,7 +33,7 @@ dg = cdev.MLDSADevice(65, 1, "cuda", sign=True)
 pk1, sk1 = dg.keygen(torch.randint(0, 256, (1, 32), dtype=torch.uint8, device="cuda", generator=g))
 vt = hostapi.KeyTable("mldsa-public", 65, pk1.cpu().numpy())
 st_ = hostapi.KeyTable("mldsa-private", 65, sk1.cpu().numpy())
-for logn in (0, 6, 10, 12, 14, 16, 18):
+for logn in [int(x) for x in os.environ.get("CIRCL_LATENCY_LOGNS", "0,6,10,12,14,16,18").split(",")]:
     n = 1 << logn
     eng = cdev.MLKEMDevice(768, n)
     m = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
