@@ -8,8 +8,8 @@
 
 int orcv_mlkem_encaps_avx2(int, const uint8_t *, int, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
 int orcv_mlkem_encaps_avx512(int, const uint8_t *, int, const uint8_t *, uint8_t *, uint8_t *, uint8_t *, size_t, size_t);
-void orcv_tables_avx2(int);
-void orcv_tables_avx512(int);
+void orcv_tables_avx2(void);
+void orcv_tables_avx512(void);
 int orcv_width_avx2(void);
 int orcv_width_avx512(void);
 void orcv_f1600_avx2(uint64_t *);
@@ -48,7 +48,8 @@ int orcv_mlkem_encaps2(int param, const uint8_t *ek, int shared, const uint8_t *
     const int isa = orcv_isa(isa_want);
     if (!isa) return -3;
     if (param != 768 && param != 1024) return -1;
-    (isa == 2 ? orcv_tables_avx512 : orcv_tables_avx2)(param);
+    static pthread_once_t once2 = PTHREAD_ONCE_INIT, once5 = PTHREAD_ONCE_INIT;
+    pthread_once(isa == 2 ? &once5 : &once2, isa == 2 ? orcv_tables_avx512 : orcv_tables_avx2);
     const size_t W = (size_t)(isa == 2 ? orcv_width_avx512() : orcv_width_avx2());
     const size_t groups = (n + W - 1) / W;
     if (threads < 1) threads = 1;

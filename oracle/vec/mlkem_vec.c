@@ -126,28 +126,24 @@ static inline uint64_t ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); re
 typedef struct { vec c[256]; } spoly;
 
 static int16_t ZETAS[128], ZETAS_QINV[128];
-static uint16_t LUT_DU[KQ];
-static uint8_t LUT_DV[KQ];
-static int lut_du, lut_dv;
+static uint16_t LUT10[KQ], LUT11[KQ];
+static uint8_t LUT4[KQ], LUT5[KQ];
 
-static void FN(tables)(int du, int dv) {
-    if (!ZETAS[1]) { /* ntt.go:16-28: Zetas[i] = 17^brv7(i) * 2^16 mod q */
-        for (int i = 0; i < 128; i++) {
-            int brv = 0;
-            for (int b = 0; b < 7; b++) brv |= ((i >> b) & 1) << (6 - b);
-            uint32_t z = 1;
-            for (int e = 0; e < brv; e++) z = z * 17 % KQ;
-            ZETAS[i] = (int16_t)((z << 16) % KQ);
-            ZETAS_QINV[i] = (int16_t)(uint16_t)((uint32_t)(uint16_t)ZETAS[i] * QINV);
-        }
+/* once per process and instruction set (oracle/vec/dispatch.c: pthread_once) */
+static void FN(tables)(void) {
+    for (int i = 0; i < 128; i++) { /* ntt.go:16-28: Zetas[i] = 17^brv7(i) * 2^16 mod q */
+        int brv = 0;
+        for (int b = 0; b < 7; b++) brv |= ((i >> b) & 1) << (6 - b);
+        uint32_t z = 1;
+        for (int e = 0; e < brv; e++) z = z * 17 % KQ;
+        ZETAS[i] = (int16_t)((z << 16) % KQ);
+        ZETAS_QINV[i] = (int16_t)(uint16_t)((uint32_t)(uint16_t)ZETAS[i] * QINV);
     }
-    if (lut_du != du || lut_dv != dv) { /* poly.go:248-332 CompressTo's multiply-shift constants, tabulated over [0, q) */
-        for (uint32_t x = 0; x < KQ; x++) {
-            LUT_DU[x] = (uint16_t)((((uint64_t)((x << du) + KQ / 2) * 20642679ull) >> 36) & ((1u << du) - 1));
-            LUT_DV[x] = (uint8_t)(((((x << dv) + KQ / 2) * 315) >> 20) & ((1u << dv) - 1));
-        }
-        lut_du = du;
-        lut_dv = dv;
+    for (uint32_t x = 0; x < KQ; x++) { /* poly.go:248-332 CompressTo's multiply-shift constants, tabulated over [0, q) */
+        LUT10[x] = (uint16_t)((((uint64_t)((x << 10) + KQ / 2) * 20642679ull) >> 36) & 1023);
+        LUT11[x] = (uint16_t)((((uint64_t)((x << 11) + KQ / 2) * 20642679ull) >> 36) & 2047);
+        LUT4[x] = (uint8_t)(((((x << 4) + KQ / 2) * 315) >> 20) & 15);
+        LUT5[x] = (uint8_t)(((((x << 5) + KQ / 2) * 315) >> 20) & 31);
     }
 }
 
@@ -315,20 +311,20 @@ static inline void from_msg(int16_t *c, const uint8_t *m) {
  * (sixteen for d = 4) per step */
 static inline void pack10(uint8_t *o, const int16_t *c) {
     for (int i = 0; i < 256; i += 8, o += 10) {
-        const uint64_t t6 = LUT_DU[(uint16_t)c[i + 6]];
-        const uint64_t lo = (uint64_t)LUT_DU[(uint16_t)c[i]] | (uint64_t)LUT_DU[(uint16_t)c[i + 1]] << 10 | (uint64_t)LUT_DU[(uint16_t)c[i + 2]] << 20 |
-                            (uint64_t)LUT_DU[(uint16_t)c[i + 3]] << 30 | (uint64_t)LUT_DU[(uint16_t)c[i + 4]] << 40 | (uint64_t)LUT_DU[(uint16_t)c[i + 5]] << 50 | t6 << 60;
-        const uint16_t hi = (uint16_t)(t6 >> 4 | (uint64_t)LUT_DU[(uint16_t)c[i + 7]] << 6);
+        const uint64_t t6 = LUT10[(uint16_t)c[i + 6]];
+        const uint64_t lo = (uint64_t)LUT10[(uint16_t)c[i]] | (uint64_t)LUT10[(uint16_t)c[i + 1]] << 10 | (uint64_t)LUT10[(uint16_t)c[i + 2]] << 20 |
+                            (uint64_t)LUT10[(uint16_t)c[i + 3]] << 30 | (uint64_t)LUT10[(uint16_t)c[i + 4]] << 40 | (uint64_t)LUT10[(uint16_t)c[i + 5]] << 50 | t6 << 60;
+        const uint16_t hi = (uint16_t)(t6 >> 4 | (uint64_t)LUT10[(uint16_t)c[i + 7]] << 6);
         memcpy(o, &lo, 8);
         memcpy(o + 8, &hi, 2);
     }
 }
 static inline void pack11(uint8_t *o, const int16_t *c) {
     for (int i = 0; i < 256; i += 8, o += 11) {
-        const uint64_t t5 = LUT_DU[(uint16_t)c[i + 5]];
-        const uint64_t lo = (uint64_t)LUT_DU[(uint16_t)c[i]] | (uint64_t)LUT_DU[(uint16_t)c[i + 1]] << 11 | (uint64_t)LUT_DU[(uint16_t)c[i + 2]] << 22 |
-                            (uint64_t)LUT_DU[(uint16_t)c[i + 3]] << 33 | (uint64_t)LUT_DU[(uint16_t)c[i + 4]] << 44 | t5 << 55;
-        const uint32_t hi = (uint32_t)(t5 >> 9 | (uint64_t)LUT_DU[(uint16_t)c[i + 6]] << 2 | (uint64_t)LUT_DU[(uint16_t)c[i + 7]] << 13);
+        const uint64_t t5 = LUT11[(uint16_t)c[i + 5]];
+        const uint64_t lo = (uint64_t)LUT11[(uint16_t)c[i]] | (uint64_t)LUT11[(uint16_t)c[i + 1]] << 11 | (uint64_t)LUT11[(uint16_t)c[i + 2]] << 22 |
+                            (uint64_t)LUT11[(uint16_t)c[i + 3]] << 33 | (uint64_t)LUT11[(uint16_t)c[i + 4]] << 44 | t5 << 55;
+        const uint32_t hi = (uint32_t)(t5 >> 9 | (uint64_t)LUT11[(uint16_t)c[i + 6]] << 2 | (uint64_t)LUT11[(uint16_t)c[i + 7]] << 13);
         memcpy(o, &lo, 8);
         memcpy(o + 8, &hi, 3);
     }
@@ -336,14 +332,14 @@ static inline void pack11(uint8_t *o, const int16_t *c) {
 static inline void pack4(uint8_t *o, const int16_t *c) {
     for (int i = 0; i < 256; i += 16, o += 8) {
         uint64_t w = 0;
-        for (int j = 0; j < 16; j++) w |= (uint64_t)LUT_DV[(uint16_t)c[i + j]] << (4 * j);
+        for (int j = 0; j < 16; j++) w |= (uint64_t)LUT4[(uint16_t)c[i + j]] << (4 * j);
         memcpy(o, &w, 8);
     }
 }
 static inline void pack5(uint8_t *o, const int16_t *c) {
     for (int i = 0; i < 256; i += 8, o += 5) {
         uint64_t w = 0;
-        for (int j = 0; j < 8; j++) w |= (uint64_t)LUT_DV[(uint16_t)c[i + j]] << (5 * j);
+        for (int j = 0; j < 8; j++) w |= (uint64_t)LUT5[(uint16_t)c[i + j]] << (5 * j);
         memcpy(o, &w, 5);
     }
 }
@@ -511,7 +507,7 @@ int FN(orcv_mlkem_encaps)(int param, const uint8_t *ek, int shared, const uint8_
     free(S);
     return 0;
 }
-void FN(orcv_tables)(int param) { FN(tables)(param == 1024 ? 11 : 10, param == 1024 ? 5 : 4); }
+void FN(orcv_tables)(void) { FN(tables)(); }
 int FN(orcv_width)(void) { return W16; }
 /* the permutation alone, for the test that pins it: 25 x N64 words, word-major */
 void FN(orcv_f1600)(uint64_t *st) { FN(f1600)(st); }
