@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- ML-KEM-768 encapsulations/sec on MI355X (BASELINE.json's metric), plus every other BASELINE config.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode M] [--no-extras] [--no-cpu-baseline] [--no-pmc] [--sample-parity]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode M] [--extras contract|all|none] [--no-cpu-baseline] [--no-pmc] [--sample-parity]
+
+OUTPUT: the LAST stdout line is the bench contract's JSON line and nothing but the contract (contract_line(): metric / value / config /
+parity / roofline / cpu_baseline / value_host_abi / strong + one figure and verdict per other BASELINE config; < 6 KB, strict JSON,
+tests/test_bench_line.py).  The full record -- every config's kernel times, rooflines, parity details, probes, notes and definitions --
+is written to bench_extras.json next to this file (--extras-file), which the line names as "extras".
 
 A "step" is one pass of the hot path over one batch of synthetic inputs that are already resident in HBM when the timed
 region starts.  The headline (default --mode encaps) is BASELINE.json configs[1]: "ML-KEM-768 Encapsulate batch=2^20 on
@@ -10,7 +15,7 @@ region starts.  The headline (default --mode encaps) is BASELINE.json configs[1]
 m_i = SHAKE256("circl-hip/m" || LE64(i))[:32] are all distinct.  Every ciphertext and shared secret of the batch is compared with the
 oracle (--sample-parity: a 2^16 sample instead).  `configs.pooled` keeps the figure of earlier rounds (a pool of 2^16 keys cycled 16x).
 
-The same JSON line carries, under "configs", a measured figure (own HIP-event kernel times, own roofline against SURVEY
+The full record carries, under "configs", a measured figure (own HIP-event kernel times, own roofline against SURVEY
 8(d)'s algorithmic bytes, own sampled oracle parity) for every other BASELINE config on this rank's GPU:
 
     decaps        ML-KEM-768 Decapsulate 2^20 of the ciphertexts just produced (config 3's second half; all ss_dec == ss_enc)
@@ -18,8 +23,11 @@ The same JSON line carries, under "configs", a measured figure (own HIP-event ke
     config4       ML-DSA-65 Verify 2^18, DISTINCT keys (GPU keygen + GPU deterministic signing), >= 1 % corrupted signatures
     config5       ML-KEM-1024 Encapsulate + ML-DSA-87 Verify submitted concurrently on two streams (per-GPU share 2^16 + 2^16)
     host_abi      the host-buffer C ABI end to end (H2D + kernels + D2H), page-locked and ordinary pageable buffers
+and with --extras all (opt-in: the default run is the contract's):
+    pooled               the figure of rounds 1-4 (keys from a pool of 2^16)
     shared_key / keyed   one key for the batch / a table of 1000 keys (the reference's parsed-key cache)
     hybrid               X-Wing and X25519MLKEM768 on resident arrays, 2^18 per GPU
+    small_batches / concurrent_callers   per-call cost of small batches; T one-item callers through the coalescer (tools/bin/concurrent_bench)
 
 --mode config3 | config4 | config5 | host makes that workload the headline (metric / value / ms_per_step) instead.
 
@@ -467,18 +475,22 @@ def cpu_baseline(work, budget_s=10.0):
                    "sample": f"first {vs} items of the same batch, {reps} pass(es) of {dtv:.2f} s, oracle/liborcvec.so with {where}"}
     except Exception as e:  # the scalar figure stands on its own
         vec = {"error": repr(e)[:200]}
+    # every figure ONCE: `value` / `per_thread` / `shared_key` are the vector port's when it ran and agreed with the scalar oracle (then the
+    # scalar oracle's own figures sit under `scalar_oracle`), the scalar oracle's otherwise
     out = {"value": scalar["value"], "unit": "encaps/s", "cores": cores, "kind": "port", "per_thread": scalar["per_thread"], "cpu": cpu_model(),
-           "shared_key": scalar["shared_key"], "sample": scalar["sample"] + " (Go toolchain absent, so not CIRCL's AVX2 path)"}
+           "isa": "scalar C (-O3 -march=x86-64-v3)", "shared_key": scalar["shared_key"],
+           "sample": scalar["sample"] + " (Go toolchain absent, so not CIRCL's AVX2 path)"}
     if vec and vec.get("value") and vec["equals_scalar_oracle_on_first_items"][1]:
-        out.update({"value": vec["value"], "per_thread": vec["per_thread"],
-                    "sample": vec["sample"] + f"; {vec['isa']}: oracle/vec/mlkem_vec.c, the batch-vectorised port (items side by side in the vector lanes; bytes equal "
+        out.update({"value": vec["value"], "per_thread": vec["per_thread"], "isa": vec["isa"],
+                    "equals_scalar_oracle_on_first_items": vec["equals_scalar_oracle_on_first_items"],
+                    "sample": vec["sample"] + "; oracle/vec/mlkem_vec.c, the batch-vectorised port (items side by side in the vector lanes; bytes equal "
                               "to the scalar oracle's, tests/test_oracle_vec.py).  Not CIRCL's own AVX2 assembler (no Go toolchain on any box), which vectorises "
                               "inside one operation; the scalar restatement of its generic Go is `scalar_oracle`",
-                    "vectorized": vec, "scalar_oracle": {k: scalar[k] for k in ("value", "unit", "per_thread", "sample", "shared_key")}})
+                    "scalar_oracle": {k: scalar[k] for k in ("value", "unit", "per_thread", "sample", "shared_key")}})
         if vec["shared_key"]["equals_scalar_oracle_on_first_items"][1]:
             out["shared_key"] = vec["shared_key"]
     elif vec:
-        out["vectorized"] = vec
+        out["vectorized_failed"] = vec
     return out
 
 
@@ -766,6 +778,128 @@ def live_valu_probe(dev_index):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the stdout line: the contract's keys only (a 20 KB line was more than the driver's parser keeps); everything else
+# goes to the extras file
+# ------------------------------------------------------------------------------------------------------------------
+LINE_MAX = 6144
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+
+def _num(x, digits=6):
+    """Floats to 6 significant digits (the line stays short; the extras file keeps full precision)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def _roof(r):
+    if not isinstance(r, dict):
+        return None
+    o = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "traffic_over_algorithmic"))
+    if isinstance(r.get("valu"), dict):
+        o["valu"] = _pick(r["valu"], ("frac", "frac_of_mix_ceiling", "ceiling_source"))
+    src = r["pmc"].get("source") if isinstance(r.get("pmc"), dict) else r.get("pmc_source")
+    o["pmc"] = {"source": src}
+    return o
+
+
+def contract_line(out, extras_name="bench_extras.json"):
+    """The ONE stdout line of the bench contract built from the full record `out`: metric / value / config / parity / roofline /
+    cpu_baseline / value_host_abi / strong, one short summary per other BASELINE config, and the name of the file that holds the rest.
+    Always strict JSON and shorter than LINE_MAX (tests/test_bench_line.py)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "key_pool", "parallelism", "mode"))
+    if len(line["config"].get("workload") or "") > 400:
+        line["config"]["workload"] = line["config"]["workload"][:397] + "..."
+    line["parity"] = _pick(out.get("parity"), ("sampled_items", "whole_batch", "bit_exact_vs_oracle", "ranks_failing"))
+    line["roofline"] = _roof(out.get("roofline"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cpu", "per_thread", "isa", "go"))
+        c["sample"] = (cb.get("sample") or "")[:240]
+        for sub in ("scalar_oracle", "shared_key", "port", "single_core_parsed_key"):
+            if isinstance(cb.get(sub), dict) and cb[sub].get("value") is not None:
+                c[sub] = _pick(cb[sub], ("value", "kind"))
+        if isinstance(cb.get("gpu_equals_reference_on_first_items"), dict):
+            c["gpu_equals_reference_on_first_items"] = cb["gpu_equals_reference_on_first_items"]
+        line["cpu_baseline"] = c
+    if isinstance(out.get("value_host_abi"), dict):
+        line["value_host_abi"] = _pick(out["value_host_abi"], ("value", "pinned", "unit"))
+    if isinstance(out.get("strong"), dict):
+        line["strong"] = _pick(out["strong"], ("value", "unit", "ms_per_step", "items_per_rank"))
+        par = out["strong"].get("parity")
+        if isinstance(par, dict):
+            line["strong"]["parity"] = _pick(par, ("sampled_items", "bit_exact_vs_oracle", "ranks_failing"))
+    pr = (out.get("per_rank") or {}).get("encaps_per_s")
+    if pr and len(pr) > 1:
+        line["per_rank"] = {"encaps_per_s": pr}
+    # the other BASELINE configs: one figure + verdict each (their rooflines, kernel times and parity details are in the extras file)
+    summ = {}
+    for name, c in (out.get("configs") or {}).items():
+        if not isinstance(c, dict) or name not in ("decaps", "config3", "config4", "config5"):
+            continue
+        e = _pick(c, ("value", "unit", "ms_per_step"))
+        for rk in ("roofline", "roofline_mlkem1024", "roofline_mldsa87"):
+            if isinstance(c.get(rk), dict):
+                e[rk] = _pick(c[rk], ("frac", "traffic_over_algorithmic"))
+                if isinstance(c[rk].get("valu"), dict):
+                    e[rk]["valu_frac_of_mix_ceiling"] = c[rk]["valu"].get("frac_of_mix_ceiling")
+        par = c.get("parity")
+        if isinstance(par, dict):
+            if "bit_exact_vs_oracle" in par:
+                e["parity"] = _pick(par, ("sampled_items", "whole_batch", "bit_exact_vs_oracle", "all_items_as_expected", "all_items_ss_dec_equals_ss_enc", "ranks_failing"))
+            else:
+                e["parity"] = {"bit_exact_vs_oracle": all(bool(v.get("bit_exact_vs_oracle")) for v in par.values() if isinstance(v, dict)),
+                               "ranks_failing": par.get("ranks_failing")}
+        summ[name] = e
+    if summ:
+        line["configs"] = summ
+    line["extras"] = extras_name
+    line["bench_wall_s"] = out.get("bench_wall_s")
+    text = json.dumps(_num(line), allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_MAX:   # cannot happen with the fields above; never print a line the driver cannot keep
+        for k in ("configs", "per_rank", "strong"):
+            line.pop(k, None)
+            text = json.dumps(_num(line), allow_nan=False, separators=(",", ":"))
+            if len(text) < LINE_MAX:
+                break
+    return text
+
+
+def _finite(x):
+    """NaN / Infinity -> None, so that both files are strict JSON."""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def emit(out, extras_path):
+    """Writes the full record to `extras_path` and returns the contract line (which names that file)."""
+    out = _finite(out)
+    name = os.path.basename(extras_path)
+    try:
+        with open(extras_path, "w") as f:
+            json.dump(out, f, indent=1, allow_nan=False)
+            f.write("\n")
+    except OSError as e:
+        print("bench.py: could not write %s (%s)" % (extras_path, e), file=sys.stderr)
+        name = None
+    return contract_line(out, name)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
     torch.distributed.run on 127.0.0.1 and a free port, exactly as the driver does for N > 1; returns its exit code."""
@@ -789,7 +923,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 20, help="ML-KEM items per GPU per step")
     ap.add_argument("--mode", default="encaps", choices=["encaps", "config3", "config4", "config5", "host"])
-    ap.add_argument("--no-extras", action="store_true", help="only the headline workload")
+    ap.add_argument("--extras", default="contract", choices=["contract", "all", "none"],
+                    help="contract (default): the headline + strong + host ABI + BASELINE configs 3/4/5 + roofline + cpu_baseline; all: also the pooled / "
+                         "shared-key / keyed / hybrid / small-batch / concurrent-caller legs; none: only the headline workload")
+    ap.add_argument("--no-extras", action="store_true", help="same as --extras none")
+    ap.add_argument("--extras-file", default=os.path.join(ROOT, "bench_extras.json"),
+                    help="where the full record goes (configs, notes, probes, definitions); the stdout line names it as `extras`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic / valu then come from profiles/*.json if they match this build)")
     ap.add_argument("--sample-parity", action="store_true", help="compare 2^16-item samples with the oracle instead of whole batches (headline: 2^20, config 4: 2^18)")
@@ -822,7 +961,10 @@ def main():
     ranks = parallel.Ranks("nccl", dev)  # nccl == RCCL on ROCm; used for the barrier / reductions only
     world, rank = ranks.world, ranks.rank
     B = args.batch
-    extras = not args.no_extras
+    if args.no_extras:
+        args.extras = "none"
+    extras = args.extras != "none"      # the BASELINE configs' legs (3, 4, 5), strong, host ABI
+    more = args.extras == "all"         # opt-in legs: pooled keys, shared key / key table, hybrids, small batches, concurrent callers
 
     if args.pmc_child:  # a few launches of the dominant kernel of every BASELINE config for the counter passes, nothing else
         w = KemWork(768, B, 0, dev, shake_inputs=False)
@@ -917,7 +1059,7 @@ def main():
 
     # ---- the figure of rounds 1-4, for continuity: the same step with keys drawn from a pool of 2^16 (77 MB of ek: fits the 256 MB
     # Infinity Cache, which 1.24 GB of distinct keys does not) ----
-    if extras and args.mode == "encaps" and kem.pool > POOLED:
+    if more and args.mode == "encaps" and kem.pool > POOLED:
         kp = KemWork(768, B, rank, dev, pool_max=POOLED)
         el_p, kern_p = Timer(ranks, ["mlkem_hash", "mlkem_encrypt"]).run(kp.encaps, 10, 2)
         v_p, el_p = parallel.whole_job_rate(ranks, B * 10, el_p)
@@ -959,7 +1101,7 @@ def main():
                                   "ms_per_pair_step": enc_ms + dec_ms, "per_rank_decaps_per_s": ranks.gather(B * ksteps / (dec_ms * 1e-3 * ksteps))}
 
     # ---- shared key / key table (the reference's parsed-key cache) ----
-    if extras and args.mode == "encaps":
+    if more and args.mode == "encaps":
         ct_s, ss_s, st_s = torch.empty_like(kem.eng.ct), torch.empty_like(kem.eng.ss), torch.empty_like(kem.eng.status)
         tm = Timer(ranks, ["mlkem_hash", "mlkem_encrypt", "mlkem_keytable"])
         el, ks = tm.run(lambda: kem.eng.encaps_shared(kem.ek[:1], kem.m, ct_s, ss_s, st_s), 5, 1)
@@ -982,7 +1124,7 @@ def main():
         del ct_s, ss_s, st_s
 
     # ---- the hybrid KEMs that carry ML-KEM-768 (X-Wing, X25519MLKEM768), composed on the device ----
-    if extras and args.mode == "encaps":
+    if more and args.mode == "encaps":
         from circl_amd import device as cdev
         nh = max(B // 4, 64)
         gh = torch.Generator(device=dev).manual_seed(9000 + rank)
@@ -1082,7 +1224,7 @@ def main():
     if args.mode == "host":
         headline = {"elapsed": B / host["pageable"]["value"] * args.steps, "value": host["pageable"]["whole_job_value"], "kern": {}}
 
-    if extras and rank == 0 and world == 1:
+    if more and rank == 0 and world == 1:
         out_cfg["small_batches"] = small_batches(dev)
         cc = concurrent_callers()
         if cc:
@@ -1179,7 +1321,8 @@ def main():
             refb = cpu_baseline_reference(kem)
             port = cpu_baseline(kem, budget_s=10.0 if refb is None else 4.0)
             out["cpu_baseline"] = dict(refb, port=port) if refb else port
-        print(json.dumps(out))
+        line = emit(out, args.extras_file)
+        print(line, flush=True)
     ranks.close()
 
 
