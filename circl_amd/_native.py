@@ -38,15 +38,18 @@ SYMBOLS = [
     "circl_hip_mlkem_public_from_private", "circl_hip_mldsa_public_from_private", "circl_hip_mldsa_public_from_private_dev",
     "circl_hip_hybrid_keytable_new", "circl_hip_hybrid_encaps_table", "circl_hip_hybrid_decaps_table",
     "circl_hip_hybrid_encaps_table_dev", "circl_hip_hybrid_decaps_table_dev",
+    "circl_hip_keytable_close", "circl_hip_keytable_async_start", "circl_hip_keytable_async_stop", "circl_hip_keytable_eventfd",
+    "circl_hip_mlkem_encaps_table_submit", "circl_hip_mlkem_decaps_table_submit", "circl_hip_mldsa_verify_table_submit",
+    "circl_hip_poll", "circl_hip_wait", "circl_hip_profile_call_stamps",
 ]
 
-OK, EPARAM, ENODEV, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
+OK, EPARAM, ENODEV, EHIP, ENOMEM, EWORKSPACE, EBUSY, EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 ALL_DEVICES = -1
 
 
 class CirclHipError(RuntimeError):
     def __init__(self, code, where, detail=""):
-        names = {EPARAM: "EPARAM", ENODEV: "ENODEV", EHIP: "EHIP", ENOMEM: "ENOMEM", EWORKSPACE: "EWORKSPACE"}
+        names = {EPARAM: "EPARAM", ENODEV: "ENODEV", EHIP: "EHIP", ENOMEM: "ENOMEM", EWORKSPACE: "EWORKSPACE", EBUSY: "EBUSY", EAGAIN: "EAGAIN"}
         super().__init__(f"{where}: {names.get(code, code)} {detail}".strip())
         self.code = code
 
@@ -121,6 +124,16 @@ def lib():
         L.circl_hip_keytable_set_coalesce.argtypes = [vp, sz, C.c_uint32]
         L.circl_hip_set_coalesce.argtypes = [sz, C.c_uint32]
         L.circl_hip_keytable_coalesce_stats.argtypes = [vp, vp, vp, vp]
+        L.circl_hip_keytable_close.argtypes = [vp]
+        L.circl_hip_keytable_async_start.argtypes = [vp, sz, C.c_uint32, i]
+        L.circl_hip_keytable_async_stop.argtypes = [vp]
+        L.circl_hip_keytable_eventfd.argtypes = [vp, i]
+        L.circl_hip_mlkem_encaps_table_submit.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
+        L.circl_hip_mlkem_decaps_table_submit.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+        L.circl_hip_mldsa_verify_table_submit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.circl_hip_poll.argtypes = [vp, vp, sz, vp]
+        L.circl_hip_wait.argtypes = [vp, C.c_uint64, C.c_int64]
+        L.circl_hip_profile_call_stamps.argtypes = [i, vp]
         L.circl_hip_mlkem_encaps_table.argtypes = [vp, vp, vp, vp, vp, vp, sz]
         L.circl_hip_mlkem_decaps_table.argtypes = [vp, vp, vp, vp, vp, sz]
         L.circl_hip_mldsa_verify_table.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz]

@@ -941,8 +941,9 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
     if (check_contexts(param, ctx_blob, ctx_off, n) == CTX_UNSUPPORTED) return CIRCL_HIP_EPARAM;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
-        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (absent key_idx: zeros; absent contexts: empty rows)
-            const int rc = coalesce_run(r->coalescer, cnt, {{sig + lo * SIG, SIG}, {reinterpret_cast<const uint8_t *>(ki), size_t(4)}},
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {  // a small call joins the table's cross-caller batch (absent key_idx: zeros; absent contexts: empty rows)
+            const int rc = coalesce_run(co, cnt, {{sig ? sig + lo * SIG : nullptr, SIG}, {reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}},
                                         {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}},
                                         [&](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
                                             return circl_hip_mldsa_verify_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[0], c.blob[0], c.off[0], c.blob[1],
@@ -950,7 +951,7 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
                                         });
             if (rc != kNotCoalesced) return rc;
         }
-        return run_pipeline(r->device, cnt, {{sig + lo * SIG, SIG}, {reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}},
+        return run_pipeline(r->device, cnt, {{sig ? sig + lo * SIG : nullptr, SIG}, {reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}},
                             {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}}, [&](size_t c) { return mldsa_ws_any(param, c); },
                             dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
                                 return circl_hip_mldsa_verify_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.in[0], c.blob[0], c.off[0],
@@ -958,6 +959,40 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
                             });
     });
 }
+
+// the asynchronous form of circl_hip_mldsa_verify_table (include/circl_hip.h: circl_hip_keytable_async_start)
+int circl_hip_mldsa_verify_table_submit(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
+                                        const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n, uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!t || t->magic != kKeytableMagic || t->family != 2 || t->private_keys || !ticket) return CIRCL_HIP_EPARAM;
+    if (n && (!sig || !ok || !msg_off || (ctx_blob && !ctx_off))) return CIRCL_HIP_EPARAM;
+    const int param = t->param;
+    const size_t SIG = circl_hip_mldsa_sig_size(param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        for (size_t i = 0; i < n; i++)
+            if (key_idx[i] >= t->nkeys) return CIRCL_HIP_EPARAM;
+    if (check_contexts(param, ctx_blob, ctx_off, n) == CTX_UNSUPPORTED) return CIRCL_HIP_EPARAM;
+    return table_submit(t, ticket, [&](const circl_hip_keytable *, Coalescer *co, uint64_t *seq) {
+        return coalesce_submit(co, n, {{sig, SIG}, {reinterpret_cast<const uint8_t *>(key_idx), size_t(4), false, false, true}},
+                               {{msg_blob, msg_off}, {ctx_blob, ctx_blob ? ctx_off : nullptr}}, {{ok, 1}}, seq, false);
+    });
+}
+}  // extern "C"
+namespace circl {
+namespace host {
+int dsa_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd) {
+    const int param = r->param;
+    const size_t SIG = circl_hip_mldsa_sig_size(param);
+    return coalescer_async_start(co, {{nullptr, SIG}, {nullptr, size_t(4), false, false, true}}, {{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, 1}},
+                                 [param](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 13, false), [r](Chunk &c) {
+                                     return circl_hip_mldsa_verify_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[0], c.blob[0], c.off[0], c.blob[1], c.off[1],
+                                                                             c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
+                                 }, want_eventfd);
+}
+}  // namespace host
+}  // namespace circl
+extern "C" {
 
 // ---- private keys prepared once: A and the NTT-domain secrets of the reference's parsed PrivateKey (internal/dilithium.go:149-179) ----
 static int mldsa_privkeys_new_one(int param, const uint8_t *sks, size_t nkeys, int device, circl_hip_keytable **out) {
@@ -1025,8 +1060,9 @@ int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *t, const uint32_t
     if (!rnd) zeros.assign(32 * std::min(n, opts.chunk_items), 0);  // deterministic signing: 32 zero bytes per item
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
-        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (absent rnd / key_idx: zeros)
-            const int rc = coalesce_run(r->coalescer, cnt, {{rnd ? rnd + lo * 32 : nullptr, size_t(32), true}, {reinterpret_cast<const uint8_t *>(ki), size_t(4)}},
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {  // a small call joins the table's cross-caller batch (absent rnd / key_idx: zeros)
+            const int rc = coalesce_run(co, cnt, {{rnd ? rnd + lo * 32 : nullptr, size_t(32), true, false, true}, {reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}},
                                         {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{sig + lo * SIG, SIG}},
                                         [&](size_t c) { return mldsa_sign_ws_any(param, c); }, opts, [&](Chunk &c) {
                                             SignCtxOk checked;  // (every caller of the batch passed check_contexts)

@@ -897,6 +897,9 @@ int circl_hip_mlkem_decaps_table_dev(const circl_hip_keytable *t, const uint32_t
                  decaps_table_dev_impl<4>(t, d_key_idx, d_ct, d_ss, d_status, n, d_ws, ws_bytes, st));
 }
 // host buffers: only the per-item data travel; the keys and what was parsed out of them are already on the table's device
+// (key_idx is the one OPTIONAL array: absent = entry 0 for every item; a NULL m / ct is CIRCL_HIP_EPARAM on every path)
+static std::vector<HIn> kem_enc_ins(const uint32_t *ki, const uint8_t *m) { return {{reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}, {m, 32, true}}; }
+static std::vector<HIn> kem_dec_ins(const uint32_t *ki, const uint8_t *ct, size_t CT) { return {{reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}, {ct, CT}}; }
 int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
                                  size_t n) {
     if (!kem_table_ok(t, 0)) return CIRCL_HIP_EPARAM;
@@ -906,15 +909,16 @@ int circl_hip_mlkem_encaps_table(const circl_hip_keytable *t, const uint32_t *ke
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
-        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {  // a small call joins the table's cross-caller batch (an absent key_idx: zeros)
-            const int rc = coalesce_run(r->coalescer, cnt, {{reinterpret_cast<const uint8_t *>(ki), size_t(4)}, {m + lo * 32, 32, true}}, {},
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {  // a small call joins the table's cross-caller batch (an absent key_idx: zeros)
+            const int rc = coalesce_run(co, cnt, kem_enc_ins(ki, m ? m + lo * 32 : nullptr), {},
                                         {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                             return circl_hip_mlkem_encaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.out[2],
                                                                                     c.cnt, c.ws, c.ws_bytes, c.st);
                                         });
             if (rc != kNotCoalesced) return rc;
         }
-        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {m + lo * 32, 32, true}}, {},
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {m ? m + lo * 32 : nullptr, 32, true}}, {},
                             {{ct + lo * CT, CT}, {ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                         c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
@@ -929,21 +933,64 @@ int circl_hip_mlkem_decaps_table(const circl_hip_keytable *t, const uint32_t *ke
         if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
-        if (r->coalescer && cnt <= coalescer_call_max(r->coalescer)) {
-            const int rc = coalesce_run(r->coalescer, cnt, {{reinterpret_cast<const uint8_t *>(ki), size_t(4)}, {ct + lo * CT, CT}}, {},
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {
+            const int rc = coalesce_run(co, cnt, kem_dec_ins(ki, ct ? ct + lo * CT : nullptr, CT), {},
                                         {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                             return circl_hip_mlkem_decaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.cnt,
                                                                                     c.ws, c.ws_bytes, c.st);
                                         });
             if (rc != kNotCoalesced) return rc;
         }
-        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * CT, CT}}, {},
+        return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct ? ct + lo * CT : nullptr, CT}}, {},
                             {{ss + lo * 32, 32, true}, {status ? status + lo : nullptr, 1}}, kem_ws_fn(), kem_opts(), [&](Chunk &c) {
                                 return circl_hip_mlkem_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                         c.cnt, c.ws, c.ws_bytes, c.st);
                             });
     });
 }
+// ---- the asynchronous form (include/circl_hip.h: circl_hip_keytable_async_start) ----
+int circl_hip_mlkem_encaps_table_submit(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                        size_t n, uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!kem_table_ok(t, 0) || !ticket || (n && (!m || !ct || !ss))) return CIRCL_HIP_EPARAM;
+    const size_t CT = circl_hip_mlkem_ct_size(t->param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
+    return table_submit(t, ticket, [&](const circl_hip_keytable *, Coalescer *co, uint64_t *seq) {
+        return coalesce_submit(co, n, kem_enc_ins(key_idx, m), {}, {{ct, CT}, {ss, 32, true}, {status, 1}}, seq, false);
+    });
+}
+int circl_hip_mlkem_decaps_table_submit(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                                        uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!kem_table_ok(t, 1) || !ticket || (n && (!ct || !ss))) return CIRCL_HIP_EPARAM;
+    const size_t CT = circl_hip_mlkem_ct_size(t->param);
+    if (n == 0) return CIRCL_HIP_OK;
+    if (key_idx)
+        if (int rc = check_key_idx(key_idx, n, t->nkeys)) return rc;
+    return table_submit(t, ticket, [&](const circl_hip_keytable *, Coalescer *co, uint64_t *seq) {
+        return coalesce_submit(co, n, kem_dec_ins(key_idx, ct, CT), {}, {{ss, 32, true}, {status, 1}}, seq, false);
+    });
+}
+}  // extern "C"
+namespace circl {
+namespace host {
+// the queue of one ML-KEM table (part): its arrays and its launch, fixed for the queue's life (`r` outlives the queue: the table owns it)
+int kem_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd) {
+    const size_t CT = circl_hip_mlkem_ct_size(r->param);
+    if (!r->private_keys)
+        return coalescer_async_start(co, kem_enc_ins(nullptr, nullptr), {}, {{nullptr, CT}, {nullptr, 32, true}, {nullptr, 1}}, kem_ws_fn(), kem_opts(), [r](Chunk &c) {
+            return circl_hip_mlkem_encaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+        }, want_eventfd);
+    return coalescer_async_start(co, kem_dec_ins(nullptr, nullptr, CT), {}, {{nullptr, 32, true}, {nullptr, 1}}, kem_ws_fn(), kem_opts(), [r](Chunk &c) {
+        return circl_hip_mlkem_decaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+    }, want_eventfd);
+}
+}  // namespace host
+}  // namespace circl
+extern "C" {
 /* PrivateKey.Public() over a batch (kem/mlkem/mlkem768/kyber.go:323-328): the encapsulation key stored inside each decapsulation
  * key (dk = s || ek || H(ek) || z, :189-201).  No device work: a strided copy. */
 int circl_hip_mlkem_public_from_private(int param, const uint8_t *dk, uint8_t *ek, size_t n) {

@@ -141,6 +141,8 @@ struct HIn {                 // fixed-size rows: item i is row i
     size_t row;
     bool secret = false;     // wipe the staging copy afterwards
     bool per_call = false;   // ONE row for the whole call (a shared key): re-staged with every chunk
+    bool optional = false;   // coalesce_run / coalesce_submit: p == nullptr means rows of ZEROS (an absent key_idx / rnd); without it a
+                             // NULL pointer is CIRCL_HIP_EPARAM there, as it is in run_pipeline
 };
 struct HBlob {               // ragged rows: item i is blob[off[i] .. off[i+1]); blob == nullptr: absent (kernels get nullptr)
     const uint8_t *blob;
@@ -185,23 +187,43 @@ size_t host_chunk_items(size_t dflt);  // CIRCL_HIP_HOST_CHUNK overrides the def
 // Bytes are those of the un-coalesced call: the kernels are the same ones, an item does not know its neighbours.
 struct Coalescer;
 Coalescer *coalescer_new(int dev, size_t max_items, unsigned max_wait_us);
-void coalescer_free(Coalescer *co);
+void coalescer_free(Coalescer *co);   // an asynchronous queue finishes what was submitted first (its dispatcher drains, then exits)
+bool coalescer_idle(Coalescer *co);   // no call inside, no batch open or running (what a setter checks before it frees one)
 size_t coalescer_call_max(const Coalescer *co);  // calls of more items than this do not join batches
 void coalescer_stats(const Coalescer *co, uint64_t *calls, uint64_t *items, uint64_t *launches);
 // Same contract as run_pipeline for a call of n <= coalescer_call_max() items.  A NULL input pointer with a non-zero row = rows
-// of zeros (an absent key_idx).  Returns kNotCoalesced (> 0) when the call cannot join (too many blob bytes, a shape that differs
-// from the coalescer's first call): the caller then runs it through run_pipeline.
+// of zeros ONLY for an input marked `optional` (an absent key_idx / rnd); otherwise CIRCL_HIP_EPARAM, as in run_pipeline.  Returns
+// kNotCoalesced (> 0) when the call cannot join (too many blob bytes, a shape that differs from the coalescer's first call, a layout
+// that could not be allocated right now): the caller then runs it through run_pipeline.
 constexpr int kNotCoalesced = 1;
 int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
                  const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch);
+
+// The ASYNCHRONOUS form (host_coalesce.hip): coalescer_async_start fixes the queue's arrays, workspace rule and launch (they outlive
+// every call) and starts its dispatcher thread; coalesce_submit copies a call's rows in, records where its results go and returns a
+// ticket sequence number at once (CIRCL_HIP_EAGAIN when every batch is busy and may_wait is false); coalescer_state: 1 done, 0 pending,
+// < 0 the batch failed; coalescer_wait blocks the ONE thread that calls it until the ticket is done or timeout_us passed (< 0: no limit).
+// coalesce_run on such a coalescer is submit + wait.
+int coalescer_async_start(Coalescer *co, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs,
+                          const std::function<size_t(size_t)> &ws_bytes, const PipeOpts &opts, const std::function<int(Chunk &)> &launch, bool want_eventfd);
+int coalesce_submit(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std::vector<HBlob> &blobs, const std::vector<HOut> &outs, uint64_t *seq,
+                    bool may_wait);
+int coalescer_state(const Coalescer *co, uint64_t seq);
+int coalescer_wait(Coalescer *co, uint64_t seq, int64_t timeout_us);
+bool coalescer_is_async(const Coalescer *co);
+int coalescer_eventfd(const Coalescer *co);
+// circl_hip_profile_call_stamps: CLOCK_MONOTONIC nanoseconds of the stages of the calling thread's last BLOCKING coalesced call
+struct CallStamps { uint64_t enter = 0, reserved = 0, copied_in = 0, closed = 0, copies_in = 0, launched = 0, done = 0, copied_out = 0; };
+extern std::atomic<bool> g_stamps_on;
+extern thread_local CallStamps g_stamps;
 
 // ... and process-wide, for the entry points that take their keys with every call (circl_hip_set_coalesce): a TLS server encapsulates
 // to a DIFFERENT, ephemeral key in every handshake -- there is no table to attach a coalescer to.  One coalescer per (entry point,
 // parameter set, device), created at its first small call.  nullptr: switched off (the default) or an unknown slot.
 enum CallOp : int { kCoKemEncaps = 0, kCoKemDecaps, kCoDsaVerify, kCoDsaVerifyInternal, kCoHybEncaps, kCoHybDecaps, kCoOps };
 Coalescer *call_coalescer(int op, int param_slot, int dev);  // param_slot: 0..3 (the entry point's own numbering of its parameter sets)
-// (coalesce_run reads a NULL input as rows of zeros -- right for an absent key_idx, wrong for a missing key array: these entry points
-// only join a batch with every input present and leave the complaint about a NULL pointer to run_pipeline)
+int call_coalescing_set(size_t max_items, uint32_t max_wait_us);  // 0: off AND drained (returns once no call is inside a process-wide coalescer)
+// (these entry points only join a batch with every input present and leave the complaint about a NULL pointer to run_pipeline)
 inline bool all_inputs_present(const std::vector<HIn> &ins) {
     for (auto &in : ins)
         if (!in.p) return false;

@@ -940,13 +940,13 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches) {
 }
 
 // keytable.h: a table of private keys is wiped before its memory goes back (the expanded rows are public, the key rows are not)
-void circl_hip_keytable_free(circl_hip_keytable *t) {
-    if (!t || t->magic != kKeytableMagic) return;
+static void keytable_release(circl_hip_keytable *t) {
     t->magic = 0;
-    for (int d = 0; d < t->nreplica; d++) circl_hip_keytable_free(t->replica[d]);
+    for (int d = 0; d < t->nreplica; d++)
+        if (t->replica[d]) keytable_release(t->replica[d]);
     delete[] t->replica;
-    if (t->inner) circl_hip_keytable_free(t->inner);
-    if (t->coalescer) { circl::host::coalescer_free(t->coalescer); t->coalescer = nullptr; }
+    if (t->inner) keytable_release(t->inner);
+    if (t->coalescer) { circl::host::coalescer_free(t->coalescer); t->coalescer = nullptr; }  // (an asynchronous queue finishes its tickets first)
     if (ndev() > 0 && t->device >= 0 && t->device < ndev() && hipSetDevice(circl::host::physical_device(t->device)) == hipSuccess) {
         if (t->d_keys) {
             if (t->private_keys) (void)hipMemset(t->d_keys, 0, t->keys_bytes);
@@ -963,6 +963,24 @@ void circl_hip_keytable_free(circl_hip_keytable *t) {
     }
     (void)hipGetLastError();
     delete t;
+}
+// Never frees under a caller: waits (up to two seconds) for the calls inside the table to return; if they do not, the table is marked
+// dead -- later calls get CIRCL_HIP_EPARAM -- and its memory is LEAKED rather than pulled from under them.
+void circl_hip_keytable_free(circl_hip_keytable *t) {
+    if (!t || t->magic != kKeytableMagic) return;
+    if (!circl::host::keytable_quiesce(t)) {
+        t->magic = 0;
+        g_err = "circl_hip_keytable_free: calls still inside the table after 2 s; the table was marked dead and leaked";
+        return;
+    }
+    keytable_release(t);
+}
+int circl_hip_keytable_close(circl_hip_keytable *t) {
+    if (!t || t->magic != kKeytableMagic) return CIRCL_HIP_EPARAM;
+    if (int rc = circl_hip_keytable_async_stop(t)) return rc;  // CIRCL_HIP_EBUSY while a call is inside (coalescers and queues otherwise go first)
+    if (t->users.load() != 0) { g_err = "the table has calls in flight"; return CIRCL_HIP_EBUSY; }
+    circl_hip_keytable_free(t);
+    return CIRCL_HIP_OK;
 }
 int circl_hip_keytable_device(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->device : CIRCL_HIP_ENODEV; }
 size_t circl_hip_keytable_nkeys(const circl_hip_keytable *t) { return (t && t->magic == kKeytableMagic) ? t->nkeys : 0; }

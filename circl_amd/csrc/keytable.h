@@ -12,7 +12,33 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <functional>
+
+namespace circl {
+namespace host {
+// How many calls are inside a table right now.  Striped: a caller counts itself in the slot of its thread (a cache line of its own), so
+// that the reactors of the asynchronous form -- millions of submits per second from a handful of threads -- do not pass ONE line around
+// (profiles/r06_async.txt: four reactors on one counter paid 1.4 us per item where one paid 0.2); a setter sums the slots.
+constexpr int kUseSlots = 16;
+struct alignas(64) UseSlot {
+    std::atomic<uint32_t> n{0};
+};
+struct UseCount {
+    UseSlot slot[kUseSlots];
+    uint32_t load() const {
+        uint32_t s = 0;
+        for (auto &x : slot) s += x.n.load();  // (seq_cst, like the callers' increments: see `frozen`)
+        return s;
+    }
+};
+inline int use_slot() {
+    static std::atomic<unsigned> next{0};
+    thread_local const int mine = (int)(next.fetch_add(1) % kUseSlots);
+    return mine;
+}
+}  // namespace host
+}  // namespace circl
 
 struct circl_hip_keytable {
     uint32_t magic;        // kKeytableMagic while alive
@@ -36,6 +62,12 @@ struct circl_hip_keytable {
     int nreplica;
     // circl_hip_keytable_set_coalesce: small host-buffer calls through this table join cross-caller batches (host_common.h)
     circl::host::Coalescer *coalescer;
+    // Lifetime of the coalescer under concurrent callers: every host-buffer call through the table counts itself
+    // in `users` while it is inside (TableUse) and skips the coalescer while `frozen` is set; a setter sets `frozen`, then requires
+    // users == 0 and an idle coalescer (else CIRCL_HIP_EBUSY) before it frees anything.  Both seq_cst: either the caller sees the
+    // freeze, or the setter sees the caller.
+    std::atomic<bool> frozen{false};
+    mutable circl::host::UseCount users;  // (cache lines of its own, behind the read-mostly fields above)
 };
 constexpr uint32_t kKeytableMagic = 0x4b544232u;  // "KTB2"
 
@@ -58,10 +90,48 @@ int keytable_replicate(int device, const std::function<int(int dev, circl_hip_ke
 // costs a host thread and a launch per device for no gain (and the contiguous split sent every one-item call to the last device).
 constexpr size_t kSmallTableCall = 1024;
 int next_replica(int nreplica);
+// a call's stay inside a table (see circl_hip_keytable::users)
+struct TableUse {
+    const circl_hip_keytable *t;  // nullptr: nothing to count (a part that is the table itself is counted once)
+    int s;
+    explicit TableUse(const circl_hip_keytable *tt) : t(tt), s(use_slot()) { if (t) t->users.slot[s].n.fetch_add(1); }
+    ~TableUse() { if (t) t->users.slot[s].n.fetch_sub(1); }
+    TableUse(const TableUse &) = delete;
+    TableUse &operator=(const TableUse &) = delete;
+};
+// the coalescer a call inside `r` (TableUse held) may use: none while a setter has the table frozen
+inline Coalescer *usable_coalescer(const circl_hip_keytable *r) { return r->frozen.load() ? nullptr : r->coalescer; }
 template <class F> int table_shard(const circl_hip_keytable *t, size_t n, F one) {
+    TableUse top(t);
     if (t->device >= 0) return one(t, size_t(0), n);
-    if (n <= kSmallTableCall && t->nreplica > 0) return one(t->replica[next_replica(t->nreplica)], size_t(0), n);
-    return shard(n, CIRCL_HIP_ALL_DEVICES, [&](int dev, size_t lo, size_t cnt) { return one(t->replica[dev], lo, cnt); });
+    auto part = [&](const circl_hip_keytable *r, size_t lo, size_t cnt) { TableUse use(r); return one(r, lo, cnt); };
+    if (n <= kSmallTableCall && t->nreplica > 0) return part(t->replica[next_replica(t->nreplica)], size_t(0), n);
+    return shard(n, CIRCL_HIP_ALL_DEVICES, [&](int dev, size_t lo, size_t cnt) { return part(t->replica[dev], lo, cnt); });
+}
+// the asynchronous queues of the two families (api_mlkem.hip, api_mldsa.hip): fix the queue's arrays and launch on `co`, start its dispatcher
+int kem_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd);
+int dsa_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd);
+// circl_hip_keytable_free: waits (bounded) until no call is inside the table; false = still busy
+bool keytable_quiesce(circl_hip_keytable *t);
+// a submitted call picks its part like a small blocking call does and says which in the ticket's top byte
+inline uint64_t make_ticket(int replica, uint64_t seq) { return ((uint64_t)(unsigned)replica << 56) | seq; }
+// One part of a table takes a submitted call: the table itself, or -- replicated -- one replica, round-robin; the ticket says which.
+template <class F> int table_submit(const circl_hip_keytable *t, uint64_t *ticket, F one) {
+    TableUse top(t);
+    int rep = 0;
+    const circl_hip_keytable *r = t;
+    if (t->device < 0) {
+        if (t->nreplica <= 0) return CIRCL_HIP_EPARAM;
+        rep = next_replica(t->nreplica);
+        r = t->replica[rep];
+    }
+    TableUse use(r != t ? r : nullptr);
+    Coalescer *co = usable_coalescer(r);
+    if (!co || !coalescer_is_async(co)) { g_err = "the table has no asynchronous queue (circl_hip_keytable_async_start)"; return CIRCL_HIP_EPARAM; }
+    uint64_t seq = 0;
+    const int rc = one(r, co, &seq);
+    if (rc == CIRCL_HIP_OK) *ticket = make_ticket(rep, seq);
+    return rc;
 }
 }  // namespace host
 }  // namespace circl

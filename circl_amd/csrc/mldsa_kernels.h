@@ -66,11 +66,20 @@ template <int MODE> struct DG {
     static constexpr int LDS_FIFO = 64 * FIFO_STRIDE;  // phase A; afterwards the staged z || hint bytes
     static constexpr int LDS_HINT1 = K * 32;           // one item's hint bitmap
     static constexpr int LDS_V_TOTAL = LDS_FIFO + LDS_XCH + LDS_HINT1 + LDS_MISC;
+    static constexpr int LDS_V_PAIR = LDS_V_TOTAL + LDS_XCH;  // the paired form (ABLATE bit 5, tools/ablate_dsa.hip only): a second exchange buffer behind the rest
     static constexpr int SCRATCH_BYTES = 64 * 768;     // 64 rows of 256 24-bit coefficients per workgroup
 };
 
 #ifndef CIRCL_DSA_WAVES_PER_EU
 #define CIRCL_DSA_WAVES_PER_EU 4
+#endif
+// Issue priority of a wavefront of mldsa_verify_kernel while it is in phases 1-3 (0 = the same as phase A's).  Those phases are chains of
+// LDS exchanges and loads with a few instructions in between -- 44 and 22 wavefront-cycles per VALU instruction against phase A's 10,
+// profiles/r06_verify_clocks.txt --: with priority their instructions need not queue behind three co-resident wavefronts' Keccak rounds.
+// Measured (profiles/r06_verify_variants.txt, alternating on one box): priority 1 or 3 alike, phases 1-3 shrink from 115 k to 79 k cycles
+// per item, phase A grows from 122 k to 147 k (it now waits for them), the kernel gains 1.6 % (ML-DSA-65) / 2.2 % (ML-DSA-87).
+#ifndef CIRCL_DSA_VERIFY_PRIO
+#define CIRCL_DSA_VERIFY_PRIO 1
 #endif
 
 constexpr size_t kBallStateBytes = 200;
@@ -555,6 +564,24 @@ template <int L> __device__ __forceinline__ void mac_rows(uint32_t (&out)[4], co
 #pragma unroll
     for (int r = 0; r < 4; r++) out[r] = dilithium::mont64(acc[r]);
 }
+// Two rows of A z-hat at once (rows stream0 and stream1 of the matrix): the 2 L row loads are all issued before the first multiply, so
+// that ONE memory round trip covers both dot products (the paired form of mldsa_verify_kernel).
+template <int L> __device__ __forceinline__ void mac_rows2(uint32_t (&out0)[4], uint32_t (&out1)[4], const uint32_t *rows, int stream0, int stream1,
+                                                          const uint32_t (&vhat)[L][4], int lane) {
+    uint64_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    detail::static_for<0, (L + 3) / 4>([&](auto ic) {
+        constexpr int j0 = 4 * decltype(ic)::v, CNT = L - j0 < 4 ? L - j0 : 4;
+        uint32_t a[CNT][4], b[CNT][4];
+#pragma unroll
+        for (int j = 0; j < CNT; j++) { load_row_l4(a[j], rows, stream0 + j0 + j, lane); load_row_l4(b[j], rows, stream1 + j0 + j, lane); }
+#pragma unroll
+        for (int j = 0; j < CNT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc0[r] += (uint64_t)a[j][r] * vhat[j0 + j][r]; acc1[r] += (uint64_t)b[j][r] * vhat[j0 + j][r]; }
+    });
+#pragma unroll
+    for (int r = 0; r < 4; r++) { out0[r] = dilithium::mont64(acc0[r]); out1[r] = dilithium::mont64(acc1[r]); }
+}
 // The positions j_t of SampleInBall the way the reference finds them (sample.go:299-339): step t = 0 .. tau-1 reads bytes
 // until one is <= i_t = 256 - tau + t.  Returns j_t in lane t.  One step is three compares + ballots, scalar bit tricks and
 // one v_readlane; a further SHAKE256 block is squeezed (keccak_f1600_coop: the wave works on the one state through LDS)
@@ -715,6 +742,14 @@ __global__ void __launch_bounds__(64) mldsa_sample_in_ball_kernel(const uint8_t 
 
 // ABLATE is a profiling aid (tools/ablate_dsa.hip): bit 0 skips phase A, bit 1 phase 1, bit 2 phases 2+3,
 // bit 3 drops the row stores of phase A, bit 4 shrinks the row loads of phase 2 to one row (L2 hits).
+// Bit 5 (32) is not an ablation but the PAIRED form of phases 1-3 (round 6's structural attempt, measured at a LOSS of 3 / 10 / 5 % for
+// ML-DSA-44 / 65 / 87 -- profiles/r06_verify_ab.txt -- and therefore instantiated by tools/ablate_dsa.hip only, not by the library): the transforms
+// run two polynomials at a time (dilithium::ntt2 / invntt2: every LDS exchange wait covers two transforms), the rows of two
+// output polynomials are fetched by one batch of loads (mac_rows2), and an odd last z polynomial shares its transform with the
+// challenge c.  Same arithmetic, same bytes.
+// Bit 6 (64): the wavefront reads the shader clock at every phase boundary of the FULL kernel and leaves, per workgroup, the cycles it
+// spent in { ticket, phase A, phase 1, phases 2+3 } and its item count at key_rows (which the per-item form does not use otherwise):
+// where the wall time of a wavefront goes when the phases of four co-resident wavefronts overlap (profiles/r06_verify_clocks.txt).
 // `scratch` holds gridDim.x slices of DG::SCRATCH_BYTES; `work` is the ticket counter (zeroed by the host)
 // or nullptr for one group per workgroup.
 // KM = mlkem::KM_SHARED: every item is verified under the ONE public key at `pk` (the reference's cached-key case: A and tr
@@ -735,6 +770,8 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
     uint32_t *xch = reinterpret_cast<uint32_t *>(smem + G::LDS_FIFO);
     uint32_t *hintbits = reinterpret_cast<uint32_t *>(smem + G::LDS_FIFO + G::LDS_XCH);
     uint8_t *misc = smem + G::LDS_FIFO + G::LDS_XCH + G::LDS_HINT1;
+    uint32_t *xch1 = reinterpret_cast<uint32_t *>(smem + G::LDS_FIFO + G::LDS_XCH + G::LDS_HINT1 + G::LDS_MISC);  // the paired form's second exchange buffer
+    constexpr bool PAIR = (ABLATE & 32) != 0;
     const int lane = threadIdx.x;
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
     uint32_t *rows = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * G::SCRATCH_BYTES);
@@ -747,15 +784,29 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
         expand_a_scratch<MODE, false, 1>(smem, rows, pk, 0, 0, 1, lane);  // rows 0 .. K L - 1, once
         rows_acquire();
     }
+    constexpr bool CLK = (ABLATE & 64) != 0;
+    uint64_t clk[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto lap = [&](int slot) {  // the cycles since the previous boundary go to `slot`
+        if constexpr (CLK) {
+            const uint64_t t = __builtin_readcyclecounter();
+            clk[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+    if constexpr (CLK) tprev = __builtin_readcyclecounter();
 
 #pragma unroll 1
   for (size_t grp = mlkem::next_group(work, lane, true, ngroups); grp < ngroups; grp = mlkem::next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * G::IT;
+    lap(0);
     if constexpr (!SHARED && !KEYED) {
         // ------------------------------ phase A ------------------------------
         __syncthreads();  // the previous group is done with the LDS the FIFOs alias
+        if constexpr (CIRCL_DSA_VERIFY_PRIO != 0) __builtin_amdgcn_s_setprio(0);
         if (!(ABLATE & 1)) expand_a_scratch<MODE, (ABLATE & 8) != 0>(smem, rows, pk, (size_t)G::PK, item0, n, lane);
         rows_acquire();
+        if constexpr (CIRCL_DSA_VERIFY_PRIO != 0) __builtin_amdgcn_s_setprio(CIRCL_DSA_VERIFY_PRIO);
+        lap(1);
     }
 
 #pragma unroll 1
@@ -769,16 +820,16 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
         bool bad = false;
         if (!(ABLATE & 2)) {
             const uint8_t *sg = sig + item * G::SIG;
-            sample_in_ball_hat<MODE, false>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // first: z-hat is not live yet
+            constexpr bool C_WITH_Z = PAIR && (L & 1);  // the challenge's transform pairs up with the odd last z polynomial
+            if constexpr (C_WITH_Z) sample_in_ball_hat<MODE, false, false, false>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // c itself, layout L1
+            else sample_in_ball_hat<MODE, false>(chat, ball_ws + item * kBallStateBytes, misc, xch, z, lane);  // first: z-hat is not live yet
             __syncthreads();
             if (lane < K * 8) hintbits[lane] = 0;
             stage_unaligned(stg, sg + P::CT, ZH_BYTES, lane);
             if (lane == 0) stg[(ZH_BYTES + 3) >> 2] = 0;  // slack dword for lds_bits
             __syncthreads();
             // z: (gamma1_bits+1)-bit fields, value gamma1 - field (pack.go:146-199); ||z||inf < gamma1 - beta
-#pragma unroll
-            for (int j = 0; j < L; j++) {
-                uint32_t c[4];
+            auto unpack_z = [&](uint32_t (&c)[4], int j) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t f = lds_bits<G::ZBITS>(stg, j * (G::ZSZ / 4), kyber::idx_l1(lane, r));
@@ -787,9 +838,33 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                     bad |= dilithium::exceeds(x, G::GAMMA1 - G::BETA);
                     c[r] = x;
                 }
-                dilithium::ntt(c, z, xch, lane);
+            };
+            if constexpr (PAIR) {
+                detail::static_for<0, L / 2>([&](auto ic) {
+                    constexpr int j = 2 * decltype(ic)::v;
+                    uint32_t c0[4], c1[4];
+                    unpack_z(c0, j);
+                    unpack_z(c1, j + 1);
+                    dilithium::ntt2(c0, c1, z, xch, xch1, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) zhat[j][r] = c[r];  // plain z-hat, < 17q
+                    for (int r = 0; r < 4; r++) { zhat[j][r] = c0[r]; zhat[j + 1][r] = c1[r]; }
+                });
+                if constexpr (C_WITH_Z) {
+                    uint32_t c0[4];
+                    unpack_z(c0, L - 1);
+                    dilithium::ntt2(c0, chat, z, xch, xch1, lane);  // plain c-hat (the products then carry 2^-32, like mac_rows' output)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) zhat[L - 1][r] = c0[r];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    uint32_t c[4];
+                    unpack_z(c, j);
+                    dilithium::ntt(c, z, xch, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) zhat[j][r] = c[r];  // plain z-hat, < 17q
+                }
             }
             // hints: strict decoding (pack.go:113-141)
             {
@@ -824,24 +899,60 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
                 for (int r = 0; r < 4; r++) zhat[j][r] = (uint32_t)(lane + j + r);
         }
         const bool failed = __any(bad);
+        lap(2);
 
         // -------------------------- phases 2 and 3 --------------------------
         uint8_t *w1out = muw1_ws + item * G::MUW1 + 64;
+        // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane, fetched as two aligned
+        // dwords (the row is 4-byte aligned)
+        auto unpack_t1 = [&](uint32_t (&t)[4], int i) {
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + kq * PK_STRIDE + 32 + 320 * i);
+            const int b = 5 * lane, d = b >> 2;
+            const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = ((uint32_t)(v >> (10 * r)) & 0x3ffu) << dilithium::D;
+        };
+        auto hinted_w1 = [&](unsigned (&w1v)[4], const uint32_t (&w)[4], int i) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nidx = kyber::idx_l1(lane, r);
+                const uint32_t hbit = (hintbits[i * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
+                w1v[r] = dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
+            }
+        };
+        const int row0 = (SHARED || KEYED) ? 0 : g * G::STREAMS;
+        if constexpr (PAIR) {
+            static_assert(K % 2 == 0, "the paired form takes the rows two at a time");
+#pragma unroll 1
+            for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i += 2) {
+                uint32_t acc0[4], acc1[4], t0[4], t1[4], w0[4], w1[4];
+                mac_rows2<L>(acc0, acc1, irows, row0 + i * L, row0 + (i + 1) * L, zhat, lane);  // 2^-32 A z-hat, < 2q
+                unpack_t1(t0, i);
+                unpack_t1(t1, i + 1);
+                dilithium::relayout2<4, 1>(t0, t1, xch, xch1, lane);
+                dilithium::ntt2(t0, t1, z, xch, xch1, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    w0[r] = dilithium::fold(acc0[r] + 2 * Q - dilithium::mont32(t0[r], chat[r]));  // as below
+                    w1[r] = dilithium::fold(acc1[r] + 2 * Q - dilithium::mont32(t1[r], chat[r]));
+                }
+                dilithium::invntt2<dilithium::INV256_RR>(w0, w1, z, xch, xch1, lane);
+                unsigned v0[4], v1[4];
+                hinted_w1(v0, w0, i);
+                hinted_w1(v1, w1, i + 1);
+                mlkem::stage_bits_l1<G::W1BITS>(xch, v0, lane);
+                mlkem::stage_bits_l1<G::W1BITS>(xch1, v1, lane);
+                mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), xch, lane, false);
+                mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * (i + 1)), xch1, lane, false);
+            }
+        } else {
 #pragma unroll 1
         for (int i = 0; i < ((ABLATE & 4) ? 0 : K); i++) {
             uint32_t acc[4] = {0, 0, 0, 0};
-            mac_rows<L>(acc, irows, (ABLATE & 16) ? 0 : ((SHARED || KEYED) ? 0 : g * G::STREAMS) + i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
+            mac_rows<L>(acc, irows, (ABLATE & 16) ? 0 : row0 + i * L, zhat, lane);  // 2^-32 A z-hat, < 2q
             uint32_t t[4], w[4];
-            {
-                // t1 (pack.go:52-66, 10-bit fields): coefficients 4 lane .. 4 lane + 3 are the 5 bytes at 5 lane,
-                // fetched as two aligned dwords (the row is 4-byte aligned), then moved to the NTT's input layout
-                const uint32_t *tp = reinterpret_cast<const uint32_t *>(pk + kq * PK_STRIDE + 32 + 320 * i);
-                const int b = 5 * lane, d = b >> 2;
-                const uint64_t v = (((uint64_t)tp[d + 1] << 32) | tp[d]) >> (8 * (b & 3));
-#pragma unroll
-                for (int r = 0; r < 4; r++) t[r] = ((uint32_t)(v >> (10 * r)) & 0x3ffu) << dilithium::D;
-                dilithium::relayout<4, 1>(t, xch, lane);
-            }
+            unpack_t1(t, i);
+            dilithium::relayout<4, 1>(t, xch, lane);  // to the NTT's input layout
             dilithium::ntt(t, z, xch, lane);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -850,18 +961,23 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
             }
             dilithium::invntt<dilithium::INV256_RR>(w, z, xch, lane);  // both terms carried 2^-32
             unsigned w1v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int nidx = kyber::idx_l1(lane, r);
-                const uint32_t hbit = (hintbits[i * 8 + (nidx >> 5)] >> (nidx & 31)) & 1;
-                w1v[r] = dilithium::use_hint<P::GAMMA2>(dilithium::csubq(w[r]), hbit);
-            }
+            hinted_w1(w1v, w, i);
             mlkem::stage_bits_l1<G::W1BITS>(xch, w1v, lane);
             mlkem::store_staged<G::W1BITS>(reinterpret_cast<uint32_t *>(w1out + G::W1SZ * i), xch, lane, false);
         }
+        }
         if (lane == 0 && failed) fail_ws[item] = 1;
+        if constexpr (CLK) { lap(3); clk[4]++; }
     }
   }
+    if constexpr (CLK) {
+        lap(0);  // (the last, empty-handed ticket)
+        if (lane == 0) {
+            uint64_t *prof = reinterpret_cast<uint64_t *>(const_cast<uint32_t *>(key_rows)) + (size_t)blockIdx.x * 5;
+#pragma unroll
+            for (int k = 0; k < 5; k++) prof[k] = clk[k];
+        }
+    }
 }
 
 // Key tables: ExpandA of every table entry, once.  Single-wave workgroups, IT entries each; entry e gets rows

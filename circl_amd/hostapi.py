@@ -318,6 +318,64 @@ class KeyTable:
         """circl_hip_keytable_set_coalesce: small calls of concurrent callers through this table share launches (0 = off)"""
         nat.check(nat.lib().circl_hip_keytable_set_coalesce(self.handle, max_items, max_wait_us), "keytable_set_coalesce")
 
+    # ---- the asynchronous form (circl_hip_keytable_async_start / *_table_submit / circl_hip_poll / circl_hip_wait) ----
+    def async_start(self, max_items, max_wait_us=0, eventfd=False):
+        nat.check(nat.lib().circl_hip_keytable_async_start(self.handle, max_items, max_wait_us, 1 if eventfd else 0), "keytable_async_start")
+
+    def async_stop(self):
+        """CIRCL_HIP_OK, or CIRCL_HIP_EBUSY (returned, not raised) while calls are inside the table"""
+        return nat.lib().circl_hip_keytable_async_stop(self.handle)
+
+    def eventfd(self, replica=0):
+        return nat.lib().circl_hip_keytable_eventfd(self.handle, replica)
+
+    def submit_encaps(self, m, ct, ss, st, key_idx=None):
+        """Returns (rc, ticket); the output arrays (caller-owned, C-contiguous uint8) are filled once the ticket is done."""
+        import ctypes as C
+        m = _u8(m, 32)
+        n = len(m)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_mlkem_encaps_table_submit(self.handle, self._kidx(key_idx, n), _p(m), _p(ct), _p(ss), _p(st), n, C.byref(t))
+        return rc, t.value
+
+    def submit_decaps(self, ct, ss, st, key_idx=None):
+        import ctypes as C
+        _, _, CT = KEM_SIZES[self.param]
+        ct = _u8(ct, CT)
+        n = len(ct)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_mlkem_decaps_table_submit(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n, C.byref(t))
+        return rc, t.value
+
+    def submit_verify(self, sigs, msgs, ok, ctxs=None, key_idx=None):
+        import ctypes as C
+        _, SIG = DSA_SIZES[self.param]
+        sigs = _u8(sigs, SIG)
+        n = len(sigs)
+        mb, mo = _blob(msgs)
+        cb, cofs = _blob(ctxs) if ctxs is not None else (None, None)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_mldsa_verify_table_submit(self.handle, self._kidx(key_idx, n), _p(sigs), _p(mb), _p(mo), _p(cb) if cb is not None else None,
+                                                           _p(cofs) if cofs is not None else None, _p(ok), n, C.byref(t))
+        return rc, t.value
+
+    def poll(self, tickets):
+        """-> list of states (1 done, 0 pending, < 0 failed)"""
+        t = np.asarray(tickets, np.uint64)
+        st = np.zeros(len(t), np.int8)
+        nat.lib().circl_hip_poll(self.handle, _p(t), len(t), _p(st))
+        return [int(x) for x in st]
+
+    def wait(self, ticket, timeout_us=-1):
+        return nat.lib().circl_hip_wait(self.handle, int(ticket), int(timeout_us))
+
+    def try_close(self):
+        """circl_hip_keytable_close: 0 and the table is gone, or CIRCL_HIP_EBUSY"""
+        rc = nat.lib().circl_hip_keytable_close(self.handle)
+        if rc == 0:
+            self.handle = None
+        return rc
+
     def coalesce_stats(self):
         """(calls, items, launches) that went through the table's coalescer"""
         import ctypes as C

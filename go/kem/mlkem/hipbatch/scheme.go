@@ -186,10 +186,12 @@ func rows(flat []byte, size int) [][]byte {
 type ResidentPublicKey struct {
 	kem.PublicKey
 	table *ResidentTable
+	rx    *reactor // serving.go: the goroutine that owns the table's asynchronous queue (nil: none)
 }
 type ResidentPrivateKey struct {
 	kem.PrivateKey
 	table *ResidentTable
+	rx    *reactor
 }
 
 // ResidentPublicKey parses pk on `device` (ML-KEM only: round-3 Kyber has no table route).
@@ -202,7 +204,7 @@ func (s *Scheme) ResidentPublicKey(pk kem.PublicKey, device int) (*ResidentPubli
 	if err != nil {
 		return nil, err
 	}
-	return &ResidentPublicKey{pk, t}, nil
+	return &ResidentPublicKey{pk, t, nil}, nil
 }
 
 // ResidentPrivateKey parses sk on `device`; kem.ErrPrivKey if its stored hash does not match (kyber.go:219-228).
@@ -220,7 +222,7 @@ func (s *Scheme) ResidentPrivateKey(sk kem.PrivateKey, device int) (*ResidentPri
 		t.Close()
 		return nil, errs[0]
 	}
-	return &ResidentPrivateKey{sk, t}, nil
+	return &ResidentPrivateKey{sk, t, nil}, nil
 }
 
 // EncapsulateBatch is len(seeds)/EncapsulationSeedSize times EncapsulateDeterministically to this key.
@@ -244,5 +246,17 @@ func (k *ResidentPrivateKey) DecapsulateBatch(cts []byte) (sss []byte, err error
 }
 
 // Close releases the device-side halves (also done by the tables' finalizers).
-func (k *ResidentPublicKey) Close()  { k.table.Close() }
-func (k *ResidentPrivateKey) Close() { k.table.Close() }
+func (k *ResidentPublicKey) Close() {
+	if k.rx != nil {
+		k.rx.stop()
+		k.rx = nil
+	}
+	k.table.Close()
+}
+func (k *ResidentPrivateKey) Close() {
+	if k.rx != nil {
+		k.rx.stop()
+		k.rx = nil
+	}
+	k.table.Close()
+}

@@ -14,18 +14,21 @@ import "C"
 // in the reference (kem/mlkem/mlkem768/kyber.go:347-386; hpke/algs.go:283-285 picks its kem.Scheme from a table).
 //
 // Its key objects are CIRCL's own with a GPU-side counterpart attached: UnmarshalBinaryPublicKey / UnmarshalBinaryPrivateKey /
-// DeriveKeyPair / GenerateKeyPair parse the key ONCE on the device (a one-entry resident table with cross-caller coalescing
-// switched on: circl_hip_keytable_set_coalesce), and every later single operation on that object is one row of whatever
-// launch the concurrent callers of the same key share.  One caller alone pays a launch and a wait per call (tens of
-// microseconds); hundreds of goroutines on one server key share launches.  A key object of the plain CIRCL scheme is
-// accepted everywhere too and takes CIRCL's own path.  Results are identical either way.
+// DeriveKeyPair / GenerateKeyPair parse the key ONCE on the device (a one-entry resident table with an ASYNCHRONOUS queue:
+// circl_hip_keytable_async_start) and start the key's reactor (reactor.go): ONE goroutine that submits and polls.  Every later
+// single operation on that object hands its request to the reactor and PARKS ON A CHANNEL -- in the Go scheduler, not in a
+// blocking cgo call: round 5's form held one OS thread per outstanding call (a goroutine inside cgo keeps its M), ten thousand
+// concurrent handshakes were ten thousand sleeping threads and 13 us of host CPU per call (profiles/r05_concurrent_final.txt);
+// now the number of threads does not depend on the number of callers, and the requests that pile up while a launch runs share the
+// next one.  One caller alone pays a launch and a completion per call (tens of microseconds).  A key object of the plain CIRCL
+// scheme is accepted everywhere too and takes CIRCL's own path.  Results are identical either way.
 //
-//	s := hipbatch.Serving("ML-KEM-768", 0)          // device 0; hipbatch.AllDevices replicates every key object
-//	sk, _ := s.UnmarshalBinaryPrivateKey(dkBytes)    // parsed on the GPU once
-//	ss, _ := s.Decapsulate(sk, ct)                   // from any number of goroutines: coalesced
+//	s := hipbatch.Serving("ML-KEM-768", 0)          // device 0
+//	sk, _ := s.UnmarshalBinaryPrivateKey(dkBytes)    // parsed on the GPU once; its reactor starts
+//	ss, _ := s.Decapsulate(sk, ct)                   // from any number of goroutines: each parks until its row is back
 //
-// NOT COMPILED IN THIS REPOSITORY'S CI (no Go toolchain in the build image); tests/cgo_shape_test.c (coalesced_single_calls)
-// and tests/test_gpu_coalesce.py drive the same C entry points in the same shape.
+// NOT COMPILED IN THIS REPOSITORY'S CI (no Go toolchain in the build image); tests/cgo_shape_test.c (async_submit_poll)
+// and tests/test_gpu_async.py drive the same C entry points in the same shape.
 
 import (
 	"crypto/rand"
@@ -51,11 +54,12 @@ type ServingScheme struct {
 	Scheme
 	device   int
 	maxItems int
-	maxWait  time.Duration
+	window   int
 }
 
-// Serving returns the serving form of an ML-KEM scheme of CIRCL's registry, or nil.  Batches hold up to 256 items and are
-// never delayed (SetBatching changes both).
+// Serving returns the serving form of an ML-KEM scheme of CIRCL's registry, or nil.  Device batches hold up to 2048 items, a key's
+// reactor keeps up to 4096 requests in flight (SetBatching changes both).  device must name ONE device (a reactor owns one
+// queue); for several GPUs make one ServingScheme per device and spread the key objects.
 func Serving(name string, device int) *ServingScheme {
 	s := Wrap(schemes.ByName(name))
 	if s == nil {
@@ -64,12 +68,15 @@ func Serving(name string, device int) *ServingScheme {
 	if _, ok := params[s.Name()]; !ok { // round-3 Kyber has no resident tables
 		return nil
 	}
-	return &ServingScheme{Scheme: *s, device: device, maxItems: 256}
+	if device < 0 {
+		return nil
+	}
+	return &ServingScheme{Scheme: *s, device: device, maxItems: 2048, window: 4096}
 }
 
-// SetBatching applies to key objects made afterwards.
-func (s *ServingScheme) SetBatching(maxItems int, maxWait time.Duration) {
-	s.maxItems, s.maxWait = maxItems, maxWait
+// SetBatching applies to key objects made afterwards: the largest device batch and the requests one key keeps in flight.
+func (s *ServingScheme) SetBatching(maxItems, window int) {
+	s.maxItems, s.window = maxItems, max(window, 1)
 }
 
 func (s *ServingScheme) public(pk kem.PublicKey) (kem.PublicKey, error) {
@@ -77,7 +84,7 @@ func (s *ServingScheme) public(pk kem.PublicKey) (kem.PublicKey, error) {
 	if err != nil {
 		return nil, err
 	}
-	if err = r.table.SetCoalesce(s.maxItems, s.maxWait); err != nil {
+	if r.rx, err = r.table.startReactor(s.maxItems, s.window); err != nil {
 		r.Close()
 		return nil, err
 	}
@@ -89,7 +96,7 @@ func (s *ServingScheme) private(sk kem.PrivateKey) (kem.PrivateKey, error) {
 	if err != nil {
 		return nil, err
 	}
-	if err = r.table.SetCoalesce(s.maxItems, s.maxWait); err != nil {
+	if r.rx, err = r.table.startReactor(s.maxItems, s.window); err != nil {
 		r.Close()
 		return nil, err
 	}
@@ -142,7 +149,8 @@ func (s *ServingScheme) Encapsulate(pk kem.PublicKey) (ct, ss []byte, err error)
 	return s.EncapsulateDeterministically(pk, seed)
 }
 
-// EncapsulateDeterministically: one row of the key's coalesced batch when pk is one of this scheme's key objects.
+// EncapsulateDeterministically: one row of whatever launch the key's reactor submits next, when pk is one of this scheme's key
+// objects; the calling goroutine parks on a channel meanwhile (reactor.go).
 func (s *ServingScheme) EncapsulateDeterministically(pk kem.PublicKey, seed []byte) (ct, ss []byte, err error) {
 	r, ok := pk.(*ResidentPublicKey)
 	if !ok {
@@ -151,7 +159,11 @@ func (s *ServingScheme) EncapsulateDeterministically(pk kem.PublicKey, seed []by
 	if len(seed) != s.EncapsulationSeedSize() {
 		return nil, nil, kem.ErrSeedSize
 	}
-	return r.EncapsulateBatch(seed)
+	if r.rx == nil { // a resident key made without a reactor (Scheme.ResidentPublicKey): the blocking call
+		return r.EncapsulateBatch(seed)
+	}
+	rp := r.rx.do(seed)
+	return rp.ct, rp.ss, rp.err
 }
 
 func (s *ServingScheme) Decapsulate(sk kem.PrivateKey, ct []byte) ([]byte, error) {
@@ -162,7 +174,11 @@ func (s *ServingScheme) Decapsulate(sk kem.PrivateKey, ct []byte) ([]byte, error
 	if len(ct) != s.CiphertextSize() {
 		return nil, kem.ErrCiphertextSize
 	}
-	return r.DecapsulateBatch(ct)
+	if r.rx == nil {
+		return r.DecapsulateBatch(ct)
+	}
+	rp := r.rx.do(ct)
+	return rp.ss, rp.err
 }
 
 // SetCallCoalescing is the same switch for keys that come WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the

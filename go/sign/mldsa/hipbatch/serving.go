@@ -12,9 +12,11 @@ import "C"
 // ServingScheme is a sign.Scheme for UNMODIFIED callers: code that holds a sign.Scheme value and calls Sign / Verify with one key
 // and one message from whatever goroutine owns the connection (sign/sign.go:48-94; sign/mldsa/mldsa65/dilithium.go:283-343).
 // UnmarshalBinaryPublicKey / UnmarshalBinaryPrivateKey / DeriveKey / GenerateKey return CIRCL's own key objects with a GPU-side
-// counterpart attached -- a one-entry resident table (A, tr; for a private key also the NTT-domain s1, s2, t0) with cross-caller
-// coalescing switched on (circl_hip_keytable_set_coalesce) -- and every later Sign / Verify on such an object is one row of whatever
-// launch the concurrent callers of the same key share.  A key object of the plain CIRCL scheme takes CIRCL's own path.  Signing is
+// counterpart attached -- a one-entry resident table (A, tr; for a private key also the NTT-domain s1, s2, t0).  A PUBLIC key's
+// table gets an asynchronous queue and a reactor goroutine (reactor.go): Verify hands its request over and parks on a channel --
+// no OS thread sleeps inside cgo per outstanding call -- and the requests that pile up while a launch runs share the next one.  A
+// PRIVATE key's table keeps cross-caller coalescing of blocking calls (circl_hip_keytable_set_coalesce: the library has no submit
+// form for signing).  A key object of the plain CIRCL scheme takes CIRCL's own path.  Signing is
 // deterministic here exactly when it is in CIRCL (sign.SignatureOpts carries no randomness: dilithium.go:283-303 signs hedged only
 // through SignTo with randomized = true, which this wrapper does not offer).
 //
@@ -46,13 +48,20 @@ func (r *ResidentKeys) SetCoalesce(maxItems int, maxWait time.Duration) error {
 type ServingPublicKey struct {
 	sign.PublicKey
 	table *ResidentKeys
+	rx    *reactor
 }
 type ServingPrivateKey struct {
 	sign.PrivateKey
 	table *ResidentKeys
 }
 
-func (k *ServingPublicKey) Close()  { k.table.Close() }
+func (k *ServingPublicKey) Close() {
+	if k.rx != nil {
+		k.rx.stop()
+		k.rx = nil
+	}
+	k.table.Close()
+}
 func (k *ServingPrivateKey) Close() { k.table.Close() }
 
 type ServingScheme struct {
@@ -85,11 +94,12 @@ func (s *ServingScheme) public(pk sign.PublicKey) (sign.PublicKey, error) {
 	if err != nil {
 		return nil, err
 	}
-	if err = t.SetCoalesce(s.maxItems, s.maxWait); err != nil {
+	rx, err := t.startReactor(max(s.maxItems, 8), 1024)
+	if err != nil {
 		t.Close()
 		return nil, err
 	}
-	return &ServingPublicKey{pk, t}, nil
+	return &ServingPublicKey{pk, t, rx}, nil
 }
 
 func (s *ServingScheme) private(sk sign.PrivateKey) (sign.PrivateKey, error) {
@@ -176,6 +186,9 @@ func (s *ServingScheme) Verify(pk sign.PublicKey, message, signature []byte, opt
 	if len(signature) != s.SignatureSize() || len(context(opts)) > 255 {
 		return false
 	}
-	res, err := r.table.Verify(nil, [][]byte{message}, signature, []string{context(opts)})
-	return err == nil && res[0]
+	if r.rx == nil {
+		res, err := r.table.Verify(nil, [][]byte{message}, signature, []string{context(opts)})
+		return err == nil && res[0]
+	}
+	return r.rx.verify(message, signature, context(opts))
 }

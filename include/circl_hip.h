@@ -49,6 +49,8 @@ extern "C" {
 #define CIRCL_HIP_EHIP (-3)     /* a HIP runtime call failed (see circl_hip_last_error) */
 #define CIRCL_HIP_ENOMEM (-4)
 #define CIRCL_HIP_EWORKSPACE (-5) /* workspace too small / misaligned pointer */
+#define CIRCL_HIP_EBUSY (-6)    /* the object has calls in flight (circl_hip_keytable_set_coalesce, _async_start / _stop, _close) */
+#define CIRCL_HIP_EAGAIN (-7)   /* a *_submit call found every batch of the queue busy: poll / wait for a ticket, then submit again */
 
 #define CIRCL_HIP_ALL_DEVICES (-1)
 
@@ -236,19 +238,69 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
  * as soon as the device has room for another batch -- so a batch holds exactly the calls that arrived while the previous ones ran,
  * nothing is delayed when the table is idle -- or after max_wait_us microseconds if that is not 0; each caller returns with its own
  * rows.  Results are byte for byte those of the same calls made one by one (same kernels; items are independent).
- *   max_items: largest batch (2 .. 8192; 0 switches coalescing off).  Set it before the table is shared between threads (the
- *   setter itself is not synchronised with calls in flight).  A replicated table coalesces per replica; its small calls (<= 1024
+ *   max_items: largest batch (2 .. 8192; 0 switches coalescing off).  CIRCL_HIP_EBUSY (nothing changed) while calls are in flight
+ *   through the table: set it before the table is shared, or retry.  A replicated table coalesces per replica; its small calls (<= 1024
  *   items) go to one replica each, round-robin.  circl_hip_keytable_coalesce_stats: calls and items that joined batches and the
  *   launches they became (items / launches = mean batch).  Served today: circl_hip_mlkem_encaps_table, circl_hip_mlkem_decaps_table,
  *   circl_hip_mldsa_verify_table, circl_hip_mldsa_sign_table / _sign_table_keyed (a server signing one handshake transcript per call). */
 int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us);
+/* Lifetime under concurrent callers: circl_hip_keytable_set_coalesce, circl_hip_keytable_async_start / _stop and circl_hip_keytable_close
+ * return CIRCL_HIP_EBUSY -- and change nothing -- while a call is inside the table or one of its batches is open or running; nothing is
+ * ever freed under a caller.  circl_hip_keytable_close(table) = circl_hip_keytable_free with that verdict (CIRCL_HIP_OK: freed);
+ * circl_hip_keytable_free itself waits up to two seconds for the calls inside to return and, should they not, marks the table dead
+ * (later calls get CIRCL_HIP_EPARAM) and LEAKS its memory instead of freeing it under them.
+ *
+ * ---- the ASYNCHRONOUS form: submit / poll, no sleeping thread per call ---------------------------------------------------------
+ * The blocking form above holds one OS thread per outstanding call (a goroutine inside a blocking cgo call holds an M: ten thousand
+ * concurrent handshakes, hpke/algs.go:283-285 or kem/hybrid/hybrid.go:95-99, would be ten thousand threads), and the sleep + wake of
+ * each of them is most of a coalesced call's host cost (profiles/r05_concurrent_final.txt: 7.6 of 13 us).  With
+ *   circl_hip_keytable_async_start(table, max_items, max_wait_us, want_eventfd)
+ * the table gets a QUEUE served by one library thread per device (the dispatcher): it closes the open batch whenever the device has
+ * room -- same group commit as above: a batch holds what arrived while its predecessors ran, nothing waits on an idle device unless
+ * max_wait_us says so -- launches it, copies the finished batch's rows STRAIGHT INTO THE SUBMITTERS' OUTPUT BUFFERS, and publishes the
+ * batch's completion.  Served: circl_hip_mlkem_encaps_table_submit (public ML-KEM table), circl_hip_mlkem_decaps_table_submit (private
+ * ML-KEM table), circl_hip_mldsa_verify_table_submit (ML-DSA public-key table).
+ *   *_submit(...same arrays as the blocking call..., n, &ticket): copies the n <= max_items / 4 items' inputs into the open batch, notes
+ *       the output pointers and returns AT ONCE: CIRCL_HIP_OK and a ticket; CIRCL_HIP_EAGAIN when every batch of the queue is busy
+ *       (nothing was taken: poll, then submit again); CIRCL_HIP_EPARAM for what the blocking call rejects (a NULL required input, a
+ *       key index >= nkeys, an unsupported context) or a table without a queue.  The output buffers (and nothing else: inputs are
+ *       copied) must stay valid and untouched until the ticket is done.  Results are byte for byte those of the blocking calls; per-
+ *       item verdicts (status / ok rows, a bad decapsulation-key entry, a non-canonical public key) arrive in the rows as always.
+ *   circl_hip_poll(table, tickets, n, state): state[i] = 1 done, 0 pending, < 0 the ticket's batch failed (a CIRCL_HIP_E* code; its
+ *       output rows were zeroed: no shared secret, ok = 0) or the ticket is not one of this table's (CIRCL_HIP_EPARAM); returns how
+ *       many are not pending.  One atomic load per ticket, no lock, no system call.  Tickets of one queue complete in the order
+ *       they were issued, so a host that keeps its outstanding tickets in a FIFO only ever needs to look at the head.
+ *   circl_hip_wait(table, ticket, timeout_us): blocks the calling thread until the ticket is done (returns its state) or timeout_us
+ *       microseconds passed (returns 0); timeout_us < 0: no limit.  ONE thread per device is all a host needs to block.
+ *   circl_hip_keytable_eventfd(table, replica): with want_eventfd != 0 the queue owns an eventfd(2) (non-blocking, counter semantics)
+ *       that the dispatcher adds 1 to after every finished batch -- put it into the host's own epoll / kqueue set and call
+ *       circl_hip_poll when it becomes readable; -1 if the table has none.  replica: 0 for a one-device table, the logical device
+ *       for a replicated one (one queue and one dispatcher per replica; a submitted call goes to one replica, round-robin, and its
+ *       ticket says which: the top byte).
+ *   circl_hip_keytable_async_stop(table): flushes and finishes every submitted call, stops the dispatchers, frees the queues
+ *       (CIRCL_HIP_EBUSY while a call is inside a *_submit); circl_hip_keytable_free does the same on the way.
+ * The blocking *_table calls keep working on such a table (they submit and wait), so one table can serve both kinds of caller. */
+int circl_hip_keytable_close(circl_hip_keytable *table);
+int circl_hip_keytable_async_start(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us, int want_eventfd);
+int circl_hip_keytable_async_stop(circl_hip_keytable *table);
+int circl_hip_keytable_eventfd(const circl_hip_keytable *table, int replica);
+int circl_hip_mlkem_encaps_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *m, uint8_t *ct, uint8_t *ss,
+                                        uint8_t *status, size_t n, uint64_t *ticket);
+int circl_hip_mlkem_decaps_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                        size_t n, uint64_t *ticket);
+int circl_hip_mldsa_verify_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob,
+                                        const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n,
+                                        uint64_t *ticket);
+int circl_hip_poll(const circl_hip_keytable *table, const uint64_t *tickets, size_t n, int8_t *state);
+int circl_hip_wait(const circl_hip_keytable *table, uint64_t ticket, int64_t timeout_us);
 /* The same for the entry points that take their keys WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the
  * client's ephemeral key share (kem/hybrid/hybrid.go:271-300 -> kem/mlkem/mlkem768/kyber.go:359-370): nothing resident to attach a
  * batch to.  circl_hip_set_coalesce(max_items, max_wait_us), process-wide, default off: small calls (<= max_items / 4 items) of
  * circl_hip_mlkem_encaps, circl_hip_mlkem_decaps, circl_hip_mldsa_verify / _verify_internal, circl_hip_hybrid_encaps and
  * circl_hip_hybrid_decaps from concurrent threads share launches per (entry point, parameter set, device); every item still brings
  * its own key, the bytes are those of the un-coalesced calls.  Call it once, before the threads start (later calls only affect
- * (entry point, parameter set, device) combinations that have not been used yet; 0 switches new joins off). */
+ * (entry point, parameter set, device) combinations that have not been used yet).  circl_hip_set_coalesce(0, 0) switches new joins off
+ * AND DRAINS: it returns once no call is inside any process-wide batch (CIRCL_HIP_EBUSY if that takes more than five seconds). */
 int circl_hip_set_coalesce(size_t max_items, uint32_t max_wait_us);
 int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *table, uint64_t *calls, uint64_t *items, uint64_t *launches);
 
@@ -556,6 +608,12 @@ int circl_hip_profile_read(int kernel, double *total_ms, uint64_t *launches);
  * (the cheapest class), with `waves_per_simd` (1..8; the Keccak probe needs ~110 VGPRs, so at most 4 are resident) wavefronts
  * on every SIMD of `device`.  About 10 ms of GPU time.  Either output may be NULL. */
 int circl_hip_profile_valu_probe(int device, int waves_per_simd, double *keccak_insts_per_s_per_simd, double *simple_insts_per_s_per_simd);
+/* Where the microseconds of ONE blocking coalesced call go (profiles/r06_one_call.txt): enable != 0 switches the time stamps on, 0 off,
+ * < 0 leaves the switch alone; out8 (may be NULL) receives the CLOCK_MONOTONIC nanoseconds of the calling thread's LAST blocking
+ * coalesced call: [0] entered, [1] rows reserved, [2] own inputs copied in, and -- for the call that led its batch, else 0 -- [3] batch
+ * closed (its turn, room on the device), [4] every caller's inputs in, [5] copies + kernels enqueued, [6] batch finished; [7] own results
+ * copied out. */
+int circl_hip_profile_call_stamps(int enable, uint64_t *out8);
 
 /* What the host-buffer pipeline's staging pools hold right now, over all (logical) devices: slots created, page-locked host bytes,
  * device bytes.  The pools grow on demand (up to CIRCL_HIP_HOST_SLOTS slots per device) and are never shrunk: after a process's largest

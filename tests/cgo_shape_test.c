@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "circl_hip.h"
 
@@ -257,6 +258,120 @@ static void coalesced_single_calls(void) {
     circl_hip_keytable_free(j.prv);
 }
 
+/* The asynchronous form as go/kem/mlkem/hipbatch/reactor.go drives it: request goroutines (threads here) hand their request to ONE
+ * device goroutine and park on a channel (a condition variable here); the device goroutine submits, polls the head of its ticket FIFO
+ * and wakes the owners.  cgo forbids C to keep a Go pointer after the call returns, so the OUTPUT rows that the library writes later
+ * live in a C-allocated arena (malloc here, C.malloc there); the INPUT rows are ordinary (unaligned) Go slices: copied before the
+ * submit returns. */
+enum { AQ_SLOTS = 32, AQ_PRODUCERS = 6, AQ_PER_PRODUCER = 50 };
+struct areq { size_t item; int decaps; int done; uint8_t ss[32]; uint8_t ct[1088]; };
+struct aq {
+    pthread_mutex_t mu; pthread_cond_t cv_req, cv_done;
+    struct areq *pending[AQ_SLOTS * 4]; size_t head, tail; int producers_left;
+    circl_hip_keytable *pub, *prv; const uint8_t *m, *ct, *ss; size_t CT, n;
+};
+static void *aq_producer(void *arg) {
+    struct aq *q = arg;
+    for (int r = 0; r < AQ_PER_PRODUCER; r++) {
+        struct areq rq = {((size_t)pthread_self() / 64 + (size_t)r * 13) % q->n, r % 3 == 0, 0, {0}, {0}};
+        pthread_mutex_lock(&q->mu);
+        q->pending[q->tail++ % (AQ_SLOTS * 4)] = &rq;
+        pthread_cond_signal(&q->cv_req);
+        while (!rq.done) pthread_cond_wait(&q->cv_done, &q->mu); /* parked: no thread sits inside the library for this request */
+        pthread_mutex_unlock(&q->mu);
+        CHECK(rq.done == 1);
+        CHECK(memcmp(rq.ss, q->ss + 32 * rq.item, 32) == 0);
+        if (!rq.decaps) CHECK(memcmp(rq.ct, q->ct + q->CT * rq.item, q->CT) == 0);
+    }
+    pthread_mutex_lock(&q->mu);
+    q->producers_left--;
+    pthread_cond_signal(&q->cv_req);
+    pthread_mutex_unlock(&q->mu);
+    return NULL;
+}
+static void async_submit_poll(void) {
+    const int param = 768;
+    const size_t n = 64, EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    uint8_t *seed = slice(64, 1), *ek = slice(EK, 3), *dk = slice(DK, 5), *m = slice(32 * n, 7), *ct = slice(CT * n, 9), *ss = slice(32 * n, 11);
+    fill(seed, 64, 91);
+    fill(m, 32 * n, 92);
+    CHECK(circl_hip_mlkem_keygen(param, seed, ek, dk, 1, 0) == 0);
+    CHECK(circl_hip_mlkem_encaps_shared(param, ek, m, ct, ss, NULL, n, 0) == 0);
+    struct aq q = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, AQ_PRODUCERS, NULL, NULL, m, ct, ss, CT, n};
+    CHECK(circl_hip_mlkem_keytable_new(param, 0, ek, 1, 0, NULL, &q.pub) == 0);
+    CHECK(circl_hip_mlkem_keytable_new(param, 1, dk, 1, 0, NULL, &q.prv) == 0);
+    uint64_t tk = 0;
+    CHECK(circl_hip_mlkem_encaps_table_submit(q.pub, NULL, m, ct, ss, NULL, 1, &tk) == CIRCL_HIP_EPARAM); /* no queue yet */
+    CHECK(circl_hip_keytable_async_start(q.pub, 64, 0, 1) == 0 && circl_hip_keytable_async_start(q.prv, 64, 0, 0) == 0);
+    CHECK(circl_hip_keytable_async_start(NULL, 64, 0, 0) == CIRCL_HIP_EPARAM);
+    const int efd = circl_hip_keytable_eventfd(q.pub, 0);
+    CHECK(efd >= 0 && circl_hip_keytable_eventfd(q.prv, 0) == -1);
+    /* the C arena of the in-flight requests' output rows, and who owns each slot */
+    uint8_t *arena_ct = malloc(CT * AQ_SLOTS), *arena_ss = malloc(32 * AQ_SLOTS), *arena_st = malloc(AQ_SLOTS);
+    struct areq *owner[AQ_SLOTS];
+    uint64_t ticket[AQ_SLOTS];
+    size_t s_head = 0, s_tail = 0; /* slots in flight: [s_head, s_tail), FIFO -- per queue tickets finish in issue order; two queues: poll both heads */
+    pthread_t th[AQ_PRODUCERS];
+    for (int t = 0; t < AQ_PRODUCERS; t++) CHECK(pthread_create(&th[t], NULL, aq_producer, &q) == 0);
+    size_t submitted = 0, finished = 0;
+    for (;;) {
+        /* take what is pending (never blocks while something is in flight) */
+        pthread_mutex_lock(&q.mu);
+        while (q.head == q.tail && s_head == s_tail && q.producers_left > 0) pthread_cond_wait(&q.cv_req, &q.mu);
+        struct areq *batch[AQ_SLOTS];
+        size_t nb = 0;
+        while (q.head != q.tail && (s_tail - s_head) + nb < AQ_SLOTS) batch[nb++] = q.pending[q.head++ % (AQ_SLOTS * 4)];
+        const int over = q.producers_left == 0 && q.head == q.tail;
+        pthread_mutex_unlock(&q.mu);
+        for (size_t k = 0; k < nb; k++) {
+            const size_t sl = s_tail % AQ_SLOTS;
+            struct areq *rq = batch[k];
+            int rc;
+            for (;;) {
+                if (rq->decaps) rc = circl_hip_mlkem_decaps_table_submit(q.prv, NULL, ct + CT * rq->item, arena_ss + 32 * sl, arena_st + sl, 1, &ticket[sl]);
+                else rc = circl_hip_mlkem_encaps_table_submit(q.pub, NULL, m + 32 * rq->item, arena_ct + CT * sl, arena_ss + 32 * sl, arena_st + sl, 1, &ticket[sl]);
+                if (rc != CIRCL_HIP_EAGAIN) break;
+                CHECK(s_head != s_tail); /* every batch busy means something of ours is in flight: wait for the oldest, try again */
+                CHECK(circl_hip_wait(owner[s_head % AQ_SLOTS]->decaps ? q.prv : q.pub, ticket[s_head % AQ_SLOTS], 1000000) == 1);
+            }
+            CHECK(rc == 0);
+            owner[sl] = rq;
+            s_tail++;
+            submitted++;
+        }
+        /* reap in issue order (the two tables are two queues: a head that is still pending stops the sweep; it is waited for below) */
+        while (s_head != s_tail) {
+            const size_t sl = s_head % AQ_SLOTS;
+            int8_t st = 0;
+            CHECK(circl_hip_poll(owner[sl]->decaps ? q.prv : q.pub, &ticket[sl], 1, &st) >= 0);
+            if (st == 0) {
+                if (nb) break; /* new work arrived this turn: look for more before blocking */
+                CHECK(circl_hip_wait(owner[sl]->decaps ? q.prv : q.pub, ticket[sl], 1000000) == 1);
+            } else {
+                CHECK(st == 1);
+            }
+            CHECK(arena_st[sl] == 0);
+            memcpy(owner[sl]->ss, arena_ss + 32 * sl, 32);
+            if (!owner[sl]->decaps) memcpy(owner[sl]->ct, arena_ct + CT * sl, CT);
+            pthread_mutex_lock(&q.mu);
+            owner[sl]->done = 1;
+            pthread_cond_broadcast(&q.cv_done);
+            pthread_mutex_unlock(&q.mu);
+            s_head++;
+            finished++;
+        }
+        if (over && s_head == s_tail) break;
+    }
+    for (int t = 0; t < AQ_PRODUCERS; t++) pthread_join(th[t], NULL);
+    CHECK(submitted == (size_t)AQ_PRODUCERS * AQ_PER_PRODUCER && finished == submitted);
+    uint64_t calls = 0, items = 0, launches = 0, v = 0;
+    CHECK(circl_hip_keytable_coalesce_stats(q.pub, &calls, &items, &launches) == 0 && calls >= 1 && items == calls && launches >= 1 && launches <= calls);
+    CHECK(read(efd, &v, sizeof v) == (ssize_t)sizeof v && v == launches); /* the eventfd counted the finished batches */
+    CHECK(circl_hip_keytable_async_stop(q.pub) == 0 && circl_hip_keytable_eventfd(q.pub, 0) == -1);
+    CHECK(circl_hip_keytable_close(q.pub) == 0 && circl_hip_keytable_close(q.prv) == 0);
+    free(arena_ct); free(arena_ss); free(arena_st);
+}
+
 int main(void) {
     CHECK(circl_hip_init() > 0);
     /* zero-length batches: nil slices become NULL pointers */
@@ -284,6 +399,7 @@ int main(void) {
     CHECK(circl_hip_keccak_f1600(NULL, 0, 24, 0) == 0);
     xof_shapes(0);
     coalesced_single_calls();
+    async_submit_poll();
     pthread_t th[3];
     for (intptr_t i = 0; i < 3; i++) CHECK(pthread_create(&th[i], NULL, thread_main, (void *)i) == 0);
     for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);

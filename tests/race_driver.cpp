@@ -90,6 +90,93 @@ struct Kem {
             CHECK(!memcmp(ss2, &ss[32 * at], 32 * k));
         }
     }
+    // The ASYNCHRONOUS form (circl_hip_keytable_async_start / *_table_submit / circl_hip_poll / circl_hip_wait): every caller thread is a
+    // reactor that keeps a window of submitted one-to-three-item calls outstanding on tables shared by all of them -- reservation word,
+    // records, staging rows, the dispatcher's completion copies into THIS thread's buffers: all cross-thread (host_coalesce.hip) -- and
+    // now and then makes a BLOCKING call through the same queue.
+    circl_hip_keytable *apub = nullptr, *aprv = nullptr;
+    void async_tables() {
+        const size_t nk = n < 9 ? n : 9;
+        CHECK(circl_hip_mlkem_keytable_new(param, 0, ek.data(), nk, CIRCL_HIP_ALL_DEVICES, nullptr, &apub) == 0);  // one queue + dispatcher per replica
+        CHECK(circl_hip_mlkem_keytable_new(param, 1, dk.data(), nk, 0, nullptr, &aprv) == 0);
+        CHECK(circl_hip_keytable_async_start(apub, 32, 0, 1) == 0);
+        CHECK(circl_hip_keytable_async_start(aprv, 16, 30, 0) == 0);
+        uint64_t tk = 0;
+        uint8_t junk[1568] = {0};
+        CHECK(circl_hip_mlkem_encaps_table_submit(apub, nullptr, nullptr, junk, junk, junk, 1, &tk) == CIRCL_HIP_EPARAM);  // a NULL required input
+        CHECK(circl_hip_mlkem_decaps_table_submit(aprv, nullptr, junk, junk, junk, 5, &tk) == CIRCL_HIP_EPARAM);           // more than max_items / 4
+    }
+    void async_calls(int caller, int count) const {
+        constexpr int W = 6;
+        struct Slot { uint64_t tk = 0; size_t at = 0, k = 0; bool enc = false, busy = false; uint8_t ct1[3 * 1568], ss1[3 * 32], st1[3]; };
+        std::vector<Slot> slots(W);
+        int head = 0, tail = 0, outstanding = 0, issued = 0;
+        auto reap = [&](bool block) {
+            while (outstanding > 0) {
+                Slot &sl = slots[head % W];
+                const circl_hip_keytable *tab = sl.enc ? apub : aprv;
+                int8_t state = 0;
+                CHECK(circl_hip_poll(tab, &sl.tk, 1, &state) == (state != 0));
+                if (state == 0) {
+                    if (!block) return;
+                    CHECK(circl_hip_wait(tab, sl.tk, 5000000) == 1);
+                } else {
+                    CHECK(state == 1);
+                }
+                if (sl.enc) CHECK(!memcmp(sl.ct1, &ct_t[CT * sl.at], CT * sl.k) && !memcmp(sl.ss1, &ss_t[32 * sl.at], 32 * sl.k) && !sl.st1[0]);
+                else CHECK(!memcmp(sl.ss1, &ss_t[32 * sl.at], 32 * sl.k));
+                sl.busy = false;
+                head++;
+                outstanding--;
+            }
+        };
+        while (issued < count) {
+            if (outstanding == W) reap(true);
+            Slot &sl = slots[tail % W];
+            sl.k = 1 + (size_t)((caller + issued) % 3);
+            sl.at = ((size_t)caller * 211 + (size_t)issued * 29) % (n - 3);
+            sl.enc = (caller + issued) % 2 == 0;
+            int rc;
+            if (sl.enc) rc = circl_hip_mlkem_encaps_table_submit(apub, &idx[sl.at], &m[32 * sl.at], sl.ct1, sl.ss1, sl.st1, sl.k, &sl.tk);
+            else rc = circl_hip_mlkem_decaps_table_submit(aprv, &idx[sl.at], &ct_t[CT * sl.at], sl.ss1, sl.st1, sl.k, &sl.tk);
+            if (rc == CIRCL_HIP_EAGAIN) { reap(true); if (!outstanding) std::this_thread::yield(); continue; }
+            CHECK(rc == 0);
+            sl.busy = true;
+            tail++;
+            outstanding++;
+            issued++;
+            reap(false);
+            if (issued % 7 == 3) {  // a blocking call through the asynchronous queue (submit + wait inside the library)
+                uint8_t ss2[32];
+                const size_t at = (sl.at + 1) % (n - 3);
+                CHECK(circl_hip_mlkem_decaps_table(aprv, &idx[at], &ct_t[CT * at], ss2, nullptr, 1) == 0);
+                CHECK(!memcmp(ss2, &ss_t[32 * at], 32));
+            }
+        }
+        reap(true);
+    }
+    // a setter on a table that callers are inside must answer CIRCL_HIP_EBUSY or succeed -- never free under them.
+    // `tog` is a third public table; one thread flips its coalescing (and, every few flips, an asynchronous queue) while the others call.
+    circl_hip_keytable *tog = nullptr;
+    void toggle_table() { CHECK(circl_hip_mlkem_keytable_new(param, 0, ek.data(), n < 9 ? n : 9, 0, nullptr, &tog) == 0); }
+    void toggle(int flips, std::atomic<int> &busy, std::atomic<int> &ok) const {
+        for (int k = 0; k < flips; k++) {
+            int rc;
+            if (k % 5 == 4) rc = circl_hip_keytable_async_start(tog, 16, 0, 0);
+            else rc = circl_hip_keytable_set_coalesce(tog, k % 2 ? 16 : 0, 0);
+            CHECK(rc == 0 || rc == CIRCL_HIP_EBUSY);
+            (rc ? busy : ok).fetch_add(1);
+            std::this_thread::yield();
+        }
+    }
+    void toggled_calls(int caller, int count) const {
+        uint8_t ct1[1568], ss1[32], st1[1];
+        for (int i = 0; i < count; i++) {
+            const size_t at = ((size_t)caller * 53 + (size_t)i * 13) % (n - 3);
+            CHECK(circl_hip_mlkem_encaps_table(tog, &idx[at], &m[32 * at], ct1, ss1, st1, 1) == 0);  // whichever path the table offers right now
+            CHECK(!memcmp(ct1, &ct_t[CT * at], CT) && !memcmp(ss1, &ss_t[32 * at], 32));
+        }
+    }
     void again(int device) const {
         std::vector<uint8_t> ek2(EK * n), dk2(DK * n), ct2(CT * n), ss2(32 * n), ss3(32 * n), st2(n);
         CHECK(circl_hip_mlkem_keygen(param, seed.data(), ek2.data(), dk2.data(), n, device) == 0);
@@ -147,6 +234,27 @@ struct Dsa {
             CHECK(ok1 == 1);
         }
     }
+    circl_hip_keytable *averifier = nullptr;
+    void async_tables() {
+        CHECK(circl_hip_mldsa_keytable_new(param, pk.data(), n < 5 ? n : 5, 0, &averifier) == 0);
+        CHECK(circl_hip_keytable_async_start(averifier, 8, 0, 0) == 0);
+    }
+    void async_calls(int caller, int count) const {  // two submitted verifications outstanding, ragged messages and contexts
+        uint64_t tk[2] = {0, 0};
+        uint8_t ok2[2] = {9, 9};
+        for (int i = 0; i < count; i++) {
+            const int s = i & 1;
+            if (i >= 2) { CHECK(circl_hip_wait(averifier, tk[s], 5000000) == 1); CHECK(ok2[s] == 1); }
+            const size_t at = ((size_t)caller * 41 + (size_t)i * 7) % n;
+            ok2[s] = 9;
+            int rc;
+            while ((rc = circl_hip_mldsa_verify_table_submit(averifier, &kidx[at], &sig_t[SIG * at], mblob.data(), &moff[at], cblob.data(), &coff[at], &ok2[s], 1, &tk[s])) ==
+                   CIRCL_HIP_EAGAIN)
+                std::this_thread::yield();
+            CHECK(rc == 0);
+        }
+        for (int s = 0; s < 2 && s < count; s++) { CHECK(circl_hip_wait(averifier, tk[s], 5000000) == 1); CHECK(ok2[s] == 1); }
+    }
     void again(int device) const {
         std::vector<uint8_t> sig2(SIG * n + 4), ok(n);
         CHECK(circl_hip_mldsa_sign(param, sk.data(), mblob.data(), moff.data(), cblob.data(), coff.data(), nullptr, sig2.data(), n, device) == 0);
@@ -195,6 +303,10 @@ int main(int argc, char **argv) {
     CHECK(circl_hip_keytable_set_coalesce(kem768.prv, 64, 50) == 0);
     CHECK(circl_hip_keytable_set_coalesce(dsa65.verifier, 8, 0) == 0);
     CHECK(circl_hip_set_coalesce(16, 0) == 0);
+    kem768.async_tables();
+    dsa65.async_tables();
+    kem768.toggle_table();
+    std::atomic<int> tog_busy{0}, tog_ok{0};
     const Hyb xwing(1, n_kem / 8 + 5);
     circl_hip_profile_enable(1);  // the profiling records are shared state too
     std::atomic<int> started{0};
@@ -213,6 +325,10 @@ int main(int argc, char **argv) {
                 }
                 kem768.small_calls(c, 24);
                 dsa65.small_calls(c, 6);
+                kem768.async_calls(c, 40);
+                dsa65.async_calls(c, 5);
+                if (c == 0) kem768.toggle(60, tog_busy, tog_ok);  // ... while the other callers are inside the toggled table
+                else kem768.toggled_calls(c, 30);
                 // an error path in the middle of everything: the Drain guard must give its slots back
                 uint8_t junk[64] = {0};
                 CHECK(circl_hip_mlkem_encaps(768, nullptr, junk, junk, junk, junk, 1, 0) == CIRCL_HIP_EPARAM);
@@ -221,6 +337,20 @@ int main(int argc, char **argv) {
         });
     }
     for (auto &t : th) t.join();
+    // the asynchronous queues: a ticket left outstanding is finished by the close (the dispatcher drains before it leaves)
+    {
+        uint64_t tk = 0;
+        uint8_t ct1[1568], ss1[32], st1[1] = {9};
+        CHECK(circl_hip_mlkem_encaps_table_submit(kem768.apub, &kem768.idx[1], &kem768.m[32], ct1, ss1, st1, 1, &tk) == 0);
+        CHECK(circl_hip_keytable_eventfd(kem768.apub, 0) >= 0 && circl_hip_keytable_eventfd(kem768.aprv, 0) == -1);
+        CHECK(circl_hip_keytable_close(kem768.apub) == 0);
+        CHECK(!memcmp(ct1, &kem768.ct_t[kem768.CT], kem768.CT) && st1[0] == 0);
+    }
+    CHECK(circl_hip_keytable_close(kem768.aprv) == 0);
+    CHECK(circl_hip_keytable_close(dsa65.averifier) == 0);
+    CHECK(circl_hip_keytable_close(kem768.tog) == 0);
+    CHECK(circl_hip_set_coalesce(0, 0) == 0);  // off AND drained: nobody is inside a process-wide batch any more
+    printf("race_driver: the toggled table answered %d setters with OK, %d with EBUSY\n", tog_ok.load(), tog_busy.load());
     circl_hip_keytable_free(kem768.pub);
     circl_hip_keytable_free(kem768.prv);
     circl_hip_keytable_free(dsa65.signer);

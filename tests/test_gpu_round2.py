@@ -11,6 +11,8 @@ import threading
 import numpy as np
 import pytest
 
+from benchrec import bench_record
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -384,12 +386,14 @@ print("proc ok")
 
 
 # ---- the bench harness -------------------------------------------------------------------------------------------
-def test_bench_py_small_run_emits_every_config():
+def test_bench_py_small_run_emits_every_config(tmp_path):
+    xf = str(tmp_path / "extras.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", str(1 << 14), "--no-pmc",
-                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+                        "--no-cpu-baseline", "--extras", "all", "--extras-file", xf], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    line, out = bench_record(r, xf)
+    assert line["parity"]["bit_exact_vs_oracle"] and line["parity"]["whole_batch"] and line["roofline"]["frac"] > 0
+    for k in ("decaps", "config3", "config4", "config5"):
+        assert line["configs"][k]["value"] > 0, k
     assert out["metric"].startswith("ML-KEM-768 encapsulations/sec") and out["steps"] == 3 and out["n_gpus"] == 1
     assert out["parity"]["bit_exact_vs_oracle"] and out["parity"]["ranks_failing"] == 0
     # one key per item, and the WHOLE batch went through the oracle (headline and config 4)
@@ -411,20 +415,19 @@ def test_bench_py_small_run_emits_every_config():
     assert out["roofline"]["frac"] > 0
 
 
-def test_bench_py_two_ranks_control_flow():
+def test_bench_py_two_ranks_control_flow(tmp_path):
     # bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU) cannot run on a 1-GPU box with
     # RCCL; with the process group on gloo and both ranks sharing the one device, everything else of the N > 1 path runs:
     # per-rank batches, barriers, max-over-ranks timing, whole-job aggregation, per-rank gathers, rank 0's JSON line
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    xf = str(tmp_path / "extras.json")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(1 << 13)],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines  # rank 0 only
-    out = json.loads(lines[0])
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", str(1 << 13),
+                        "--extras-file", xf], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    line, out = bench_record(r, xf)
+    assert len(line["per_rank"]["encaps_per_s"]) == 2 and line["strong"]["items_per_rank"] == [1 << 12] * 2 and "cpu_baseline" not in line
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["parity"]["ranks_failing"] == 0
     assert len(out["per_rank"]["encaps_per_s"]) == 2
     cfg = out["configs"]

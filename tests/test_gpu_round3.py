@@ -11,6 +11,8 @@ import sys
 
 import pytest
 
+from benchrec import bench_record
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,18 +65,17 @@ def test_config3_stated_shape_through_one_call():
 
 
 @pytest.mark.parametrize("mode", ["config3", "config5"])
-def test_bench_py_eight_ranks(mode):
+def test_bench_py_eight_ranks(mode, tmp_path):
     # bench.py --gpus 8 as the driver launches it, with the process group on gloo and the 8 ranks sharing this box's GPU(s):
     # per-rank batches, barriers, max-over-ranks timing, whole-job aggregation, per-rank gathers, ONE JSON line from rank 0
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
+    xf = str(tmp_path / "extras.json")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", str(1 << 12),
-                        "--mode", mode, "--no-pmc"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines
-    out = json.loads(lines[0])
+                        "--mode", mode, "--no-pmc", "--extras-file", xf], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    line, out = bench_record(r, xf)   # the contract line (< 6 KB) and the full record it names
+    assert line["n_gpus"] == 8 and line["config"]["mode"] == mode and line["value"] > 0
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["mode"] == mode and out["value"] > 0
     cfg = out["configs"]
     if mode == "config3":

@@ -11,23 +11,25 @@ import textwrap
 
 import pytest
 
+from benchrec import bench_record
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_py_launches_its_own_eight_ranks():
+def test_bench_py_launches_its_own_eight_ranks(tmp_path):
     # `python bench.py --gpus 8` WITHOUT a launcher: it must start 8 ranks itself and report n_gpus 8, with the strong-scaling
     # block (one batch of --batch items split n/G) beside the weak figure (ranks share this box's GPU, process group on gloo)
     env = dict(os.environ, CIRCL_DIST_BACKEND="gloo", CIRCL_BENCH_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    xf = str(tmp_path / "extras.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", str(1 << 12),
-                        "--mode", "encaps", "--no-extras", "--no-pmc"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines
-    out = json.loads(lines[0])
+                        "--mode", "encaps", "--no-extras", "--no-pmc", "--extras-file", xf], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    line, out = bench_record(r, xf)
+    # what the driver's SCALE run keeps of an 8-rank line: the strong block and the per-rank rates, inside the 6 KB
+    assert line["n_gpus"] == 8 and line["strong"]["items_per_rank"] == [512] * 8 and len(line["per_rank"]["encaps_per_s"]) == 8
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["parity"]["ranks_failing"] == 0
     st = out["strong"]
     assert st["scaling"] == "strong" and st["batch_total"] == 1 << 12 and st["items_per_rank"] == [512] * 8

@@ -92,9 +92,11 @@ def test_bench_cpu_baseline_leg_reports_both_ports():
     work = types.SimpleNamespace(param=768, ek=torch.from_numpy(ek), m=torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
     r = bench.cpu_baseline(work, budget_s=0.5)
     assert r["kind"] == "port" and r["unit"] == "encaps/s" and r["cores"] >= 1 and r["value"] > 0 and "sample" in r
-    v = r["vectorized"]
-    assert v["equals_scalar_oracle_on_first_items"][1] and v["shared_key"]["equals_scalar_oracle_on_first_items"][1]
-    assert r["value"] == v["value"] and r["shared_key"] == v["shared_key"]
+    # every figure ONCE (the vectorised block used to be printed twice): `value` / `per_thread` / `shared_key` are the vector
+    # port's, checked against the scalar oracle; the scalar oracle's own figures sit under `scalar_oracle`
+    assert "vectorized" not in r and "vectorized_failed" not in r
+    assert r["equals_scalar_oracle_on_first_items"][1] and r["shared_key"]["equals_scalar_oracle_on_first_items"][1]
+    assert r["isa"].startswith("AVX") and r["per_thread"] * r["cores"] == pytest.approx(r["value"])
     assert r["scalar_oracle"]["value"] > 0 and r["scalar_oracle"]["shared_key"]["value"] > 0
     assert r["value"] > r["scalar_oracle"]["value"]  # a vectorised port slower than the scalar restatement would be a bug
 

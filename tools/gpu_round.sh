@@ -10,6 +10,8 @@
 #   bench        bench.py exactly as the driver runs it (N = 1): the contract line + bench_extras.json        -> bench.json, bench_extras.json
 #   stats        rocprofv3 --kernel-trace --stats of a bench.py run                                            -> kernel_stats.txt
 #   verify_pmc   SQ / TCC counters of mldsa_verify_kernel<65> (2^18) and <87> (2^16)                         -> verify_pmc.txt
+#   verify_phases  phase ablation of mldsa_verify_kernel + the VALU probe under --pmc: per-phase cycles per instruction -> verify_phases.txt
+#   verify_clocks  the FULL verify kernel with the shader clock read at its phase boundaries (tools/bin/ablate_dsa clocks)  -> verify_clocks.txt
 #   tests        the whole GPU suite + smoke()                                                                  -> gpu_tests.log
 #   async        tools/bin/concurrent_bench --async: R reactor threads x W outstanding one-item requests       -> async.txt
 #   one_call     where the microseconds of ONE one-item table call go (library's own timestamps)               -> one_call.txt
@@ -64,6 +66,36 @@ step_verify_pmc() {
   note "verify_pmc"; cat "$OUT/verify_pmc.txt"
 }
 
+step_verify_phases() {
+  { hdr "tools/verify_phases.sh 65 18; tools/verify_phases.sh 87 16   (phase ablation of mldsa_verify_kernel under rocprofv3 --pmc, three counter groups)"
+    timeout 600 bash tools/verify_phases.sh 65 18 2>&1 | grep -v amdgpu.ids
+    timeout 600 bash tools/verify_phases.sh 87 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/verify_phases.txt"
+  note "verify_phases"; cat "$OUT/verify_phases.txt"
+}
+
+step_verify_clocks() {
+  { hdr "tools/bin/ablate_dsa clocks {65 18 | 87 16 }   (mldsa_verify_kernel<MODE, 64 | ...>: s_memtime at every phase boundary, summed per workgroup)"
+    timeout 300 tools/bin/ablate_dsa clocks 65 18 2>&1 | grep -v amdgpu.ids
+    timeout 300 tools/bin/ablate_dsa clocks 87 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/verify_clocks.txt"
+  note "verify_clocks"; cat "$OUT/verify_clocks.txt"
+}
+
+step_verify_variants() {
+  # build-time variants of the verify kernel, alternating on this box (VARIANTS=1 bash tools/build_tools.sh built them)
+  { hdr "for r in 1 2 3: tools/bin/ablate_dsa{,_prio0,_prio1,_prio3} clocks {65 18|87 16} 16; tools/bin/ablate_dsa_w5 clocks ... 20   (row 'full' of each)"
+    for r in 1 2 3; do
+      for pn in "65 18" "87 16"; do
+        for v in "" _prio0 _prio1 _prio3 _w5; do
+          [ -x tools/bin/ablate_dsa$v ] || continue
+          bpc=16; [ "$v" = _w5 ] && bpc=20
+          echo -n "round $r ML-DSA-$pn variant '${v:-base}' ($bpc per CU): "
+          timeout 120 tools/bin/ablate_dsa$v clocks $pn $bpc 2>&1 | grep "^full  " | cut -c1-230
+        done
+      done
+    done; } > "$OUT/verify_variants.txt"
+  note "verify_variants"; cat "$OUT/verify_variants.txt"
+}
+
 step_tests() {
   sha256sum circl_amd/libcirclhip.so > "$OUT/lib.sha256"
   { hdr "python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12; python -c 'import __graft_entry__ as g; g.smoke()'"
@@ -101,8 +133,13 @@ step_verify_ab() {
 }
 
 step_concurrent() {
-  { hdr "tools/bin/concurrent_bench <op> 256 0 1 2.0 1 16 64   (T blocking callers, one item each, coalesced)"
-    for op in encaps decaps; do timeout 120 tools/bin/concurrent_bench $op 256 0 1 2.0 1 16 64 2>&1 | grep -v amdgpu.ids; done; } > "$OUT/concurrent.txt"
+  { hdr "CIRCL_HIP_COALESCE_DONE={0,2} tools/bin/concurrent_bench <op> 256 0 1 2.0 1 16 64   (T blocking callers, one item each, coalesced; completion by stream sync / by a polled flag)"
+    for op in encaps decaps; do
+      for dm in 0 2; do
+        echo "-- $op, CIRCL_HIP_COALESCE_DONE=$dm"
+        CIRCL_HIP_COALESCE_DONE=$dm timeout 120 tools/bin/concurrent_bench $op 256 0 1 2.0 1 16 64 2>&1 | grep -v amdgpu.ids
+      done
+    done; } > "$OUT/concurrent.txt"
   note "concurrent"; cat "$OUT/concurrent.txt"
 }
 
