@@ -512,7 +512,7 @@ int circl_hip_hybrid_keygen(int scheme, const uint8_t *seed, uint8_t *pk, uint8_
         return run_pipeline(dev, cnt, {{seed + lo * s.seed, s.seed, true}}, {}, {{pk + lo * s.pk, s.pk}, {sk + lo * s.sk, s.sk, true}},
                             hybrid_ws_fn(scheme), hybrid_opts(scheme),
                             [&](Chunk &c) { return circl_hip_hybrid_keygen_dev(scheme, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
@@ -530,7 +530,7 @@ int circl_hip_hybrid_encaps(int scheme, const uint8_t *pk, const uint8_t *eseed,
             if (rc != kNotCoalesced) return rc;
         }
         return run_pipeline(dev, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n, int device) {
@@ -546,7 +546,7 @@ int circl_hip_hybrid_decaps(int scheme, const uint8_t *sk, const uint8_t *ct, ui
             if (rc != kNotCoalesced) return rc;
         }
         return run_pipeline(dev, cnt, ins, {}, outs, hybrid_ws_fn(scheme), hybrid_opts(scheme), launch);
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 static int check_idx(const uint32_t *key_idx, size_t n, size_t nkeys) {
@@ -572,7 +572,7 @@ int circl_hip_hybrid_encaps_table(const circl_hip_keytable *t, const uint32_t *k
                                 return circl_hip_hybrid_encaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                          c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
-    });
+    }, kHeavyOneDeviceMax);
 }
 int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n) {
     if (!t || t->magic != kKeytableMagic || t->family != 3 || !t->private_keys) return CIRCL_HIP_EPARAM;
@@ -590,7 +590,7 @@ int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *k
                                 return circl_hip_hybrid_decaps_table_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[0]) : nullptr, c.in[1], c.out[0], c.out[1],
                                                                          c.cnt, c.ws, c.ws_bytes, c.st);
                             });
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 }  // extern "C"

@@ -121,7 +121,7 @@ template <int MODE> size_t mldsa_table_bytes(size_t nkeys) {
 // ... and, with keys that are NOT parsed beforehand (tr and the matrix expansion inside the workgroup), up to 2^CIRCL_HIP_DSA_CHAIN_ITEM
 // (measured, tools/dsa_latency.py at 2^9: ML-DSA-44 142 against 224 us, ML-DSA-65 170 / 205, ML-DSA-87 296 / 218 -- so 2^9 up to K = 6, 2^8 beyond)
 inline size_t dsa_chain_batch(bool resident = true, int k = 6) {
-    static const int lg_r = env_int("CIRCL_HIP_DSA_CHAIN", 10, 0, 16), lg_i = env_int("CIRCL_HIP_DSA_CHAIN_ITEM", -1, -1, 16);
+    static const int lg_r = env_int("CIRCL_HIP_DSA_CHAIN", 11, 0, 16), lg_i = env_int("CIRCL_HIP_DSA_CHAIN_ITEM", -1, -1, 16);
     const int lg = resident ? lg_r : (lg_i >= 0 ? lg_i : (k <= 6 ? 9 : 8));
     return lg <= 0 ? size_t(0) : size_t(1) << lg;
 }
@@ -250,7 +250,7 @@ int mldsa_keygen_dev_impl(const uint8_t *seed32, uint8_t *pk, uint8_t *sk, size_
     uint8_t *scratch = reinterpret_cast<uint8_t *>(work) + 256;
     // small batches: the whole key generation of an item in ONE launch, a workgroup of K wavefronts per key (mldsa_keygen_chain_kernel);
     // up to 2^CIRCL_HIP_DSA_KEYGEN_CHAIN keys (0: never), and only while the workspace holds a scratch slice per IT items
-    static const size_t chain_keys = [] { const int lg = env_int("CIRCL_HIP_DSA_KEYGEN_CHAIN", 8, 0, 12); return lg <= 0 ? size_t(0) : size_t(1) << lg; }();
+    static const size_t chain_keys = [] { const int lg = env_int("CIRCL_HIP_DSA_KEYGEN_CHAIN", 9, 0, 12); return lg <= 0 ? size_t(0) : size_t(1) << lg; }();
     if (n <= chain_keys && mldsa_groups<MODE>(n) <= mldsa_scratch_blocks<MODE>(n)) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_KEYGEN, st);
         hipLaunchKernelGGL(mldsa_keygen_chain_kernel<MODE>, dim3((unsigned)n), dim3(DP<MODE>::K * 64), 0, st, seed32, es, pk, sk, scratch, n);
@@ -825,7 +825,7 @@ int mldsa_sign_host(int param, const uint8_t *sk, const uint8_t *msg_blob, const
                                 return mldsa_sign_dev_any(param, c.in[0], c.blob[0], c.off[0], c.blob[1], c.off[1], c.in[1], internal, c.out[0], c.cnt, c.ws,
                                                           c.ws_bytes, c.st, shared);
                             });
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 int mldsa_verify_host(int param, const uint8_t *pk, const uint8_t *sig, const uint8_t *msg_blob, const uint64_t *msg_off,
@@ -1080,7 +1080,7 @@ int circl_hip_mldsa_sign_table_keyed(const circl_hip_keytable *t, const uint32_t
                                 return circl_hip_mldsa_sign_table_keyed_dev(r, ki ? reinterpret_cast<const uint32_t *>(c.in[1]) : nullptr, c.blob[0], c.off[0], c.blob[1],
                                                                             c.off[1], c.in[0], 0, c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
                             });
-    });
+    }, kHeavyOneDeviceMax);
 }
 int circl_hip_mldsa_sign_table(const circl_hip_keytable *t, const uint8_t *msg_blob, const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off,
                                const uint8_t *rnd, uint8_t *sig, size_t n) {
@@ -1180,7 +1180,7 @@ int circl_hip_mldsa_keygen(int param, const uint8_t *seed32, uint8_t *pk, uint8_
         return run_pipeline(dev, cnt, {{seed32 + lo * 32, 32, true}}, {}, {{pk + lo * PK, PK}, {sk + lo * SK, SK, true}},
                             [&](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 14, true),
                             [&](Chunk &c) { return circl_hip_mldsa_keygen_dev(param, c.in[0], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); });
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 size_t circl_hip_mldsa_sign_workspace_size(int param, size_t n) { return mldsa_sign_ws_any(param, n); }

@@ -54,7 +54,7 @@ size_t kem_cache_bytes(size_t entries) { return up256((std::max<size_t>(entries,
 // Resident private keys: batches up to 2^CIRCL_HIP_KEM_CHAIN items (0 = never) decapsulate in one launch (mlkem_decaps_chain_kernel)
 // ... and encapsulate in one launch up to 2^CIRCL_HIP_KEM_CHAIN_ENCAPS items (mlkem_encaps_chain_kernel)
 size_t kem_chain_batch(bool decaps = true) {
-    static const int lg_d = env_int("CIRCL_HIP_KEM_CHAIN", 10, 0, 20), lg_e = env_int("CIRCL_HIP_KEM_CHAIN_ENCAPS", 10, 0, 20);
+    static const int lg_d = env_int("CIRCL_HIP_KEM_CHAIN", 11, 0, 20), lg_e = env_int("CIRCL_HIP_KEM_CHAIN_ENCAPS", 10, 0, 20);
     const int lg = decaps ? lg_d : lg_e;
     return lg <= 0 ? size_t(0) : size_t(1) << lg;
 }
@@ -562,8 +562,10 @@ int encaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     const size_t stride = key_idx ? (size_t)Gm::EK : 0;
     if (n <= kem_chain_batch(false)) {  // one launch, a wavefront per item: G -> PRF -> K-PKE.Encrypt (mlkem_encaps_chain_kernel)
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_ENCRYPT, st);
+        circl::TailFlag tail{nullptr, nullptr, 0};  // a coalesced batch's completion flag, raised by this launch's last workgroup (the kernel
+        take_tail_flag(&tail.flag, &tail.count, &tail.value);  // keeps everything in LDS: no workspace to wipe behind it)
         hipLaunchKernelGGL(mlkem_encaps_chain_kernel<K>, dim3((unsigned)n), dim3(64), 0, st, (const uint8_t *)t->d_keys, (size_t)Gm::EK, kx, key_rows, key_h, m, ct,
-                           ss, status, n);
+                           ss, status, n, tail);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -605,7 +607,9 @@ int decaps_table_dev_impl(const circl_hip_keytable *t, const uint32_t *key_idx, 
     // (mlkem_decaps_chain_kernel: J beside Decrypt -> G -> PRF -> re-encryption, one barrier, then the select)
     if (n <= kem_chain_batch()) {
         ProfScope ps(CIRCL_HIP_KERNEL_MLKEM_DECRYPT, st);
-        hipLaunchKernelGGL(mlkem_decaps_chain_kernel<K>, dim3((unsigned)n), dim3(128), 0, st, dk, (size_t)Gm::DK, kx, key_rows, key_status, ct, ss, status, n);
+        circl::TailFlag tail{nullptr, nullptr, 0};
+        take_tail_flag(&tail.flag, &tail.count, &tail.value);
+        hipLaunchKernelGGL(mlkem_decaps_chain_kernel<K>, dim3((unsigned)n), dim3(128), 0, st, dk, (size_t)Gm::DK, kx, key_rows, key_status, ct, ss, status, n, tail);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }

@@ -54,7 +54,7 @@ int circl_hip_x25519(const uint8_t *scalar, const uint8_t *point, uint8_t *out, 
         return run_pipeline(dev, cnt, ins, {}, {{out + lo * 32, 32, true}, {ok ? ok + lo : nullptr, 1}}, no_ws, opts, [&](Chunk &c) {
             return circl_hip_x25519_dev(c.in[0], point ? c.in[1] : nullptr, c.out[0], c.out[1], c.cnt, c.st);
         });
-    });
+    }, kHeavyOneDeviceMax);
 }
 
 }  // extern "C"

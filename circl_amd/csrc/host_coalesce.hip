@@ -49,6 +49,7 @@ namespace host {
 
 std::atomic<bool> g_stamps_on{false};
 thread_local CallStamps g_stamps;
+thread_local TailOffer g_tail_offer;
 
 namespace {
 
@@ -156,6 +157,7 @@ struct CoBatch {
     // (CIRCL_HIP_COALESCE_DONE): whoever waits for the batch polls host memory instead of calling into the runtime
     std::atomic<uint32_t> *flag = nullptr;
     uint32_t *flag_dev = nullptr;
+    unsigned *count_dev = nullptr;  // the workgroup counter of a launch that raises the flag itself (TailFlag): 256 bytes behind the workspace
     uint32_t gen = 0, uses = 0;
     bool wiped = false;       // the stream's finish kernel zeroes the device staging (completion mode 2): wipe_device has nothing to add
     bool zc = false;          // the launched batch ran zero-copy
@@ -307,7 +309,7 @@ int lay_out(Coalescer *co, const std::vector<HIn> &ins, const std::vector<HBlob>
     co->d_out_base = co->hin_bytes;
     co->ws_ofs = co->hin_bytes + co->hout_bytes;
     co->ws_cap = up256(ws_bytes(N));
-    co->d_bytes = co->ws_ofs + co->ws_cap;
+    co->d_bytes = co->ws_ofs + co->ws_cap + 256;
     const int nb = co->inflight_max + 3;  // one open, inflight_max running, two being read out
     for (int i = 0; i < nb; i++) {
         CoBatch *b = new CoBatch;
@@ -321,6 +323,8 @@ int lay_out(Coalescer *co, const std::vector<HIn> &ins, const std::vector<HBlob>
         b->flag = reinterpret_cast<std::atomic<uint32_t> *>(b->hout + co->flag_ofs);
         b->flag_dev = b->hout_dev ? reinterpret_cast<uint32_t *>(b->hout_dev + co->flag_ofs) : nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d), co->d_bytes));
+        b->count_dev = reinterpret_cast<unsigned *>(b->d + co->d_bytes - 256);
+        HIP_TRY(hipMemset(b->count_dev, 0, 256));
         HIP_TRY(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
         if (co->blocking) HIP_TRY(hipEventCreateWithFlags(&b->ev, hipEventBlockingSync | hipEventDisableTiming));
         if (co->async) {
@@ -438,7 +442,18 @@ int enqueue(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_b
         }
     }
     for (size_t k = 0; k < co->out_row.size(); k++) c.out.push_back(out_base + co->out_ofs[k]);
-    if (int rc = launch(c)) return rc;
+    // a zero-copy batch in completion mode 2 offers its flag to the launch itself (host_common.h TailOffer)
+    const bool offer = zc && co->done_mode == 2 && b->flag_dev;
+    g_tail_offer = offer ? TailOffer{b->flag_dev, b->count_dev, b->gen + 1, false} : TailOffer{};
+    const int lrc = launch(c);
+    const bool tail_taken = g_tail_offer.taken;
+    g_tail_offer = TailOffer{};
+    if (lrc) return lrc;
+    if (tail_taken) {  // the launch raises the flag; it ran on page-locked rows and left nothing secret in the workspace
+        b->gen++;
+        b->wiped = true;
+        return CIRCL_HIP_OK;
+    }
     for (size_t k = 0; k < co->out_row.size() && !zc; k++)
         if (co->out_row[k]) HIP_TRY(hipMemcpyAsync(b->hout + co->out_ofs[k], b->d + co->d_out_base + co->out_ofs[k], co->out_row[k] * cnt, hipMemcpyDeviceToHost, b->st));
     if (co->done_mode && b->flag_dev) {

@@ -212,6 +212,23 @@ int coalescer_state(const Coalescer *co, uint64_t seq);
 int coalescer_wait(Coalescer *co, uint64_t seq, int64_t timeout_us);
 bool coalescer_is_async(const Coalescer *co);
 int coalescer_eventfd(const Coalescer *co);
+// The completion flag of a coalesced batch written by the batch's OWN launch (keccak_dev.h TailFlag): enqueue() offers it here -- only for a
+// batch that runs zero-copy, so that nothing of the device staging is left to wipe -- around the table's launch call; a one-launch route
+// whose kernel keeps nothing secret in the workspace takes it (take_tail_flag) and passes it to its kernel.  Not taken: the coalescer
+// enqueues its finish kernel as before.  Thread-local: the offer is made and consumed on the launching thread, within one call.
+struct TailOffer {
+    uint32_t *flag = nullptr;
+    unsigned *count = nullptr;
+    uint32_t value = 0;
+    bool taken = false;
+};
+extern thread_local TailOffer g_tail_offer;
+inline bool take_tail_flag(uint32_t **flag, unsigned **count, uint32_t *value) {
+    if (!g_tail_offer.flag || g_tail_offer.taken) return false;
+    g_tail_offer.taken = true;
+    *flag = g_tail_offer.flag; *count = g_tail_offer.count; *value = g_tail_offer.value;
+    return true;
+}
 // circl_hip_profile_call_stamps: CLOCK_MONOTONIC nanoseconds of the stages of the calling thread's last BLOCKING coalesced call
 struct CallStamps { uint64_t enter = 0, reserved = 0, copied_in = 0, closed = 0, copies_in = 0, launched = 0, done = 0, copied_out = 0; };
 extern std::atomic<bool> g_stamps_on;
@@ -231,7 +248,13 @@ inline bool all_inputs_present(const std::vector<HIn> &ins) {
 }
 
 // Contiguous split of [0,n) over the visible devices, one host thread each (pinned to the device's NUMA node), no collective.
-int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn);
+// device = CIRCL_HIP_ALL_DEVICES: a call of at most `one_device_max` items goes to ONE device, round-robin (a thread and a launch per device
+// for a handful of items cost more than they return); a larger one is split contiguously, one host thread per device.  The default suits
+// operations of tens of microseconds per launch (ML-KEM, ML-DSA verification); the ones whose small batches are LATENCY-bound for
+// hundreds of microseconds -- ML-DSA signing's rounds, the X25519 ladder of the hybrids, key generation -- pass kHeavyOneDeviceMax, so
+// that a few hundred of them already use every device.
+constexpr size_t kOneDeviceMax = 1024, kHeavyOneDeviceMax = 64;
+int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn, size_t one_device_max = kOneDeviceMax);
 
 
 // host_runtime.hip: two library-owned non-blocking streams of device `dev` for calls that fork internally

@@ -77,8 +77,9 @@ uint8_t *pinned_device_ptr(void *p) {
 }
 size_t zero_copy_bytes() {
     // measured (profiles/r05_zerocopy.txt): against enqueued copies a resident-key call of 64 items takes 41 instead of 64 us, of 256
-    // items 64 instead of 90; at 1 MB the two meet, and beyond it kernels that read an input more than once (a decapsulation's dk) lose
-    static const size_t v = (size_t)env_int("CIRCL_HIP_ZEROCOPY_KB", 1024, 0, 1 << 20) << 10;
+    // items 64 instead of 90; the two meet between 2 and 4 MB (tools/route_check.py, profiles/r06_routes.txt: at 2 MB zero-copy still wins by
+    // 14-16 %, at 4 MB an encapsulation is level and a decapsulation, which reads its ciphertext twice, loses 38 %)
+    static const size_t v = (size_t)env_int("CIRCL_HIP_ZEROCOPY_KB", 2048, 0, 1 << 20) << 10;
     return v;
 }
 
@@ -861,7 +862,7 @@ int next_replica(int nreplica) {
 }
 
 // ---- shard ----------------------------------------------------------------------------------------
-int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn) {
+int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size_t cnt)> &fn, size_t one_device_max) {
     const int nd = ndev();
     if (nd <= 0) return CIRCL_HIP_ENODEV;
     if (device >= 0) return device < nd ? fn(device, size_t(0), n) : CIRCL_HIP_ENODEV;
@@ -869,7 +870,7 @@ int shard(size_t n, int device, const std::function<int(int dev, size_t lo, size
     if (nd == 1) return fn(0, size_t(0), n);
     // a SMALL call goes to ONE device, taken round-robin (keytable.h table_shard does the same): a thread and a launch per device
     // for a handful of items cost more than they return, and the contiguous split sent every one-item call to the last device
-    if (n <= kSmallTableCall) return fn(next_replica(nd), size_t(0), n);
+    if (n <= one_device_max) return fn(next_replica(nd), size_t(0), n);
     std::vector<int> rcs(nd, 0);
     std::vector<std::string> errs(nd);
     std::vector<std::thread> th;

@@ -82,6 +82,30 @@ struct KeyIdx {
     CIRCL_HD uint32_t operator[](size_t i) const { const uint32_t k = p[i]; return k < last ? k : last; }
 };
 
+// A launch that tells the HOST it is over: the one-launch routes of small resident-key batches take an optional TailFlag; every
+// workgroup makes its results visible system-wide and counts itself, the last one re-arms the counter and raises `flag` (a dword in
+// page-locked host memory) to `value`.  The coalescer polls that flag instead of enqueueing a second kernel behind the batch
+// (host_coalesce.hip, completion mode 2: the flag kernel cost a one-item call ~3 us of its 24).  flag == nullptr: nothing happens.
+struct TailFlag {
+    uint32_t *flag;
+    unsigned *count;
+    uint32_t value;
+};
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void tail_signal(const TailFlag &t) {
+    if (t.flag == nullptr) return;  // (uniform)
+    __threadfence_system();         // this thread's result rows ...
+    __syncthreads();                // ... and those of the whole workgroup are out
+    if (threadIdx.x == 0) {
+        if (atomicAdd(t.count, 1u) == gridDim.x - 1) {  // the last workgroup of the launch
+            *t.count = 0;
+            __threadfence_system();
+            __hip_atomic_store(t.flag, t.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+
 // Round constants of FIPS 202 (the reference tabulates the same 24 values in
 // internal/sha3/rc.go:4-29), split into (hi,lo) halves.
 #define CIRCL_RC_LIST                                                                              \

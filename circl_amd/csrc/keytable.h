@@ -101,11 +101,11 @@ struct TableUse {
 };
 // the coalescer a call inside `r` (TableUse held) may use: none while a setter has the table frozen
 inline Coalescer *usable_coalescer(const circl_hip_keytable *r) { return r->frozen.load() ? nullptr : r->coalescer; }
-template <class F> int table_shard(const circl_hip_keytable *t, size_t n, F one) {
+template <class F> int table_shard(const circl_hip_keytable *t, size_t n, F one, size_t one_replica_max = kSmallTableCall) {
     TableUse top(t);
     if (t->device >= 0) return one(t, size_t(0), n);
     auto part = [&](const circl_hip_keytable *r, size_t lo, size_t cnt) { TableUse use(r); return one(r, lo, cnt); };
-    if (n <= kSmallTableCall && t->nreplica > 0) return part(t->replica[next_replica(t->nreplica)], size_t(0), n);
+    if (n <= one_replica_max && t->nreplica > 0) return part(t->replica[next_replica(t->nreplica)], size_t(0), n);
     return shard(n, CIRCL_HIP_ALL_DEVICES, [&](int dev, size_t lo, size_t cnt) { return part(t->replica[dev], lo, cnt); });
 }
 // the asynchronous queues of the two families (api_mlkem.hip, api_mldsa.hip): fix the queue's arrays and launch on `co`, start its dispatcher

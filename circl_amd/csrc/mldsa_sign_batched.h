@@ -804,8 +804,11 @@ __global__ void __launch_bounds__(64, 4) sign_finish_kernel(SignState st, int cu
 // on one wavefront -- 2K + L inverse transforms one after the other -- with a wavefront per polynomial: r0 = w0 - c s2 row by row, z = y + c s1
 // polynomial by polynomial, c t0 and the hints row by row, a workgroup barrier and a shared verdict between the three tests (their order
 // is free: all three must pass), the rows' hint counts prefix-summed through LDS.  Every wavefront builds c-hat itself (SampleInBall + one
-// transform, ~3 us side by side instead of a broadcast).  Same bytes as sign_finish_body.  `fin`: [0] the shared verdict, [1 + i] row i's
-// hint count.  Every branch on `fin` is workgroup-uniform (read behind a barrier).
+// transform, ~3 us side by side instead of a broadcast).  Same bytes as sign_finish_body.  `fin`: [0] / [K + 1] / [K + 2] the shared verdicts of
+// the r0, z and hint tests, [1 + i] row i's hint count.  ONE WORD PER TEST: each is zeroed by the caller before the phases
+// start, written only during its own phase and read only behind that phase's barrier -- with a single word, a wavefront that was slow
+// to read it after the r0 barrier could pick up a sibling's veto from the NEXT phase, leave early and mis-pair every barrier after it.
+// Every branch on `fin` is therefore workgroup-uniform.
 template <int MODE>
 __device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *__restrict__ sig, size_t slot, size_t item, uint32_t off, bool direct,
                                                  int wave, int lane, uint32_t *xch, const dilithium::LaneZetas &z, uint8_t *zpk, uint8_t *hbytes,
@@ -827,8 +830,8 @@ __device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *_
         for (int r = 0; r < 4; r++) t[r] = dilithium::fold(dilithium::mont32(sv[r], chat[r]));
         dilithium::invntt<dilithium::INV256_R, NW>(t, z, xch, lane);
     };
-    auto veto = [&](bool bad) {
-        if (__any(bad) && lane == 0) atomicOr(&fin[0], 1u);
+    auto veto = [&](bool bad, int word) {
+        if (__any(bad) && lane == 0) atomicOr(&fin[word], 1u);
     };
     // ---- r0 = w0 - c s2, row `wave`; parked in LDS (the area that will hold the packed z) and written back only when every row is in range ----
     uint32_t *r0l = reinterpret_cast<uint32_t *>(zpk);
@@ -844,7 +847,7 @@ __device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *_
             bad |= dilithium::exceeds(v[r], P::GAMMA2 - G::BETA);
         }
         store_poly24(r0l + i * kPackedRowDwords, v, lane);
-        veto(bad);
+        veto(bad, 0);
     }
     if (threadIdx.x < 24) reinterpret_cast<uint32_t *>(hbytes)[threadIdx.x] = 0;
     __syncthreads();
@@ -874,10 +877,10 @@ __device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *_
         }
         mlkem::stage_bits_l1<G::ZBITS, NW>(xch, f, lane);
         for (int d = lane; d < 8 * G::ZBITS; d += 64) reinterpret_cast<uint32_t *>(zpk + G::ZSZ * l)[d] = xch[d];
-        veto(bad);
+        veto(bad, K + 1);
     }
     __syncthreads();
-    if (fin[0]) return;
+    if (fin[K + 1]) return;
     // ---- c t0 and the hints of row `wave` (dilithium.go:431-450): the row's hint bits as four ballots, its count to LDS ----
     unsigned long long hmask[4];
     unsigned count = 0;
@@ -897,10 +900,10 @@ __device__ __forceinline__ void sign_finish_rows(const SignState &st, uint8_t *_
             count += (unsigned)__popcll(hmask[r]);
         }
         if (lane == 0) fin[1 + i] = count;
-        veto(bad);
+        veto(bad, K + 2);
     }
     __syncthreads();
-    if (fin[0]) return;
+    if (fin[K + 2]) return;
     unsigned before = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < K; i++) {
@@ -958,7 +961,7 @@ __global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(Sign
     __shared__ __attribute__((aligned(16))) uint8_t zpk[K * kPackedRowDwords * 4 > L * G::ZSZ ? K * kPackedRowDwords * 4 : L * G::ZSZ];
     __shared__ __attribute__((aligned(16))) uint8_t hbytes[96];
     __shared__ __attribute__((aligned(16))) uint8_t blk_all[K][144];
-    __shared__ unsigned fin[1 + K];
+    __shared__ unsigned fin[3 + K];  // (sign_finish_rows: three verdict words and K hint counts)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *xch = xch_all[wave];
     const dilithium::LaneZetas z = dilithium::load_lane_zetas(lane);
@@ -1044,7 +1047,7 @@ __global__ void __launch_bounds__(DP<MODE>::K * 64) sign_round_chain_kernel(Sign
         __threadfence_block();
         __syncthreads();
         // ---- C: the challenge, wavefront 0 alone (a chain of dependent permutations) ----
-        if (threadIdx.x == 0) fin[0] = 0;
+        if (threadIdx.x == 0) fin[0] = fin[K + 1] = fin[K + 2] = 0;  // (the barrier behind phase C publishes them; nobody reads them before)
         if (wave == 0) {
             const int j = lane & 31;
             const CoopLane c = coop_lane(coop_ws[0], lane);

@@ -30,6 +30,13 @@
 #include "kyber_dev.h"
 
 // minimum waves per SIMD the scratch-variant kernels are register-allocated for (<= 512 / VGPRs)
+// Issue priority of a wavefront of mlkem_encrypt_kernel while it is in its ring phase (0 = the same as the sampling phases'): the ring phase
+// is chains of LDS exchanges with a few instructions in between, the sampling phases are Keccak rounds back to back -- see
+// CIRCL_DSA_VERIFY_PRIO (mldsa_kernels.h) for the same idea.  Measured (profiles/r06_kem_prio_ab.txt, two libraries alternating on one box,
+// three rounds): mlkem_encrypt_kernel<3> 6.31 -> 6.14 ms per 2^20, the headline 1.411 -> 1.438e8 encapsulations/s (+1.9 %).
+#ifndef CIRCL_KEM_RING_PRIO
+#define CIRCL_KEM_RING_PRIO 1
+#endif
 #ifndef CIRCL_KEM_WAVES_PER_EU
 #define CIRCL_KEM_WAVES_PER_EU 4
 #endif
@@ -958,6 +965,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * gi;
+    if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if constexpr (SHARED) {
         __syncthreads();  // phase C of the previous group is done with the noise
         if (gi * Gm::NOISE <= 32) prf_streams_split<K, Gm::NOISE, K>(lds_noise, r_ws, 32, item0, n, lane, (int)gi);  // (wave-uniform)
@@ -990,6 +998,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     // of the lane index, so that they are not live (or spilled) across the sampling phases' 100-register Keccak rounds.
     int lane_ring = lane;
     asm volatile("" : "+v"(lane_ring));
+    if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(CIRCL_KEM_RING_PRIO);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane_ring);
 #pragma unroll 1
     for (int g = 0; g < ((ABLATE & 4) ? 0 : (int)gi); g++) {
@@ -1492,7 +1501,7 @@ __global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kerne
                                                                  const KeyIdx key_idx,
                                                                  const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_status,
                                                                  const uint8_t *__restrict__ ct, uint8_t *__restrict__ ss, uint8_t *__restrict__ status,
-                                                                 size_t n) {
+                                                                 size_t n, const TailFlag tail = TailFlag{nullptr, nullptr, 0}) {
     using Gm = Geom<K>;
     using P = Params<K>;
     __shared__ __attribute__((aligned(16))) uint64_t coopw[RESIDENT ? 2 : 3][100];
@@ -1667,6 +1676,7 @@ __global__ void __launch_bounds__(RESIDENT ? 128 : 256) mlkem_decaps_chain_kerne
         }
         if (lane == 0) status[item] = verdict;
     }
+    if constexpr (RESIDENT) tail_signal(tail);  // (the coalescer's completion flag: every wavefront of a resident-key workgroup gets here)
 }
 
 // The encapsulation to a resident key, small batches, in ONE launch: a wavefront per item runs (K, r) = G(m || H(ek)) on the
@@ -1681,7 +1691,7 @@ __global__ void __launch_bounds__(RESIDENT ? 64 : 128) mlkem_encaps_chain_kernel
                                                                 const KeyIdx key_idx,
                                                                 const int16_t *__restrict__ key_rows, const uint8_t *__restrict__ key_h,
                                                                 const uint8_t *__restrict__ m, uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
-                                                                uint8_t *__restrict__ status, size_t n) {
+                                                                uint8_t *__restrict__ status, size_t n, const TailFlag tail = TailFlag{nullptr, nullptr, 0}) {
     using Gm = Geom<K>;
     using P = Params<K>;
     __shared__ __attribute__((aligned(16))) uint64_t coopw[100];
@@ -1826,6 +1836,7 @@ __global__ void __launch_bounds__(RESIDENT ? 64 : 128) mlkem_encaps_chain_kernel
     }
     if (lane == 0) status[item] = reject ? 1 : 0;
     if (lane < 8) reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = reject ? 0u : reinterpret_cast<const uint32_t *>(kr)[lane];
+    if constexpr (RESIDENT) tail_signal(tail);
 }
 
 // one key for the batch: every item's status byte is the key's verdict

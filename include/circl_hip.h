@@ -16,6 +16,10 @@
  *     item's outputs are zero-filled.
  *   - `device` >= 0 selects one GPU; CIRCL_HIP_ALL_DEVICES (-1) splits the batch into
  *     contiguous shards, one per visible GPU, with no collective (items are independent).
+ *     A SMALL call is not split: it goes to ONE device, taken round-robin (a host thread and a launch per device for a
+ *     handful of items cost more than they return) -- up to 1024 items for ML-KEM and ML-DSA verification, up to 64 for the
+ *     operations whose small batches are latency-bound for hundreds of microseconds (ML-DSA signing and key generation,
+ *     X25519 and the hybrids), so that a few hundred of those already use every device.
  *   - the *_dev variants take DEVICE pointers and a hipStream_t (as void*), enqueue the
  *     kernels and return without synchronising: this is what bench.py times with inputs
  *     already resident in HBM.  All device pointers must be 16-byte aligned.

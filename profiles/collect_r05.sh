@@ -6,7 +6,7 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* of the headline kernels (separate passes)                      -> r05_pmc.txt, traffic.json, valu.json
 #   4. device-resident microbench at 2^18 / 2^20, small-batch latency sweep                                          -> r05_microbench*.txt, r05_latency.txt
 #   5. signing rates of every parameter set, ML-DSA latencies                                                        -> r05_sign_rates.txt, r05_dsa_latency.txt
-# (concurrent callers, zero-copy, host cost of a node, signing A/B: tools/gpu_r05_{a,b,c}.sh -> profiles/r05_*.txt)
+# (concurrent callers, zero-copy, host cost of a node, signing A/B: tools/archive/gpu_r05_{a,b,c}.sh -> profiles/r05_*.txt)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_r05

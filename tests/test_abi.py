@@ -143,3 +143,22 @@ __global__ void order_probe(uint32_t *out, const uint32_t *in) {
     kinds = ["w" if ("write" in x or "store" in x) else "r" for x in lds]
     assert kinds == ["w", "r"] * 4, kinds
     assert "s_barrier" not in body
+
+
+def test_route_check_knows_the_librarys_defaults():
+    """tools/route_check.py judges the DEFAULT thresholds: the defaults it assumes must be the ones compiled into the library."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("route_check", os.path.join(root, "tools", "route_check.py"))
+    rc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rc)
+    src = "".join(open(p).read() for p in (os.path.join(root, "circl_amd", "csrc", f) for f in ("api_mlkem.hip", "api_mldsa.hip", "host_runtime.hip")))
+    for case, (_what, knob, dflt, _a, _b) in rc.CASES.items():
+        m = re.search(r'env_int\("%s", (-?\d+),' % knob, src)
+        assert m, knob
+        compiled = int(m.group(1))
+        if knob == "CIRCL_HIP_DSA_CHAIN_ITEM":  # (-1 = by parameter set: 9 up to K = 6, 8 beyond -- api_mldsa.hip dsa_chain_batch)
+            assert compiled == -1 and re.search(r"k <= 6 \? 9 : 8", src) and dflt == (8 if case.endswith("87") else 9)
+        else:
+            assert compiled == dflt, (knob, compiled, dflt)
