@@ -750,6 +750,10 @@ void complete(Coalescer *co, CoBatch *b, int rc) {
 
 void async_main(Coalescer *co) {
     (void)hipSetDevice(physical_device(co->dev));
+    pin_to(dev_info(co->dev).cpus);  // (the device's NUMA node: the staging it reads and writes lives there)
+    // ONE thread closes, launches AND copies finished batches out.  Splitting it -- a launcher and a completer side by side -- was built and
+    // measured (profiles/r06_async_ab.txt): no gain at two batches in flight (-5...-10 %), level at three, for twice the polling CPU: the
+    // queue is a closed loop bound by a batch's own latency (launch + kernel + flag ~ 30 us, copy-out 10-20), not by this loop's turn-around.
     std::deque<CoBatch *> fifo;  // launched, oldest first
     uint64_t idle_since = 0;
     for (;;) {

@@ -55,6 +55,7 @@ struct DeviceInfo {
     std::vector<int> cpus;       // CPUs of that node this process may run on (empty: no pinning)
 };
 const DeviceInfo &dev_info(int dev);
+void pin_to(const std::vector<int> &cpus);  // the calling thread may run on these CPUs only (nothing happens for an empty list)
 int current_device();            // hipGetDevice, 0 on failure
 inline int cu_count() { return dev_info(current_device()).cus; }  // of the CURRENT device (launch geometry)
 int max_cu_count();              // over all visible devices (workspace sizing: valid whichever device runs the call)

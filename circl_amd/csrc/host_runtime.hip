@@ -152,6 +152,8 @@ const DeviceTable &devs() {
     return *g_devs;
 }
 
+}  // namespace
+
 void pin_to(const std::vector<int> &cpus) {
     if (cpus.empty()) return;
     cpu_set_t set;
@@ -159,8 +161,6 @@ void pin_to(const std::vector<int> &cpus) {
     for (int c : cpus) CPU_SET(c, &set);
     (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
-
-}  // namespace
 
 int ndev() { return devs().n; }
 int physical_device(int dev) {

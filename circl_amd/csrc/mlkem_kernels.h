@@ -933,7 +933,7 @@ enum EncryptMode { ENCAPS = 0, REENCRYPT = 1, ENCAPS_LENIENT = 2 };
 //              with plain cached loads; groups are GS items.  This is the reference's parsed-key cache
 //              (kem/mlkem/mlkem768/kyber.go:39-43) for a batch over a handful of distinct keys.
 enum KeyMode { KM_ITEM = 0, KM_SHARED = 1, KM_KEYED = 2 };
-template <int K, int MODE, int ABLATE = 0, bool SCRATCH = true, int KM = KM_ITEM>
+template <int K, int MODE, int ABLATE_ARG = 0, bool SCRATCH = true, int KM = KM_ITEM>
 __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlkem_encrypt_kernel(const uint8_t *__restrict__ ek, size_t ek_stride,
                                                           const uint8_t *__restrict__ m, const uint8_t *__restrict__ r_ws,
                                                           uint8_t *__restrict__ ct, uint8_t *__restrict__ ss,
@@ -942,6 +942,20 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                                                           const KeyIdx key_idx, const int16_t *__restrict__ key_rows) {
     using Gm = Geom<K>;
     using P = Params<K>;
+    // ABLATE_ARG bit 3 (8) is not an ablation: the wavefront reads the shader clock at its phase boundaries and leaves, per workgroup, the
+    // cycles it spent in { ticket, sampling (matrix + PRF), ring phase } and its item count at key_rows (unused by the per-item form):
+    // tools/clocks_kem.hip, profiles/r06_kem_clocks.txt
+    constexpr int ABLATE = ABLATE_ARG & 7;
+    constexpr bool CLK = (ABLATE_ARG & 8) != 0;
+    uint64_t clk[4] = {0, 0, 0, 0}, tprev = 0;
+    auto lap = [&](int slot) {
+        if constexpr (CLK) {
+            const uint64_t t = __builtin_readcyclecounter();
+            clk[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+    if constexpr (CLK) tprev = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lds_a = smem;                                     // LDS variant: matrix buffer; scratch variant: FIFO
     uint8_t *lds_noise = SCRATCH ? smem : smem + Gm::LDS_A;    // the FIFO is dead once phase A is over
@@ -965,6 +979,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * gi;
+    lap(0);
     if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if constexpr (SHARED) {
         __syncthreads();  // phase C of the previous group is done with the noise
@@ -999,6 +1014,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
     int lane_ring = lane;
     asm volatile("" : "+v"(lane_ring));
     if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(CIRCL_KEM_RING_PRIO);
+    lap(1);
     const kyber::LaneZetas z = kyber::load_lane_zetas(lane_ring);
 #pragma unroll 1
     for (int g = 0; g < ((ABLATE & 4) ? 0 : (int)gi); g++) {
@@ -1110,8 +1126,18 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
                 reinterpret_cast<uint32_t *>(ss + item * 32)[lane] = dead ? 0u : (mismatch ? rj : kb);
             }
         }
+        if constexpr (CLK) clk[3]++;
     }
+    lap(2);
   }
+    if constexpr (CLK) {
+        lap(0);  // (the last, empty-handed ticket)
+        if (lane == 0) {
+            uint64_t *prof = reinterpret_cast<uint64_t *>(const_cast<int16_t *>(key_rows)) + (size_t)blockIdx.x * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) prof[q] = clk[q];
+        }
+    }
 }
 
 // ---- key tables: A^T of every table entry, once ---------------------------------------------------

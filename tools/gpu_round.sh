@@ -12,6 +12,7 @@
 #   verify_pmc   SQ / TCC counters of mldsa_verify_kernel<65> (2^18) and <87> (2^16)                         -> verify_pmc.txt
 #   verify_phases  phase ablation of mldsa_verify_kernel + the VALU probe under --pmc: per-phase cycles per instruction -> verify_phases.txt
 #   verify_clocks  the FULL verify kernel with the shader clock read at its phase boundaries (tools/bin/ablate_dsa clocks)  -> verify_clocks.txt
+#   kem_clocks   the headline kernel with the shader clock read at its phase boundaries (tools/bin/clocks_kem)             -> kem_clocks.txt
 #   tests        the whole GPU suite + smoke()                                                                  -> gpu_tests.log
 #   async        tools/bin/concurrent_bench --async: R reactor threads x W outstanding one-item requests       -> async.txt
 #   one_call     where the microseconds of ONE one-item table call go (library's own timestamps)               -> one_call.txt
@@ -78,6 +79,13 @@ step_verify_clocks() {
     timeout 300 tools/bin/ablate_dsa clocks 65 18 2>&1 | grep -v amdgpu.ids
     timeout 300 tools/bin/ablate_dsa clocks 87 16 2>&1 | grep -v amdgpu.ids; } > "$OUT/verify_clocks.txt"
   note "verify_clocks"; cat "$OUT/verify_clocks.txt"
+}
+
+step_kem_clocks() {
+  { hdr "tools/bin/clocks_kem 20; tools/bin/clocks_kem_prio0 20   (mlkem_encrypt_kernel<K, ENCAPS, 8>: s_memtime at the phase boundaries, summed per workgroup)"
+    timeout 300 tools/bin/clocks_kem 20 2>&1 | grep -v amdgpu.ids
+    timeout 300 tools/bin/clocks_kem_prio0 20 2>&1 | grep -v amdgpu.ids; } > "$OUT/kem_clocks.txt"
+  note "kem_clocks"; cat "$OUT/kem_clocks.txt"
 }
 
 step_verify_variants() {
