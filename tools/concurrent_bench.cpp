@@ -270,7 +270,7 @@ static int one_call_main(int argc, char **argv) {
             circl_hip_profile_call_stamps(0, nullptr);
             auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             printf("%s, one blocking caller, completion mode %d (%s): call %.1f us median =", opn, mode,
-                   mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "flag via hipStreamWriteValue32, polled" : "flag via a one-lane kernel, polled", med(d[7]));
+                   mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "flag via hipStreamWriteValue32, polled" : "flag raised by the batch's own launch (or its finish kernel), polled", med(d[7]));
             double sum = 0;
             for (int k = 0; k < 7; k++) { printf(" %s %.1f |", names[k], med(d[k])); sum += med(d[k]); }
             printf(" (stages sum %.1f)  mismatches %zu\n", sum, bad);
