@@ -555,6 +555,15 @@ static int check_idx(const uint32_t *key_idx, size_t n, size_t nkeys) {
             if (key_idx[i] >= nkeys) return CIRCL_HIP_EPARAM;
     return CIRCL_HIP_OK;
 }
+// host buffers through a resident hybrid table.  key_idx is the one OPTIONAL array (absent: entry 0 for every item).  A small call joins the
+// table's cross-caller batch (circl_hip_keytable_set_coalesce) or, submitted, its asynchronous queue (circl_hip_keytable_async_start) -- the
+// X25519 ladder makes ONE hybrid launch ~0.8 ms whatever it holds, so these are the calls that gain most from sharing it.
+static std::vector<HIn> hyb_enc_ins(const uint32_t *ki, const uint8_t *eseed, const Desc &s) {
+    return {{reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}, {eseed, s.eseed, true}};
+}
+static std::vector<HIn> hyb_dec_ins(const uint32_t *ki, const uint8_t *ct, const Desc &s) {
+    return {{reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}, {ct, s.ct}};
+}
 int circl_hip_hybrid_encaps_table(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status,
                                   size_t n) {
     if (!t || t->magic != kKeytableMagic || t->family != 3 || t->private_keys) return CIRCL_HIP_EPARAM;
@@ -566,6 +575,16 @@ int circl_hip_hybrid_encaps_table(const circl_hip_keytable *t, const uint32_t *k
     const int scheme = t->scheme;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {
+            const int rc = coalesce_run(co, cnt, hyb_enc_ins(ki, eseed + lo * s.eseed, s), {},
+                                        {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}}, hybrid_ws_fn(scheme), hybrid_opts(scheme),
+                                        [&](Chunk &c) {
+                                            return circl_hip_hybrid_encaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.out[2],
+                                                                                     c.cnt, c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {eseed + lo * s.eseed, s.eseed, true}}, {},
                             {{ct + lo * s.ct, s.ct}, {ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
                             hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
@@ -584,6 +603,15 @@ int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *k
     const int scheme = t->scheme;
     return table_shard(t, n, [&](const circl_hip_keytable *r, size_t lo, size_t cnt) {
         const uint32_t *ki = key_idx ? key_idx + lo : nullptr;
+        Coalescer *co = usable_coalescer(r);
+        if (co && cnt <= coalescer_call_max(co)) {
+            const int rc = coalesce_run(co, cnt, hyb_dec_ins(ki, ct + lo * s.ct, s), {}, {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
+                                        hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
+                                            return circl_hip_hybrid_decaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.cnt,
+                                                                                     c.ws, c.ws_bytes, c.st);
+                                        });
+            if (rc != kNotCoalesced) return rc;
+        }
         return run_pipeline(r->device, cnt, {{reinterpret_cast<const uint8_t *>(ki), ki ? size_t(4) : size_t(0)}, {ct + lo * s.ct, s.ct}}, {},
                             {{ss + lo * s.ss, s.ss, true}, {status ? status + lo : nullptr, 1}},
                             hybrid_ws_fn(scheme), hybrid_opts(scheme), [&](Chunk &c) {
@@ -592,5 +620,51 @@ int circl_hip_hybrid_decaps_table(const circl_hip_keytable *t, const uint32_t *k
                             });
     }, kHeavyOneDeviceMax);
 }
+// ---- the asynchronous form (include/circl_hip.h: circl_hip_keytable_async_start) ----
+int circl_hip_hybrid_encaps_table_submit(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *eseed, uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                         size_t n, uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!t || t->magic != kKeytableMagic || t->family != 3 || t->private_keys || !ticket) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(t->scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!eseed || !ct || !ss) return CIRCL_HIP_EPARAM;
+    TRY(check_idx(key_idx, n, t->nkeys));
+    return table_submit(t, ticket, [&](const circl_hip_keytable *, Coalescer *co, uint64_t *seq) {
+        return coalesce_submit(co, n, hyb_enc_ins(key_idx, eseed, s), {}, {{ct, s.ct}, {ss, s.ss, true}, {status, 1}}, seq, false);
+    });
+}
+int circl_hip_hybrid_decaps_table_submit(const circl_hip_keytable *t, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status, size_t n,
+                                         uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!t || t->magic != kKeytableMagic || t->family != 3 || !t->private_keys || !ticket) return CIRCL_HIP_EPARAM;
+    Desc s;
+    if (!desc_of(t->scheme, s)) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    if (!ct || !ss) return CIRCL_HIP_EPARAM;
+    TRY(check_idx(key_idx, n, t->nkeys));
+    return table_submit(t, ticket, [&](const circl_hip_keytable *, Coalescer *co, uint64_t *seq) {
+        return coalesce_submit(co, n, hyb_dec_ins(key_idx, ct, s), {}, {{ss, s.ss, true}, {status, 1}}, seq, false);
+    });
+}
 
 }  // extern "C"
+namespace circl {
+namespace host {
+// the queue of one hybrid table (part): its arrays and its launch, fixed for the queue's life (`r` outlives the queue: the table owns it)
+int hyb_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd) {
+    Desc s;
+    if (!desc_of(r->scheme, s)) return CIRCL_HIP_EPARAM;
+    const int scheme = r->scheme;
+    if (!r->private_keys)
+        return coalescer_async_start(co, hyb_enc_ins(nullptr, nullptr, s), {}, {{nullptr, s.ct}, {nullptr, s.ss, true}, {nullptr, 1}}, hybrid_ws_fn(scheme), hybrid_opts(scheme),
+                                     [r](Chunk &c) {
+                                         return circl_hip_hybrid_encaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.out[2], c.cnt,
+                                                                                  c.ws, c.ws_bytes, c.st);
+                                     }, want_eventfd);
+    return coalescer_async_start(co, hyb_dec_ins(nullptr, nullptr, s), {}, {{nullptr, s.ss, true}, {nullptr, 1}}, hybrid_ws_fn(scheme), hybrid_opts(scheme), [r](Chunk &c) {
+        return circl_hip_hybrid_decaps_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[0]), c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+    }, want_eventfd);
+}
+}  // namespace host
+}  // namespace circl

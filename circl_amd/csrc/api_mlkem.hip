@@ -511,6 +511,7 @@ PipeOpts kem_opts() {
     o.chunk_items = host_chunk_items(size_t(1) << 15);
     o.wipe_device = true;
     o.ws_secret_bytes = [](size_t cnt) { return up256(kKemWsPerItem * cnt); };
+    o.tail_flag_ok = true;  // (every coalesced ML-KEM launch is exactly one *_dev call; the resident-key one-launch routes take the offer)
     return o;
 }
 // (a host-buffer chunk beyond 2^13 items is PCIe-bound whichever route it takes: it gets the workspace of the scratch routes, so

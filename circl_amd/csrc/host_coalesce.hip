@@ -443,7 +443,7 @@ int enqueue(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_b
     }
     for (size_t k = 0; k < co->out_row.size(); k++) c.out.push_back(out_base + co->out_ofs[k]);
     // a zero-copy batch in completion mode 2 offers its flag to the launch itself (host_common.h TailOffer)
-    const bool offer = zc && co->done_mode == 2 && b->flag_dev;
+    const bool offer = zc && co->done_mode == 2 && b->flag_dev && opts.tail_flag_ok;
     g_tail_offer = offer ? TailOffer{b->flag_dev, b->count_dev, b->gen + 1, false} : TailOffer{};
     const int lrc = launch(c);
     const bool tail_taken = g_tail_offer.taken;
@@ -1131,7 +1131,7 @@ int circl_hip_keytable_coalesce_stats(const circl_hip_keytable *t, uint64_t *cal
 // ---- the asynchronous form ----
 int circl_hip_keytable_async_start(circl_hip_keytable *t, size_t max_items, uint32_t max_wait_us, int want_eventfd) {
     if (!t || t->magic != kKeytableMagic || max_items == 0) return CIRCL_HIP_EPARAM;
-    if (!((t->family == 1) || (t->family == 2 && !t->private_keys))) { g_err = "asynchronous queues serve ML-KEM tables and ML-DSA public-key tables"; return CIRCL_HIP_EPARAM; }
+    if (!(t->family == 1 || t->family == 3 || (t->family == 2 && !t->private_keys))) { g_err = "asynchronous queues serve ML-KEM tables, hybrid KEM tables and ML-DSA public-key tables"; return CIRCL_HIP_EPARAM; }
     std::vector<circl_hip_keytable *> parts;
     if (int rc = freeze_parts(t, parts)) return rc;
     int rc = CIRCL_HIP_OK;
@@ -1140,7 +1140,8 @@ int circl_hip_keytable_async_start(circl_hip_keytable *t, size_t max_items, uint
         Coalescer *co = coalescer_new(r->device, max_items, max_wait_us);
         if (!co) { rc = CIRCL_HIP_ENOMEM; break; }
         co->owner_counts = true;
-        rc = r->family == 1 ? kem_table_async_start(r, co, want_eventfd != 0) : dsa_table_async_start(r, co, want_eventfd != 0);
+        rc = r->family == 1 ? kem_table_async_start(r, co, want_eventfd != 0)
+                            : r->family == 3 ? hyb_table_async_start(r, co, want_eventfd != 0) : dsa_table_async_start(r, co, want_eventfd != 0);
         if (rc != CIRCL_HIP_OK) { coalescer_free(co); break; }
         r->coalescer = co;
     }

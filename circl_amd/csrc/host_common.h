@@ -172,6 +172,10 @@ struct PipeOpts {
     // the per-item slots m', r', K', J; the matrix scratch behind them is public) = only the secret inputs, the secret
     // outputs and that prefix are zeroed, a few hundred KB instead of the 134 MB scratch.
     std::function<size_t(size_t)> ws_secret_bytes;
+    // coalesced batches only: the launch is ONE call of an entry point whose one-launch route may raise the batch's completion flag
+    // itself (TailOffer below).  Never set where the launch runs further kernels behind such a call (the hybrids call the ML-KEM table
+    // entry points and then the X25519 ladder and the combiner: the flag would go up before they ran).
+    bool tail_flag_ok = false;
 };
 // Runs items [0, n) on device `dev`: per chunk  stage-in (host threads) -> H2D -> launch -> D2H -> stage-out (host threads),
 // with `depth` chunks in flight on separate streams.  ws_bytes(cnt) = workspace the launch needs for cnt items.

@@ -111,6 +111,7 @@ template <class F> int table_shard(const circl_hip_keytable *t, size_t n, F one,
 // the asynchronous queues of the two families (api_mlkem.hip, api_mldsa.hip): fix the queue's arrays and launch on `co`, start its dispatcher
 int kem_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd);
 int dsa_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd);
+int hyb_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd);
 // circl_hip_keytable_free: waits (bounded) until no call is inside the table; false = still busy
 bool keytable_quiesce(circl_hip_keytable *t);
 // a submitted call picks its part like a small blocking call does and says which in the ticket's top byte

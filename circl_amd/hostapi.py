@@ -347,6 +347,22 @@ class KeyTable:
         rc = nat.lib().circl_hip_mlkem_decaps_table_submit(self.handle, self._kidx(key_idx, n), _p(ct), _p(ss), _p(st), n, C.byref(t))
         return rc, t.value
 
+    def submit_hybrid_encaps(self, eseeds, ct, ss, st, key_idx=None):
+        import ctypes as C
+        es = _u8(eseeds, HYBRID_SIZES[self.param]["eseed"])
+        n = len(es)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_hybrid_encaps_table_submit(self.handle, self._kidx(key_idx, n), _p(es), _p(ct), _p(ss), _p(st), n, C.byref(t))
+        return rc, t.value
+
+    def submit_hybrid_decaps(self, ct_in, ss, st, key_idx=None):
+        import ctypes as C
+        c = _u8(ct_in, HYBRID_SIZES[self.param]["ct"])
+        n = len(c)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_hybrid_decaps_table_submit(self.handle, self._kidx(key_idx, n), _p(c), _p(ss), _p(st), n, C.byref(t))
+        return rc, t.value
+
     def submit_verify(self, sigs, msgs, ok, ctxs=None, key_idx=None):
         import ctypes as C
         _, SIG = DSA_SIZES[self.param]

@@ -246,7 +246,8 @@ int circl_hip_mldsa_verify_table_dev(const circl_hip_keytable *table, const uint
  *   through the table: set it before the table is shared, or retry.  A replicated table coalesces per replica; its small calls (<= 1024
  *   items) go to one replica each, round-robin.  circl_hip_keytable_coalesce_stats: calls and items that joined batches and the
  *   launches they became (items / launches = mean batch).  Served today: circl_hip_mlkem_encaps_table, circl_hip_mlkem_decaps_table,
- *   circl_hip_mldsa_verify_table, circl_hip_mldsa_sign_table / _sign_table_keyed (a server signing one handshake transcript per call). */
+ *   circl_hip_mldsa_verify_table, circl_hip_mldsa_sign_table / _sign_table_keyed (a server signing one handshake transcript per call),
+ *   circl_hip_hybrid_encaps_table / _decaps_table. */
 int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us);
 /* Lifetime under concurrent callers: circl_hip_keytable_set_coalesce, circl_hip_keytable_async_start / _stop and circl_hip_keytable_close
  * return CIRCL_HIP_EBUSY -- and change nothing -- while a call is inside the table or one of its batches is open or running; nothing is
@@ -263,7 +264,9 @@ int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items,
  * room -- same group commit as above: a batch holds what arrived while its predecessors ran, nothing waits on an idle device unless
  * max_wait_us says so -- launches it, copies the finished batch's rows STRAIGHT INTO THE SUBMITTERS' OUTPUT BUFFERS, and publishes the
  * batch's completion.  Served: circl_hip_mlkem_encaps_table_submit (public ML-KEM table), circl_hip_mlkem_decaps_table_submit (private
- * ML-KEM table), circl_hip_mldsa_verify_table_submit (ML-DSA public-key table).
+ * ML-KEM table), circl_hip_mldsa_verify_table_submit (ML-DSA public-key table), circl_hip_hybrid_encaps_table_submit / _decaps_table_submit
+ * (X-Wing / X25519MLKEM768 / Kyber-X25519 tables: kem/hybrid/hybrid.go:95-99, kem/xwing/xwing.go:259,288 -- one hybrid launch costs an
+ * X25519 ladder, ~0.8 ms, whatever it holds: the calls that gain most from sharing it).
  *   *_submit(...same arrays as the blocking call..., n, &ticket): copies the n <= max_items / 4 items' inputs into the open batch, notes
  *       the output pointers and returns AT ONCE: CIRCL_HIP_OK and a ticket; CIRCL_HIP_EAGAIN when every batch of the queue is busy
  *       (nothing was taken: poll, then submit again); CIRCL_HIP_EPARAM for what the blocking call rejects (a NULL required input, a
@@ -295,6 +298,10 @@ int circl_hip_mlkem_decaps_table_submit(const circl_hip_keytable *table, const u
 int circl_hip_mldsa_verify_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *sig, const uint8_t *msg_blob,
                                         const uint64_t *msg_off, const uint8_t *ctx_blob, const uint64_t *ctx_off, uint8_t *ok, size_t n,
                                         uint64_t *ticket);
+int circl_hip_hybrid_encaps_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *eseed, uint8_t *ct, uint8_t *ss,
+                                         uint8_t *status, size_t n, uint64_t *ticket);
+int circl_hip_hybrid_decaps_table_submit(const circl_hip_keytable *table, const uint32_t *key_idx, const uint8_t *ct, uint8_t *ss, uint8_t *status,
+                                         size_t n, uint64_t *ticket);
 int circl_hip_poll(const circl_hip_keytable *table, const uint64_t *tickets, size_t n, int8_t *state);
 int circl_hip_wait(const circl_hip_keytable *table, uint64_t ticket, int64_t timeout_us);
 /* The same for the entry points that take their keys WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the

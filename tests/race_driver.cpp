@@ -278,6 +278,33 @@ struct Hyb {
         CHECK(circl_hip_hybrid_keygen(s, seed.data(), pk.data(), sk.data(), n, 0) == 0);
         CHECK(circl_hip_hybrid_encaps(s, pk.data(), es.data(), ct.data(), ss.data(), st.data(), n, 0) == 0);
     }
+    // a resident hybrid table with an asynchronous queue, shared by every caller thread (one hybrid launch = an X25519 ladder: the calls
+    // that share it gain most); each caller keeps two submitted encapsulations outstanding
+    circl_hip_keytable *apub = nullptr;
+    void async_table() {
+        CHECK(circl_hip_hybrid_keytable_new(scheme, 0, pk.data(), n < 4 ? n : 4, 0, nullptr, &apub) == 0);
+        CHECK(circl_hip_keytable_async_start(apub, 16, 0, 0) == 0);
+    }
+    void async_calls(int caller, int count) const {
+        const size_t nk = n < 4 ? n : 4;
+        uint64_t tk[2] = {0, 0};
+        size_t at[2] = {0, 0};
+        std::vector<uint8_t> ct1(2 * CT), ss1(2 * SS), st1(2, 9);
+        for (int i = 0; i < count + 2; i++) {
+            const int sl = i & 1;
+            if (i >= 2) {
+                CHECK(circl_hip_wait(apub, tk[sl], 5000000) == 1);
+                CHECK(!memcmp(&ct1[CT * sl], &ct[CT * at[sl]], CT) && !memcmp(&ss1[SS * sl], &ss[SS * at[sl]], SS) && st1[sl] == 0);
+            }
+            if (i >= count) continue;
+            at[sl] = ((size_t)caller * 5 + (size_t)i) % nk;  // item k encapsulates to ITS OWN key (entry k): the answers of the plain batch call above
+            const uint32_t ki = (uint32_t)at[sl];
+            int rc;
+            while ((rc = circl_hip_hybrid_encaps_table_submit(apub, &ki, &es[ES * at[sl]], &ct1[CT * sl], &ss1[SS * sl], &st1[sl], 1, &tk[sl])) == CIRCL_HIP_EAGAIN)
+                std::this_thread::yield();
+            CHECK(rc == 0);
+        }
+    }
     void again(int device) const {
         std::vector<uint8_t> ct2(CT * n), ss2(SS * n), ss3(SS * n), st(n);
         CHECK(circl_hip_hybrid_encaps(scheme, pk.data(), es.data(), ct2.data(), ss2.data(), st.data(), n, device) == 0);
@@ -307,7 +334,8 @@ int main(int argc, char **argv) {
     dsa65.async_tables();
     kem768.toggle_table();
     std::atomic<int> tog_busy{0}, tog_ok{0};
-    const Hyb xwing(1, n_kem / 8 + 5);
+    Hyb xwing(1, n_kem / 8 + 5);
+    xwing.async_table();
     circl_hip_profile_enable(1);  // the profiling records are shared state too
     std::atomic<int> started{0};
     std::vector<std::thread> th;
@@ -327,6 +355,7 @@ int main(int argc, char **argv) {
                 dsa65.small_calls(c, 6);
                 kem768.async_calls(c, 40);
                 dsa65.async_calls(c, 5);
+                xwing.async_calls(c, 4);
                 if (c == 0) kem768.toggle(60, tog_busy, tog_ok);  // ... while the other callers are inside the toggled table
                 else kem768.toggled_calls(c, 30);
                 // an error path in the middle of everything: the Drain guard must give its slots back
@@ -349,6 +378,7 @@ int main(int argc, char **argv) {
     CHECK(circl_hip_keytable_close(kem768.aprv) == 0);
     CHECK(circl_hip_keytable_close(dsa65.averifier) == 0);
     CHECK(circl_hip_keytable_close(kem768.tog) == 0);
+    CHECK(circl_hip_keytable_close(xwing.apub) == 0);
     CHECK(circl_hip_set_coalesce(0, 0) == 0);  // off AND drained: nobody is inside a process-wide batch any more
     printf("race_driver: the toggled table answered %d setters with OK, %d with EBUSY\n", tog_ok.load(), tog_busy.load());
     circl_hip_keytable_free(kem768.pub);

@@ -232,3 +232,77 @@ def test_setters_refuse_while_calls_are_in_flight_and_nothing_is_freed_under_a_c
     _threads(9, body)
     assert seen["ok"] + seen["busy"] == 300
     tab.close()
+
+
+@pytest.mark.parametrize("scheme_name", ["XWING", "X25519MLKEM768"])
+def test_hybrid_tables_submit_and_coalesce_equal_the_plain_calls(scheme_name):
+    """The hybrid KEM tables (kem/xwing/xwing.go:259,288; kem/hybrid/hybrid.go:95-99) through the asynchronous queue and through blocking
+    coalescing: the bytes of circl_hip_hybrid_encaps / _decaps made alone (those are checked against the oracle by tests/test_gpu_hybrid.py).
+    One hybrid launch runs further kernels BEHIND the ML-KEM table call inside it: its batches must not take the tail-flag offer (the flag
+    would go up before the X25519 ladder and the combiner ran) -- a premature completion would show here as wrong shared secrets."""
+    from circl_amd import hostapi
+    scheme = getattr(hostapi, scheme_name)
+    S = hostapi.HYBRID_SIZES[scheme]
+    rng = np.random.default_rng(scheme)
+    nkeys, pool = 3, 48
+    pk, sk = hostapi.hybrid_keygen(scheme, rng.integers(0, 256, (nkeys, S["seed"]), dtype=np.uint8))
+    idx = rng.integers(0, nkeys, pool).astype(np.uint32)
+    es = rng.integers(0, 256, (pool, S["eseed"]), dtype=np.uint8)
+    ct0, ss0, st0 = hostapi.hybrid_encaps(scheme, pk[idx], es)
+    assert not st0.any()
+    ct_in = ct0.copy()
+    ct_in[::5, 7] ^= 4                                       # implicit rejection on the lattice half for every fifth item
+    ssd0, std0 = hostapi.hybrid_decaps(scheme, sk[idx], ct_in)
+    pub = hostapi.KeyTable("hybrid-public", scheme, pk)
+    prv = hostapi.KeyTable("hybrid-private", scheme, sk)
+    # ---- asynchronous ----
+    pub.async_start(32, 0)
+    prv.async_start(32, 0)
+    wp, wq = Window(pub, 6), Window(prv, 6)
+    r = np.random.default_rng(1)
+    for k in range(30):
+        n = int(r.choice([1, 1, 2, 4]))
+        lo = int(r.integers(0, pool - n))
+        w, enc = (wp, True) if k % 2 == 0 else (wq, False)
+        while not w.room():
+            w.reap(block=True)
+        ss, st = np.full((n, S["ss"]), 0xAA, np.uint8), np.full(n, 0xAA, np.uint8)
+        if enc:
+            ct = np.full((n, S["ct"]), 0xAA, np.uint8)
+            rc, tk = pub.submit_hybrid_encaps(es[lo:lo + n], ct, ss, st, key_idx=idx[lo:lo + n])
+        else:
+            ct = None
+            rc, tk = prv.submit_hybrid_decaps(ct_in[lo:lo + n], ss, st, key_idx=idx[lo:lo + n])
+        if rc == EAGAIN:
+            w.reap(block=True)
+            continue
+        assert rc == 0, rc
+
+        def chk(enc=enc, ct=ct, ss=ss, st=st, lo=lo, n=n):
+            if enc:
+                assert (ct == ct0[lo:lo + n]).all() and (ss == ss0[lo:lo + n]).all() and not st.any(), (lo, n)
+            else:
+                assert (ss == ssd0[lo:lo + n]).all() and (st == std0[lo:lo + n]).all(), (lo, n)
+        w.push(tk, chk)
+        w.reap()
+    wp.reap(block=True)
+    wq.reap(block=True)
+    assert wp.done + wq.done >= 20
+    assert pub.async_stop() == 0 and prv.async_stop() == 0
+    # ---- blocking, coalesced across four threads ----
+    pub.set_coalesce(16)
+    prv.set_coalesce(16)
+
+    def body(t):
+        rr = np.random.default_rng(100 + t)
+        for _ in range(6):
+            lo = int(rr.integers(0, pool - 2))
+            ct, ss, st = pub.hybrid_encaps(es[lo:lo + 2], idx[lo:lo + 2])
+            assert (ct == ct0[lo:lo + 2]).all() and (ss == ss0[lo:lo + 2]).all() and not st.any()
+            ss2, st2 = prv.hybrid_decaps(ct_in[lo:lo + 1], idx[lo:lo + 1])
+            assert (ss2 == ssd0[lo:lo + 1]).all() and (st2 == std0[lo:lo + 1]).all()
+    _threads(4, body)
+    calls, items, launches = pub.coalesce_stats()
+    assert calls == 24 and items == 48 and 1 <= launches <= calls
+    pub.close()
+    prv.close()
