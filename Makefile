@@ -20,6 +20,7 @@ oracle:
 example: lib
 	gcc -O2 -Iinclude examples/encaps_batch.c -Lcircl_amd -lcirclhip -Wl,-rpath,$(CURDIR)/circl_amd -Wl,-rpath,$(ROCM)/lib -o build/encaps_batch
 	gcc -O2 -Iinclude examples/resident_keys.c -Lcircl_amd -lcirclhip -Wl,-rpath,$(CURDIR)/circl_amd -Wl,-rpath,$(ROCM)/lib -o build/resident_keys
+	gcc -O2 -Iinclude examples/async_epoll.c -Lcircl_amd -lcirclhip -Wl,-rpath,$(CURDIR)/circl_amd -Wl,-rpath,$(ROCM)/lib -o build/async_epoll
 
 # ---- sanitizer builds of the HOST side (device code cannot be instrumented) --------------------------------------------
 # `make tsan` / `make asan`: every host function of the library -- the runtime (slots, movers, streams, shard) and the host

@@ -1164,8 +1164,20 @@ static Coalescer *ticket_queue(const circl_hip_keytable *t, uint64_t ticket, uin
     const circl_hip_keytable *r = t->device < 0 ? (rep < t->nreplica ? t->replica[rep] : nullptr) : (rep == 0 ? t : nullptr);
     return r && coalescer_is_async(r->coalescer) ? r->coalescer : nullptr;
 }
+// poll and wait are calls INSIDE the table like any other (a setter that freed the queue under them would leave them reading freed memory):
+// they count themselves (TableUse) and, should a setter have the table frozen at that moment, report "pending" -- the setter sees them,
+// answers CIRCL_HIP_EBUSY and thaws; the next poll reads the queue again.
 int circl_hip_poll(const circl_hip_keytable *t, const uint64_t *tickets, size_t n, int8_t *state) {
     if (n && (!tickets || !state)) return CIRCL_HIP_EPARAM;
+    if (!t || t->magic != kKeytableMagic) {
+        for (size_t i = 0; i < n; i++) state[i] = (int8_t)CIRCL_HIP_EPARAM;
+        return (int)n;
+    }
+    TableUse use(t);
+    if (t->frozen.load()) {
+        for (size_t i = 0; i < n; i++) state[i] = 0;
+        return 0;
+    }
     int done = 0;
     for (size_t i = 0; i < n; i++) {
         uint64_t seq = 0;
@@ -1177,6 +1189,9 @@ int circl_hip_poll(const circl_hip_keytable *t, const uint64_t *tickets, size_t 
     return done;
 }
 int circl_hip_wait(const circl_hip_keytable *t, uint64_t ticket, int64_t timeout_us) {
+    if (!t || t->magic != kKeytableMagic) return CIRCL_HIP_EPARAM;
+    TableUse use(t);
+    if (t->frozen.load()) return 0;  // (a setter is looking at the table right now: it will find this call and back off)
     uint64_t seq = 0;
     Coalescer *co = ticket_queue(t, ticket, &seq);
     if (!co) return CIRCL_HIP_EPARAM;

@@ -285,7 +285,7 @@ int circl_hip_keytable_set_coalesce(circl_hip_keytable *table, size_t max_items,
  *       for a replicated one (one queue and one dispatcher per replica; a submitted call goes to one replica, round-robin, and its
  *       ticket says which: the top byte).
  *   circl_hip_keytable_async_stop(table): flushes and finishes every submitted call, stops the dispatchers, frees the queues
- *       (CIRCL_HIP_EBUSY while a call is inside a *_submit); circl_hip_keytable_free does the same on the way.
+ *       (CIRCL_HIP_EBUSY while a call is inside the table: a *_submit, a circl_hip_poll, a thread blocked in circl_hip_wait); circl_hip_keytable_free does the same on the way.
  * The blocking *_table calls keep working on such a table (they submit and wait), so one table can serve both kinds of caller. */
 int circl_hip_keytable_close(circl_hip_keytable *table);
 int circl_hip_keytable_async_start(circl_hip_keytable *table, size_t max_items, uint32_t max_wait_us, int want_eventfd);

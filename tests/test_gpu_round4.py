@@ -139,10 +139,11 @@ def test_resident_decapsulation_chain_route_boundaries():
 
 
 def test_c_examples_build_and_run():
-    # examples/*.c: the C ABI from plain C, as a cgo stub would call it -- batches of distinct keys, and parsed key objects (resident tables)
+    # examples/*.c: the C ABI from plain C, as a cgo stub would call it -- batches of distinct keys, parsed key objects (resident tables), and the
+    # asynchronous form from ONE event-loop thread with the queue's eventfd in its epoll set
     out = os.path.join(ROOT, "build")
     os.makedirs(out, exist_ok=True)
-    for name, args, needle in (("encaps_batch", ["3000"], " 0 mismatches"), ("resident_keys", [], "mismatches 0")):
+    for name, args, needle in (("encaps_batch", ["3000"], " 0 mismatches"), ("resident_keys", [], "mismatches 0"), ("async_epoll", [], "mismatches 0")):
         exe = os.path.join(out, name)
         subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"), "-L", os.path.join(ROOT, "circl_amd"),
                                "-lcirclhip", "-Wl,-rpath," + os.path.join(ROOT, "circl_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
