@@ -448,9 +448,9 @@ int enqueue(Coalescer *co, CoBatch *b, const std::function<size_t(size_t)> &ws_b
     const int lrc = launch(c);
     const bool tail_taken = g_tail_offer.taken;
     g_tail_offer = TailOffer{};
+    if (tail_taken) b->gen++;  // (whatever the launch reports afterwards: a kernel that took the offer will write this value -- the next use must not mistake it for its own)
     if (lrc) return lrc;
     if (tail_taken) {  // the launch raises the flag; it ran on page-locked rows and left nothing secret in the workspace
-        b->gen++;
         b->wiped = true;
         return CIRCL_HIP_OK;
     }

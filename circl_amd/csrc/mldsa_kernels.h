@@ -1444,6 +1444,8 @@ __global__ void __launch_bounds__(64, CIRCL_DSA_WAVES_PER_EU)
         }
     }
     __syncthreads();
+    // (issue priority for the ring phases, as in mldsa_verify_kernel, was measured here and not kept: ML-DSA-44 / 65 level, ML-DSA-87 -1.8 %,
+    // profiles/r06_keygen_prio_ab.txt)
 
 #pragma unroll 1
     for (int g = 0; g < G::IT; g++) {

@@ -1909,6 +1909,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
 #pragma unroll 1
   for (size_t grp = next_group(work, lane, true, ngroups); grp < ngroups; grp = next_group(work, lane, false, ngroups)) {
     const size_t item0 = grp * Gm::G;
+    if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(0);  // (as mlkem_encrypt_kernel: the ring phase below gets issue priority)
     if constexpr (SCRATCH && Gm::HALVES == 1) {
         __syncthreads();
         sample_matrix_and_prf<K, false, 2 * K, 2 * K>(lds_a, lds_noise, xch, rows, rs_ws, 64, rs_ws + 32, 64,
@@ -1930,6 +1931,7 @@ __global__ void __launch_bounds__(64, SCRATCH ? CIRCL_KEM_WAVES_PER_EU : 1) mlke
         }
     }
 
+    if constexpr (CIRCL_KEM_RING_PRIO != 0) __builtin_amdgcn_s_setprio(CIRCL_KEM_RING_PRIO);
 #pragma unroll 1
     for (int g = 0; g < Gm::G; g++) {
         const size_t item = item0 + g;
