@@ -41,6 +41,8 @@ SYMBOLS = [
     "circl_hip_keytable_close", "circl_hip_keytable_async_start", "circl_hip_keytable_async_stop", "circl_hip_keytable_eventfd",
     "circl_hip_mlkem_encaps_table_submit", "circl_hip_mlkem_decaps_table_submit", "circl_hip_mldsa_verify_table_submit",
     "circl_hip_hybrid_encaps_table_submit", "circl_hip_hybrid_decaps_table_submit",
+    "circl_hip_queue_open", "circl_hip_queue_close", "circl_hip_queue_eventfd", "circl_hip_queue_stats", "circl_hip_queue_submit", "circl_hip_queue_poll",
+    "circl_hip_queue_wait",
     "circl_hip_poll", "circl_hip_wait", "circl_hip_profile_call_stamps",
 ]
 
@@ -134,6 +136,13 @@ def lib():
         L.circl_hip_mldsa_verify_table_submit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.circl_hip_hybrid_encaps_table_submit.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
         L.circl_hip_hybrid_decaps_table_submit.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+        L.circl_hip_queue_open.argtypes = [i, i, i, sz, i, vp]
+        L.circl_hip_queue_close.argtypes = [vp]
+        L.circl_hip_queue_eventfd.argtypes = [vp]
+        L.circl_hip_queue_stats.argtypes = [vp, vp, vp, vp]
+        L.circl_hip_queue_submit.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
+        L.circl_hip_queue_poll.argtypes = [vp, vp, sz, vp]
+        L.circl_hip_queue_wait.argtypes = [vp, C.c_uint64, C.c_int64]
         L.circl_hip_poll.argtypes = [vp, vp, sz, vp]
         L.circl_hip_wait.argtypes = [vp, C.c_uint64, C.c_int64]
         L.circl_hip_profile_call_stamps.argtypes = [i, vp]

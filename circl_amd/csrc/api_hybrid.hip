@@ -651,6 +651,23 @@ int circl_hip_hybrid_decaps_table_submit(const circl_hip_keytable *t, const uint
 }  // extern "C"
 namespace circl {
 namespace host {
+// circl_hip_queue for the hybrids with the key in the call -- what a TLS 1.3 server does per X25519MLKEM768 handshake (kem/hybrid/hybrid.go:271-300):
+// the arrays and the launch of circl_hip_hybrid_encaps / _decaps
+int hyb_call_queue_start(bool decaps, int scheme, Coalescer *co, bool want_eventfd, QueueShape *sh) {
+    Desc s;
+    if (!desc_of(scheme, s)) return CIRCL_HIP_EPARAM;
+    if (!decaps) {
+        *sh = QueueShape{s.pk, s.eseed, s.ct, s.ss, false, true};
+        return coalescer_async_start(co, {{nullptr, s.pk}, {nullptr, s.eseed, true}}, {}, {{nullptr, s.ct}, {nullptr, s.ss, true}, {nullptr, 1}}, hybrid_ws_fn(scheme),
+                                     hybrid_opts(scheme), [scheme](Chunk &c) {
+                                         return circl_hip_hybrid_encaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+                                     }, want_eventfd);
+    }
+    *sh = QueueShape{s.sk, s.ct, 0, s.ss, true, false};
+    return coalescer_async_start(co, {{nullptr, s.sk, true}, {nullptr, s.ct}}, {}, {{nullptr, s.ss, true}, {nullptr, 1}}, hybrid_ws_fn(scheme), hybrid_opts(scheme),
+                                 [scheme](Chunk &c) { return circl_hip_hybrid_decaps_dev(scheme, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st); },
+                                 want_eventfd);
+}
 // the queue of one hybrid table (part): its arrays and its launch, fixed for the queue's life (`r` outlives the queue: the table owns it)
 int hyb_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd) {
     Desc s;

@@ -982,6 +982,22 @@ int circl_hip_mlkem_decaps_table_submit(const circl_hip_keytable *t, const uint3
 }  // extern "C"
 namespace circl {
 namespace host {
+// circl_hip_queue for ML-KEM with the key in the call (a TLS 1.3 server encapsulates once per handshake, to the client's ephemeral key:
+// kem/mlkem/mlkem768/kyber.go:359-370 behind kem/hybrid/hybrid.go:95-99): the arrays and the launch of circl_hip_mlkem_encaps / _decaps
+int kem_call_queue_start(bool decaps, int param, Coalescer *co, bool want_eventfd, QueueShape *sh) {
+    const size_t EK = circl_hip_mlkem_ek_size(param), DK = circl_hip_mlkem_dk_size(param), CT = circl_hip_mlkem_ct_size(param);
+    if (!EK) return CIRCL_HIP_EPARAM;
+    if (!decaps) {
+        *sh = QueueShape{EK, 32, CT, 32, false, true};
+        return coalescer_async_start(co, {{nullptr, EK}, {nullptr, 32, true}}, {}, {{nullptr, CT}, {nullptr, 32, true}, {nullptr, 1}}, kem_ws_fn(), kem_opts(), [param](Chunk &c) {
+            return circl_hip_mlkem_encaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.out[2], c.cnt, c.ws, c.ws_bytes, c.st);
+        }, want_eventfd);
+    }
+    *sh = QueueShape{DK, CT, 0, 32, true, false};
+    return coalescer_async_start(co, {{nullptr, DK, true}, {nullptr, CT}}, {}, {{nullptr, 32, true}, {nullptr, 1}}, kem_ws_fn(), kem_opts(), [param](Chunk &c) {
+        return circl_hip_mlkem_decaps_dev(param, c.in[0], c.in[1], c.out[0], c.out[1], c.cnt, c.ws, c.ws_bytes, c.st);
+    }, want_eventfd);
+}
 // the queue of one ML-KEM table (part): its arrays and its launch, fixed for the queue's life (`r` outlives the queue: the table owns it)
 int kem_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_eventfd) {
     const size_t CT = circl_hip_mlkem_ct_size(r->param);

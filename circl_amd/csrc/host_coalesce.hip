@@ -1209,3 +1209,109 @@ int circl_hip_profile_call_stamps(int enable, uint64_t *out8) {
 }
 
 }  // extern "C"
+
+// ---- circl_hip_queue: the asynchronous form for keys that come WITH the call -------------------------------------------------------------
+// A queue is a coalescer with a dispatcher (above) that belongs to no table: one operation, one parameter set, one device.  Lifetime as for
+// tables: every call counts itself inside; close refuses (CIRCL_HIP_EBUSY) while one is, finishes what was submitted, then frees.
+struct circl_hip_queue {
+    uint32_t magic;
+    int op, param, device;
+    Coalescer *co;
+    QueueShape sh;
+    std::atomic<bool> closing{false};
+    mutable UseCount users;
+};
+namespace {
+constexpr uint32_t kQueueMagic = 0x51554531u;  // "QUE1"
+struct QueueUse {
+    const circl_hip_queue *q;
+    int s;
+    explicit QueueUse(const circl_hip_queue *qq) : q(qq), s(use_slot()) { q->users.slot[s].n.fetch_add(1); }
+    ~QueueUse() { q->users.slot[s].n.fetch_sub(1); }
+};
+inline bool queue_ok(const circl_hip_queue *q) { return q && q->magic == kQueueMagic; }
+}  // namespace
+
+extern "C" {
+
+int circl_hip_queue_open(int op, int param, int device, size_t max_items, int want_eventfd, circl_hip_queue **out) {
+    if (out) *out = nullptr;
+    if (!out || op < CIRCL_HIP_QUEUE_MLKEM_ENCAPS || op > CIRCL_HIP_QUEUE_HYBRID_DECAPS || max_items == 0) return CIRCL_HIP_EPARAM;
+    if (device < 0 || device >= ndev()) return ndev() > 0 ? CIRCL_HIP_ENODEV : CIRCL_HIP_ENODEV;
+    circl_hip_queue *q = new (std::nothrow) circl_hip_queue();
+    if (!q) return CIRCL_HIP_ENOMEM;
+    q->magic = kQueueMagic; q->op = op; q->param = param; q->device = device;
+    q->co = coalescer_new(device, max_items, 0);
+    if (!q->co) { delete q; return CIRCL_HIP_ENOMEM; }
+    q->co->owner_counts = true;  // (every call into it holds a QueueUse)
+    const bool decaps = op == CIRCL_HIP_QUEUE_MLKEM_DECAPS || op == CIRCL_HIP_QUEUE_HYBRID_DECAPS;
+    const int rc = op <= CIRCL_HIP_QUEUE_MLKEM_DECAPS ? kem_call_queue_start(decaps, param, q->co, want_eventfd != 0, &q->sh)
+                                                      : hyb_call_queue_start(decaps, param, q->co, want_eventfd != 0, &q->sh);
+    if (rc != CIRCL_HIP_OK) {
+        coalescer_free(q->co);
+        delete q;
+        return rc;
+    }
+    *out = q;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_queue_close(circl_hip_queue *q) {
+    if (!queue_ok(q)) return CIRCL_HIP_EPARAM;
+    q->closing.store(true);  // (seq_cst against the callers' count: either they see it, or it sees them)
+    if (q->users.load() != 0) {
+        q->closing.store(false);
+        g_err = "the queue has calls in flight";
+        return CIRCL_HIP_EBUSY;
+    }
+    coalescer_free(q->co);  // finishes every submitted call first (the dispatcher drains before it leaves)
+    q->magic = 0;
+    delete q;
+    return CIRCL_HIP_OK;
+}
+int circl_hip_queue_eventfd(const circl_hip_queue *q) { return queue_ok(q) ? coalescer_eventfd(q->co) : -1; }
+int circl_hip_queue_stats(const circl_hip_queue *q, uint64_t *calls, uint64_t *items, uint64_t *launches) {
+    if (!queue_ok(q)) return CIRCL_HIP_EPARAM;
+    coalescer_stats(q->co, calls, items, launches);
+    return CIRCL_HIP_OK;
+}
+int circl_hip_queue_submit(circl_hip_queue *q, const uint8_t *key, const uint8_t *in, uint8_t *out0, uint8_t *ss, uint8_t *status, size_t n, uint64_t *ticket) {
+    if (ticket) *ticket = 0;
+    if (!queue_ok(q) || !ticket) return CIRCL_HIP_EPARAM;
+    if (n == 0) return CIRCL_HIP_OK;
+    const bool encaps = q->sh.out0 != 0;
+    if (!key || !in || !ss || (encaps && !out0)) { g_err = "a required pointer is NULL"; return CIRCL_HIP_EPARAM; }
+    QueueUse use(q);
+    if (q->closing.load()) return CIRCL_HIP_EPARAM;
+    std::vector<HOut> outs;
+    if (encaps) outs.push_back({out0, q->sh.out0});
+    outs.push_back({ss, q->sh.ss, true});
+    outs.push_back({status, 1});
+    uint64_t seq = 0;
+    const int rc = coalesce_submit(q->co, n, {{key, q->sh.key, q->sh.key_secret}, {in, q->sh.in, q->sh.in_secret}}, {}, outs, &seq, false);
+    if (rc == CIRCL_HIP_OK) *ticket = seq;
+    return rc;
+}
+int circl_hip_queue_poll(const circl_hip_queue *q, const uint64_t *tickets, size_t n, int8_t *state) {
+    if (n && (!tickets || !state)) return CIRCL_HIP_EPARAM;
+    if (!queue_ok(q)) {
+        for (size_t i = 0; i < n; i++) state[i] = (int8_t)CIRCL_HIP_EPARAM;
+        return (int)n;
+    }
+    QueueUse use(q);
+    int done = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int s = q->closing.load() ? 0 : coalescer_state(q->co, tickets[i]);
+        state[i] = (int8_t)s;
+        done += s != 0;
+    }
+    return done;
+}
+int circl_hip_queue_wait(const circl_hip_queue *q, uint64_t ticket, int64_t timeout_us) {
+    if (!queue_ok(q)) return CIRCL_HIP_EPARAM;
+    QueueUse use(q);
+    if (q->closing.load()) return 0;
+    return coalescer_wait(q->co, ticket, timeout_us);
+}
+
+}  // extern "C"
+

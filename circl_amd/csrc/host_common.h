@@ -234,6 +234,14 @@ inline bool take_tail_flag(uint32_t **flag, unsigned **count, uint32_t *value) {
     *flag = g_tail_offer.flag; *count = g_tail_offer.count; *value = g_tail_offer.value;
     return true;
 }
+// circl_hip_queue (include/circl_hip.h): the asynchronous form of the entry points that take their keys WITH the call.  The api unit that owns
+// an operation fixes the queue's arrays and launch on `co` and says how long the rows are (api_mlkem.hip, api_hybrid.hip).
+struct QueueShape {
+    size_t key = 0, in = 0, out0 = 0, ss = 0;  // bytes per row: the key that comes with the item, its input, the ciphertext (encapsulation only), the secret
+    bool key_secret = false, in_secret = false;
+};
+int kem_call_queue_start(bool decaps, int param, Coalescer *co, bool want_eventfd, QueueShape *shape);
+int hyb_call_queue_start(bool decaps, int scheme, Coalescer *co, bool want_eventfd, QueueShape *shape);
 // circl_hip_profile_call_stamps: CLOCK_MONOTONIC nanoseconds of the stages of the calling thread's last BLOCKING coalesced call
 struct CallStamps { uint64_t enter = 0, reserved = 0, copied_in = 0, closed = 0, copies_in = 0, launched = 0, done = 0, copied_out = 0; };
 extern std::atomic<bool> g_stamps_on;

@@ -651,3 +651,49 @@ def hybrid_decaps(scheme, sk, ct, device=0):
     ss, st = np.empty((n, S["ss"]), np.uint8), np.empty(n, np.uint8)
     nat.check(nat.lib().circl_hip_hybrid_decaps(scheme, _p(sk), _p(ct), _p(ss), _p(st), n, device), "hybrid decaps")
     return ss, st
+
+
+class CallQueue:
+    """circl_hip_queue: the asynchronous form of the entry points that take their keys WITH the call (a TLS 1.3 server encapsulates to the client's
+    ephemeral key).  op: "mlkem-encaps", "mlkem-decaps" (param 512 / 768 / 1024), "hybrid-encaps", "hybrid-decaps" (param = the hybrid scheme id)."""
+    OPS = {"mlkem-encaps": 1, "mlkem-decaps": 2, "hybrid-encaps": 3, "hybrid-decaps": 4}
+
+    def __init__(self, op, param, max_items, device=0, eventfd=False):
+        import ctypes as C
+        self.op, self.param = op, param
+        self.handle = C.c_void_p()
+        nat.check(nat.lib().circl_hip_queue_open(self.OPS[op], param, device, max_items, 1 if eventfd else 0, C.byref(self.handle)), "queue_open")
+
+    def submit(self, key, inp, out0, ss, st):
+        """(rc, ticket); key / inp: C-contiguous uint8 rows (copied before the call returns), out0 (None for a decapsulation) / ss / st: filled when the ticket is done"""
+        import ctypes as C
+        key, inp = np.ascontiguousarray(key, np.uint8), np.ascontiguousarray(inp, np.uint8)
+        n = len(inp)
+        t = C.c_uint64()
+        rc = nat.lib().circl_hip_queue_submit(self.handle, _p(key), _p(inp), None if out0 is None else _p(out0), _p(ss), None if st is None else _p(st), n, C.byref(t))
+        return rc, t.value
+
+    def poll(self, tickets):
+        t = np.asarray(tickets, np.uint64)
+        st = np.zeros(len(t), np.int8)
+        nat.lib().circl_hip_queue_poll(self.handle, _p(t), len(t), _p(st))
+        return [int(x) for x in st]
+
+    def wait(self, ticket, timeout_us=-1):
+        return nat.lib().circl_hip_queue_wait(self.handle, int(ticket), int(timeout_us))
+
+    def eventfd(self):
+        return nat.lib().circl_hip_queue_eventfd(self.handle)
+
+    def stats(self):
+        import ctypes as C
+        c, i, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        nat.check(nat.lib().circl_hip_queue_stats(self.handle, C.byref(c), C.byref(i), C.byref(l)), "queue_stats")
+        return c.value, i.value, l.value
+
+    def close(self):
+        """CIRCL_HIP_OK (the queue is gone) or CIRCL_HIP_EBUSY"""
+        rc = nat.lib().circl_hip_queue_close(self.handle)
+        if rc == 0:
+            self.handle = None
+        return rc

@@ -304,6 +304,33 @@ int circl_hip_hybrid_decaps_table_submit(const circl_hip_keytable *table, const 
                                          size_t n, uint64_t *ticket);
 int circl_hip_poll(const circl_hip_keytable *table, const uint64_t *tickets, size_t n, int8_t *state);
 int circl_hip_wait(const circl_hip_keytable *table, uint64_t ticket, int64_t timeout_us);
+/* ---- the asynchronous form for keys that come WITH the call: circl_hip_queue ------------------------------------------------------
+ * A TLS 1.3 server encapsulates once per handshake, to the CLIENT'S ephemeral key (kem/hybrid/hybrid.go:271-300 ->
+ * kem/mlkem/mlkem768/kyber.go:359-370): there is no resident table to hang a queue on.  A circl_hip_queue is that queue by itself: one
+ * operation, one parameter set, one device, the same dispatcher thread, tickets, poll / wait / eventfd as above.
+ *   circl_hip_queue_open(op, param, device, max_items, want_eventfd, &q): op = CIRCL_HIP_QUEUE_MLKEM_ENCAPS / _MLKEM_DECAPS (param 512 / 768 /
+ *       1024) or CIRCL_HIP_QUEUE_HYBRID_ENCAPS / _HYBRID_DECAPS (param = the CIRCL_HIP_HYBRID_* scheme); device >= 0.
+ *   circl_hip_queue_submit(q, key, in, out0, ss, status, n, &ticket): n <= max_items / 4 items, each with its OWN key row.
+ *       encapsulation: key = n encapsulation (public) keys, in = n seeds m (ML-KEM: 32 bytes; hybrids: their eseed), out0 = n ciphertexts;
+ *       decapsulation: key = n decapsulation (private) keys, in = n ciphertexts, out0 unused (NULL).
+ *       ss = n shared secrets, status = n per-item status bytes (may be NULL).  key and in are copied before the call returns; out0 / ss /
+ *       status must stay valid until the ticket is done.  Returns as the *_table_submit calls do (CIRCL_HIP_EAGAIN: poll, submit again).
+ *   circl_hip_queue_poll / _wait / _eventfd: as circl_hip_poll / circl_hip_wait / circl_hip_keytable_eventfd.
+ *   circl_hip_queue_close: CIRCL_HIP_EBUSY while a call is inside the queue; otherwise finishes every submitted call, then frees.
+ * Bytes are those of circl_hip_mlkem_encaps / _decaps / circl_hip_hybrid_encaps / _decaps on the same rows. */
+#define CIRCL_HIP_QUEUE_MLKEM_ENCAPS 1
+#define CIRCL_HIP_QUEUE_MLKEM_DECAPS 2
+#define CIRCL_HIP_QUEUE_HYBRID_ENCAPS 3
+#define CIRCL_HIP_QUEUE_HYBRID_DECAPS 4
+typedef struct circl_hip_queue circl_hip_queue;
+int circl_hip_queue_open(int op, int param, int device, size_t max_items, int want_eventfd, circl_hip_queue **out);
+int circl_hip_queue_close(circl_hip_queue *q);
+int circl_hip_queue_eventfd(const circl_hip_queue *q);
+int circl_hip_queue_stats(const circl_hip_queue *q, uint64_t *calls, uint64_t *items, uint64_t *launches); /* as circl_hip_keytable_coalesce_stats */
+int circl_hip_queue_submit(circl_hip_queue *q, const uint8_t *key, const uint8_t *in, uint8_t *out0, uint8_t *ss, uint8_t *status, size_t n,
+                           uint64_t *ticket);
+int circl_hip_queue_poll(const circl_hip_queue *q, const uint64_t *tickets, size_t n, int8_t *state);
+int circl_hip_queue_wait(const circl_hip_queue *q, uint64_t ticket, int64_t timeout_us);
 /* The same for the entry points that take their keys WITH the call -- a TLS 1.3 server encapsulates once per handshake, to the
  * client's ephemeral key share (kem/hybrid/hybrid.go:271-300 -> kem/mlkem/mlkem768/kyber.go:359-370): nothing resident to attach a
  * batch to.  circl_hip_set_coalesce(max_items, max_wait_us), process-wide, default off: small calls (<= max_items / 4 items) of

@@ -155,6 +155,27 @@ struct Kem {
         }
         reap(true);
     }
+    // circl_hip_queue: the asynchronous form with the key in the call, one queue shared by every caller thread; each keeps two encapsulations outstanding
+    circl_hip_queue *cq = nullptr;
+    void call_queue() { CHECK(circl_hip_queue_open(CIRCL_HIP_QUEUE_MLKEM_ENCAPS, param, 0, 32, 1, &cq) == 0); }
+    void queue_calls(int caller, int count) const {
+        uint64_t tk[2] = {0, 0};
+        size_t at[2] = {0, 0};
+        std::vector<uint8_t> ct1(2 * CT), ss1(2 * 32), st1(2, 9);
+        for (int i = 0; i < count + 2; i++) {
+            const int sl = i & 1;
+            if (i >= 2) {
+                CHECK(circl_hip_queue_wait(cq, tk[sl], 5000000) == 1);
+                CHECK(!memcmp(&ct1[CT * sl], &ct[CT * at[sl]], CT) && !memcmp(&ss1[32 * sl], &ss[32 * at[sl]], 32) && st1[sl] == 0);
+            }
+            if (i >= count) continue;
+            at[sl] = ((size_t)caller * 97 + (size_t)i * 31) % n;  // item k under ITS OWN key (row k): the answers of the plain batch call in the constructor
+            int rc;
+            while ((rc = circl_hip_queue_submit(cq, &ek[EK * at[sl]], &m[32 * at[sl]], &ct1[CT * sl], &ss1[32 * sl], &st1[sl], 1, &tk[sl])) == CIRCL_HIP_EAGAIN)
+                std::this_thread::yield();
+            CHECK(rc == 0);
+        }
+    }
     // a setter on a table that callers are inside must answer CIRCL_HIP_EBUSY or succeed -- never free under them.
     // `tog` is a third public table; one thread flips its coalescing (and, every few flips, an asynchronous queue) while the others call.
     circl_hip_keytable *tog = nullptr;
@@ -331,6 +352,7 @@ int main(int argc, char **argv) {
     CHECK(circl_hip_keytable_set_coalesce(dsa65.verifier, 8, 0) == 0);
     CHECK(circl_hip_set_coalesce(16, 0) == 0);
     kem768.async_tables();
+    kem768.call_queue();
     dsa65.async_tables();
     kem768.toggle_table();
     std::atomic<int> tog_busy{0}, tog_ok{0};
@@ -356,6 +378,7 @@ int main(int argc, char **argv) {
                 kem768.async_calls(c, 40);
                 dsa65.async_calls(c, 5);
                 xwing.async_calls(c, 4);
+                kem768.queue_calls(c, 12);
                 if (c == 0) kem768.toggle(60, tog_busy, tog_ok);  // ... while the other callers are inside the toggled table
                 else kem768.toggled_calls(c, 30);
                 // an error path in the middle of everything: the Drain guard must give its slots back
@@ -379,6 +402,7 @@ int main(int argc, char **argv) {
     CHECK(circl_hip_keytable_close(dsa65.averifier) == 0);
     CHECK(circl_hip_keytable_close(kem768.tog) == 0);
     CHECK(circl_hip_keytable_close(xwing.apub) == 0);
+    CHECK(circl_hip_queue_eventfd(kem768.cq) >= 0 && circl_hip_queue_close(kem768.cq) == 0);
     CHECK(circl_hip_set_coalesce(0, 0) == 0);  // off AND drained: nobody is inside a process-wide batch any more
     printf("race_driver: the toggled table answered %d setters with OK, %d with EBUSY\n", tog_ok.load(), tog_busy.load());
     circl_hip_keytable_free(kem768.pub);

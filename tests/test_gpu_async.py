@@ -306,3 +306,78 @@ def test_hybrid_tables_submit_and_coalesce_equal_the_plain_calls(scheme_name):
     assert calls == 24 and items == 48 and 1 <= launches <= calls
     pub.close()
     prv.close()
+
+
+def test_call_queues_equal_the_oracle_and_the_plain_calls():
+    """circl_hip_queue: keys that come WITH the call (a TLS 1.3 server encapsulates to the client's ephemeral key: kem/hybrid/hybrid.go:271-300 ->
+    kem/mlkem/mlkem768/kyber.go:359-370).  ML-KEM-768 encapsulation and decapsulation against the oracle -- every item under its own key, a
+    non-canonical public key (kem.ErrPubKey, status 1) and a private key whose stored hash does not match (kem.ErrPrivKey, status 2) among them --
+    and X25519MLKEM768 encapsulation against circl_hip_hybrid_encaps; two threads submit and poll each queue."""
+    from circl_amd import hostapi
+    rng = np.random.default_rng(77)
+    pool = 120
+    ek, dk = orc.mlkem_keygen(768, rng.integers(0, 256, (pool, 64), dtype=np.uint8))
+    ek[5, 0:2] = 0xFF                                        # coefficient 0 = 0xFFF >= q: UnpackMLKEM rejects it (cpapke.go:45-55)
+    dk[9, -40] ^= 1                                          # H(ek) inside dk no longer matches
+    m = rng.integers(0, 256, (pool, 32), dtype=np.uint8)
+    ct0, ss0, st0 = orc.mlkem_encaps(768, ek, m)
+    assert st0[5] == 1 and st0.sum() == 1
+    ct_in = ct0.copy()
+    ct_in[::4, 20] ^= 8
+    ssd0, std0 = orc.mlkem_decaps(768, dk, ct_in)
+    assert std0[9] == 2
+    S = hostapi.HYBRID_SIZES[hostapi.X25519MLKEM768]
+    hpk, _hsk = hostapi.hybrid_keygen(hostapi.X25519MLKEM768, rng.integers(0, 256, (pool, S["seed"]), dtype=np.uint8))
+    hes = rng.integers(0, 256, (pool, S["eseed"]), dtype=np.uint8)
+    hct0, hss0, hst0 = hostapi.hybrid_encaps(hostapi.X25519MLKEM768, hpk, hes)
+    qe = hostapi.CallQueue("mlkem-encaps", 768, 64)
+    qd = hostapi.CallQueue("mlkem-decaps", 768, 32, eventfd=True)
+    qh = hostapi.CallQueue("hybrid-encaps", hostapi.X25519MLKEM768, 32)
+    assert qd.eventfd() >= 0 and qe.eventfd() == -1
+
+    def body(t):
+        r = np.random.default_rng(t)
+        we, wd, wh = Window(qe, 8), Window(qd, 8), Window(qh, 4)
+        for k in range(45):
+            n = int(r.choice([1, 1, 2, 3]))
+            lo = int(r.integers(0, pool - n))
+            kind = k % 3
+            w = (we, wd, wh)[kind]
+            while not w.room():
+                w.reap(block=True)
+            if kind == 0:
+                ct, ss, st = np.full((n, 1088), 0xAA, np.uint8), np.full((n, 32), 0xAA, np.uint8), np.full(n, 0xAA, np.uint8)
+                rc, tk = qe.submit(ek[lo:lo + n], m[lo:lo + n], ct, ss, st)
+                chk = lambda ct=ct, ss=ss, st=st, lo=lo, n=n: (_eq(ct, ct0[lo:lo + n]), _eq(ss, ss0[lo:lo + n]), _eq(st, st0[lo:lo + n]))
+            elif kind == 1:
+                ss, st = np.full((n, 32), 0xAA, np.uint8), np.full(n, 0xAA, np.uint8)
+                rc, tk = qd.submit(dk[lo:lo + n], ct_in[lo:lo + n], None, ss, st)
+                chk = lambda ss=ss, st=st, lo=lo, n=n: (_eq(ss, ssd0[lo:lo + n]), _eq(st, std0[lo:lo + n]))
+            else:
+                ct, ss = np.full((n, S["ct"]), 0xAA, np.uint8), np.full((n, S["ss"]), 0xAA, np.uint8)
+                rc, tk = qh.submit(hpk[lo:lo + n], hes[lo:lo + n], ct, ss, None)   # (status is optional)
+                chk = lambda ct=ct, ss=ss, lo=lo, n=n: (_eq(ct, hct0[lo:lo + n]), _eq(ss, hss0[lo:lo + n]))
+            if rc == EAGAIN:
+                w.reap(block=True)
+                continue
+            assert rc == 0, rc
+            w.push(tk, chk)
+            w.reap()
+        for w in (we, wd, wh):
+            w.reap(block=True)
+        assert we.done + wd.done + wh.done >= 30
+    _threads(2, body)
+    calls, items, launches = qe.stats()
+    assert calls >= 20 and items >= calls and 1 <= launches <= calls
+    ss = np.zeros((1, 32), np.uint8)
+    rc, _ = qd.submit(dk[:1], ct_in[:1], None, ss, None)     # left outstanding: close finishes it
+    assert rc == 0
+    assert qe.poll([1 << 40])[0] == EPARAM                   # a ticket this queue never issued
+    rc, _ = qe.submit(ek[:40], m[:40], np.zeros((40, 1088), np.uint8), np.zeros((40, 32), np.uint8), None)
+    assert rc == EPARAM                                      # more items than a submitted call may hold (max_items / 4)
+    assert qe.close() == 0 and qd.close() == 0 and qh.close() == 0   # (qd finishes its outstanding ticket first)
+    assert (ss == ssd0[:1]).all()
+
+
+def _eq(a, b):
+    assert (a == b).all(), (a, b)

@@ -7,7 +7,7 @@
 // ONE ordinary batch call made beforehand (bit-exact under concurrency, whatever batches the calls ended up in).
 //
 //   concurrent_bench <op: encaps|decaps|verify|sign|encaps_item> <coalesce max_items (0 = off)> <max_wait_us> <items per call> <seconds> <T> [T ...]
-//   concurrent_bench --async <op: encaps|decaps|verify> <R reactor threads> <W requests outstanding per reactor> <seconds> [max_items] [items per request]
+//   concurrent_bench --async <op: encaps|decaps|verify|encaps_call|decaps_call> <R reactor threads> <W requests outstanding per reactor> <seconds> [max_items] [items per request]
 //       the ASYNCHRONOUS form (circl_hip_keytable_async_start / *_table_submit / circl_hip_poll / circl_hip_wait): every reactor keeps W one-item
 //       requests outstanding -- submit until the window is full, poll the oldest tickets, block in circl_hip_wait only when nothing moved --
 //       the shape of ONE goroutine (or one epoll loop) per device serving every connection's handshake.  Latency = submit -> seen done.
@@ -77,6 +77,8 @@ struct Work {
     size_t EK, DK, CT, PK, SK, SIG;
     std::vector<uint32_t> kidx;
     circl_hip_keytable *table = nullptr;
+    circl_hip_queue *queue = nullptr;   // ops "encaps_call" / "decaps_call": the key comes with every item (circl_hip_queue)
+    std::vector<uint8_t> ekeys, dkeys;  // ... NK key rows each
     std::vector<uint8_t> m, ct, ss, st, sig, ok, mblob;
     std::vector<uint64_t> moff;
     void make(const std::string &op) {
@@ -84,7 +86,17 @@ struct Work {
         PK = circl_hip_mldsa_pk_size(dsa); SK = circl_hip_mldsa_sk_size(dsa); SIG = circl_hip_mldsa_sig_size(dsa);
         kidx.resize(POOL);
         for (size_t i = 0; i < POOL; i++) kidx[i] = (uint32_t)((i * 5 + i / 7) % NK);
-        if (op == "encaps" || op == "decaps") {
+        if (op == "encaps_call" || op == "decaps_call") {
+            std::vector<uint8_t> seed = bytes(64 * NK, 1);
+            ekeys.resize(EK * NK); dkeys.resize(DK * NK);
+            CHECK(circl_hip_mlkem_keygen(kem, seed.data(), ekeys.data(), dkeys.data(), NK, 0) == 0);
+            m = bytes(32 * POOL, 2);
+            ct.resize(CT * POOL); ss.resize(32 * POOL); st.resize(POOL);
+            circl_hip_keytable *pub = nullptr;
+            CHECK(circl_hip_mlkem_keytable_new(kem, 0, ekeys.data(), NK, 0, nullptr, &pub) == 0);
+            CHECK(circl_hip_mlkem_encaps_table(pub, kidx.data(), m.data(), ct.data(), ss.data(), st.data(), POOL) == 0);  // the answers
+            circl_hip_keytable_free(pub);
+        } else if (op == "encaps" || op == "decaps") {
             std::vector<uint8_t> seed = bytes(64 * NK, 1), ek(EK * NK), dk(DK * NK);
             CHECK(circl_hip_mlkem_keygen(kem, seed.data(), ek.data(), dk.data(), NK, 0) == 0);
             m = bytes(32 * POOL, 2);
@@ -133,8 +145,11 @@ static int async_main(int argc, char **argv) {
     CHECK(circl_hip_init() > 0);
     Work w;
     w.make(op);
-    CHECK(circl_hip_keytable_async_start(w.table, max_items, 0, 0) == 0);
-    const size_t CT = w.CT, SIG = w.SIG, POOL = Work::POOL;
+    const bool by_call = op == "encaps_call" || op == "decaps_call";
+    if (by_call) CHECK(circl_hip_queue_open(op == "encaps_call" ? CIRCL_HIP_QUEUE_MLKEM_ENCAPS : CIRCL_HIP_QUEUE_MLKEM_DECAPS, Work::kem, 0, max_items, 0, &w.queue) == 0);
+    else CHECK(circl_hip_keytable_async_start(w.table, max_items, 0, 0) == 0);
+    const size_t CT = w.CT, SIG = w.SIG, POOL = Work::POOL, EK = w.EK, DK = w.DK;
+    CHECK(!by_call || per == 1);  // (one key row per item: the pool's answers are per (item, key index))
     struct Slot { uint64_t ticket; size_t at; Clock::time_point t0; std::vector<uint8_t> o_ct, o_ss, o_st; };
     std::atomic<int> started{0};
     std::atomic<bool> stop{false};
@@ -144,7 +159,8 @@ static int async_main(int argc, char **argv) {
     rusage ru0{};
     getrusage(RUSAGE_SELF, &ru0);
     uint64_t c0 = 0, i0 = 0, l0 = 0;
-    circl_hip_keytable_coalesce_stats(w.table, &c0, &i0, &l0);
+    if (by_call) circl_hip_queue_stats(w.queue, &c0, &i0, &l0);
+    else circl_hip_keytable_coalesce_stats(w.table, &c0, &i0, &l0);
     std::vector<std::thread> th;
     for (int t = 0; t < R; t++) {
         th.emplace_back([&, t] {
@@ -158,8 +174,8 @@ static int async_main(int argc, char **argv) {
             while (started.load() < R + 1) std::this_thread::yield();
             auto drain_one = [&](Slot &sl) {
                 bool good;
-                if (op == "encaps") good = !memcmp(sl.o_ct.data(), &w.ct[CT * sl.at], CT * per) && !memcmp(sl.o_ss.data(), &w.ss[32 * sl.at], 32 * per);
-                else if (op == "decaps") good = !memcmp(sl.o_ss.data(), &w.ss[32 * sl.at], 32 * per);
+                if (op == "encaps" || op == "encaps_call") good = !memcmp(sl.o_ct.data(), &w.ct[CT * sl.at], CT * per) && !memcmp(sl.o_ss.data(), &w.ss[32 * sl.at], 32 * per);
+                else if (op == "decaps" || op == "decaps_call") good = !memcmp(sl.o_ss.data(), &w.ss[32 * sl.at], 32 * per);
                 else good = !memcmp(sl.o_st.data(), &w.ok[sl.at], per);
                 if (!good) mismatches.fetch_add(1);
                 if (lat[t].size() < lat[t].capacity()) lat[t].push_back(std::chrono::duration<float, std::micro>(Clock::now() - sl.t0).count());
@@ -172,7 +188,9 @@ static int async_main(int argc, char **argv) {
                     sl.at = at;
                     sl.t0 = Clock::now();
                     int rc;
-                    if (op == "encaps") rc = circl_hip_mlkem_encaps_table_submit(w.table, &w.kidx[at], &w.m[32 * at], sl.o_ct.data(), sl.o_ss.data(), sl.o_st.data(), per, &sl.ticket);
+                    if (op == "encaps_call") rc = circl_hip_queue_submit(w.queue, &w.ekeys[EK * w.kidx[at]], &w.m[32 * at], sl.o_ct.data(), sl.o_ss.data(), sl.o_st.data(), 1, &sl.ticket);
+                    else if (op == "decaps_call") rc = circl_hip_queue_submit(w.queue, &w.dkeys[DK * w.kidx[at]], &w.ct[CT * at], nullptr, sl.o_ss.data(), sl.o_st.data(), 1, &sl.ticket);
+                    else if (op == "encaps") rc = circl_hip_mlkem_encaps_table_submit(w.table, &w.kidx[at], &w.m[32 * at], sl.o_ct.data(), sl.o_ss.data(), sl.o_st.data(), per, &sl.ticket);
                     else if (op == "decaps") rc = circl_hip_mlkem_decaps_table_submit(w.table, &w.kidx[at], &w.ct[CT * at], sl.o_ss.data(), sl.o_st.data(), per, &sl.ticket);
                     else rc = circl_hip_mldsa_verify_table_submit(w.table, &w.kidx[at], &w.sig[SIG * at], w.mblob.data(), &w.moff[at], nullptr, nullptr, sl.o_st.data(), per, &sl.ticket);
                     if (rc == CIRCL_HIP_EAGAIN) { again[t]++; break; }
@@ -184,7 +202,8 @@ static int async_main(int argc, char **argv) {
                 }
                 while (!fifo.empty()) {  // tickets of one queue complete in issue order: only the head needs a look
                     int8_t state = 0;
-                    circl_hip_poll(w.table, &slots[fifo.front()].ticket, 1, &state);
+                    if (by_call) circl_hip_queue_poll(w.queue, &slots[fifo.front()].ticket, 1, &state);
+                    else circl_hip_poll(w.table, &slots[fifo.front()].ticket, 1, &state);
                     if (state == 0) break;
                     CHECK(state == 1);
                     drain_one(slots[fifo.front()]);
@@ -194,7 +213,8 @@ static int async_main(int argc, char **argv) {
                 }
                 if (!moved && !fifo.empty()) {  // nothing to submit, nothing finished: park this ONE thread until the oldest ticket is done
                     waits[t]++;
-                    (void)circl_hip_wait(w.table, slots[fifo.front()].ticket, 200);
+                    if (by_call) (void)circl_hip_queue_wait(w.queue, slots[fifo.front()].ticket, 200);
+                    else (void)circl_hip_wait(w.table, slots[fifo.front()].ticket, 200);
                 }
             }
             rusage ru{};
@@ -219,7 +239,8 @@ static int async_main(int argc, char **argv) {
     std::sort(all.begin(), all.end());
     auto q = [&](double f) { return all.empty() ? 0.f : all[std::min(all.size() - 1, (size_t)(f * all.size()))]; };
     uint64_t c1 = 0, i1 = 0, l1 = 0;
-    circl_hip_keytable_coalesce_stats(w.table, &c1, &i1, &l1);
+    if (by_call) circl_hip_queue_stats(w.queue, &c1, &i1, &l1);
+    else circl_hip_keytable_coalesce_stats(w.table, &c1, &i1, &l1);
     rusage ru1{};
     getrusage(RUSAGE_SELF, &ru1);
     const double pu = us_of(ru1.ru_utime, ru0.ru_utime), ps = us_of(ru1.ru_stime, ru0.ru_stime), n = (double)std::max<uint64_t>(total, 1);
@@ -231,7 +252,8 @@ static int async_main(int argc, char **argv) {
            (unsigned long long)eag, (unsigned long long)wt, (unsigned long long)mismatches.load());
     fflush(stdout);
     CHECK(mismatches.load() == 0);
-    CHECK(circl_hip_keytable_close(w.table) == 0);
+    if (by_call) CHECK(circl_hip_queue_close(w.queue) == 0);
+    else CHECK(circl_hip_keytable_close(w.table) == 0);
     return 0;
 }
 
@@ -307,6 +329,8 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> kidx(POOL);
     for (size_t i = 0; i < POOL; i++) kidx[i] = (uint32_t)((i * 5 + i / 7) % NK);
     circl_hip_keytable *table = nullptr;
+    circl_hip_queue *queue = nullptr;   // ops "encaps_call" / "decaps_call": the key comes with every item (circl_hip_queue)
+    std::vector<uint8_t> ekeys, dkeys;  // ... NK key rows each
     std::vector<uint8_t> m, ct, ss, st, sig, ok, mblob;
     std::vector<uint64_t> moff;
     const size_t MSG = 32;

@@ -118,6 +118,12 @@ step_async() {
       for rw in "1 64" "1 256" "2 128" "4 64" "4 128" "4 256" "4 1024"; do
         timeout 60 tools/bin/concurrent_bench --async $op $rw 2.0 2>&1 | grep -v amdgpu.ids
       done
+    done
+    echo "# keys that come WITH the call (circl_hip_queue: every item brings its own key -- a TLS server's encapsulation to the client's ephemeral key)"
+    for op in encaps_call decaps_call; do
+      for rw in "1 256" "4 64" "4 128" "4 256"; do
+        timeout 60 tools/bin/concurrent_bench --async $op $rw 2.0 2>&1 | grep -v amdgpu.ids
+      done
     done; } > "$OUT/async.txt"
   note "async"; cat "$OUT/async.txt"
 }
