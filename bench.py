@@ -27,7 +27,7 @@ and with --extras all (opt-in: the default run is the contract's):
     pooled               the figure of rounds 1-4 (keys from a pool of 2^16)
     shared_key / keyed   one key for the batch / a table of 1000 keys (the reference's parsed-key cache)
     hybrid               X-Wing and X25519MLKEM768 on resident arrays, 2^18 per GPU
-    small_batches / concurrent_callers   per-call cost of small batches; T one-item callers through the coalescer (tools/bin/concurrent_bench)
+    small_batches / concurrent_callers   per-call cost of small batches; T one-item callers through the coalescer and R reactors on the asynchronous form (tools/bin/concurrent_bench)
 
 --mode config3 | config4 | config5 | host makes that workload the headline (metric / value / ms_per_step) instead.
 
@@ -356,6 +356,20 @@ def concurrent_callers(seconds=1.0):
                 if cpu:
                     pts["T%s" % m.group(1)]["host_cpu_us_per_call"] = float(cpu.group(1))
         out[name] = pts if (r.returncode == 0 and pts) else {"error": (r.stdout + r.stderr)[-300:]}
+    # the asynchronous form (circl_hip_keytable_async_start / *_table_submit / circl_hip_poll; circl_hip_queue for keys with the call): R reactor
+    # threads, W one-item requests outstanding each, nobody asleep inside the library per call
+    asy = {}
+    for op in ("encaps", "decaps", "encaps_call"):
+        for R, W in ((1, 256), (4, 128)):
+            try:
+                r = subprocess.run([exe, "--async", op, str(R), str(W), str(seconds)], capture_output=True, text=True, timeout=120)
+                m = re.search(r"(\d+) items/s\s+latency us p50\s+([0-9.]+) p99\s+([0-9.]+).*?host CPU ([0-9.]+) us per item.*?mismatches (\d+)", r.stdout)
+                asy["%s_R%d_W%d" % (op, R, W)] = ({"items_per_s": float(m.group(1)), "p50_us": float(m.group(2)), "p99_us": float(m.group(3)),
+                                                   "host_cpu_us_per_item": float(m.group(4)), "mismatches": int(m.group(5))}
+                                                  if (r.returncode == 0 and m) else {"error": (r.stdout + r.stderr)[-300:]})
+            except Exception as e:  # noqa: BLE001
+                asy["%s_R%d_W%d" % (op, R, W)] = {"error": str(e)[-200:]}
+    out["async_reactors"] = asy
     return out
 
 

@@ -1237,7 +1237,7 @@ extern "C" {
 int circl_hip_queue_open(int op, int param, int device, size_t max_items, int want_eventfd, circl_hip_queue **out) {
     if (out) *out = nullptr;
     if (!out || op < CIRCL_HIP_QUEUE_MLKEM_ENCAPS || op > CIRCL_HIP_QUEUE_HYBRID_DECAPS || max_items == 0) return CIRCL_HIP_EPARAM;
-    if (device < 0 || device >= ndev()) return ndev() > 0 ? CIRCL_HIP_ENODEV : CIRCL_HIP_ENODEV;
+    if (device < 0 || device >= ndev()) return CIRCL_HIP_ENODEV;  // (a queue lives on ONE device: CIRCL_HIP_ALL_DEVICES is not accepted)
     circl_hip_queue *q = new (std::nothrow) circl_hip_queue();
     if (!q) return CIRCL_HIP_ENOMEM;
     q->magic = kQueueMagic; q->op = op; q->param = param; q->device = device;

@@ -403,6 +403,9 @@ def test_bench_py_small_run_emits_every_config(tmp_path):
     # the many-concurrent-callers leg (tools/bin/concurrent_bench, built by build()): coalesced beats uncoalesced, nothing mismatches
     cc = cfg.get("concurrent_callers")
     assert cc and cc["encaps_coalesced"]["T64"]["mismatches"] == 0 and cc["encaps_coalesced"]["T64"]["ops_per_s"] > 2 * cc["encaps_uncoalesced"]["T64"]["ops_per_s"]
+    ar = cc["async_reactors"]  # the submit / poll form: R reactors x W outstanding one-item requests, every result compared by the tool
+    assert all(v.get("mismatches") == 0 and v["items_per_s"] > 0 for v in ar.values()), ar
+    assert ar["encaps_R4_W128"]["items_per_s"] > cc["encaps_coalesced"]["T64"]["ops_per_s"]
     assert out["roofline"]["valu"] is None or out["roofline"]["valu"]["ceiling_source"] in ("live", None)  # (--no-pmc: no instruction count to price)
     for k in ("decaps", "config3", "config4", "config5", "host_abi", "shared_key", "keyed"):
         assert k in cfg, k
