@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <sys/resource.h>
 
 #include <deque>
@@ -133,6 +134,32 @@ struct Work {
 
 static double us_of(const timeval &a, const timeval &b) { return (double)(a.tv_sec - b.tv_sec) * 1e6 + (a.tv_usec - b.tv_usec); }
 
+// CB_PIN=1: the reactor threads stay on the CPUs of the device's NUMA node (where the library's dispatcher and its page-locked staging live) --
+// what a server that cares about its tail does; the default leaves them where the scheduler puts them
+static void pin_to_device_node(int device) {
+    const char *e = getenv("CB_PIN");
+    if (!e || atoi(e) == 0) return;
+    int cus = 0, node = -1;
+    if (circl_hip_device_info(device, &cus, &node) != 0 || node < 0) return;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    cpu_set_t set, allowed;
+    CPU_ZERO(&set);
+    sched_getaffinity(0, sizeof allowed, &allowed);
+    int a = 0, b = 0;
+    char sep = 0;
+    while (fscanf(f, "%d", &a) == 1) {
+        b = a;
+        if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b) != 1) b = a; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+        for (int c = a; c <= b; c++) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) CPU_SET(c, &set);
+        if (sep != ',') break;
+    }
+    fclose(f);
+    if (CPU_COUNT(&set) > 0) sched_setaffinity(0, sizeof set, &set);
+}
+
 // ---- --async: R reactors x W outstanding requests ----
 static int async_main(int argc, char **argv) {
     if (argc < 6) { fprintf(stderr, "usage: %s --async <encaps|decaps|verify> <R> <W> <seconds> [max_items] [items per request]\n", argv[0]); return 2; }
@@ -164,6 +191,7 @@ static int async_main(int argc, char **argv) {
     std::vector<std::thread> th;
     for (int t = 0; t < R; t++) {
         th.emplace_back([&, t] {
+            pin_to_device_node(0);
             std::vector<Slot> slots(W);
             for (auto &sl : slots) { sl.o_ct.resize(CT * per); sl.o_ss.resize(32 * per); sl.o_st.resize(per); }
             std::deque<size_t> fifo, freel;  // outstanding (oldest first) / free slot indices
