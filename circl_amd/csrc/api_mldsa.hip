@@ -154,8 +154,10 @@ int mldsa_verify_dev_impl(const uint8_t *pk, size_t nkeys, const uint32_t *key_i
         const uint32_t *rows = reinterpret_cast<const uint32_t *>(cached->d_table);
         const uint8_t *key_tr = cached->d_table + up256(padded * G::STREAMS * kPackedRowDwords * 4);
         ProfScope ps(CIRCL_HIP_KERNEL_MLDSA_VERIFY, st);
+        circl::TailFlag tail{nullptr, nullptr, 0};  // (the whole call is this ONE launch and verification holds no secret: a coalesced batch's flag may ride on it)
+        take_tail_flag(&tail.flag, &tail.count, &tail.value);
         hipLaunchKernelGGL(mldsa_verify_chain_kernel<MODE>, dim3((unsigned)n), dim3((DP<MODE>::K + 1) * 64), 0, st, pk, kx, rows, key_tr, sig, msg_blob,
-                           msg_off, ctx_blob, ctx_off, internal, ok, n, (uint8_t *)nullptr, (size_t)G::PK);
+                           msg_off, ctx_blob, ctx_off, internal, ok, n, (uint8_t *)nullptr, (size_t)G::PK, tail);
         HIP_TRY(hipGetLastError());
         return CIRCL_HIP_OK;
     }
@@ -362,6 +364,14 @@ PipeOpts dsa_opts(size_t dflt_chunk, bool secret, int depth = 3) {
     o.chunk_items = host_chunk_items(dflt_chunk);
     o.wipe_device = secret;
     o.depth = depth;
+    return o;
+}
+
+// a coalesced batch through a resident public-key table: its launch is ONE circl_hip_mldsa_verify_table_dev call, whose one-launch route may raise
+// the batch's completion flag itself (host_common.h TailOffer); nothing of a verification is secret
+PipeOpts dsa_verify_table_opts() {
+    PipeOpts o = dsa_opts(size_t(1) << 13, false);
+    o.tail_flag_ok = true;
     return o;
 }
 
@@ -945,7 +955,7 @@ int circl_hip_mldsa_verify_table(const circl_hip_keytable *t, const uint32_t *ke
         if (co && cnt <= coalescer_call_max(co)) {  // a small call joins the table's cross-caller batch (absent key_idx: zeros; absent contexts: empty rows)
             const int rc = coalesce_run(co, cnt, {{sig ? sig + lo * SIG : nullptr, SIG}, {reinterpret_cast<const uint8_t *>(ki), size_t(4), false, false, true}},
                                         {{msg_blob, msg_off + lo}, {ctx_blob, ctx_blob ? ctx_off + lo : nullptr}}, {{ok + lo, 1}},
-                                        [&](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 13, false), [&](Chunk &c) {
+                                        [&](size_t c) { return mldsa_ws_any(param, c); }, dsa_verify_table_opts(), [&](Chunk &c) {
                                             return circl_hip_mldsa_verify_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[0], c.blob[0], c.off[0], c.blob[1],
                                                                                     c.off[1], c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
                                         });
@@ -985,7 +995,7 @@ int dsa_table_async_start(const circl_hip_keytable *r, Coalescer *co, bool want_
     const int param = r->param;
     const size_t SIG = circl_hip_mldsa_sig_size(param);
     return coalescer_async_start(co, {{nullptr, SIG}, {nullptr, size_t(4), false, false, true}}, {{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, 1}},
-                                 [param](size_t c) { return mldsa_ws_any(param, c); }, dsa_opts(size_t(1) << 13, false), [r](Chunk &c) {
+                                 [param](size_t c) { return mldsa_ws_any(param, c); }, dsa_verify_table_opts(), [r](Chunk &c) {
                                      return circl_hip_mldsa_verify_table_dev(r, reinterpret_cast<const uint32_t *>(c.in[1]), c.in[0], c.blob[0], c.off[0], c.blob[1], c.off[1],
                                                                              c.out[0], c.cnt, c.ws, c.ws_bytes, c.st);
                                  }, want_eventfd);

@@ -1040,7 +1040,8 @@ __global__ void __launch_bounds__((DP<MODE>::K + (RESIDENT ? 1 : 2)) * 64)
     mldsa_verify_chain_kernel(const uint8_t *__restrict__ pk_table, const KeyIdx key_idx, const uint32_t *__restrict__ key_rows,
                               const uint8_t *__restrict__ key_tr, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ msg_blob,
                               const uint64_t *__restrict__ msg_off, const uint8_t *__restrict__ ctx_blob, const uint64_t *__restrict__ ctx_off,
-                              int internal, uint8_t *__restrict__ ok, size_t n, uint8_t *__restrict__ scratch, size_t pk_stride) {
+                              int internal, uint8_t *__restrict__ ok, size_t n, uint8_t *__restrict__ scratch, size_t pk_stride,
+                              const TailFlag tail = TailFlag{nullptr, nullptr, 0}) {
     using G = DG<MODE>;
     using P = DP<MODE>;
     constexpr int K = P::K, L = P::L, TRW = P::TR / 8, HB = P::OMEGA + K;
@@ -1266,6 +1267,7 @@ __global__ void __launch_bounds__((DP<MODE>::K + (RESIDENT ? 1 : 2)) * 64)
         for (int k = 0; k <= K; k++) failed |= bad_w[k];
         if (half == 0 && j == 0) ok[item] = (diff == 0 && failed == 0) ? 1 : 0;
     }
+    if constexpr (RESIDENT) tail_signal(tail);  // (a coalesced batch's completion flag, raised by the launch's last workgroup: keccak_dev.h TailFlag)
 }
 
 // ---- kernel F -----------------------------------------------------------------------------------

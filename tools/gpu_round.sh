@@ -119,6 +119,10 @@ step_async() {
         timeout 60 tools/bin/concurrent_bench --async $op $rw 2.0 2>&1 | grep -v amdgpu.ids
       done
     done
+    echo "# ML-DSA-65 verification through a resident public-key table (circl_hip_mldsa_verify_table_submit)"
+    for rw in "1 64" "4 64" "4 128"; do
+      timeout 60 tools/bin/concurrent_bench --async verify $rw 2.0 2>&1 | grep -v amdgpu.ids
+    done
     echo "# keys that come WITH the call (circl_hip_queue: every item brings its own key -- a TLS server's encapsulation to the client's ephemeral key)"
     for op in encaps_call decaps_call; do
       for rw in "1 256" "4 64" "4 128" "4 256"; do
