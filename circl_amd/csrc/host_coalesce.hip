@@ -152,7 +152,6 @@ struct CoBatch {
     uint8_t *hin = nullptr, *hout = nullptr, *d = nullptr;
     uint8_t *hin_dev = nullptr, *hout_dev = nullptr;
     hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;  // blocking-sync event (the leader sleeps until the batch is done instead of polling the stream)
     // completion flag: a dword at the end of the page-locked output area that the stream writes AFTER the batch's last operation
     // (CIRCL_HIP_COALESCE_DONE): whoever waits for the batch polls host memory instead of calling into the runtime
     std::atomic<uint32_t> *flag = nullptr;
@@ -200,8 +199,6 @@ struct Coalescer {
     size_t max_items = 0, call_max = 0;
     unsigned max_wait_us = 0;
     int inflight_max = 2;
-    int spin = 0;  // gate spins before sleeping (0 when callers may outnumber the CPUs)
-    bool blocking = false;  // the leader sleeps on an interrupt-driven event instead of hipStreamSynchronize's polling
     int done_mode = 2;      // how a batch's end is noticed -- 0: hipStreamSynchronize / hipStreamQuery; 1: a flag in page-locked memory written by
                             // hipStreamWriteValue32, polled; 2: the flag written by the stream's finish kernel (which also wipes), polled
 
@@ -261,7 +258,6 @@ void free_batches(Coalescer *co) {
     if (!co->batches.empty() && hipSetDevice(physical_device(co->dev)) == hipSuccess) {
         for (CoBatch *b : co->batches) {
             if (b->st) { (void)hipStreamSynchronize(b->st); (void)hipStreamDestroy(b->st); }
-            if (b->ev) (void)hipEventDestroy(b->ev);
             if (b->hin) { memset(b->hin, 0, co->hin_bytes); (void)pinned_free(b->hin); }
             if (b->hout) { memset(b->hout, 0, co->hout_bytes); (void)pinned_free(b->hout); }
             if (b->d) (void)hipFree(b->d);
@@ -326,7 +322,6 @@ int lay_out(Coalescer *co, const std::vector<HIn> &ins, const std::vector<HBlob>
         b->count_dev = reinterpret_cast<unsigned *>(b->d + co->d_bytes - 256);
         HIP_TRY(hipMemset(b->count_dev, 0, 256));
         HIP_TRY(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
-        if (co->blocking) HIP_TRY(hipEventCreateWithFlags(&b->ev, hipEventBlockingSync | hipEventDisableTiming));
         if (co->async) {
             b->recs = new (std::nothrow) CallRec[N];
             if (!b->recs) return CIRCL_HIP_ENOMEM;
@@ -506,9 +501,6 @@ int await_done(Coalescer *co, CoBatch *b, int rc) {
             if ((i & 1023) == 1023 && now_ns() - t0 > 2000000ull) { se = hipStreamSynchronize(b->st); break; }
         }
         if ((++b->uses & 63) == 0) (void)hipStreamQuery(b->st);  // lets the runtime retire the stream's finished commands now and then
-    } else if (b->ev) {
-        se = hipEventRecord(b->ev, b->st);
-        if (se == hipSuccess) se = hipEventSynchronize(b->ev);
     } else {
         se = hipStreamSynchronize(b->st);
     }
@@ -829,8 +821,6 @@ Coalescer *coalescer_new(int dev, size_t max_items, unsigned max_wait_us) {
     co->call_max = std::max<size_t>(1, co->max_items / 4);
     co->max_wait_us = std::min(max_wait_us, 100000u);
     co->inflight_max = env_int("CIRCL_HIP_COALESCE_INFLIGHT", 2, 1, 8);
-    co->spin = env_int("CIRCL_HIP_COALESCE_SPIN", 0, 0, 1 << 20);
-    co->blocking = env_int("CIRCL_HIP_COALESCE_BLOCKING", 0, 0, 1) != 0;
     co->done_mode = env_int("CIRCL_HIP_COALESCE_DONE", 2, 0, 2);  // (measured: profiles/r06_one_call.txt -- one caller 31 -> 24 us, 64 callers +11 %)
     co->spin_us = (unsigned)env_int("CIRCL_HIP_ASYNC_SPIN_US", 20, 0, 100000);
     for (auto &r : co->rc_ring) r.store(0, std::memory_order_relaxed);
@@ -975,7 +965,7 @@ int coalesce_run(Coalescer *co, size_t n, const std::vector<HIn> &ins, const std
     STAMP(copied_in);
 
     if (leader) flush(co, b, ws_bytes, opts, launch);
-    else b->done.wait(co->spin);
+    else b->done.wait(0);  // (polling the gate before sleeping was measured in round 5 and lost: callers may outnumber the CPUs)
 
     // ---- results ----
     const int rc = b->rc;

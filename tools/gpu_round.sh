@@ -16,7 +16,7 @@
 #   tests        the whole GPU suite + smoke()                                                                  -> gpu_tests.log
 #   async        tools/bin/concurrent_bench --async: R reactor threads x W outstanding one-item requests       -> async.txt
 #   one_call     where the microseconds of ONE one-item table call go (library's own timestamps)               -> one_call.txt
-#   routes       circl_hip_selftest_routes: both sides of every route cut-over on this box                     -> routes.txt
+#   routes       tools/route_check.py: both sides of every route cut-over on this box                          -> routes.txt
 #   verify_ab    A/B of mldsa_verify_kernel variants (CIRCL_HIP_DSA_VERIFY_* knobs), alternating               -> verify_ab.txt
 #   concurrent   the blocking coalescer's T-thread table (round 5's measurement, for comparison)               -> concurrent.txt
 set -u
@@ -139,7 +139,7 @@ step_one_call() {
 }
 
 step_routes() {
-  { hdr "python tools/route_check.py   (circl_hip_selftest_routes)"
+  { hdr "python tools/route_check.py   (both routes of every cut-over at 1/2, 1, 2 and 4 x its threshold)"
     timeout 600 python tools/route_check.py 2>&1 | grep -v amdgpu.ids; echo "route_check rc=$?"; } > "$OUT/routes.txt"
   note "routes"; cat "$OUT/routes.txt"
 }
