@@ -140,7 +140,7 @@ step_one_call() {
 
 step_routes() {
   { hdr "python tools/route_check.py   (both routes of every cut-over at 1/2, 1, 2 and 4 x its threshold)"
-    timeout 600 python tools/route_check.py 2>&1 | grep -v amdgpu.ids; echo "route_check rc=$?"; } > "$OUT/routes.txt"
+    timeout 900 python tools/route_check.py 2>&1 | grep -v amdgpu.ids; echo "route_check rc=${PIPESTATUS[0]}"; } > "$OUT/routes.txt"
   note "routes"; cat "$OUT/routes.txt"
 }
 
