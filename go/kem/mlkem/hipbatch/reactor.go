@@ -53,6 +53,7 @@ type reply struct {
 }
 
 type request struct {
+	key  []byte     // call queues only: the packed key that comes with the item
 	in   []byte     // encapsulation seed or ciphertext
 	done chan reply // capacity 1: the reactor never blocks on an owner
 }
@@ -64,8 +65,14 @@ type flight struct {
 	reqs   []*request
 }
 
+// A reactor serves ONE queue of the library: a resident table's (k != nil: circl_hip_keytable_async_start) or a call queue's (q != nil:
+// circl_hip_queue_open -- every item brings its own key: a TLS server's encapsulation to the client's ephemeral share).
 type reactor struct {
 	k       *ResidentTable
+	q       *C.circl_hip_queue
+	decaps  bool
+	keySize int
+	keys    []byte // call queues: the pending calls' key rows, side by side
 	reqs    chan *request
 	wake    chan struct{}
 	quit    chan struct{}
@@ -93,9 +100,9 @@ func (k *ResidentTable) startReactor(maxItems, window int) (*reactor, error) {
 	if err := status(C.circl_hip_keytable_async_start(k.t, C.size_t(maxItems), 0, 1), "keytable_async_start"); err != nil {
 		return nil, err
 	}
-	r := &reactor{k: k, reqs: make(chan *request, window), wake: make(chan struct{}, 1), quit: make(chan struct{}),
+	r := &reactor{k: k, decaps: k.private, reqs: make(chan *request, window), wake: make(chan struct{}, 1), quit: make(chan struct{}),
 		window: window, callMax: max(1, maxItems/4), ctSize: k.s.CiphertextSize(), errQueueClosed: errors.New("circl-hip: the key object was closed")}
-	if k.private {
+	if r.decaps {
 		r.inSize = k.s.CiphertextSize()
 	} else {
 		r.inSize = k.s.EncapsulationSeedSize()
@@ -104,9 +111,35 @@ func (k *ResidentTable) startReactor(maxItems, window int) (*reactor, error) {
 	r.arenaSS = C.malloc(C.size_t(window * 32))
 	r.arenaST = C.malloc(C.size_t(window))
 	r.scratch = make([]byte, r.callMax*r.inSize)
-	// the queue's eventfd through the runtime poller: a Read parks the goroutine, not a thread.  The library owns its descriptor,
-	// so the os.File gets a dup of it (same counter; closed by stop, which is also what ends the completions goroutine)
-	if fd := int(C.circl_hip_keytable_eventfd(k.t, 0)); fd >= 0 {
+	r.start(int(C.circl_hip_keytable_eventfd(k.t, 0)))
+	return r, nil
+}
+
+// newCallReactor opens a call queue for s's encapsulations with the key in the call (circl_hip_queue_open) and starts its goroutines.
+func newCallReactor(s kem.Scheme, device, maxItems, window int) (*reactor, error) {
+	p, ok := params[s.Name()]
+	if !ok {
+		return nil, kem.ErrTypeMismatch
+	}
+	r := &reactor{reqs: make(chan *request, window), wake: make(chan struct{}, 1), quit: make(chan struct{}), window: window,
+		callMax: max(1, maxItems/4), ctSize: s.CiphertextSize(), keySize: s.PublicKeySize(), inSize: s.EncapsulationSeedSize(),
+		errQueueClosed: errors.New("circl-hip: the scheme's call queue was closed")}
+	if err := status(C.circl_hip_queue_open(C.int(C.CIRCL_HIP_QUEUE_MLKEM_ENCAPS), p, C.int(device), C.size_t(maxItems), 1, &r.q), "queue_open"); err != nil {
+		return nil, err
+	}
+	r.arenaCT = C.malloc(C.size_t(window * r.ctSize))
+	r.arenaSS = C.malloc(C.size_t(window * 32))
+	r.arenaST = C.malloc(C.size_t(window))
+	r.scratch = make([]byte, r.callMax*r.inSize)
+	r.keys = make([]byte, r.callMax*r.keySize)
+	r.start(int(C.circl_hip_queue_eventfd(r.q)))
+	return r, nil
+}
+
+// start: the queue's eventfd through the runtime poller -- a Read parks the goroutine, not a thread.  The library owns its descriptor, so
+// the os.File gets a dup of it (same counter; closed by stop, which is also what ends the completions goroutine) -- and the goroutines.
+func (r *reactor) start(fd int) {
+	if fd >= 0 {
 		if d, err := syscall.Dup(fd); err == nil {
 			syscall.SetNonblock(d, true)
 			r.efd = os.NewFile(uintptr(d), "circl-hip-eventfd")
@@ -117,7 +150,6 @@ func (k *ResidentTable) startReactor(maxItems, window int) (*reactor, error) {
 	if r.efd != nil {
 		go r.completions()
 	}
-	return r, nil
 }
 
 func (r *reactor) completions() {
@@ -133,9 +165,11 @@ func (r *reactor) completions() {
 	}
 }
 
-// do is what a request goroutine runs: hand the request over, park until the reply is there.
-func (r *reactor) do(in []byte) reply {
-	rq := &request{in: in, done: make(chan reply, 1)}
+// do is what a request goroutine runs: hand the request over, park until the reply is there (key: call queues only).
+func (r *reactor) do(in []byte) reply { return r.doKeyed(nil, in) }
+
+func (r *reactor) doKeyed(key, in []byte) reply {
+	rq := &request{key: key, in: in, done: make(chan reply, 1)}
 	select {
 	case r.reqs <- rq:
 	case <-r.quit:
@@ -212,6 +246,15 @@ func (r *reactor) submit(reqs []*request) bool {
 	var rc C.int
 	ss := (*C.uint8_t)(unsafe.Add(r.arenaSS, r.tail*32))
 	st := (*C.uint8_t)(unsafe.Add(r.arenaST, r.tail))
+	if r.q != nil { // a call queue: the key rows travel with the call (public keys: nothing to clear)
+		for i, rq := range reqs {
+			copy(r.keys[i*r.keySize:], rq.key)
+		}
+		ct := (*C.uint8_t)(unsafe.Add(r.arenaCT, r.tail*r.ctSize))
+		rc = C.circl_hip_queue_submit(r.q, ptr(r.keys[:n*r.keySize]), ptr(r.scratch[:n*r.inSize]), ct, ss, st, C.size_t(n), &ticket)
+		clear(r.scratch[:n*r.inSize])
+		return r.submitted(rc, ticket, reqs)
+	}
 	r.k.mu.RLock()
 	if r.k.t == nil {
 		r.k.mu.RUnlock()
@@ -220,7 +263,7 @@ func (r *reactor) submit(reqs []*request) bool {
 		}
 		return true
 	}
-	if r.k.private {
+	if r.decaps {
 		rc = C.circl_hip_mlkem_decaps_table_submit(r.k.t, nil, ptr(r.scratch[:n*r.inSize]), ss, st, C.size_t(n), &ticket)
 	} else {
 		ct := (*C.uint8_t)(unsafe.Add(r.arenaCT, r.tail*r.ctSize))
@@ -228,11 +271,17 @@ func (r *reactor) submit(reqs []*request) bool {
 	}
 	r.k.mu.RUnlock()
 	clear(r.scratch[:n*r.inSize]) // (the library has its copy; encapsulation seeds are secret)
+	return r.submitted(rc, ticket, reqs)
+}
+
+// submitted books a submit's outcome: false = CIRCL_HIP_EAGAIN (nothing was taken; a completion has to come first)
+func (r *reactor) submitted(rc C.int, ticket C.uint64_t, reqs []*request) bool {
+	n := len(reqs)
 	if rc == C.CIRCL_HIP_EAGAIN {
 		return false
 	}
 	if rc != 0 {
-		err := status(rc, "table_submit")
+		err := status(rc, "submit")
 		for _, rq := range reqs {
 			rq.done <- reply{err: err}
 		}
@@ -249,13 +298,17 @@ func (r *reactor) reap() {
 	for len(r.fifo) > 0 {
 		f := &r.fifo[0]
 		var state C.int8_t
-		r.k.mu.RLock()
-		if r.k.t != nil {
-			C.circl_hip_poll(r.k.t, &f.ticket, 1, &state)
+		if r.q != nil {
+			C.circl_hip_queue_poll(r.q, &f.ticket, 1, &state)
 		} else {
-			state = C.int8_t(C.CIRCL_HIP_EPARAM)
+			r.k.mu.RLock()
+			if r.k.t != nil {
+				C.circl_hip_poll(r.k.t, &f.ticket, 1, &state)
+			} else {
+				state = C.int8_t(C.CIRCL_HIP_EPARAM)
+			}
+			r.k.mu.RUnlock()
 		}
-		r.k.mu.RUnlock()
 		if state == 0 {
 			return
 		}
@@ -270,7 +323,7 @@ func (r *reactor) reap() {
 			}
 			if rp.err == nil {
 				rp.ss = C.GoBytes(unsafe.Add(r.arenaSS, s*32), 32)
-				if !r.k.private {
+				if !r.decaps {
 					rp.ct = C.GoBytes(unsafe.Add(r.arenaCT, s*r.ctSize), C.int(r.ctSize))
 				}
 			}
@@ -294,11 +347,16 @@ func (r *reactor) drain(pending []*request) {
 func (r *reactor) stop() {
 	close(r.quit)
 	r.stopped.Wait()
-	r.k.mu.Lock()
-	if r.k.t != nil {
-		C.circl_hip_keytable_async_stop(r.k.t) // (finishes what was submitted: nothing writes the arena afterwards)
+	if r.q != nil {
+		C.circl_hip_queue_close(r.q) // (the reactor goroutine has left: nobody is inside the queue; what was submitted is finished first)
+		r.q = nil
+	} else {
+		r.k.mu.Lock()
+		if r.k.t != nil {
+			C.circl_hip_keytable_async_stop(r.k.t) // (finishes what was submitted: nothing writes the arena afterwards)
+		}
+		r.k.mu.Unlock()
 	}
-	r.k.mu.Unlock()
 	if r.efd != nil {
 		r.efd.Close() // the completions goroutine's Read fails and it leaves
 	}

@@ -32,6 +32,7 @@ import "C"
 
 import (
 	"crypto/rand"
+	"sync"
 	"time"
 
 	"github.com/cloudflare/circl/kem"
@@ -55,6 +56,10 @@ type ServingScheme struct {
 	device   int
 	maxItems int
 	window   int
+
+	callOnce sync.Once // the call queue for encapsulations to keys that are NOT resident: opened at the first such call
+	call     *reactor
+	callErr  error
 }
 
 // Serving returns the serving form of an ML-KEM scheme of CIRCL's registry, or nil.  Device batches hold up to 2048 items, a key's
@@ -72,6 +77,15 @@ func Serving(name string, device int) *ServingScheme {
 		return nil
 	}
 	return &ServingScheme{Scheme: *s, device: device, maxItems: 2048, window: 4096}
+}
+
+// Close stops the scheme's call queue (key objects are closed one by one).
+func (s *ServingScheme) Close() {
+	s.callOnce.Do(func() {}) // (a queue that was never opened stays unopened)
+	if s.call != nil {
+		s.call.stop()
+		s.call = nil
+	}
 }
 
 // SetBatching applies to key objects made afterwards: the largest device batch and the requests one key keeps in flight.
@@ -154,7 +168,22 @@ func (s *ServingScheme) Encapsulate(pk kem.PublicKey) (ct, ss []byte, err error)
 func (s *ServingScheme) EncapsulateDeterministically(pk kem.PublicKey, seed []byte) (ct, ss []byte, err error) {
 	r, ok := pk.(*ResidentPublicKey)
 	if !ok {
-		return s.Scheme.EncapsulateDeterministically(pk, seed)
+		// a key that was not made by this scheme -- a TLS server's case: every handshake encapsulates once, to the CLIENT'S ephemeral key
+		// (kem/hybrid/hybrid.go:271-300).  Its packed form travels with the request through the scheme's call queue (circl_hip_queue):
+		// the requests of the connections that arrive while a launch runs share the next one.
+		if len(seed) != s.EncapsulationSeedSize() {
+			return nil, nil, kem.ErrSeedSize
+		}
+		s.callOnce.Do(func() { s.call, s.callErr = newCallReactor(s.Scheme.Scheme, s.device, s.maxItems, s.window) })
+		if s.callErr != nil {
+			return s.Scheme.EncapsulateDeterministically(pk, seed) // no device: CIRCL's own path
+		}
+		b, err := pk.MarshalBinary()
+		if err != nil {
+			return nil, nil, err
+		}
+		rp := s.call.doKeyed(b, seed)
+		return rp.ct, rp.ss, rp.err
 	}
 	if len(seed) != s.EncapsulationSeedSize() {
 		return nil, nil, kem.ErrSeedSize
