@@ -10,6 +10,42 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from circl_amd import hostapi  # noqa: E402
 from oracle import orc, hybrid as ohyb  # noqa: E402
 
+
+
+def _same(a, b, what):
+    assert (np.asarray(a) == np.asarray(b)).all(), what
+
+
+def drive(q, calls, width):
+    """The asynchronous form from one thread: `calls` = [(submit, check)], at most `width` tickets outstanding; q.poll / q.wait as KeyTable and
+    CallQueue offer them.  Tickets of one queue finish in issue order."""
+    fifo = []
+
+    def reap(block):
+        while fifo:
+            st = q.poll([fifo[0][0]])[0]
+            if st == 0:
+                if not block:
+                    return
+                st = q.wait(fifo[0][0], 5_000_000)
+            assert st == 1, ("ticket state", st)
+            fifo.pop(0)[1]()
+    for submit, check in calls:
+        while True:
+            while len(fifo) >= width:
+                reap(True)
+            rc, tk = submit()
+            if rc == -7:  # CIRCL_HIP_EAGAIN: every device batch busy
+                reap(True)
+                continue
+            assert rc == 0, ("submit", rc)
+            fifo.append((tk, check))
+            reap(False)
+            break
+    while fifo:
+        reap(True)
+
+
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 it = 0
@@ -41,6 +77,38 @@ while time.time() < t_end:
     assert (ctk == ctg).all() and (ssk == ssg).all() and not stk.any(), ("encaps keyed", p, n, nk)
     ssdk, stdk = hostapi.mlkem_decaps_keyed(p, dk[:nk], idx, ctk)
     assert (ssdk == ssk).all() and not stdk.any(), ("decaps keyed", p, n, nk)
+    # the asynchronous form over the same answers: resident tables (random batch limit, random call sizes, a window of tickets) and a call queue
+    na = min(n, 160)
+    mi = int(rng.choice([8, 64, 512]))
+    pub, prv = hostapi.KeyTable("mlkem-public", p, ek[:nk]), hostapi.KeyTable("mlkem-private", p, dk[:nk])
+    pub.async_start(mi, 0)
+    prv.async_start(mi, int(rng.choice([0, 40])))
+    qe = hostapi.CallQueue("mlkem-encaps", p, mi)
+    CTB = ctk.shape[1]
+    calls, lo = [], 0
+    while lo < na:
+        c = int(min(na - lo, rng.integers(1, mi // 4 + 1)))
+        a, b = lo, lo + c
+        oc, os_, ost = np.full((c, CTB), 0xAA, np.uint8), np.full((c, 32), 0xAA, np.uint8), np.full(c, 0xAA, np.uint8)
+        od, odst = np.full((c, 32), 0xAA, np.uint8), np.full(c, 0xAA, np.uint8)
+        qc, qs, qst = np.full((c, CTB), 0xAA, np.uint8), np.full((c, 32), 0xAA, np.uint8), np.full(c, 0xAA, np.uint8)
+        calls.append((lambda a=a, b=b, oc=oc, os_=os_, ost=ost: pub.submit_encaps(m[a:b], oc, os_, ost, key_idx=idx[a:b]),
+                      lambda a=a, b=b, oc=oc, os_=os_, ost=ost: (_same(oc, ctk[a:b], "async encaps"), _same(os_, ssk[a:b], "async encaps ss"), _same(ost, stk[a:b], "st"))))
+        calls.append((lambda a=a, b=b, od=od, odst=odst: prv.submit_decaps(ctk[a:b], od, odst, key_idx=idx[a:b]),
+                      lambda a=a, b=b, od=od, odst=odst: (_same(od, ssk[a:b], "async decaps"), _same(odst, stdk[a:b], "st"))))
+        lo = b
+    drive(pub, calls[0::2], int(rng.choice([1, 4, 16])))
+    drive(prv, calls[1::2], int(rng.choice([1, 4, 16])))
+    qcalls, lo = [], 0
+    while lo < na:
+        c = int(min(na - lo, rng.integers(1, mi // 4 + 1)))
+        a, b = lo, lo + c
+        qc, qs, qst = np.full((c, CTB), 0xAA, np.uint8), np.full((c, 32), 0xAA, np.uint8), np.full(c, 0xAA, np.uint8)
+        qcalls.append((lambda a=a, b=b, qc=qc, qs=qs, qst=qst: qe.submit(ek[a:b], m[a:b], qc, qs, qst),
+                       lambda a=a, b=b, qc=qc, qs=qs: (_same(qc, ct0[a:b], "queue encaps"), _same(qs, ss0[a:b], "queue encaps ss"))))
+        lo = b
+    drive(qe, qcalls, int(rng.choice([2, 8])))
+    assert pub.try_close() == 0 and prv.try_close() == 0 and qe.close() == 0, "close"
 
     d = int(rng.choice([44, 65, 87, 2, 3, 5]))
     n = int(rng.choice([1, 3, 15, 16, 17, 100, 513, 1025, 3000, 9000]))
@@ -61,6 +129,21 @@ while time.time() < t_end:
     idx = rng.integers(0, nk, n).astype(np.uint32)
     okk = hostapi.mldsa_verify_keyed(d, pk[:nk], idx, sig, msgs)
     assert okk.tolist() == orc.mldsa_verify(d, pk[idx], sig, msgs).tolist(), ("verify keyed", d, n, nk)
+    if d in (44, 65, 87):  # (resident tables are ML-DSA's) the asynchronous verification over the same verdicts, ragged messages
+        na = min(n, 60)
+        ver = hostapi.KeyTable("mldsa-public", d, pk[:nk])
+        mi = int(rng.choice([8, 32]))
+        ver.async_start(mi, 0)
+        vcalls, lo = [], 0
+        while lo < na:
+            c = int(min(na - lo, rng.integers(1, mi // 4 + 1)))
+            a, b = lo, lo + c
+            ov = np.full(c, 0xAA, np.uint8)
+            vcalls.append((lambda a=a, b=b, ov=ov: ver.submit_verify(sig[a:b], msgs[a:b], ov, key_idx=idx[a:b]),
+                           lambda a=a, b=b, ov=ov: _same(ov, okk[a:b], "async verify")))
+            lo = b
+        drive(ver, vcalls, int(rng.choice([1, 6])))
+        assert ver.try_close() == 0
     # X25519 and the hybrid KEMs (device composition, pair kernel, fixed-base comb)
     n = int(rng.choice([1, 2, 63, 64, 65, 700, 5000]))
     k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
