@@ -78,3 +78,11 @@ def test_readme_numbers_quote_the_committed_bench_record():
         g = re.search(pattern, s, re.S)
         assert g, pattern
         _close(_num(g.group(1)), actual, what)
+
+
+def test_sync_docs_has_nothing_to_do():
+    """tools/sync_docs.py --check: the documents already carry the committed record's figures (and its patterns still find their sentences)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sync_docs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
