@@ -2,9 +2,13 @@
 // and sign/schemes/schemes_test.go:17-108 exercise the Go interfaces.  Needs a GPU (run from
 // tests/test_gpu_host_mirror.py).  Prints "OK" on success.
 #include <cstdio>
+#include <thread>
+#include <future>
+#include <atomic>
 #include <cstring>
 
 #include "circl/kem.hpp"
+#include "circl/serving.hpp"
 #include "circl/sign.hpp"
 
 #define REQUIRE(c)                                                        \
@@ -191,6 +195,51 @@ int main() {
         const sign::PublicKey dpa = dall.UnmarshalBinaryPublicKey(dk.first.MarshalBinary());
         sign::Bytes msg{9, 8, 7};
         REQUIRE(dall.Sign(dsa, msg) == d1->Sign(dk.second, msg) && dall.Verify(dpa, msg, dall.Sign(dsa, msg)));
+    }
+    {
+        // kem::Serving (include/circl/serving.hpp): the compiled counterpart of go/kem/mlkem/hipbatch/{reactor,serving}.go -- key objects with
+        // an asynchronous queue and ONE reactor thread each; six caller threads issue single operations (futures), every result must be
+        // kem::Scheme's own (kem/mlkem/mlkem768/kyber.go:347-386)
+        const kem::Scheme *s = kem::ByName("ML-KEM-768");
+        kem::Serving srv(s, 0, 64, 128);
+        auto kp = s->DeriveKeyPair(kem::Bytes(64, 11));
+        auto spk = srv.UnmarshalBinaryPublicKey(kp.first.MarshalBinary());
+        auto ssk = srv.UnmarshalBinaryPrivateKey(kp.second.MarshalBinary());
+        constexpr int T = 6, N = 40;
+        std::vector<std::thread> th;
+        std::atomic<int> bad{0};
+        for (int t = 0; t < T; t++) {
+            th.emplace_back([&, t] {
+                std::vector<std::future<kem::ServingKey::Result>> enc;
+                std::vector<kem::Bytes> seeds;
+                for (int i = 0; i < N; i++) {
+                    kem::Bytes seed(32);
+                    for (int b = 0; b < 32; b++) seed[b] = (uint8_t)(t * 41 + i * 7 + b);
+                    seeds.push_back(seed);
+                    enc.push_back(srv.EncapsulateAsync(*spk, seed));  // N requests outstanding from this thread alone
+                }
+                for (int i = 0; i < N; i++) {
+                    const kem::ServingKey::Result r = enc[i].get();
+                    const auto want = s->EncapsulateDeterministically(kp.first, seeds[i]);
+                    if (r.first != want.first || r.second != want.second) bad++;
+                    kem::Bytes ct = r.first;
+                    if (i % 3 == 0) ct[5] ^= 1;  // implicit rejection: not an error, the reference's pseudo-random secret
+                    if (srv.Decapsulate(*ssk, ct) != s->Decapsulate(kp.second, ct)) bad++;
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        REQUIRE(bad.load() == 0);
+        REQUIRE(throws<kem::ErrSeedSize>([&] { srv.EncapsulateAsync(*spk, kem::Bytes(5)); }));
+        REQUIRE(throws<kem::ErrCiphertextSize>([&] { srv.DecapsulateAsync(*ssk, kem::Bytes(5)); }));
+        REQUIRE(throws<kem::ErrTypeMismatch>([&] { srv.EncapsulateAsync(*ssk, kem::Bytes(32)); }));
+        kem::Bytes badsk = kp.second.MarshalBinary();
+        badsk[badsk.size() - 40] ^= 1;  // the stored H(ek) no longer matches: kem.ErrPrivKey at parse time (kyber.go:219-228)
+        REQUIRE(throws<kem::ErrPrivKey>([&] { srv.UnmarshalBinaryPrivateKey(badsk); }));
+        // a key object goes away with requests still in flight: they are finished first
+        auto f = srv.EncapsulateAsync(*spk, kem::Bytes(32, 9));
+        spk.reset();
+        REQUIRE(f.get().second == s->EncapsulateDeterministically(kp.first, kem::Bytes(32, 9)).second);
     }
     std::printf("OK\n");
     return 0;

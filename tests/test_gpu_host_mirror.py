@@ -1,4 +1,4 @@
-"""Builds and runs tests/host_mirror_test.cpp: the C++ host layer (include/circl/{kem,sign}.hpp) that
+"""Builds and runs tests/host_mirror_test.cpp: the C++ host layer (include/circl/{kem,sign,serving}.hpp) that
 mirrors the reference's kem.Scheme / sign.Scheme above the C ABI."""
 import os
 import subprocess
